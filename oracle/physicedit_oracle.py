@@ -1,0 +1,505 @@
+"""CPU ORACLE for the PhysicEdit denoising hot path.  TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module.  The product path (physicedit_amd/*) never does and fails loudly when the HIP library is
+missing.
+
+What it is: an independent, functional restatement (plain functions over a state-dict, no
+nn.Module tree) of the reference's algorithm for the path named in BASELINE.json `north_star`:
+
+    flow-match scheduler -> [adapter on 64 special tokens -> DiT forward] x {posi, nega}
+    -> CFG combine -> Euler step, x N steps -> VAE decode         (+ VAE encode of the edit image)
+
+It is written with torch CPU ops because the reference's arithmetic IS "bf16 tensors through
+torch CPU ops": every rounding boundary is reproduced by using the same op
+at the same place, in bf16.  Each function cites the reference file:line it follows
+(paths relative to /root/reference/DiffSynth-Studio/diffsynth/).
+
+Pinning: the reference ships no tests and no golden vectors.  This oracle is
+pinned against outputs of the reference itself, imported in the build container by
+`tests/golden/make_golden.py`, which wrote the fixtures `tests/golden/*.safetensors`;
+`tests/test_oracle_golden.py` replays them (CPU, `-m "not gpu"`).
+
+`dtype=torch.float32` runs the same graph in fp32 (used for the "distance to fp32 truth" parity
+bound in tests; never a reference behaviour).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+# ======================================================================================
+# scheduler   (schedulers/flow_match.py)
+# ======================================================================================
+class FlowMatchTables:
+    """FlowMatchScheduler as QwenImagePhysicPipeline configures it
+    (pipelines/qwen_image_physical.py:192: sigma_min=0, sigma_max=1, extra_one_step=True,
+    exponential_shift=True, exponential_shift_mu=0.8, shift_terminal=0.02)."""
+
+    def __init__(self, num_inference_steps: int = 100, dynamic_shift_len: Optional[int] = None,
+                 denoising_strength: float = 1.0, exponential_shift_mu: Optional[float] = None):
+        self.set_timesteps(num_inference_steps, dynamic_shift_len, denoising_strength, exponential_shift_mu)
+
+    @staticmethod
+    def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=8192, base_shift=0.5, max_shift=0.9):
+        # flow_match.py:114-125
+        m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+        b = base_shift - m * base_seq_len
+        return image_seq_len * m + b
+
+    def set_timesteps(self, num_inference_steps, dynamic_shift_len=None, denoising_strength=1.0,
+                      exponential_shift_mu=None):
+        # flow_match.py:34-69 with the pipeline's constructor flags folded in
+        sigma_min, sigma_max = 0.0, 1.0
+        sigma_start = sigma_min + (sigma_max - sigma_min) * denoising_strength
+        sigmas = torch.linspace(sigma_start, sigma_min, num_inference_steps + 1)[:-1]  # extra_one_step
+        if exponential_shift_mu is not None:
+            mu = exponential_shift_mu
+        elif dynamic_shift_len is not None:
+            mu = self.calculate_shift(dynamic_shift_len)
+        else:
+            mu = 0.8
+        sigmas = math.exp(mu) / (math.exp(mu) + (1 / sigmas - 1))  # exponential_shift
+        one_minus_z = 1 - sigmas  # shift_terminal = 0.02
+        scale_factor = one_minus_z[-1] / (1 - 0.02)
+        sigmas = 1 - (one_minus_z / scale_factor)
+        self.mu = mu
+        self.sigmas = sigmas
+        self.timesteps = sigmas * 1000
+
+    def step(self, model_output, progress_id, sample):
+        # utils/__init__.py:150-156 -> flow_match.py:72-82 (argmin over |timesteps - t| == progress_id)
+        sigma = self.sigmas[progress_id]
+        if progress_id + 1 >= len(self.timesteps):
+            sigma_ = 0
+        else:
+            sigma_ = self.sigmas[progress_id + 1]
+        return sample + model_output * (sigma_ - sigma)
+
+
+def adapter_t_range() -> Tuple[float, float]:
+    """t_min/t_max handed to VisualThinkingDualAdapter (qwen_image_physical.py:225): min/max of the
+    DEFAULT 100-step, mu=0.8 timetable built in the scheduler constructor."""
+    tab = FlowMatchTables(100)
+    return tab.timesteps.min().item(), tab.timesteps.max().item()
+
+
+# ======================================================================================
+# small ops   (models/utils.py, models/qwen_image_dit.py)
+# ======================================================================================
+def rmsnorm(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float = 1e-6) -> torch.Tensor:
+    # models/utils.py:250-257
+    input_dtype = x.dtype
+    variance = x.to(torch.float32).square().mean(-1, keepdim=True)
+    x = x * torch.rsqrt(variance + eps)
+    x = x.to(input_dtype)
+    if weight is not None:
+        x = x * weight
+    return x
+
+
+def timestep_sinusoid(timestep: torch.Tensor) -> torch.Tensor:
+    """get_timestep_embedding(models/utils.py:189-216) as TimestepEmbeddings(256, 3072, scale=1000,
+    align_dtype_to_timestep=True, flip_sin_to_cos=True, downscale_freq_shift=0) calls it (:274-293).
+    `timestep` is already t/1000 in the pipeline dtype, shape [B]."""
+    half_dim = 128
+    exponent = -math.log(10000) * torch.arange(start=0, end=half_dim, dtype=torch.float32)
+    exponent = exponent / (half_dim - 0)
+    emb = torch.exp(exponent)
+    emb = emb.to(timestep.dtype)  # align_dtype_to_timestep
+    emb = timestep[:, None].float() * emb[None, :]
+    emb = 1000 * emb
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    emb = torch.cat([emb[:, half_dim:], emb[:, :half_dim]], dim=-1)  # flip_sin_to_cos
+    return emb
+
+
+def time_text_embed(sd: SD, timestep: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    # models/utils.py:290-293 + _DiffusersCompatibleTimestepProj :260-271
+    p = "time_text_embed.timestep_embedder."
+    x = timestep_sinusoid(timestep).to(dtype)
+    x = F.linear(x, sd[p + "linear_1.weight"], sd[p + "linear_1.bias"])
+    x = F.silu(x)
+    x = F.linear(x, sd[p + "linear_2.weight"], sd[p + "linear_2.bias"])
+    return x
+
+
+_AXES_DIM = (16, 56, 56)
+_THETA = 10000
+
+
+def _rope_params(index: torch.Tensor, dim: int) -> torch.Tensor:
+    # qwen_image_dit.py:80-91
+    freqs = torch.outer(index, 1.0 / torch.pow(_THETA, torch.arange(0, dim, 2).to(torch.float32).div(dim)))
+    return torch.polar(torch.ones_like(freqs), freqs)
+
+
+def rope_tables(img_shapes: Sequence[Tuple[int, int, int]], txt_len: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """QwenEmbedRope.forward (qwen_image_dit.py:123-165) with scale_rope=True, axes (16,56,56).
+    Returns complex64 (vid_freqs [S_img,64], txt_freqs [T,64])."""
+    vid = []
+    max_vid_index = 0
+    for idx, (frame, height, width) in enumerate(img_shapes):
+        fr = _rope_params(torch.arange(idx, idx + frame), _AXES_DIM[0])  # pos_freqs[0][idx:idx+frame]
+        h_idx = torch.cat([torch.arange(-(height - height // 2), 0), torch.arange(0, height // 2)])
+        w_idx = torch.cat([torch.arange(-(width - width // 2), 0), torch.arange(0, width // 2)])
+        fh = _rope_params(h_idx, _AXES_DIM[1])
+        fw = _rope_params(w_idx, _AXES_DIM[2])
+        freqs = torch.cat([
+            fr.view(frame, 1, 1, -1).expand(frame, height, width, -1),
+            fh.view(1, height, 1, -1).expand(frame, height, width, -1),
+            fw.view(1, 1, width, -1).expand(frame, height, width, -1),
+        ], dim=-1).reshape(frame * height * width, -1)
+        vid.append(freqs)
+        max_vid_index = max(height // 2, width // 2, max_vid_index)
+    t_idx = torch.arange(max_vid_index, max_vid_index + txt_len)
+    txt = torch.cat([_rope_params(t_idx, d) for d in _AXES_DIM], dim=1)
+    return torch.cat(vid, dim=0).contiguous(), txt.contiguous()
+
+
+def apply_rope(x: torch.Tensor, freqs_cis: torch.Tensor) -> torch.Tensor:
+    # qwen_image_dit.py:51-57 ; x [B,H,S,D], freqs [S,D/2] complex
+    x_rotated = torch.view_as_complex(x.float().reshape(*x.shape[:-1], -1, 2))
+    x_out = torch.view_as_real(x_rotated * freqs_cis).flatten(3)
+    return x_out.type_as(x)
+
+
+def patchify(latents: torch.Tensor) -> torch.Tensor:
+    # "B C (H P) (W Q) -> B (H W) (C P Q)", P=Q=2 (qwen_image_physical.py:1344)
+    B, C, H2, W2 = latents.shape
+    H, W = H2 // 2, W2 // 2
+    x = latents.reshape(B, C, H, 2, W, 2).permute(0, 2, 4, 1, 3, 5)
+    return x.reshape(B, H * W, C * 4)
+
+
+def unpatchify(image: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    # "B (H W) (C P Q) -> B C (H P) (W Q)" (qwen_image_physical.py:1402)
+    B = image.shape[0]
+    x = image.reshape(B, H, W, 16, 2, 2).permute(0, 3, 1, 4, 2, 5)
+    return x.reshape(B, 16, H * 2, W * 2)
+
+
+# ======================================================================================
+# DiT block   (models/qwen_image_dit.py:247-401)
+# ======================================================================================
+def _modulate(x, mod_params):
+    # qwen_image_dit.py:355-357
+    shift, scale, gate = mod_params.chunk(3, dim=-1)
+    return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1), gate.unsqueeze(1)
+
+
+def _heads(x: torch.Tensor, h: int = 24) -> torch.Tensor:
+    B, S, HD = x.shape
+    return x.reshape(B, S, h, HD // h).permute(0, 2, 1, 3)
+
+
+def joint_attention(sd: SD, p: str, image, text, rope) -> Tuple[torch.Tensor, torch.Tensor]:
+    # QwenDoubleStreamAttention.forward, qwen_image_dit.py:274-316
+    a = p + "attn."
+    img_q = F.linear(image, sd[a + "to_q.weight"], sd[a + "to_q.bias"])
+    img_k = F.linear(image, sd[a + "to_k.weight"], sd[a + "to_k.bias"])
+    img_v = F.linear(image, sd[a + "to_v.weight"], sd[a + "to_v.bias"])
+    txt_q = F.linear(text, sd[a + "add_q_proj.weight"], sd[a + "add_q_proj.bias"])
+    txt_k = F.linear(text, sd[a + "add_k_proj.weight"], sd[a + "add_k_proj.bias"])
+    txt_v = F.linear(text, sd[a + "add_v_proj.weight"], sd[a + "add_v_proj.bias"])
+    seq_txt = txt_q.shape[1]
+    img_q, img_k, img_v = _heads(img_q), _heads(img_k), _heads(img_v)
+    txt_q, txt_k, txt_v = _heads(txt_q), _heads(txt_k), _heads(txt_v)
+    img_q, img_k = rmsnorm(img_q, sd[a + "norm_q.weight"]), rmsnorm(img_k, sd[a + "norm_k.weight"])
+    txt_q, txt_k = rmsnorm(txt_q, sd[a + "norm_added_q.weight"]), rmsnorm(txt_k, sd[a + "norm_added_k.weight"])
+    img_freqs, txt_freqs = rope
+    img_q, img_k = apply_rope(img_q, img_freqs), apply_rope(img_k, img_freqs)
+    txt_q, txt_k = apply_rope(txt_q, txt_freqs), apply_rope(txt_k, txt_freqs)
+    q = torch.cat([txt_q, img_q], dim=2)
+    k = torch.cat([txt_k, img_k], dim=2)
+    v = torch.cat([txt_v, img_v], dim=2)
+    # qwen_image_flash_attention, SDPA branch (:37-38); CPU has no FA3
+    x = F.scaled_dot_product_attention(q, k, v)
+    B, H, S, D = x.shape
+    x = x.permute(0, 2, 1, 3).reshape(B, S, H * D).to(q.dtype)
+    txt_o, img_o = x[:, :seq_txt, :], x[:, seq_txt:, :]
+    img_o = F.linear(img_o, sd[a + "to_out.0.weight"], sd[a + "to_out.0.bias"])
+    txt_o = F.linear(txt_o, sd[a + "to_add_out.weight"], sd[a + "to_add_out.bias"])
+    return img_o, txt_o
+
+
+def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    # QwenFeedForward + ApproximateGELU, qwen_image_dit.py:42-49,228-245
+    x = F.linear(x, sd[p + "net.0.proj.weight"], sd[p + "net.0.proj.bias"])
+    x = x * torch.sigmoid(1.702 * x)
+    return F.linear(x, sd[p + "net.2.weight"], sd[p + "net.2.bias"])
+
+
+def block_forward(sd: SD, i: int, image, text, temb, rope) -> Tuple[torch.Tensor, torch.Tensor]:
+    # QwenImageTransformerBlock.forward, qwen_image_dit.py:359-401.  Returns (text, image).
+    p = f"transformer_blocks.{i}."
+    D = image.shape[-1]
+    st = F.silu(temb)
+    img_mod = F.linear(st, sd[p + "img_mod.1.weight"], sd[p + "img_mod.1.bias"])
+    txt_mod = F.linear(st, sd[p + "txt_mod.1.weight"], sd[p + "txt_mod.1.bias"])
+    img_mod_attn, img_mod_mlp = img_mod.chunk(2, dim=-1)
+    txt_mod_attn, txt_mod_mlp = txt_mod.chunk(2, dim=-1)
+
+    img_m, img_gate = _modulate(F.layer_norm(image, (D,), eps=1e-6), img_mod_attn)
+    txt_m, txt_gate = _modulate(F.layer_norm(text, (D,), eps=1e-6), txt_mod_attn)
+    img_attn, txt_attn = joint_attention(sd, p, img_m, txt_m, rope)
+    image = image + img_gate * img_attn
+    text = text + txt_gate * txt_attn
+
+    img_m2, img_gate2 = _modulate(F.layer_norm(image, (D,), eps=1e-6), img_mod_mlp)
+    txt_m2, txt_gate2 = _modulate(F.layer_norm(text, (D,), eps=1e-6), txt_mod_mlp)
+    image = image + img_gate2 * feed_forward(sd, p + "img_mlp.", img_m2)
+    text = text + txt_gate2 * feed_forward(sd, p + "txt_mlp.", txt_m2)
+    return text, image
+
+
+# ======================================================================================
+# adapter   (pipelines/helpers.py:123-164)
+# ======================================================================================
+def adapter_alpha(timestep: torch.Tensor, t_min: float, t_max: float) -> torch.Tensor:
+    # helpers.py:142-150
+    alpha = (timestep - t_min) / (t_max - t_min + 1e-6)
+    return alpha.clamp(0.0, 1.0).view(-1, 1, 1)
+
+
+def adapter_forward(ad: SD, x: torch.Tensor, timestep: torch.Tensor, t_min: float, t_max: float):
+    # VisualThinkingDualAdapter.forward, helpers.py:152-164
+    def head(n):
+        h = F.linear(x, ad[n + ".0.weight"], ad[n + ".0.bias"])
+        h = F.gelu(h)
+        return F.linear(h, ad[n + ".2.weight"], ad[n + ".2.bias"])
+    pred_dino, pred_vae = head("head_dino"), head("head_vae")
+    alpha_view = adapter_alpha(timestep, t_min, t_max).type_as(pred_dino)
+    mixed = alpha_view * pred_dino + (1 - alpha_view) * pred_vae
+    return mixed, pred_dino, pred_vae
+
+
+# ======================================================================================
+# model_fn   (pipelines/qwen_image_physical.py:1302-1403)
+# ======================================================================================
+def num_layers_of(sd: SD) -> int:
+    n = 0
+    while f"transformer_blocks.{n}.img_mod.1.weight" in sd:
+        n += 1
+    return n
+
+
+def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Tensor,
+             prompt_emb: torch.Tensor, special_token_mask: Optional[torch.Tensor],
+             height: int, width: int, edit_latents=None,
+             t_min: float = 20.0, t_max: float = 1000.0) -> torch.Tensor:
+    """One DiT forward at inference (is_train=False).  MUTATES `prompt_emb` IN PLACE on the
+    special-token rows exactly as the reference does (:1336)."""
+    if special_token_mask is not None:
+        special = prompt_emb[special_token_mask].view(prompt_emb.shape[0], -1, prompt_emb.size(-1))
+        special, _, _ = adapter_forward(ad, special, timestep, t_min, t_max)
+        prompt_emb[special_token_mask] = special.reshape(-1, prompt_emb.size(-1))
+
+    img_shapes = [(latents.shape[0], latents.shape[2] // 2, latents.shape[3] // 2)]
+    T = prompt_emb.shape[1]
+    timestep = timestep / 1000
+    image = patchify(latents)
+    image_seq_len = image.shape[1]
+    if edit_latents is not None:
+        edit_list = edit_latents if isinstance(edit_latents, (list, tuple)) else [edit_latents]
+        img_shapes += [(e.shape[0], e.shape[2] // 2, e.shape[3] // 2) for e in edit_list]
+        image = torch.cat([image] + [patchify(e) for e in edit_list], dim=1)
+
+    image = F.linear(image, sd["img_in.weight"], sd["img_in.bias"])
+    conditioning = time_text_embed(sd, timestep, image.dtype)
+    text = F.linear(rmsnorm(prompt_emb, sd["txt_norm.weight"]), sd["txt_in.weight"], sd["txt_in.bias"])
+    vid_f, txt_f = rope_tables(img_shapes, T)
+
+    for i in range(num_layers_of(sd)):
+        text, image = block_forward(sd, i, image, text, conditioning, (vid_f, txt_f))
+
+    # AdaLayerNorm(single=True), models/utils.py:304-309
+    emb = F.linear(F.silu(conditioning), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
+    scale, shift = emb.unsqueeze(1).chunk(2, dim=2)
+    image = F.layer_norm(image, (image.shape[-1],), eps=1e-6) * (1 + scale) + shift
+    image = F.linear(image, sd["proj_out.weight"], sd["proj_out.bias"])
+    image = image[:, :image_seq_len]
+    return unpatchify(image, height // 16, width // 16)
+
+
+def denoise_loop(sd: SD, ad: Optional[SD], noise: torch.Tensor, prompt_emb_posi: torch.Tensor,
+                 prompt_emb_nega: Optional[torch.Tensor], mask_posi, mask_nega,
+                 height: int, width: int, num_inference_steps: int, cfg_scale: float = 4.0,
+                 edit_latents=None, dtype=torch.bfloat16) -> torch.Tensor:
+    """QwenImagePhysicPipeline.__call__ lines 600 + 644-661 (loop only; prologue outputs are the
+    arguments).  prompt_emb_* are cloned once here and then mutated across steps like the
+    reference's `inputs_posi` / `inputs_nega` dict entries."""
+    tab = FlowMatchTables(num_inference_steps, dynamic_shift_len=(height // 16) * (width // 16))
+    t_min, t_max = adapter_t_range()
+    latents = noise.clone()
+    pe_p = prompt_emb_posi.clone()
+    pe_n = prompt_emb_nega.clone() if prompt_emb_nega is not None else None
+    for progress_id, timestep in enumerate(tab.timesteps):
+        t = timestep.unsqueeze(0).to(dtype=dtype)
+        pred = model_fn(sd, ad, latents, t, pe_p, mask_posi, height, width, edit_latents, t_min, t_max)
+        if cfg_scale != 1.0:
+            pred_n = model_fn(sd, ad, latents, t, pe_n, mask_nega, height, width, edit_latents, t_min, t_max)
+            pred = pred_n + cfg_scale * (pred - pred_n)
+        latents = tab.step(pred, progress_id, latents)
+    return latents
+
+
+# ======================================================================================
+# LoRA merge   (lora/__init__.py:28-45)
+# ======================================================================================
+def lora_merge(sd: SD, lora: SD, alpha: float = 1.0, dtype=torch.bfloat16) -> int:
+    """GeneralLoRALoader.load on the DiT state-dict, in place.  Returns #tensors updated."""
+    n = 0
+    for key in list(lora.keys()):
+        if ".lora_B." not in key:
+            continue
+        keys = key.split(".")
+        if len(keys) > keys.index("lora_B") + 2:
+            keys.pop(keys.index("lora_B") + 1)
+        keys.pop(keys.index("lora_B"))
+        if keys[0] == "diffusion_model":
+            keys.pop(0)
+        keys.pop(-1)
+        target = ".".join(keys) + ".weight"
+        if target not in sd:
+            continue
+        up = lora[key].to(dtype=dtype)
+        down = lora[key.replace(".lora_B.", ".lora_A.")].to(dtype=dtype)
+        sd[target] = sd[target].to(dtype=dtype) + alpha * torch.mm(up, down)
+        n += 1
+    return n
+
+
+# ======================================================================================
+# VAE   (models/qwen_image_vae.py) -- single frame, feat_cache=None
+# ======================================================================================
+_VAE_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+             0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+_VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+            3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+
+
+# `VAE_CONV_MODE`: "3d" (default) evaluates the causal Conv3d literally like the reference --
+# bit-exact with it; "2d" evaluates the mathematically identical 2-D conv with the last temporal
+# tap (1/3 of the MACs; what the HIP path computes).  The two differ only by fp32 accumulation
+# order inside the conv primitive (tests/test_oracle_golden.py::test_G7_vae quantifies it).
+VAE_CONV_MODE = "3d"
+
+
+def _conv3(vs: SD, name: str, x: torch.Tensor) -> torch.Tensor:
+    """QwenImageCausalConv3d at T=1 without cache (qwen_image_vae.py:40-50): pad
+    (W:1,1  H:1,1  T:2,0) with zeros then Conv3d.  The two causal pad frames are zeros, so only
+    temporal tap 2 contributes -> equals a 2-D conv with weight[:, :, 2].
+    1x1x1 kernels have no padding and a single tap."""
+    w = vs[name + ".weight"]
+    if VAE_CONV_MODE == "3d" and w.dim() == 5:
+        x5 = x.unsqueeze(2)
+        if w.shape[-1] == 3:
+            x5 = F.pad(x5, (1, 1, 1, 1, 2, 0))
+        return F.conv3d(x5, w, vs[name + ".bias"]).squeeze(2)
+    w2 = w[:, :, -1] if w.dim() == 5 else w
+    pad = 1 if w2.shape[-1] == 3 else 0
+    return F.conv2d(x, w2, vs[name + ".bias"], padding=pad)
+
+
+def _rms_norm_c(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
+    # QwenImageRMS_norm.forward (:76-77), channel_first, bias=False -> "+ 0.0"
+    C = x.shape[1]
+    return F.normalize(x, dim=1) * (C ** 0.5) * gamma.reshape(1, C, 1, 1) + 0.0
+
+
+def _res_block(vs: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    # QwenImageResidualBlock.forward (:112-152), feat_cache None
+    h = _conv3(vs, p + "conv_shortcut", x) if (p + "conv_shortcut.weight") in vs else x
+    x = F.silu(_rms_norm_c(x, vs[p + "norm1.gamma"]))
+    x = _conv3(vs, p + "conv1", x)
+    x = F.silu(_rms_norm_c(x, vs[p + "norm2.gamma"]))
+    x = _conv3(vs, p + "conv2", x)
+    return x + h
+
+
+def _attn_block(vs: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    # QwenImageAttentionBlock.forward (:173-198), T=1
+    identity = x
+    B, C, H, W = x.shape
+    x = _rms_norm_c(x, vs[p + "norm.gamma"])
+    qkv = F.conv2d(x, vs[p + "to_qkv.weight"], vs[p + "to_qkv.bias"])
+    qkv = qkv.reshape(B, 1, C * 3, -1).permute(0, 1, 3, 2).contiguous()
+    q, k, v = qkv.chunk(3, dim=-1)
+    x = F.scaled_dot_product_attention(q, k, v)
+    x = x.squeeze(1).permute(0, 2, 1).reshape(B, C, H, W)
+    x = F.conv2d(x, vs[p + "proj.weight"], vs[p + "proj.bias"])
+    return x + identity
+
+
+def _mid_block(vs: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    x = _res_block(vs, p + "resnets.0.", x)
+    x = _attn_block(vs, p + "attentions.0.", x)
+    return _res_block(vs, p + "resnets.1.", x)
+
+
+def vae_encode(vs: SD, x: torch.Tensor) -> torch.Tensor:
+    """QwenImageVAE.encode (:706-717) + QwenImageEncoder3d.forward (:411-448) on [B,3,H,W]."""
+    x = _conv3(vs, "encoder.conv_in", x)
+    idx = 0
+    for i in range(4):
+        for _ in range(2):
+            x = _res_block(vs, f"encoder.down_blocks.{idx}.", x)
+            idx += 1
+        if i != 3:
+            # QwenImageResample downsample2d/3d without cache (:248-252, :285-287): ZeroPad2d((0,1,0,1)) + stride-2 conv
+            p = f"encoder.down_blocks.{idx}.resample.1"
+            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), vs[p + ".weight"], vs[p + ".bias"], stride=2)
+            idx += 1
+    x = _mid_block(vs, "encoder.mid_block.", x)
+    x = F.silu(_rms_norm_c(x, vs["encoder.norm_out.gamma"]))
+    x = _conv3(vs, "encoder.conv_out", x)
+    x = _conv3(vs, "quant_conv", x)
+    x = x[:, :16]
+    mean = torch.tensor(_VAE_MEAN).view(1, 16, 1, 1).to(dtype=x.dtype)
+    std = (1 / torch.tensor(_VAE_STD).view(1, 16, 1, 1)).to(dtype=x.dtype)
+    return (x - mean) * std
+
+
+def vae_decode(vs: SD, x: torch.Tensor) -> torch.Tensor:
+    """QwenImageVAE.decode (:719-729) + QwenImageDecoder3d.forward (:601-636) on [B,16,h,w]."""
+    mean = torch.tensor(_VAE_MEAN).view(1, 16, 1, 1).to(dtype=x.dtype)
+    std = (1 / torch.tensor(_VAE_STD).view(1, 16, 1, 1)).to(dtype=x.dtype)
+    x = x / std + mean
+    x = _conv3(vs, "post_quant_conv", x)
+    x = _conv3(vs, "decoder.conv_in", x)
+    x = _mid_block(vs, "decoder.mid_block.", x)
+    for i in range(4):
+        for j in range(3):
+            x = _res_block(vs, f"decoder.up_blocks.{i}.resnets.{j}.", x)
+        if i != 3:
+            # QwenImageUpsample: nearest-exact 2x computed in fp32 then cast back (:213-214), + Conv2d(C, C/2, 3, pad 1)
+            x = F.interpolate(x.float(), scale_factor=(2.0, 2.0), mode="nearest-exact").type_as(x)
+            p = f"decoder.up_blocks.{i}.upsamplers.0.resample.1"
+            x = F.conv2d(x, vs[p + ".weight"], vs[p + ".bias"], padding=1)
+    x = F.silu(_rms_norm_c(x, vs["decoder.norm_out.gamma"]))
+    return _conv3(vs, "decoder.conv_out", x)
+
+
+# ======================================================================================
+# image <-> tensor   (utils/__init__.py:60-83)
+# ======================================================================================
+def preprocess_image(img_u8_hwc, dtype=torch.bfloat16) -> torch.Tensor:
+    import numpy as np
+    image = torch.Tensor(np.array(img_u8_hwc, dtype=np.float32))
+    image = image.to(dtype=dtype)
+    image = image * ((1 - (-1)) / 255) + (-1)
+    return image.permute(2, 0, 1).unsqueeze(0)
+
+
+def vae_output_to_u8(vae_output: torch.Tensor) -> torch.Tensor:
+    # reduce "B C H W -> H W C" mean, scale, clip, truncate to uint8
+    x = vae_output.mean(dim=0).permute(1, 2, 0)
+    image = ((x - (-1)) * (255 / (1 - (-1)))).clip(0, 255)
+    return image.to(device="cpu", dtype=torch.uint8)

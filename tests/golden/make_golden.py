@@ -1,0 +1,353 @@
+"""Generate tests/golden/* from the REAL reference, imported from /root/reference.
+
+Runs ONLY in the build container (the reference never travels to the GPU box).  The fixtures it
+writes are data: seeds/shapes in, reference outputs out.  Weights and inputs are NOT stored --
+they are regenerated on both sides from `physicedit_amd.synth` seeds and loaded into the
+reference modules with `load_state_dict(assign=True)`.
+
+    python tests/golden/make_golden.py            # all groups
+    python tests/golden/make_golden.py G4 G5      # selected groups
+
+Import recipe: SURVEY.md section 8c (stub imageio/modelscope, import transformers first, then stub
+torchvision).
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/DiffSynth-Studio")
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return lambda *a, **k: None
+
+
+for n in ("imageio", "modelscope"):
+    sys.modules[n] = _Stub(n)
+import transformers  # noqa: E402
+from transformers import Qwen2_5_VLModel, Qwen2_5_VLForConditionalGeneration, Dinov2WithRegistersModel  # noqa: E402,F401
+for n in ("torchvision", "torchvision.transforms"):
+    sys.modules[n] = _Stub(n)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+from diffsynth.models.qwen_image_dit import (QwenImageDiT, QwenImageTransformerBlock, QwenEmbedRope,  # noqa: E402
+                                              apply_rotary_emb_qwen)
+from diffsynth.models.qwen_image_vae import QwenImageVAE, QwenImageCausalConv3d  # noqa: E402
+from diffsynth.models.utils import RMSNorm, TimestepEmbeddings  # noqa: E402
+from diffsynth.schedulers.flow_match import FlowMatchScheduler  # noqa: E402
+from diffsynth.pipelines.qwen_image_physical import model_fn_qwen_image  # noqa: E402
+from diffsynth.pipelines.helpers import VisualThinkingDualAdapter  # noqa: E402
+from diffsynth.lora import GeneralLoRALoader  # noqa: E402
+from diffsynth.utils import BasePipeline  # noqa: E402
+
+from physicedit_amd import synth  # noqa: E402
+
+BF = torch.bfloat16
+torch.set_grad_enabled(False)
+
+
+def save(name, tensors, meta=None):
+    tensors = {k: v.contiguous() for k, v in tensors.items()}
+    save_file(tensors, os.path.join(HERE, name + ".safetensors"),
+              metadata={k: json.dumps(v) for k, v in (meta or {}).items()})
+    sz = os.path.getsize(os.path.join(HERE, name + ".safetensors"))
+    print(f"wrote {name}.safetensors ({sz/1e6:.2f} MB)")
+
+
+def ref_scheduler():
+    # qwen_image_physical.py:192
+    return FlowMatchScheduler(sigma_min=0, sigma_max=1, extra_one_step=True, exponential_shift=True,
+                              exponential_shift_mu=0.8, shift_terminal=0.02)
+
+
+def build_dit(num_layers, seed):
+    with torch.device("meta"):
+        dit = QwenImageDiT(num_layers=num_layers)
+    sd = synth.make_state_dict(synth.dit_layout(num_layers), seed)
+    dit.load_state_dict(sd, assign=True, strict=True)
+    # non-persistent tables were created on meta: rebuild the rope module on CPU
+    dit.pos_embed = QwenEmbedRope(theta=10000, axes_dim=[16, 56, 56], scale_rope=True)
+    return dit.eval(), sd
+
+
+def build_adapter(seed):
+    sch = ref_scheduler()
+    t_min, t_max = sch.timesteps.min().item(), sch.timesteps.max().item()  # :225
+    with torch.device("meta"):
+        ad = VisualThinkingDualAdapter(in_dim=3584, out_dim=3584, t_min=t_min, t_max=t_max)
+    sd = synth.make_state_dict(synth.adapter_layout(), seed)
+    ad.load_state_dict(sd, assign=True, strict=True)
+    return ad.eval(), sd, (t_min, t_max)
+
+
+def build_vae(seed):
+    with torch.device("meta"):
+        vae = QwenImageVAE()
+    sd = synth.make_state_dict(synth.vae_layout(), seed)
+    vae.load_state_dict(sd, assign=True, strict=True)
+    # mean/std are plain attributes created under the meta context: rebuild like __init__ (:667-704)
+    ref = QwenImageVAE.__new__(QwenImageVAE)
+    import oracle.physicedit_oracle as O
+    vae.mean = torch.tensor(O._VAE_MEAN).view(1, 16, 1, 1, 1)
+    vae.std = 1 / torch.tensor(O._VAE_STD).view(1, 16, 1, 1, 1)
+    return vae.eval(), sd
+
+
+# ------------------------------------------------------------------------------------------
+def G0_layout():
+    with torch.device("meta"):
+        dit = QwenImageDiT(num_layers=1)
+        vae = QwenImageVAE()
+        ad = VisualThinkingDualAdapter(3584, 3584, 20.0, 1000.0)
+    out = {
+        "dit_1layer": [[k, list(v.shape)] for k, v in dit.state_dict().items()],
+        "vae": [[k, list(v.shape)] for k, v in vae.state_dict().items()],
+        "adapter": [[k, list(v.shape)] for k, v in ad.state_dict().items()],
+    }
+    with open(os.path.join(HERE, "layout_keys.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote layout_keys.json")
+
+
+def G1_scheduler():
+    t = {}
+    sch = ref_scheduler()
+    t["default_timesteps"] = sch.timesteps.clone()
+    for steps, S0 in ((4, 1024), (4, 64), (40, 4096), (50, 6889)):
+        sch = ref_scheduler()
+        sch.set_timesteps(steps, denoising_strength=1.0, dynamic_shift_len=S0, exponential_shift_mu=None)
+        t[f"sigmas_{steps}_{S0}"] = sch.sigmas.clone()
+        t[f"timesteps_{steps}_{S0}"] = sch.timesteps.clone()
+        t[f"timesteps_bf16_{steps}_{S0}"] = sch.timesteps.to(BF)
+        # scheduler.step on a fixed sample/pred (flow_match.py:72-82)
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn((1, 16, 8, 8), generator=g).to(BF)
+        v = torch.randn((1, 16, 8, 8), generator=g).to(BF)
+        outs = [sch.step(v, sch.timesteps[i], x) for i in range(steps)]
+        t[f"step_{steps}_{S0}"] = torch.stack(outs)
+    save("G1_scheduler", t)
+
+
+def G2_time_embed():
+    sd = synth.make_state_dict([kv for kv in synth.dit_layout(0) if kv[0].startswith("time_text_embed")], 1234)
+    with torch.device("meta"):
+        m = TimestepEmbeddings(256, 3072, diffusers_compatible_format=True, scale=1000, align_dtype_to_timestep=True)
+    m.load_state_dict({k[len("time_text_embed."):]: v for k, v in sd.items()}, assign=True, strict=True)
+    sch = ref_scheduler()
+    sch.set_timesteps(40, dynamic_shift_len=4096)
+    ts = sch.timesteps.to(BF)
+    outs, sins = [], []
+    for i in range(len(ts)):
+        tt = ts[i:i + 1] / 1000  # qwen_image_physical.py:1342
+        sins.append(m.time_proj(tt))
+        outs.append(m(tt, BF))
+    save("G2_time_embed", {"sinusoid_f32": torch.cat(sins), "temb": torch.cat(outs)})
+
+
+def G3_norm_rope():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((1, 24, 37, 128), generator=g).to(BF)
+    w = synth.make_tensor(5, "norm_q.weight", (128,))
+    n = RMSNorm(128, eps=1e-6)
+    n.weight = torch.nn.Parameter(w)
+    y = n(x)
+    rope = QwenEmbedRope(theta=10000, axes_dim=[16, 56, 56], scale_rope=True)
+    vid, txt = rope([(1, 8, 8), (1, 6, 10)], [37], device=torch.device("cpu"))
+    xr = apply_rotary_emb_qwen(x, txt)
+    rope2 = QwenEmbedRope(theta=10000, axes_dim=[16, 56, 56], scale_rope=True)
+    vid2, txt2 = rope2([(1, 64, 64), (1, 64, 64)], [512], device=torch.device("cpu"))
+    x3584 = torch.randn((1, 9, 3584), generator=g).to(BF)
+    n2 = RMSNorm(3584, eps=1e-6)
+    n2.weight = torch.nn.Parameter(synth.make_tensor(5, "txt_norm.weight", (3584,)))
+    save("G3_norm_rope", {
+        "rms_in": x, "rms_w": w, "rms_out": y, "rope_out": xr,
+        "vid_re": vid.real.contiguous(), "vid_im": vid.imag.contiguous(),
+        "txt_re": txt.real.contiguous(), "txt_im": txt.imag.contiguous(),
+        "vid64_sum": torch.stack([vid2.real.double().sum(), vid2.imag.double().sum(),
+                                  (vid2.real.double() * torch.arange(vid2.shape[0]).double()[:, None]).sum()]),
+        "txt64_sum": torch.stack([txt2.real.double().sum(), txt2.imag.double().sum()]),
+        "vid64_rows": torch.view_as_real(vid2[[0, 63, 64, 4095, 4096, 8191]]).contiguous(),
+        "txt64_rows": torch.view_as_real(txt2[[0, 1, 511]]).contiguous(),
+        "rms3584_in": x3584, "rms3584_out": n2(x3584),
+    })
+
+
+def _block_inputs(S_img, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn((1, S_img, 3072), generator=g).to(BF)
+    text = torch.randn((1, T, 3072), generator=g).to(BF)
+    temb = (torch.randn((1, 3072), generator=g) * 0.5).to(BF)
+    return image, text, temb
+
+
+def G4_block():
+    dit, sd = build_dit(1, 1234)
+    image, text, temb = _block_inputs(128, 40, 44)
+    rope = dit.pos_embed([(1, 8, 8), (1, 8, 8)], [40], device=torch.device("cpu"))
+    blk = dit.transformer_blocks[0]
+    text_o, image_o = blk(image=image, text=text, temb=temb, image_rotary_emb=rope)
+    # fp32 truth of the same block (weights upcast) for the parity-bound statement
+    blk32 = blk.float()
+    t32, i32 = blk32(image=image.float(), text=text.float(), temb=temb.float(), image_rotary_emb=rope)
+    save("G4_block", {"text_out": text_o, "image_out": image_o, "text_out_f32": t32, "image_out_f32": i32},
+         meta={"S_img": 128, "T": 40, "seed_inputs": 44, "seed_weights": 1234,
+               "img_shapes": [[1, 8, 8], [1, 8, 8]]})
+
+
+def _model_fn_inputs(h, w, T, n_special, seed):
+    noise = synth.make_noise(seed, h, w)
+    g = torch.Generator().manual_seed(seed + 100)
+    edit = torch.randn((1, 16, h // 8, w // 8), generator=g).to(BF)
+    pe = synth.make_prompt_emb(seed + 7, T)
+    mask = synth.make_special_token_mask(T, n_special)
+    return noise, edit, pe, mask
+
+
+def G5_model_fn():
+    dit, sd = build_dit(2, 1234)
+    ad, adsd, _ = build_adapter(4321)
+    h = w = 256
+    T, nsp = 48, 16
+    noise, edit, pe, mask = _model_fn_inputs(h, w, T, nsp, 0)
+    outs = {}
+    pe_run = pe.clone()
+    pm = torch.ones((1, T), dtype=torch.long)
+    for call, tval in enumerate((986.96, 749.27)):
+        t = torch.tensor([tval]).to(BF)
+        lat, _ = model_fn_qwen_image(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad,
+                                     latents=noise, timestep=t, prompt_emb=pe_run, prompt_emb_mask=pm,
+                                     special_token_mask=mask, height=h, width=w, edit_latents=edit,
+                                     is_train=False)
+        outs[f"latents_call{call}"] = lat
+        outs[f"prompt_emb_after_call{call}"] = pe_run.clone()
+    # same without adapter / special tokens / edit latents (QwenImagePipeline special case)
+    lat, _ = model_fn_qwen_image(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=None,
+                                 latents=noise, timestep=torch.tensor([500.0]).to(BF), prompt_emb=pe.clone(),
+                                 prompt_emb_mask=pm, special_token_mask=None, height=h, width=w,
+                                 edit_latents=None, is_train=False)
+    outs["latents_plain"] = lat
+    save("G5_model_fn", outs, meta={"h": h, "w": w, "T": T, "n_special": nsp, "seed": 0,
+                                    "timesteps": [986.96, 749.27], "layers": 2})
+
+
+def G6_loop():
+    dit, sd = build_dit(2, 1234)
+    ad, adsd, _ = build_adapter(4321)
+    h = w = 128
+    steps = 4
+    noise, edit, pe_p, mask_p = _model_fn_inputs(h, w, 40, 16, 0)
+    pe_n = synth.make_prompt_emb(8, 24)
+    mask_n = synth.make_special_token_mask(24, 16)
+    outs = {}
+    for cfg in (1.0, 4.0):
+        sch = ref_scheduler()
+        sch.set_timesteps(steps, denoising_strength=1.0, dynamic_shift_len=(h // 16) * (w // 16))  # :600
+        latents = noise.clone()
+        pp, pn = pe_p.clone(), pe_n.clone()
+        for progress_id, timestep in enumerate(sch.timesteps):  # :648-661
+            timestep = timestep.unsqueeze(0).to(dtype=BF)
+            kw = dict(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad, latents=latents,
+                      height=h, width=w, edit_latents=edit, is_train=False, timestep=timestep,
+                      progress_id=progress_id)
+            posi, _ = model_fn_qwen_image(prompt_emb=pp, prompt_emb_mask=torch.ones((1, 40), dtype=torch.long),
+                                          special_token_mask=mask_p, **kw)
+            if cfg != 1.0:
+                nega, _ = model_fn_qwen_image(prompt_emb=pn, prompt_emb_mask=torch.ones((1, 24), dtype=torch.long),
+                                              special_token_mask=mask_n, **kw)
+                pred = nega + cfg * (posi - nega)
+            else:
+                pred = posi
+            latents = sch.step(pred, sch.timesteps[progress_id], latents)  # utils/__init__.py:150-156
+            outs[f"latents_cfg{cfg}_step{progress_id}"] = latents.clone()
+    save("G6_loop", outs, meta={"h": h, "w": w, "steps": steps, "T_pos": 40, "T_neg": 24, "n_special": 16})
+
+
+def G7_vae():
+    vae, sd = build_vae(77)
+    outs = {}
+    for R in (64, 96):
+        img = synth.make_edit_image_u8(R, R, seed=R)
+        x = BasePipeline.preprocess_image(types.SimpleNamespace(torch_dtype=BF, device="cpu"), img)
+        z = vae.encode(x)
+        outs[f"enc_{R}"] = z
+        g = torch.Generator().manual_seed(R)
+        lat = torch.randn((1, 16, R // 8, R // 8), generator=g).to(BF)
+        outs[f"dec_{R}"] = vae.decode(lat)
+    # conv3d(T=1, causal pad) vs conv2d(last tap) identity on one layer
+    conv = vae.decoder.up_blocks[3].resnets[0].conv1
+    g = torch.Generator().manual_seed(9)
+    xin = torch.randn((1, 96, 1, 24, 24), generator=g).to(BF)
+    y3 = conv(xin)
+    y2 = torch.nn.functional.conv2d(xin[:, :, 0], conv.weight[:, :, 2], conv.bias, padding=1)
+    outs["conv3d_ref"] = y3[:, :, 0].contiguous()
+    outs["conv2d_lasttap"] = y2
+    # RMS norm boundary probe
+    n = vae.decoder.norm_out
+    xn = torch.randn((1, 96, 1, 8, 8), generator=g).to(BF) * 3
+    outs["rmsnorm_in"] = xn[:, :, 0].contiguous()
+    outs["rmsnorm_out"] = n(xn)[:, :, 0].contiguous()
+    save("G7_vae", outs)
+
+
+def G8_lora():
+    layout = synth.dit_block_layout(0)
+    with torch.device("meta"):
+        dit = QwenImageDiT(num_layers=1)
+    sd = synth.make_state_dict(synth.dit_layout(1), 1234)
+    dit.load_state_dict(sd, assign=True, strict=True)
+    lora = synth.make_lora(4321, 1, 8)
+    GeneralLoRALoader(device="cpu", torch_dtype=BF).load(dit, lora, alpha=1.0)
+    merged = dit.state_dict()
+    outs = {}
+    for t in synth.LORA_TARGETS:
+        k = f"transformer_blocks.0.{t}.weight"
+        outs[k + ".head"] = merged[k][:64, :256].contiguous()
+        outs[k + ".sum"] = merged[k].double().sum().reshape(1)
+    k = "transformer_blocks.0.img_mlp.net.0.proj.weight"  # NOT a target: must be untouched
+    outs[k + ".sum"] = merged[k].double().sum().reshape(1)
+    save("G8_lora", outs, meta={"rank": 8, "seed_lora": 4321, "seed_weights": 1234})
+
+
+def G9_adapter():
+    ad, adsd, (t_min, t_max) = build_adapter(4321)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((1, 64, 3584), generator=g).to(BF)
+    outs = {"t_range": torch.tensor([t_min, t_max], dtype=torch.float64)}
+    for tv in (1000.0, 748.0, 300.0, 20.0):
+        mixed, d, v = ad(x, torch.tensor([tv]).to(BF))
+        outs[f"mixed_{int(tv)}"] = mixed
+        outs[f"alpha_{int(tv)}"] = ad._get_alpha(torch.tensor([tv]).to(BF), "cpu").float().reshape(1)
+    outs["dino"] = d
+    outs["vae"] = v
+    save("G9_adapter", outs)
+
+
+def G10_image():
+    ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
+    ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")
+    x = BasePipeline.preprocess_image(ns, ramp)
+    g = torch.Generator().manual_seed(10)
+    y = (torch.randn((1, 3, 16, 16), generator=g) * 0.8).to(BF)
+    img = BasePipeline.vae_output_to_image(ns, y)
+    save("G10_image", {"pre": x, "post_in": y, "post_u8": torch.from_numpy(np.array(img))})
+
+
+GROUPS = {k: v for k, v in list(globals().items()) if k[0] == "G" and k[1].isdigit()}
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or sorted(GROUPS, key=lambda s: int(s[1:].split("_")[0]))
+    for name in want:
+        fn = [v for k, v in GROUPS.items() if k.split("_")[0] == name.split("_")[0]][0]
+        print("==", fn.__name__)
+        fn()

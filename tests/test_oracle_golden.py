@@ -1,0 +1,211 @@
+"""Pin oracle/physicedit_oracle.py against outputs of the imported reference (tests/golden/*,
+written by tests/golden/make_golden.py).  CPU only.  Bit-exact unless a test states otherwise."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.physicedit_oracle as O
+from physicedit_amd import synth
+
+BF = torch.bfloat16
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def assert_same(a, b, what=""):
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert a.dtype == b.dtype, (what, a.dtype, b.dtype)
+    if not torch.equal(a, b):
+        d = (a.float() - b.float()).abs()
+        raise AssertionError(f"{what}: {int((d > 0).sum())}/{d.numel()} differ, max {d.max().item():.3e}")
+
+
+def test_layout_matches_reference():
+    with open(os.path.join(HERE, "golden", "layout_keys.json")) as f:
+        ref = json.load(f)
+    assert [[k, list(s)] for k, s in synth.dit_layout(1)] == ref["dit_1layer"]
+    assert [[k, list(s)] for k, s in synth.vae_layout()] == ref["vae"]
+    assert [[k, list(s)] for k, s in synth.adapter_layout()] == ref["adapter"]
+
+
+def test_G1_scheduler(golden):
+    g = golden("G1_scheduler")
+    assert_same(O.FlowMatchTables(100).timesteps, g["default_timesteps"], "default timesteps")
+    for steps, S0 in ((4, 1024), (4, 64), (40, 4096), (50, 6889)):
+        tab = O.FlowMatchTables(steps, dynamic_shift_len=S0)
+        assert_same(tab.sigmas, g[f"sigmas_{steps}_{S0}"], "sigmas")
+        assert_same(tab.timesteps, g[f"timesteps_{steps}_{S0}"], "timesteps")
+        assert_same(tab.timesteps.to(BF), g[f"timesteps_bf16_{steps}_{S0}"], "timesteps bf16")
+        gen = torch.Generator().manual_seed(11)
+        x = torch.randn((1, 16, 8, 8), generator=gen).to(BF)
+        v = torch.randn((1, 16, 8, 8), generator=gen).to(BF)
+        outs = torch.stack([tab.step(v, i, x) for i in range(steps)])
+        assert_same(outs, g[f"step_{steps}_{S0}"], "euler step")
+    tab = O.FlowMatchTables(40, dynamic_shift_len=4096)
+    assert abs(tab.mu - 0.693548) < 1e-6
+    assert abs(tab.timesteps[-1].item() - 20.0) < 1e-3
+
+
+def test_G2_time_embed(golden):
+    g = golden("G2_time_embed")
+    sd = synth.make_state_dict([kv for kv in synth.dit_layout(0) if kv[0].startswith("time_text_embed")], 1234)
+    ts = O.FlowMatchTables(40, dynamic_shift_len=4096).timesteps.to(BF)
+    sin = torch.cat([O.timestep_sinusoid(ts[i:i + 1] / 1000) for i in range(40)])
+    assert_same(sin, g["sinusoid_f32"], "sinusoid")
+    temb = torch.cat([O.time_text_embed(sd, ts[i:i + 1] / 1000, BF) for i in range(40)])
+    assert_same(temb, g["temb"], "temb")
+    # batched == per-row (the HIP path hoists all timesteps into one GEMM)
+    temb_b = O.time_text_embed(sd, ts / 1000, BF)
+    assert (temb_b.float() - temb.float()).abs().max() <= 2 ** -6
+
+
+def test_G3_norm_rope(golden):
+    g = golden("G3_norm_rope")
+    assert_same(O.rmsnorm(g["rms_in"], g["rms_w"]), g["rms_out"], "rmsnorm128")
+    vid, txt = O.rope_tables([(1, 8, 8), (1, 6, 10)], 37)
+    assert_same(vid.real.contiguous(), g["vid_re"], "vid re")
+    assert_same(vid.imag.contiguous(), g["vid_im"], "vid im")
+    assert_same(txt.real.contiguous(), g["txt_re"], "txt re")
+    assert_same(txt.imag.contiguous(), g["txt_im"], "txt im")
+    assert_same(O.apply_rope(g["rms_in"], txt), g["rope_out"], "rope apply")
+    vid2, txt2 = O.rope_tables([(1, 64, 64), (1, 64, 64)], 512)
+    assert_same(torch.view_as_real(vid2[[0, 63, 64, 4095, 4096, 8191]]).contiguous(), g["vid64_rows"], "vid64 rows")
+    assert_same(torch.view_as_real(txt2[[0, 1, 511]]).contiguous(), g["txt64_rows"], "txt64 rows")
+    s = torch.stack([vid2.real.double().sum(), vid2.imag.double().sum(),
+                     (vid2.real.double() * torch.arange(vid2.shape[0]).double()[:, None]).sum()])
+    assert torch.allclose(s, g["vid64_sum"], rtol=0, atol=1e-6)
+    w = synth.make_tensor(5, "txt_norm.weight", (3584,))
+    assert_same(O.rmsnorm(g["rms3584_in"], w), g["rms3584_out"], "rmsnorm3584")
+
+
+def _block_inputs(S_img, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn((1, S_img, 3072), generator=g).to(BF)
+    text = torch.randn((1, T, 3072), generator=g).to(BF)
+    temb = (torch.randn((1, 3072), generator=g) * 0.5).to(BF)
+    return image, text, temb
+
+
+def test_G4_block(golden):
+    g = golden("G4_block")
+    sd = synth.make_state_dict(synth.dit_block_layout(0), 1234)
+    image, text, temb = _block_inputs(128, 40, 44)
+    rope = O.rope_tables([(1, 8, 8), (1, 8, 8)], 40)
+    text_o, image_o = O.block_forward(sd, 0, image, text, temb, rope)
+    assert_same(text_o, g["text_out"], "block text")
+    assert_same(image_o, g["image_out"], "block image")
+    # the same graph in fp32 reproduces the reference's fp32 run (used as the parity yardstick)
+    sd32 = {k: v.float() for k, v in sd.items()}
+    t32, i32 = O.block_forward(sd32, 0, image.float(), text.float(), temb.float(), rope)
+    assert (t32 - g["text_out_f32"]).abs().max() < 1e-4
+    assert (i32 - g["image_out_f32"]).abs().max() < 1e-4
+
+
+def _model_fn_inputs(h, w, T, n_special, seed):
+    noise = synth.make_noise(seed, h, w)
+    g = torch.Generator().manual_seed(seed + 100)
+    edit = torch.randn((1, 16, h // 8, w // 8), generator=g).to(BF)
+    pe = synth.make_prompt_emb(seed + 7, T)
+    mask = synth.make_special_token_mask(T, n_special)
+    return noise, edit, pe, mask
+
+
+def test_G5_model_fn_inplace_quirk(golden):
+    g = golden("G5_model_fn")
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    t_min, t_max = O.adapter_t_range()
+    noise, edit, pe, mask = _model_fn_inputs(256, 256, 48, 16, 0)
+    pe_run = pe.clone()
+    for call, tval in enumerate((986.96, 749.27)):
+        t = torch.tensor([tval]).to(BF)
+        lat = O.model_fn(sd, ad, noise, t, pe_run, mask, 256, 256, edit, t_min, t_max)
+        assert_same(pe_run, g[f"prompt_emb_after_call{call}"], f"prompt_emb after call {call}")
+        assert_same(lat, g[f"latents_call{call}"], f"latents call {call}")
+    # non-special rows never change; special rows change on every call
+    m = mask[0]
+    assert torch.equal(pe_run[0, ~m], pe[0, ~m])
+    assert not torch.equal(g["prompt_emb_after_call0"][0, m], g["prompt_emb_after_call1"][0, m])
+    lat = O.model_fn(sd, None, noise, torch.tensor([500.0]).to(BF), pe.clone(), None, 256, 256, None)
+    assert_same(lat, g["latents_plain"], "plain model_fn")
+
+
+@pytest.mark.parametrize("cfg", [1.0, 4.0])
+def test_G6_loop(golden, cfg):
+    g = golden("G6_loop")
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    noise, edit, pe_p, mask_p = _model_fn_inputs(128, 128, 40, 16, 0)
+    pe_n = synth.make_prompt_emb(8, 24)
+    mask_n = synth.make_special_token_mask(24, 16)
+    lat = O.denoise_loop(sd, ad, noise, pe_p, pe_n, mask_p, mask_n, 128, 128, 4, cfg_scale=cfg, edit_latents=edit)
+    assert_same(lat, g[f"latents_cfg{cfg}_step3"], f"loop cfg {cfg}")
+
+
+def test_G7_vae(golden):
+    g = golden("G7_vae")
+    vs = synth.make_state_dict(synth.vae_layout(), 77)
+    # the restatement's premise: causal conv3d at T=1 == conv2d with the last temporal tap
+    d = (g["conv3d_ref"].float() - g["conv2d_lasttap"].float()).abs()
+    assert d.max() <= 2 ** -7 * g["conv3d_ref"].float().abs().max()
+    for R in (64, 96):
+        x = O.preprocess_image(synth.make_edit_image_u8(R, R, seed=R))
+        gen = torch.Generator().manual_seed(R)
+        lat = torch.randn((1, 16, R // 8, R // 8), generator=gen).to(BF)
+        O.VAE_CONV_MODE = "3d"      # literal causal conv3d: bit-exact with the reference
+        z, y = O.vae_encode(vs, x), O.vae_decode(vs, lat)
+        assert_same(z, g[f"enc_{R}"], f"vae enc {R}")
+        assert_same(y, g[f"dec_{R}"], f"vae dec {R}")
+        try:
+            O.VAE_CONV_MODE = "2d"  # last-tap 2-D conv: same math, other accumulation order
+            z2, y2 = O.vae_encode(vs, x), O.vae_decode(vs, lat)
+        finally:
+            O.VAE_CONV_MODE = "3d"
+        for got, ref, what in ((z2, z, "enc"), (y2, y, "dec")):
+            diff = (got.float() - ref.float()).abs()
+            tol = 2 ** -6 * ref.float().abs().clamp_min(1.0)   # <= 2 bf16 ulp of max(|ref|,1)
+            assert (diff <= tol).all(), (what, R, diff.max().item())
+    gen = torch.Generator().manual_seed(9)
+    _ = torch.randn((1, 96, 1, 24, 24), generator=gen)
+    xn = (torch.randn((1, 96, 1, 8, 8), generator=gen).to(BF) * 3)[:, :, 0]
+    assert_same(xn.contiguous(), g["rmsnorm_in"], "rmsnorm in")
+    assert_same(O._rms_norm_c(xn, vs["decoder.norm_out.gamma"]), g["rmsnorm_out"], "vae rmsnorm")
+
+
+def test_G8_lora(golden):
+    g, meta = golden("G8_lora", with_meta=True)
+    sd = synth.make_state_dict(synth.dit_layout(1), 1234)
+    lora = synth.make_lora(4321, 1, meta["rank"])
+    before = sd["transformer_blocks.0.img_mlp.net.0.proj.weight"].clone()
+    n = O.lora_merge(sd, lora, alpha=1.0)
+    assert n == 12
+    for t in synth.LORA_TARGETS:
+        k = f"transformer_blocks.0.{t}.weight"
+        assert_same(sd[k][:64, :256].contiguous(), g[k + ".head"], k)
+        assert sd[k].double().sum().item() == g[k + ".sum"].item()
+    assert torch.equal(sd["transformer_blocks.0.img_mlp.net.0.proj.weight"], before)
+
+
+def test_G9_adapter(golden):
+    g = golden("G9_adapter")
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    t_min, t_max = O.adapter_t_range()
+    assert g["t_range"][0].item() == t_min and g["t_range"][1].item() == t_max
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn((1, 64, 3584), generator=gen).to(BF)
+    for tv in (1000.0, 748.0, 300.0, 20.0):
+        t = torch.tensor([tv]).to(BF)
+        mixed, d, v = O.adapter_forward(ad, x, t, t_min, t_max)
+        assert_same(mixed, g[f"mixed_{int(tv)}"], f"mixed {tv}")
+        assert O.adapter_alpha(t, t_min, t_max).float().item() == g[f"alpha_{int(tv)}"].item()
+    assert_same(d, g["dino"], "dino head")
+    assert_same(v, g["vae"], "vae head")
+
+
+def test_G10_image(golden):
+    g = golden("G10_image")
+    ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
+    assert_same(O.preprocess_image(ramp), g["pre"], "preprocess")
+    assert_same(O.vae_output_to_u8(g["post_in"]), g["post_u8"], "postprocess")
