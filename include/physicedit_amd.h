@@ -1,0 +1,173 @@
+/* physicedit_amd -- C-ABI of the MI355X-native PhysicEdit denoising hot path.
+ *
+ * The reference (liangbingzhao/PhysicEdit) is pure Python: it has no FFI of its own.  Its operator
+ * boundary for this path is the Python call
+ *     model_fn_qwen_image(dit=, visual_thinking_adapter=, latents=, timestep=, prompt_emb=, ...)
+ *         DiffSynth-Studio/diffsynth/pipelines/qwen_image_physical.py:1302-1403
+ * driven by QwenImagePhysicPipeline.__call__ (:644-661) plus vae.encode / vae.decode
+ *         DiffSynth-Studio/diffsynth/models/qwen_image_vae.py:706,719.
+ * This header is what a ctypes binding of those call sites binds instead (INTEGRATION.md shows the
+ * stub).  Conventions:
+ *   - every data pointer is a DEVICE pointer into a caller-owned buffer (a torch tensor's
+ *     data_ptr()); the library borrows it for the call and never frees it;
+ *   - bf16 tensors are contiguous unless a row stride is given; shapes are explicit ints;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream) passed as void*;
+ *   - every entry point returns 0 on success, <0 on failure (pe_last_error() has the message);
+ *     nothing throws across the boundary; no entry point synchronises the device;
+ *   - scratch memory is a caller-provided workspace (size from pe_dit_workspace_bytes).
+ */
+#ifndef PHYSICEDIT_AMD_H
+#define PHYSICEDIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PE_OK 0
+#define PE_ERR_INVALID_ARG (-1)
+#define PE_ERR_UNSUPPORTED (-2)
+#define PE_ERR_HIP (-3)
+
+/* Last error message of the calling thread ("" if none). */
+const char* pe_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int pe_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Granular operators (each is one kernel launch; used by the parity tests and by the composites)
+ * ------------------------------------------------------------------------------------------- */
+
+/* epilogue selector for pe_gemm_bf16 */
+enum {
+    PE_EPI_BIAS = 0,      /* torch.nn.functional.linear                                              */
+    PE_EPI_GELU_SIG = 1,  /* ApproximateGELU  qwen_image_dit.py:42-49   y*sigmoid(1.702 y)            */
+    PE_EPI_GELU_ERF = 2,  /* nn.GELU()        pipelines/helpers.py:127-131                            */
+    PE_EPI_GATE_RES = 3,  /* res + gate*y     qwen_image_dit.py:386-387,398-399 ; lora/__init__.py:41 */
+    PE_EPI_SILU = 5       /* Linear + SiLU    models/utils.py:267-269                                 */
+};
+
+/* out[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias[N]); bf16, fp32 accumulate.
+ * gate[N] (nullable => 1) and res[M,N] (row stride ldr, may alias out) only for PE_EPI_GATE_RES.
+ * Requires K % 64 == 0, N % 8 == 0, lda/ldo/ldr % 8 == 0. */
+int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
+                 int M, int N, int K, const void* gate, const void* res, int ldr, void* stream);
+
+/* Fused QKV projection of one stream (QwenDoubleStreamAttention.forward, qwen_image_dit.py:282-302):
+ * x[M,K] @ Wqkv[3*H*128,K]^T + b, per-head RMSNorm(q,k) (weights norm_q_w/norm_k_w [128]), RoPE(q,k)
+ * with fp32 tables rope_cos/rope_sin [M,64]; writes head-major Q,K [H][S_pad][128] at rows
+ * seq_off..seq_off+M and the transposed/permuted Vt [H][128][S_pad] consumed by pe_flash_attn. */
+int pe_qkv_rmsnorm_rope(const void* x, int ldx, const void* Wqkv, const void* bqkv, int M, int H, int K,
+                        const void* norm_q_w, const void* norm_k_w, const float* rope_cos,
+                        const float* rope_sin, void* q_out, void* k_out, void* vt_out, int seq_off, int S_pad,
+                        void* stream);
+
+/* softmax(Q K^T * scale) V over the joint sequence, no mask (qwen_image_flash_attention, :14-39).
+ * Q,K [H][S_pad][128], Vt [H][128][S_pad] as written by pe_qkv_rmsnorm_rope; out [S][ldo] "s (h d)". */
+int pe_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo,
+                  float scale, void* stream);
+
+/* LayerNorm(no affine, eps) * (1 + scale) + shift on rows of width 3072; rows [0,rows_a) use
+ * (shift_a, scale_a), the remaining rows (shift_b, scale_b)  (qwen_image_dit.py:355-357,372-376). */
+int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
+                   const void* scale_a, const void* shift_b, const void* scale_b, float eps, void* stream);
+
+/* RMSNorm with weight over rows of width 3584 (txt_norm; models/utils.py:250-257). */
+int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, void* stream);
+
+/* "C (H 2) (W 2) -> (H W) (C 2 2)" and back (qwen_image_physical.py:1344,1402); latents [C,H2,W2]. */
+int pe_patchify(const void* latents, void* tokens, int C, int H2, int W2, void* stream);
+int pe_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, void* stream);
+
+/* latents_out = latents + (nega + cfg*(posi-nega)) * dsigma   (qwen_image_physical.py:656 +
+ * schedulers/flow_match.py:81); use_cfg = 0 => noise_pred = posi (cfg_scale == 1.0 branch, :654). */
+int pe_cfg_euler_step(const void* posi, const void* nega, const void* latents, void* latents_out, size_t n,
+                      float cfg_scale, int use_cfg, float dsigma, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DiT composite
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pe_dit_block_weights {
+    /* image stream */
+    const void *img_mod_w, *img_mod_b;           /* img_mod.1            [18432,3072],[18432] */
+    const void *img_qkv_w, *img_qkv_b;           /* to_q|to_k|to_v       [9216,3072],[9216]   */
+    const void *norm_q_w, *norm_k_w;             /* attn.norm_q/norm_k   [128]                */
+    const void *img_out_w, *img_out_b;           /* attn.to_out.0        [3072,3072],[3072]   */
+    const void *img_mlp_up_w, *img_mlp_up_b;     /* img_mlp.net.0.proj   [12288,3072]         */
+    const void *img_mlp_down_w, *img_mlp_down_b; /* img_mlp.net.2        [3072,12288]         */
+    /* text stream */
+    const void *txt_mod_w, *txt_mod_b;           /* txt_mod.1 */
+    const void *txt_qkv_w, *txt_qkv_b;           /* add_q_proj|add_k_proj|add_v_proj */
+    const void *norm_added_q_w, *norm_added_k_w;
+    const void *txt_out_w, *txt_out_b;           /* attn.to_add_out */
+    const void *txt_mlp_up_w, *txt_mlp_up_b;
+    const void *txt_mlp_down_w, *txt_mlp_down_b;
+} pe_dit_block_weights;
+
+typedef struct pe_dit_weights {
+    int num_layers;
+    const void *time_w1, *time_b1;     /* time_text_embed.timestep_embedder.linear_1 [3072,256] */
+    const void *time_w2, *time_b2;     /* ...linear_2 [3072,3072] */
+    const void* txt_norm_w;            /* [3584] */
+    const void *img_in_w, *img_in_b;   /* [3072,64] */
+    const void *txt_in_w, *txt_in_b;   /* [3072,3584] */
+    const void *norm_out_w, *norm_out_b; /* norm_out.linear [6144,3072] */
+    const void *proj_out_w, *proj_out_b; /* [64,3072] */
+    const pe_dit_block_weights* blocks;  /* host array [num_layers]; copied by pe_dit_create */
+} pe_dit_weights;
+
+typedef struct pe_adapter_weights {    /* VisualThinkingDualAdapter, pipelines/helpers.py:123-140 */
+    const void *dino_w0, *dino_b0, *dino_w2, *dino_b2; /* [10752,3584],[10752],[3584,10752],[3584] */
+    const void *vae_w0, *vae_b0, *vae_w2, *vae_b2;
+} pe_adapter_weights;
+
+/* geometry + per-call inputs of one model_fn_qwen_image call */
+typedef struct pe_dit_call {
+    const void* latents;        /* [16,h8,w8] bf16 (B = 1) */
+    int h8, w8;
+    int n_edit;                 /* 0..4 edit/context latents */
+    const void* edit_latents[4];
+    int edit_h8[4], edit_w8[4];
+    void* prompt_emb;           /* [T,3584] bf16, special rows MUTATED IN PLACE (:1336) */
+    int T;
+    const int* special_idx;     /* device int32[n_special]: rows of prompt_emb under special_token_mask */
+    int n_special;              /* 0 => no adapter (QwenImagePipeline behaviour) */
+    float alpha, one_minus_alpha; /* adapter mix weights as bf16-rounded floats (helpers.py:142-150,158) */
+    const float *rope_cos_img, *rope_sin_img; /* [S_img,64] fp32, QwenEmbedRope vid_freqs */
+    const float *rope_cos_txt, *rope_sin_txt; /* [T,64]     fp32, QwenEmbedRope txt_freqs */
+    int step;                   /* row of the tables built by pe_dit_prepare */
+    void* noise_pred;           /* out: [16,h8,w8] bf16 */
+} pe_dit_call;
+
+typedef struct pe_dit* pe_dit_handle;
+
+int pe_dit_create(const pe_dit_weights* w, const pe_adapter_weights* adapter /* nullable */, pe_dit_handle* out);
+void pe_dit_destroy(pe_dit_handle h);
+
+/* Bytes of workspace needed for sequences up to (S_img_max image tokens, T_max text tokens) and
+ * n_steps prepared timesteps. */
+size_t pe_dit_workspace_bytes(pe_dit_handle h, int S_img_max, int T_max, int n_steps);
+
+/* Bind a workspace (zero-fills the regions that must start finite).  Must precede prepare/forward. */
+int pe_dit_bind_workspace(pe_dit_handle h, void* workspace, size_t bytes, int S_img_max, int T_max, int n_steps,
+                          void* stream);
+
+/* Hoisted timestep work, once per image: sinusoid [n_steps,256] bf16 (TemporalTimesteps output cast
+ * to bf16, models/utils.py:291) -> time MLP -> temb[n_steps,3072]; then for every block and both
+ * streams mod = Linear(SiLU(temb)) (qwen_image_dit.py:369-370) and norm_out.linear(SiLU(temb))
+ * (models/utils.py:305).  The same rows serve the posi and the nega forward of a step. */
+int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void* stream);
+
+/* One model_fn_qwen_image call (is_train=False): adapter on the special tokens (in place),
+ * patchify, embeds, all blocks, AdaLN head, unpatchify. */
+int pe_dit_forward(pe_dit_handle h, const pe_dit_call* call, void* stream);
+
+/* Debug/test taps: device pointers into the bound workspace (valid after pe_dit_forward). */
+const void* pe_dit_debug_ptr(pe_dit_handle h, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHYSICEDIT_AMD_H */

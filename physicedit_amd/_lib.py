@@ -1,0 +1,105 @@
+"""ctypes binding of libphysicedit_amd.so (include/physicedit_amd.h).
+
+There is NO fallback: if the library is not built, `lib()` raises.  Nothing here imports the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libphysicedit_amd.so")
+
+c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class PeError(RuntimeError):
+    pass
+
+
+class DitBlockWeights(C.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "img_mod_w", "img_mod_b", "img_qkv_w", "img_qkv_b", "norm_q_w", "norm_k_w",
+        "img_out_w", "img_out_b", "img_mlp_up_w", "img_mlp_up_b", "img_mlp_down_w", "img_mlp_down_b",
+        "txt_mod_w", "txt_mod_b", "txt_qkv_w", "txt_qkv_b", "norm_added_q_w", "norm_added_k_w",
+        "txt_out_w", "txt_out_b", "txt_mlp_up_w", "txt_mlp_up_b", "txt_mlp_down_w", "txt_mlp_down_b")]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [("num_layers", c_int)] + [(n, c_void_p) for n in (
+        "time_w1", "time_b1", "time_w2", "time_b2", "txt_norm_w", "img_in_w", "img_in_b",
+        "txt_in_w", "txt_in_b", "norm_out_w", "norm_out_b", "proj_out_w", "proj_out_b")] + [
+        ("blocks", C.POINTER(DitBlockWeights))]
+
+
+class AdapterWeights(C.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "dino_w0", "dino_b0", "dino_w2", "dino_b2", "vae_w0", "vae_b0", "vae_w2", "vae_b2")]
+
+
+class DitCall(C.Structure):
+    _fields_ = [
+        ("latents", c_void_p), ("h8", c_int), ("w8", c_int),
+        ("n_edit", c_int), ("edit_latents", c_void_p * 4), ("edit_h8", c_int * 4), ("edit_w8", c_int * 4),
+        ("prompt_emb", c_void_p), ("T", c_int),
+        ("special_idx", c_void_p), ("n_special", c_int),
+        ("alpha", c_float), ("one_minus_alpha", c_float),
+        ("rope_cos_img", c_void_p), ("rope_sin_img", c_void_p),
+        ("rope_cos_txt", c_void_p), ("rope_sin_txt", c_void_p),
+        ("step", c_int), ("noise_pred", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/physicedit_amd.h declares
+SIGNATURES = {
+    "pe_last_error": (C.c_char_p, []),
+    "pe_abi_version": (c_int, []),
+    "pe_gemm_bf16": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                             c_void_p, c_void_p, c_int, c_void_p]),
+    "pe_qkv_rmsnorm_rope": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pe_flash_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "pe_ln_modulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_float, c_void_p]),
+    "pe_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "pe_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pe_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pe_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_void_p]),
+    "pe_dit_create": (c_int, [C.POINTER(DitWeights), C.POINTER(AdapterWeights), C.POINTER(c_void_p)]),
+    "pe_dit_destroy": (None, [c_void_p]),
+    "pe_dit_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "pe_dit_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "pe_dit_prepare": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "pe_dit_forward": (c_int, [c_void_p, C.POINTER(DitCall), c_void_p]),
+    "pe_dit_debug_ptr": (c_void_p, [c_void_p, C.c_char_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PeError(
+                f"{LIB_PATH} is missing: build it with `python -m physicedit_amd.build` "
+                "(hipcc --offload-arch=gfx950).  physicedit_amd has no CPU/PyTorch fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().pe_last_error().decode("utf-8", "replace")
+        raise PeError(f"{what or 'physicedit_amd'} failed (rc={rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

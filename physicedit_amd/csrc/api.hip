@@ -1,0 +1,88 @@
+// C-ABI entry points for the granular operators + error plumbing (include/physicedit_amd.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/physicedit_amd.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace pe {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PE_ERR_HIP, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return PE_OK;
+}
+
+}  // namespace pe
+
+using namespace pe;
+
+extern "C" {
+
+const char* pe_last_error(void) { return g_err; }
+int pe_abi_version(void) { return 1; }
+
+int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
+                 int M, int N, int K, const void* gate, const void* res, int ldr, void* stream) {
+    PE_REQUIRE(epilogue != EPI_QKV, "pe_gemm_bf16: use pe_qkv_rmsnorm_rope for the QKV epilogue");
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.W = W; p.bias = bias; p.out = out;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldo = ldo;
+    p.gate = gate; p.res = res; p.ldr = ldr;
+    return launch_gemm(epilogue, &p, 1, (hipStream_t)stream);
+}
+
+int pe_qkv_rmsnorm_rope(const void* x, int ldx, const void* Wqkv, const void* bqkv, int M, int H, int K,
+                        const void* norm_q_w, const void* norm_k_w, const float* rope_cos,
+                        const float* rope_sin, void* q_out, void* k_out, void* vt_out, int seq_off, int S_pad,
+                        void* stream) {
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.W = Wqkv; p.bias = bqkv;
+    p.M = M; p.N = 3 * H * 128; p.K = K; p.lda = ldx;
+    p.norm_q_w = norm_q_w; p.norm_k_w = norm_k_w; p.rope_cos = rope_cos; p.rope_sin = rope_sin;
+    p.q_out = q_out; p.k_out = k_out; p.vt_out = vt_out; p.seq_off = seq_off; p.S_pad = S_pad;
+    return launch_gemm(EPI_QKV, &p, 1, (hipStream_t)stream);
+}
+
+int pe_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo,
+                  float scale, void* stream) {
+    return launch_flash_attn(q, k, vt, out, H, S, S_pad, ldo, scale, (hipStream_t)stream);
+}
+
+int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
+                   const void* scale_a, const void* shift_b, const void* scale_b, float eps, void* stream) {
+    return launch_ln_modulate(x, out, rows, dim, rows_a, shift_a, scale_a, shift_b, scale_b, eps, (hipStream_t)stream);
+}
+
+int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, void* stream) {
+    return launch_rmsnorm(x, w, out, rows, dim, eps, (hipStream_t)stream);
+}
+
+int pe_patchify(const void* latents, void* tokens, int C, int H2, int W2, void* stream) {
+    return launch_patchify(latents, tokens, C, H2, W2, (hipStream_t)stream);
+}
+
+int pe_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, void* stream) {
+    return launch_unpatchify(tokens, latents, C, H2, W2, (hipStream_t)stream);
+}
+
+int pe_cfg_euler_step(const void* posi, const void* nega, const void* latents, void* latents_out, size_t n,
+                      float cfg_scale, int use_cfg, float dsigma, void* stream) {
+    return launch_cfg_euler(posi, nega, latents, latents_out, n, cfg_scale, use_cfg, dsigma, (hipStream_t)stream);
+}
+
+}  // extern "C"

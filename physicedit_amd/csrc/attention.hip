@@ -1,0 +1,217 @@
+// Joint (image + text) flash attention for gfx950, head dim 128, no mask, bf16 in / fp32 softmax.
+//
+// Replaces qwen_image_flash_attention (DiffSynth-Studio/diffsynth/models/qwen_image_dit.py:14-39;
+// CPU oracle = the SDPA branch :37) for q,k,v [1,24,S,128] -> [1,S,3072].  Numerics follow SDPA:
+// scores, softmax statistics and the P.V accumulation in fp32, P rounded to bf16 for the second
+// matmul, one rounding of the normalised output to bf16.
+//
+// Data layout (private contract with the QKV GEMM epilogue in gemm.hip):
+//   Q, K : [H][S_pad][128] bf16 (RMSNorm + RoPE already applied)
+//   Vt   : [H][128][S_pad] bf16, V transposed, and inside every aligned group of 16 tokens the
+//          token with in-group index j sits at position perm16(j) = swap(bit2, bit3): stored order
+//          [0-3, 8-11, 4-7, 12-15].  Pad columns (>= S) are zero.
+//   out  : [S][ldo] bf16, head h in columns h*128..h*128+127  ("b s (n d)")
+//
+// Structure: one work-group = 8 waves x 32 query rows = 256 rows of one head; K and Vt tiles of 64
+// keys go HBM -> LDS by LDS-DMA, double buffered, one barrier per tile.  Both matmuls are computed
+// TRANSPOSED so that all softmax state is lane-local:
+//   S^T[key][q] = K . Q^T   : MFMA A = K fragment (from LDS), B = Q fragment (registers, loaded once)
+//       -> lane (q = lane&31) holds 16 of the 32 keys of a 32-key sub-tile, its partner lane^32 the rest
+//   O^T[d][q]  += Vt . P^T  : MFMA A = Vt fragment (from LDS), B = P fragment
+//       -> the B fragment of k-step (t,kk') wants, in lane half h, keys {16kk'+4h+r} U {16kk'+8+4h+r};
+//          those are exactly accumulator quads 2kk', 2kk'+1 of S^T that the lane already holds, and
+//          thanks to the perm16 storage order they are ONE contiguous 16-B chunk of a Vt row.
+//          No permlane / LDS round trip for P.
+// LDS tiles are XOR-swizzled at 16-B granularity (applied on the LDS-DMA source address and on the
+// read) so every ds_read_b128 lane group is bank-conflict free.
+#include "common.h"
+#include "kernels.h"
+
+namespace pe {
+
+constexpr int ATT_THREADS = 512;
+constexpr int KV_TILE = 64;
+constexpr int ATT_STAGE = 2 * KV_TILE * 128 * 2;  // K tile 16 KiB + Vt tile 16 KiB
+constexpr int ATT_LDS = 2 * ATT_STAGE;            // 64 KiB
+constexpr int Q_BLOCK = 256;
+
+__global__ void __launch_bounds__(ATT_THREADS, 2)
+flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
+                  bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, int nqb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // block -> (head, q-block): consecutive remapped ids walk the q-blocks of one head, so the
+    // work-groups resident on one XCD share that head's K/V in its L2.
+    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int head = bid / nqb;
+    const int qb = bid - head * nqb;
+    const int q0 = qb * Q_BLOCK + w * 32;
+
+    const bf16* Qh = Q + (size_t)head * S_pad * 128;
+    const bf16* Kh = K + (size_t)head * S_pad * 128;
+    const bf16* Vh = Vt + (size_t)head * 128 * S_pad;
+
+    // Q fragments (MFMA B operand): lane supplies Q[q0 + l31][kk*16 + h*8 .. +8)
+    bf16x8 qf[8];
+    {
+        const int qrow = min(q0 + l31, S - 1);
+        const bf16* qp = Qh + (size_t)qrow * 128 + h * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
+    }
+
+    // staging: wave w moves K pieces {2w, 2w+1} (4 rows x 256 B each) and Vt pieces {2w, 2w+1}
+    // (8 rows x 128 B each)
+    const bf16* k_src[2];
+    const bf16* v_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = w * 2 + i;
+        const int krow = piece * 4 + (lane >> 4);
+        const int kchunk = (lane & 15) ^ (krow & 15);
+        k_src[i] = Kh + (size_t)krow * 128 + kchunk * 8;
+        const int vrow = piece * 8 + (lane >> 3);
+        const int vchunk = (lane & 7) ^ ((vrow >> 1) & 7);
+        v_src[i] = Vh + (size_t)vrow * S_pad + vchunk * 8;
+    }
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * ATT_STAGE + w * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16(k_src[i] + (size_t)t * KV_TILE * 128, base + i * 1024);
+            glds16(v_src[i] + t * KV_TILE, base + KV_TILE * 256 + i * 1024);
+        }
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY;  // running max, in the scaled log2 domain
+    float l_run = 0.f;        // this lane's partial row sum (its 32 of every 64 keys)
+
+    const int k_off = l31 * 256;                    // K row l31 (+32 rows for the second sub-tile)
+    const int ksw = l31 & 15;
+    const int v_off = KV_TILE * 256 + l31 * 128;    // Vt row d = l31 (+32 rows per dt)
+    const int vsw = (l31 >> 1) & 7;
+
+    const int nt = (S + KV_TILE - 1) / KV_TILE;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        const char* Sb = smem + (t & 1) * ATT_STAGE;
+
+        // ---- S^T = K . Q^T  (two 32-key sub-tiles)
+        f32x16 st[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[s2][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(Sb + k_off + s2 * 32 * 256 + (((kk * 2 + h) ^ ksw) << 4));
+                st[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[s2], 0, 0, 0);
+            }
+        }
+        // st[s2][4a+r] = score(q = q0+l31, key = t*64 + s2*32 + 8a + 4h + r)
+        if (t == nt - 1 && (S & (KV_TILE - 1)) != 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (key >= S) st[s2][r] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax, lane-local except one exchange with the partner lane
+        float mx = st[0][0];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[s2][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * scale_log2);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[s2][r] * scale_log2 - m_new);
+                st[s2][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // ---- O^T += Vt . P^T
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pf[e] = (bf16)st[s2][(2 * k2) * 4 + e];
+                    pf[4 + e] = (bf16)st[s2][(2 * k2 + 1) * 4 + e];
+                }
+                const int vchunk = s2 * 4 + k2 * 2 + h;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 vf = *(const bf16x8*)(Sb + v_off + dt * 32 * 128 + ((vchunk ^ vsw) << 4));
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- normalise and store: o[dt][4a+r] = O[q0+l31][dt*32 + 8a + 4h + r]
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < S) {
+        bf16* op = out + (size_t)q * ldo + head * 128 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[dt][4 * a + r] * inv);
+                *(bf16x4*)(op + dt * 32 + 8 * a) = v;
+            }
+    }
+}
+
+int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
+                      int ldo, float scale, hipStream_t stream) {
+    PE_REQUIRE(q && k && vt && out, "flash_attn: null pointer");
+    PE_REQUIRE(H > 0 && S > 0, "flash_attn: empty problem (H=%d S=%d)", H, S);
+    PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
+               S_pad, KV_TILE, S);
+    PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    const int nqb = (S + Q_BLOCK - 1) / Q_BLOCK;
+    const float scale_log2 = scale * 1.44269504088896340736f;
+    hipLaunchKernelGGL(flash_attn_kernel, dim3(H * nqb), dim3(ATT_THREADS), ATT_LDS, stream, (const bf16*)q,
+                       (const bf16*)k, (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, nqb);
+    return check_launch("flash_attn_kernel");
+}
+
+}  // namespace pe

@@ -1,0 +1,348 @@
+// DiT composite: one model_fn_qwen_image call as a fixed sequence of kernel launches on one stream.
+// Mirrors DiffSynth-Studio/diffsynth/pipelines/qwen_image_physical.py:1302-1403 and
+// models/qwen_image_dit.py:359-401 (block).  Host code only: every FLOP is in gemm.hip /
+// attention.hip / elementwise.hip.
+//
+// Joint sequence order inside the library is [image tokens | text tokens] (the reference
+// concatenates [text | image], qwen_image_dit.py:304-306).  Attention is invariant under a
+// permutation of the keys and the per-row outputs are routed back to their own stream, so only the
+// fp32 summation order differs; image-first keeps the big image stream 16-token aligned for the
+// transposed-V layout whatever the prompt length.
+#include <new>
+#include <string.h>
+#include <string>
+
+#include "../../include/physicedit_amd.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace pe;
+
+namespace {
+constexpr int D = 3072, FF = 12288, HEADS = 24, TXT = 3584, PATCH = 64, AD_HID = 10752, MOD = 6 * D;
+constexpr int MAX_SPECIAL = 256;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+}  // namespace
+
+struct pe_dit {
+    pe_dit_weights w;
+    pe_dit_block_weights* blocks = nullptr;
+    bool has_adapter = false;
+    pe_adapter_weights ad;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int S_img_max = 0, T_max = 0, n_steps_max = 0, S_pad_max = 0;
+    int n_steps = 0;
+    // carved regions (bf16 unless noted)
+    char *temb, *silu_temb, *t_hidden, *mod_tab, *final_tab;
+    char *x, *xmod, *q, *k, *vt, *attn, *hbuf, *patches, *pe_norm, *proj;
+    char *sp_in, *sp_hid, *sp_dino, *sp_vae;
+};
+
+static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
+    const int L = h->w.num_layers;
+    const size_t S = (size_t)S_img + T;
+    const size_t S_pad = align_up(S, 64);
+    size_t off = 0;
+    auto take = [&](char** p, size_t bytes) {
+        if (p) *p = base ? base + off : nullptr;
+        off += align_up(bytes, 256);
+    };
+    take(&h->temb, (size_t)n_steps * D * 2);
+    take(&h->silu_temb, (size_t)n_steps * D * 2);
+    take(&h->t_hidden, (size_t)n_steps * D * 2);
+    take(&h->mod_tab, (size_t)n_steps * L * 2 * MOD * 2);
+    take(&h->final_tab, (size_t)n_steps * 2 * D * 2);
+    take(&h->x, S * D * 2);
+    take(&h->xmod, S * D * 2);
+    take(&h->q, (size_t)HEADS * S_pad * 128 * 2);
+    take(&h->k, (size_t)HEADS * S_pad * 128 * 2);
+    take(&h->vt, (size_t)HEADS * 128 * S_pad * 2);
+    take(&h->attn, S * D * 2);
+    take(&h->hbuf, S * FF * 2);
+    take(&h->patches, (size_t)S_img * PATCH * 2);
+    take(&h->pe_norm, (size_t)T * TXT * 2);
+    take(&h->proj, (size_t)S_img * PATCH * 2);
+    take(&h->sp_in, (size_t)MAX_SPECIAL * TXT * 2);
+    take(&h->sp_hid, (size_t)MAX_SPECIAL * AD_HID * 2);
+    take(&h->sp_dino, (size_t)MAX_SPECIAL * TXT * 2);
+    take(&h->sp_vae, (size_t)MAX_SPECIAL * TXT * 2);
+    return off;
+}
+
+extern "C" {
+
+int pe_dit_create(const pe_dit_weights* w, const pe_adapter_weights* adapter, pe_dit_handle* out) {
+    PE_REQUIRE(w && out, "pe_dit_create: null argument");
+    PE_REQUIRE(w->num_layers >= 0 && w->num_layers <= 1024, "pe_dit_create: num_layers=%d", w->num_layers);
+    PE_REQUIRE(w->num_layers == 0 || w->blocks, "pe_dit_create: blocks is null");
+    pe_dit* h = new (std::nothrow) pe_dit();
+    PE_REQUIRE(h, "pe_dit_create: out of host memory");
+    h->w = *w;
+    h->blocks = new (std::nothrow) pe_dit_block_weights[w->num_layers > 0 ? w->num_layers : 1];
+    if (!h->blocks) { delete h; return set_error(PE_ERR_INVALID_ARG, "pe_dit_create: out of host memory"); }
+    for (int i = 0; i < w->num_layers; ++i) h->blocks[i] = w->blocks[i];
+    h->w.blocks = h->blocks;
+    if (adapter) { h->ad = *adapter; h->has_adapter = true; }
+    *out = h;
+    return PE_OK;
+}
+
+void pe_dit_destroy(pe_dit_handle h) {
+    if (!h) return;
+    delete[] h->blocks;
+    delete h;
+}
+
+size_t pe_dit_workspace_bytes(pe_dit_handle h, int S_img_max, int T_max, int n_steps) {
+    if (!h || S_img_max <= 0 || T_max <= 0 || n_steps <= 0) return 0;
+    pe_dit tmp = *h;
+    return carve(&tmp, S_img_max, T_max, n_steps, nullptr);
+}
+
+int pe_dit_bind_workspace(pe_dit_handle h, void* workspace, size_t bytes, int S_img_max, int T_max, int n_steps,
+                          void* stream) {
+    PE_REQUIRE(h && workspace, "pe_dit_bind_workspace: null argument");
+    PE_REQUIRE(S_img_max > 0 && T_max > 0 && n_steps > 0, "pe_dit_bind_workspace: bad sizes");
+    PE_REQUIRE(((uintptr_t)workspace & 255) == 0, "pe_dit_bind_workspace: workspace must be 256-B aligned");
+    const size_t need = carve(h, S_img_max, T_max, n_steps, (char*)workspace);
+    if (need > bytes) {
+        h->ws = nullptr;
+        return set_error(PE_ERR_INVALID_ARG, "pe_dit_bind_workspace: need %zu bytes, got %zu", need, bytes);
+    }
+    h->ws = (char*)workspace;
+    h->ws_bytes = bytes;
+    h->S_img_max = S_img_max;
+    h->T_max = T_max;
+    h->n_steps_max = n_steps;
+    h->S_pad_max = (int)align_up((size_t)S_img_max + T_max, 64);
+    h->n_steps = 0;
+    // Vt pad columns are never written but are multiplied by P = 0: they must be finite.
+    // Q/K pad rows only feed masked scores.  Zero all three once.
+    hipError_t e = hipMemsetAsync(h->q, 0, (size_t)(h->attn - h->q), (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
+    return PE_OK;
+}
+
+int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void* stream_) {
+    PE_REQUIRE(h && h->ws, "pe_dit_prepare: no workspace bound");
+    PE_REQUIRE(sinusoid_bf16 && n_steps > 0 && n_steps <= h->n_steps_max, "pe_dit_prepare: n_steps=%d (max %d)",
+               n_steps, h->n_steps_max);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int L = h->w.num_layers;
+    int rc;
+    GemmProblem p;
+    // time MLP: linear_1 + SiLU, linear_2   (models/utils.py:260-271)
+    memset(&p, 0, sizeof(p));
+    p.A = sinusoid_bf16; p.lda = 256; p.W = h->w.time_w1; p.bias = h->w.time_b1;
+    p.out = h->t_hidden; p.ldo = D; p.M = n_steps; p.N = D; p.K = 256;
+    if ((rc = launch_gemm(EPI_SILU, &p, 1, stream))) return rc;
+    memset(&p, 0, sizeof(p));
+    p.A = h->t_hidden; p.lda = D; p.W = h->w.time_w2; p.bias = h->w.time_b2;
+    p.out = h->temb; p.ldo = D; p.M = n_steps; p.N = D; p.K = D;
+    if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+    if ((rc = launch_silu(h->temb, h->silu_temb, (size_t)n_steps * D, stream))) return rc;
+    // modulation rows for every block / stream: [step][layer][stream][18432]
+    const int ld = L * 2 * MOD;
+    for (int l = 0; l < L; ++l) {
+        GemmProblem pp[2];
+        memset(pp, 0, sizeof(pp));
+        for (int s = 0; s < 2; ++s) {
+            pp[s].A = h->silu_temb; pp[s].lda = D;
+            pp[s].W = s == 0 ? h->blocks[l].img_mod_w : h->blocks[l].txt_mod_w;
+            pp[s].bias = s == 0 ? h->blocks[l].img_mod_b : h->blocks[l].txt_mod_b;
+            pp[s].out = h->mod_tab + ((size_t)l * 2 + s) * MOD * 2; pp[s].ldo = ld;
+            pp[s].M = n_steps; pp[s].N = MOD; pp[s].K = D;
+        }
+        if ((rc = launch_gemm(EPI_BIAS, pp, 2, stream))) return rc;
+    }
+    memset(&p, 0, sizeof(p));
+    p.A = h->silu_temb; p.lda = D; p.W = h->w.norm_out_w; p.bias = h->w.norm_out_b;
+    p.out = h->final_tab; p.ldo = 2 * D; p.M = n_steps; p.N = 2 * D; p.K = D;
+    if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+    h->n_steps = n_steps;
+    return PE_OK;
+}
+
+int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
+    PE_REQUIRE(h && c, "pe_dit_forward: null argument");
+    PE_REQUIRE(h->ws, "pe_dit_forward: no workspace bound");
+    PE_REQUIRE(c->step >= 0 && c->step < h->n_steps, "pe_dit_forward: step %d not prepared (n_steps=%d)", c->step,
+               h->n_steps);
+    PE_REQUIRE(c->latents && c->prompt_emb && c->noise_pred, "pe_dit_forward: null tensor");
+    PE_REQUIRE(c->h8 > 0 && c->w8 > 0 && c->h8 % 2 == 0 && c->w8 % 2 == 0, "pe_dit_forward: latent %dx%d", c->h8, c->w8);
+    PE_REQUIRE(c->n_edit >= 0 && c->n_edit <= 4, "pe_dit_forward: n_edit=%d", c->n_edit);
+    PE_REQUIRE(c->T > 0 && c->T <= h->T_max, "pe_dit_forward: T=%d (max %d)", c->T, h->T_max);
+    PE_REQUIRE(c->rope_cos_img && c->rope_sin_img && c->rope_cos_txt && c->rope_sin_txt, "pe_dit_forward: null rope table");
+    PE_REQUIRE(c->n_special >= 0 && c->n_special <= MAX_SPECIAL, "pe_dit_forward: n_special=%d", c->n_special);
+    PE_REQUIRE(c->n_special == 0 || (h->has_adapter && c->special_idx), "pe_dit_forward: special tokens without adapter");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int L = h->w.num_layers;
+    const int S0 = (c->h8 / 2) * (c->w8 / 2);
+    int S_img = S0;
+    for (int i = 0; i < c->n_edit; ++i) {
+        PE_REQUIRE(c->edit_latents[i] && c->edit_h8[i] % 2 == 0 && c->edit_w8[i] % 2 == 0, "pe_dit_forward: edit latent %d", i);
+        S_img += (c->edit_h8[i] / 2) * (c->edit_w8[i] / 2);
+    }
+    PE_REQUIRE(S_img <= h->S_img_max, "pe_dit_forward: S_img=%d (max %d)", S_img, h->S_img_max);
+    const int T = c->T;
+    const int S = S_img + T;
+    const int S_pad = (int)align_up((size_t)S, 64);
+    int rc;
+    GemmProblem p, pp[2];
+
+    // ---- 1. adapter on the special tokens, scattered back IN PLACE  (:1333-1336)
+    if (c->n_special > 0) {
+        const int ns = c->n_special;
+        if ((rc = launch_gather_rows(c->prompt_emb, c->special_idx, h->sp_in, ns, TXT, stream))) return rc;
+        for (int head = 0; head < 2; ++head) {
+            const void* w0 = head == 0 ? h->ad.dino_w0 : h->ad.vae_w0;
+            const void* b0 = head == 0 ? h->ad.dino_b0 : h->ad.vae_b0;
+            const void* w2 = head == 0 ? h->ad.dino_w2 : h->ad.vae_w2;
+            const void* b2 = head == 0 ? h->ad.dino_b2 : h->ad.vae_b2;
+            memset(&p, 0, sizeof(p));
+            p.A = h->sp_in; p.lda = TXT; p.W = w0; p.bias = b0; p.out = h->sp_hid; p.ldo = AD_HID;
+            p.M = ns; p.N = AD_HID; p.K = TXT;
+            if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream))) return rc;
+            memset(&p, 0, sizeof(p));
+            p.A = h->sp_hid; p.lda = AD_HID; p.W = w2; p.bias = b2; p.out = head == 0 ? h->sp_dino : h->sp_vae;
+            p.ldo = TXT; p.M = ns; p.N = TXT; p.K = AD_HID;
+            if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+        }
+        if ((rc = launch_adapter_mix_scatter(h->sp_dino, h->sp_vae, c->alpha, c->one_minus_alpha, c->special_idx,
+                                             c->prompt_emb, ns, TXT, stream)))
+            return rc;
+    }
+
+    // ---- 2. patchify + img_in ; txt_norm + txt_in   (:1344-1366)
+    {
+        char* tok = h->patches;
+        if ((rc = launch_patchify(c->latents, tok, 16, c->h8, c->w8, stream))) return rc;
+        tok += (size_t)S0 * PATCH * 2;
+        for (int i = 0; i < c->n_edit; ++i) {
+            if ((rc = launch_patchify(c->edit_latents[i], tok, 16, c->edit_h8[i], c->edit_w8[i], stream))) return rc;
+            tok += (size_t)(c->edit_h8[i] / 2) * (c->edit_w8[i] / 2) * PATCH * 2;
+        }
+        if ((rc = launch_rmsnorm(c->prompt_emb, h->w.txt_norm_w, h->pe_norm, T, TXT, 1e-6f, stream))) return rc;
+        memset(pp, 0, sizeof(pp));
+        pp[0].A = h->patches; pp[0].lda = PATCH; pp[0].W = h->w.img_in_w; pp[0].bias = h->w.img_in_b;
+        pp[0].out = h->x; pp[0].ldo = D; pp[0].M = S_img; pp[0].N = D; pp[0].K = PATCH;
+        if ((rc = launch_gemm(EPI_BIAS, &pp[0], 1, stream))) return rc;
+        pp[1].A = h->pe_norm; pp[1].lda = TXT; pp[1].W = h->w.txt_in_w; pp[1].bias = h->w.txt_in_b;
+        pp[1].out = h->x + (size_t)S_img * D * 2; pp[1].ldo = D; pp[1].M = T; pp[1].N = D; pp[1].K = TXT;
+        if ((rc = launch_gemm(EPI_BIAS, &pp[1], 1, stream))) return rc;
+    }
+
+    char* x_img = h->x;
+    char* x_txt = h->x + (size_t)S_img * D * 2;
+    char* xm_img = h->xmod;
+    char* xm_txt = h->xmod + (size_t)S_img * D * 2;
+    const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+
+    // ---- 3. transformer blocks  (qwen_image_dit.py:359-401)
+    for (int l = 0; l < L; ++l) {
+        const pe_dit_block_weights& B = h->blocks[l];
+        const char* mod_img = h->mod_tab + (((size_t)c->step * L + l) * 2 + 0) * MOD * 2;
+        const char* mod_txt = h->mod_tab + (((size_t)c->step * L + l) * 2 + 1) * MOD * 2;
+        // chunk order inside each 3*D half: (shift, scale, gate)  (:356)
+        auto sh = [&](const char* m, int half) { return m + (size_t)(half * 3 + 0) * D * 2; };
+        auto sc = [&](const char* m, int half) { return m + (size_t)(half * 3 + 1) * D * 2; };
+        auto gt = [&](const char* m, int half) { return m + (size_t)(half * 3 + 2) * D * 2; };
+
+        // norm1 + modulate (both streams, one launch)
+        if ((rc = launch_ln_modulate(h->x, h->xmod, S, D, S_img, sh(mod_img, 0), sc(mod_img, 0), sh(mod_txt, 0),
+                                     sc(mod_txt, 0), 1e-6f, stream)))
+            return rc;
+        // QKV projections + per-head RMSNorm + RoPE, head-major Q/K, transposed V
+        memset(pp, 0, sizeof(pp));
+        for (int s = 0; s < 2; ++s) {
+            pp[s].A = s == 0 ? xm_img : xm_txt; pp[s].lda = D;
+            pp[s].W = s == 0 ? B.img_qkv_w : B.txt_qkv_w;
+            pp[s].bias = s == 0 ? B.img_qkv_b : B.txt_qkv_b;
+            pp[s].M = s == 0 ? S_img : T; pp[s].N = 3 * D; pp[s].K = D;
+            pp[s].norm_q_w = s == 0 ? B.norm_q_w : B.norm_added_q_w;
+            pp[s].norm_k_w = s == 0 ? B.norm_k_w : B.norm_added_k_w;
+            pp[s].rope_cos = s == 0 ? c->rope_cos_img : c->rope_cos_txt;
+            pp[s].rope_sin = s == 0 ? c->rope_sin_img : c->rope_sin_txt;
+            pp[s].q_out = h->q; pp[s].k_out = h->k; pp[s].vt_out = h->vt;
+            pp[s].seq_off = s == 0 ? 0 : S_img; pp[s].S_pad = S_pad;
+        }
+        if ((rc = launch_gemm(EPI_QKV, pp, 2, stream))) return rc;
+        // joint attention
+        if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, stream))) return rc;
+        // output projections + gated residual (in place on x)
+        memset(pp, 0, sizeof(pp));
+        for (int s = 0; s < 2; ++s) {
+            pp[s].A = h->attn + (s == 0 ? 0 : (size_t)S_img * D * 2); pp[s].lda = D;
+            pp[s].W = s == 0 ? B.img_out_w : B.txt_out_w;
+            pp[s].bias = s == 0 ? B.img_out_b : B.txt_out_b;
+            pp[s].out = s == 0 ? x_img : x_txt; pp[s].ldo = D;
+            pp[s].res = pp[s].out; pp[s].ldr = D;
+            pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 0);
+            pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = D;
+        }
+        if ((rc = launch_gemm(EPI_GATE_RES, pp, 2, stream))) return rc;
+        // norm2 + modulate
+        if ((rc = launch_ln_modulate(h->x, h->xmod, S, D, S_img, sh(mod_img, 1), sc(mod_img, 1), sh(mod_txt, 1),
+                                     sc(mod_txt, 1), 1e-6f, stream)))
+            return rc;
+        // MLP up + ApproximateGELU
+        memset(pp, 0, sizeof(pp));
+        for (int s = 0; s < 2; ++s) {
+            pp[s].A = s == 0 ? xm_img : xm_txt; pp[s].lda = D;
+            pp[s].W = s == 0 ? B.img_mlp_up_w : B.txt_mlp_up_w;
+            pp[s].bias = s == 0 ? B.img_mlp_up_b : B.txt_mlp_up_b;
+            pp[s].out = h->hbuf + (s == 0 ? 0 : (size_t)S_img * FF * 2); pp[s].ldo = FF;
+            pp[s].M = s == 0 ? S_img : T; pp[s].N = FF; pp[s].K = D;
+        }
+        if ((rc = launch_gemm(EPI_GELU_SIG, pp, 2, stream))) return rc;
+        // MLP down + gated residual
+        memset(pp, 0, sizeof(pp));
+        for (int s = 0; s < 2; ++s) {
+            pp[s].A = h->hbuf + (s == 0 ? 0 : (size_t)S_img * FF * 2); pp[s].lda = FF;
+            pp[s].W = s == 0 ? B.img_mlp_down_w : B.txt_mlp_down_w;
+            pp[s].bias = s == 0 ? B.img_mlp_down_b : B.txt_mlp_down_b;
+            pp[s].out = s == 0 ? x_img : x_txt; pp[s].ldo = D;
+            pp[s].res = pp[s].out; pp[s].ldr = D;
+            pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 1);
+            pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = FF;
+        }
+        if ((rc = launch_gemm(EPI_GATE_RES, pp, 2, stream))) return rc;
+    }
+
+    // ---- 4. AdaLayerNorm(single) head on the S0 kept rows, proj_out, unpatchify  (:1398-1402)
+    {
+        const char* fin = h->final_tab + (size_t)c->step * 2 * D * 2;
+        const char* f_scale = fin;                      // scale, shift = emb.chunk(2)  (models/utils.py:307)
+        const char* f_shift = fin + (size_t)D * 2;
+        if ((rc = launch_ln_modulate(h->x, h->xmod, S0, D, S0, f_shift, f_scale, f_shift, f_scale, 1e-6f, stream)))
+            return rc;
+        memset(&p, 0, sizeof(p));
+        p.A = h->xmod; p.lda = D; p.W = h->w.proj_out_w; p.bias = h->w.proj_out_b;
+        p.out = h->proj; p.ldo = PATCH; p.M = S0; p.N = PATCH; p.K = D;
+        if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+        if ((rc = launch_unpatchify(h->proj, c->noise_pred, 16, c->h8, c->w8, stream))) return rc;
+    }
+    return PE_OK;
+}
+
+const void* pe_dit_debug_ptr(pe_dit_handle h, const char* name) {
+    if (!h || !h->ws || !name) return nullptr;
+    const std::string n(name);
+    if (n == "x") return h->x;
+    if (n == "xmod") return h->xmod;
+    if (n == "q") return h->q;
+    if (n == "k") return h->k;
+    if (n == "vt") return h->vt;
+    if (n == "attn") return h->attn;
+    if (n == "hbuf") return h->hbuf;
+    if (n == "temb") return h->temb;
+    if (n == "mod_tab") return h->mod_tab;
+    if (n == "final_tab") return h->final_tab;
+    if (n == "proj") return h->proj;
+    return nullptr;
+}
+
+}  // extern "C"

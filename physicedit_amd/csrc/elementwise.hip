@@ -1,0 +1,271 @@
+// HBM-bound row / element-wise kernels of the DiT forward and the sampler (gfx950).
+// Every arithmetic step rounds to bf16 exactly where the reference's bf16 torch graph does
+// (SURVEY.md Appendix A); loads and stores are 16 B per lane.
+#include "common.h"
+#include "kernels.h"
+
+namespace pe {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm(elementwise_affine=False, eps) -> x*(1+scale) + shift
+//   QwenImageTransformerBlock._modulate   qwen_image_dit.py:355-357, norms :337,344,351,352
+//   AdaLayerNorm(single)                  models/utils.py:304-309
+// One wave per row (dim = 3072: 6 x 16 B per lane, row kept in registers, two-pass moments in fp32).
+// ------------------------------------------------------------------------------------------------
+template <int VPL>  // 16-B vectors per lane; dim = VPL * 512
+__global__ void __launch_bounds__(256) ln_modulate_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
+                                                          int rows, int dim, int rows_a,
+                                                          const bf16* __restrict__ shift_a,
+                                                          const bf16* __restrict__ scale_a,
+                                                          const bf16* __restrict__ shift_b,
+                                                          const bf16* __restrict__ scale_b, float eps) {
+    const int lane = lane_id();
+    const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16* xr = x + (size_t)row * dim;
+    float v[VPL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const bf16x8 t = *(const bf16x8*)(xr + (i * 64 + lane) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[i][j] = (float)t[j];
+            sum += v[i][j];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[i][j] - mean;
+            sq += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)dim + eps);
+    const bf16* shift = row < rows_a ? shift_a : shift_b;
+    const bf16* scale = row < rows_a ? scale_a : scale_b;
+    bf16* orow = out + (size_t)row * dim;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        const bf16x8 sc = *(const bf16x8*)(scale + c);
+        const bf16x8 sh = *(const bf16x8*)(shift + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float n = bf16r((v[i][j] - mean) * rstd);   // LayerNorm output (bf16)
+            const float s1 = bf16r(1.0f + (float)sc[j]);       // 1 + scale
+            const float p = bf16r(n * s1);                     // x * (1 + scale)
+            o[j] = (bf16)(p + (float)sh[j]);                   // + shift
+        }
+        *(bf16x8*)(orow + c) = o;
+    }
+}
+
+int launch_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
+                       const void* scale_a, const void* shift_b, const void* scale_b, float eps,
+                       hipStream_t stream) {
+    PE_REQUIRE(x && out && shift_a && scale_a, "ln_modulate: null pointer");
+    PE_REQUIRE(rows > 0, "ln_modulate: rows=%d", rows);
+    PE_REQUIRE(dim == 3072, "ln_modulate: dim=%d unsupported (DiT width 3072 only)", dim);
+    if (!shift_b) shift_b = shift_a;
+    if (!scale_b) scale_b = scale_a;
+    hipLaunchKernelGGL((ln_modulate_kernel<6>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x,
+                       (bf16*)out, rows, dim, rows_a, (const bf16*)shift_a, (const bf16*)scale_a,
+                       (const bf16*)shift_b, (const bf16*)scale_b, eps);
+    return check_launch("ln_modulate_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm with weight (models/utils.py:250-257): txt_norm over 3584.  One wave per row.
+// ------------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ void __launch_bounds__(256) rmsnorm_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                      bf16* __restrict__ out, int rows, int dim, float eps) {
+    const int lane = lane_id();
+    const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16* xr = x + (size_t)row * dim;
+    float v[VPL][8];
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const bf16x8 t = *(const bf16x8*)(xr + (i * 64 + lane) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[i][j] = (float)t[j];
+            sq += v[i][j] * v[i][j];
+        }
+    }
+    const float rs = rsqrtf(wave_sum(sq) / (float)dim + eps);
+    bf16* orow = out + (size_t)row * dim;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        const bf16x8 wv = *(const bf16x8*)(w + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(bf16r(v[i][j] * rs) * (float)wv[j]);
+        *(bf16x8*)(orow + c) = o;
+    }
+}
+
+int launch_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, hipStream_t stream) {
+    PE_REQUIRE(x && w && out, "rmsnorm: null pointer");
+    PE_REQUIRE(rows > 0, "rmsnorm: rows=%d", rows);
+    PE_REQUIRE(dim == 3584, "rmsnorm: dim=%d unsupported (text width 3584 only)", dim);
+    hipLaunchKernelGGL((rmsnorm_kernel<7>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x,
+                       (const bf16*)w, (bf16*)out, rows, dim, eps);
+    return check_launch("rmsnorm_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// SiLU (torch.nn.SiLU on bf16: fp32 inside, one rounding)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const bf16x8 t = *(const bf16x8*)(x + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = (float)t[j];
+            o[j] = (bf16)(y / (1.0f + __expf(-y)));
+        }
+        *(bf16x8*)(out + i * 8) = o;
+    }
+}
+
+int launch_silu(const void* x, void* out, size_t n, hipStream_t stream) {
+    PE_REQUIRE(x && out, "silu: null pointer");
+    PE_REQUIRE(n % 8 == 0 && n > 0, "silu: n=%zu must be a positive multiple of 8", n);
+    const size_t n8 = n / 8;
+    const int grid = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(silu_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)x, (bf16*)out, n8);
+    return check_launch("silu_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// patchify "C (H P) (W Q) -> (H W) (C P Q)", P=Q=2  (qwen_image_physical.py:1344) and its inverse (:1402)
+// latents [C, H2, W2]; tokens [(H2/2)*(W2/2), C*4].  One thread per (token, channel): 4 elements.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) patchify_kernel(const bf16* __restrict__ lat, bf16* __restrict__ tok,
+                                                       int C, int H2, int W2, int inverse) {
+    const int Wt = W2 / 2;
+    const size_t total = (size_t)(H2 / 2) * Wt * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t t = i / C;
+        const int wi = (int)(t % Wt), hi = (int)(t / Wt);
+        bf16* tp = tok + t * (size_t)(C * 4) + c * 4;
+        bf16* lp = const_cast<bf16*>(lat) + ((size_t)c * H2 + 2 * hi) * W2 + 2 * wi;
+        if (!inverse) {
+            const bf16x2 r0 = *(const bf16x2*)lp;
+            const bf16x2 r1 = *(const bf16x2*)(lp + W2);
+            bf16x4 o;
+            o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
+            *(bf16x4*)tp = o;
+        } else {
+            const bf16x4 v = *(const bf16x4*)tp;
+            bf16x2 r0, r1;
+            r0[0] = v[0]; r0[1] = v[1]; r1[0] = v[2]; r1[1] = v[3];
+            *(bf16x2*)lp = r0;
+            *(bf16x2*)(lp + W2) = r1;
+        }
+    }
+}
+
+static int launch_patch(const void* lat, void* tok, int C, int H2, int W2, int inverse, hipStream_t stream) {
+    PE_REQUIRE(lat && tok, "patchify: null pointer");
+    PE_REQUIRE(C > 0 && H2 > 0 && W2 > 0 && H2 % 2 == 0 && W2 % 2 == 0, "patchify: bad shape C=%d H=%d W=%d", C, H2, W2);
+    const size_t total = (size_t)(H2 / 2) * (W2 / 2) * C;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)lat, (bf16*)tok, C, H2, W2, inverse);
+    return check_launch("patchify_kernel");
+}
+int launch_patchify(const void* latents, void* tokens, int C, int H2, int W2, hipStream_t stream) {
+    return launch_patch(latents, tokens, C, H2, W2, 0, stream);
+}
+int launch_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, hipStream_t stream) {
+    return launch_patch(latents, const_cast<void*>(tokens), C, H2, W2, 1, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// special-token gather / adapter mix + in-place scatter
+//   prompt_emb[special_token_mask] -> adapter -> prompt_emb[special_token_mask] = ...
+//   (qwen_image_physical.py:1333-1336; mix: helpers.py:160-162)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_rows_kernel(const bf16* __restrict__ src, const int* __restrict__ idx,
+                                                          bf16* __restrict__ dst, int dim8) {
+    const int r = (int)blockIdx.x;
+    const bf16* s = src + (size_t)idx[r] * dim8 * 8;
+    bf16* d = dst + (size_t)r * dim8 * 8;
+    for (int i = (int)threadIdx.x; i < dim8; i += 256) *(bf16x8*)(d + i * 8) = *(const bf16x8*)(s + i * 8);
+}
+
+int launch_gather_rows(const void* src, const int* idx, void* dst, int nrows, int dim, hipStream_t stream) {
+    PE_REQUIRE(src && idx && dst, "gather_rows: null pointer");
+    PE_REQUIRE(nrows > 0 && dim % 8 == 0, "gather_rows: bad shape %d x %d", nrows, dim);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows), dim3(256), 0, stream, (const bf16*)src, idx, (bf16*)dst, dim / 8);
+    return check_launch("gather_rows_kernel");
+}
+
+__global__ void __launch_bounds__(256) adapter_mix_scatter_kernel(const bf16* __restrict__ dino,
+                                                                  const bf16* __restrict__ vae, float alpha,
+                                                                  float oma, const int* __restrict__ idx,
+                                                                  bf16* __restrict__ pe, int dim8) {
+    const int r = (int)blockIdx.x;
+    const bf16* a = dino + (size_t)r * dim8 * 8;
+    const bf16* b = vae + (size_t)r * dim8 * 8;
+    bf16* d = pe + (size_t)idx[r] * dim8 * 8;
+    for (int i = (int)threadIdx.x; i < dim8; i += 256) {
+        const bf16x8 av = *(const bf16x8*)(a + i * 8);
+        const bf16x8 bv = *(const bf16x8*)(b + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(bf16r(alpha * (float)av[j]) + bf16r(oma * (float)bv[j]));
+        *(bf16x8*)(d + i * 8) = o;
+    }
+}
+
+int launch_adapter_mix_scatter(const void* dino, const void* vae, float alpha, float one_minus_alpha,
+                               const int* idx, void* prompt_emb, int nrows, int dim, hipStream_t stream) {
+    PE_REQUIRE(dino && vae && idx && prompt_emb, "adapter_mix: null pointer");
+    PE_REQUIRE(nrows > 0 && dim % 8 == 0, "adapter_mix: bad shape %d x %d", nrows, dim);
+    hipLaunchKernelGGL(adapter_mix_scatter_kernel, dim3(nrows), dim3(256), 0, stream, (const bf16*)dino,
+                       (const bf16*)vae, alpha, one_minus_alpha, idx, (bf16*)prompt_emb, dim / 8);
+    return check_launch("adapter_mix_scatter_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFG combine + Euler step in one pass over the latent
+//   noise_pred = nega + cfg*(posi - nega)                  qwen_image_physical.py:656
+//   latents    = latents + noise_pred * (sigma' - sigma)   schedulers/flow_match.py:81
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cfg_euler_kernel(const bf16* __restrict__ posi, const bf16* __restrict__ nega,
+                                                        const bf16* __restrict__ lat, bf16* __restrict__ out,
+                                                        size_t n, float cfg, int use_cfg, float dsigma) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float np = (float)posi[i];
+        if (use_cfg) {
+            const float ng = (float)nega[i];
+            const float d = bf16r(np - ng);
+            const float e = bf16r(cfg * d);
+            np = bf16r(ng + e);
+        }
+        out[i] = (bf16)((float)lat[i] + bf16r(np * dsigma));
+    }
+}
+
+int launch_cfg_euler(const void* posi, const void* nega, const void* latents, void* out, size_t n,
+                     float cfg_scale, int use_cfg, float dsigma, hipStream_t stream) {
+    PE_REQUIRE(posi && latents && out && (!use_cfg || nega), "cfg_euler: null pointer");
+    PE_REQUIRE(n > 0, "cfg_euler: empty");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)posi, (const bf16*)nega,
+                       (const bf16*)latents, (bf16*)out, n, cfg_scale, use_cfg, dsigma);
+    return check_launch("cfg_euler_kernel");
+}
+
+}  // namespace pe

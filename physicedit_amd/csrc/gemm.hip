@@ -1,0 +1,358 @@
+// bf16 MFMA GEMM for gfx950:  out = epilogue(A[M,K] . W[N,K]^T + bias)
+//
+// Replaces every torch.nn.functional.linear on the DiT hot path of the reference
+// (DiffSynth-Studio/diffsynth/models/qwen_image_dit.py:282-283,313-314 QKV/out projections,
+// :48,240 MLP, :333-336,347-350 modulation, :416-417,430 in/out embeds; pipelines/helpers.py:127-137
+// adapter heads), with the element-wise op that follows each Linear in the reference fused into the
+// epilogue AT THE REFERENCE'S ROUNDING BOUNDARIES: the Linear result is
+// rounded to bf16 first (acc + bias -> bf16), then each following op rounds again.
+//
+// Structure (MI355X-first, not a CUDA tiling):
+//   * 256x256x64 block tile, 512 threads = 8 waves as 4(M) x 2(N); each wave owns 64x128 of C as
+//     2x4 v_mfma_f32_32x32x16_bf16 tiles (128 fp32 accumulators / lane).
+//   * A and W tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip),
+//     double buffered (2 x 64 KiB of the CU's 160 KiB), one barrier per K tile.
+//   * LDS image is [row][64 k] bf16 = 128 B rows; the 16-B chunk index is XORed with (row>>1)&7 so
+//     every ds_read_b128 lane group covers all 64 banks.  LDS-DMA writes lane-linear, so the
+//     permutation is applied to the per-lane SOURCE address and again on the read.
+//   * operands are fed "swapped" (MFMA A-operand = W fragment, B-operand = activation fragment):
+//     each lane then holds 4 consecutive N columns of one M row per accumulator quad.
+//   * epilogue: y = bf16(acc + bias) is transposed through the (now free) LDS so every lane owns
+//     8 consecutive columns of a row: 16-B bias/gate/residual loads and 16-B stores, 256-B segments.
+//   * work-group ids are remapped XCD-aware (8 private L2s) and walk 8-tile-tall bands.
+//   * "grouped" launch: up to 2 problems (image stream + text stream) share one grid.
+#include "common.h"
+#include "kernels.h"
+
+namespace pe {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int GEMM_THREADS = 512;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 64 KiB
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;        // 128 KiB
+constexpr int BAND = 8;
+
+struct GemmArgs {
+    GemmProblem p[2];
+    int tiles0;
+};
+
+PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+template <int EPI>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+
+    int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int pi = bid >= args.tiles0 ? 1 : 0;
+    const GemmProblem& P = args.p[pi];
+    bid -= pi ? args.tiles0 : 0;
+    const int M = P.M, N = P.N, K = P.K;
+    int m0, n0;
+    {
+        const int tilesM = P.tilesM, tilesN = P.tilesN;
+        const int per_band = BAND * tilesN;
+        const int band = bid / per_band;
+        const int rem = bid - band * per_band;
+        const int gm = min(BAND, tilesM - band * BAND);
+        const int tn = rem / gm;
+        const int tm = band * BAND + (rem - tn * gm);
+        m0 = tm * BM;
+        n0 = tn * BN;
+    }
+
+    // ---- staging sources: wave w moves pieces w*4..w*4+3 (1 KiB = 8 rows x 128 B) of A and of W
+    const bf16* a_src[4];
+    const bf16* w_src[4];
+    {
+        const bf16* A = (const bf16*)P.A;
+        const bf16* W = (const bf16*)P.W;
+        const int rin = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (w * 4 + i) * 8 + rin;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            const int gr = min(m0 + row, M - 1);
+            const int gn = min(n0 + row, N - 1);
+            a_src[i] = A + (size_t)gr * P.lda + chunk * 8;
+            w_src[i] = W + (size_t)gn * K + chunk * 8;
+        }
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES + w * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(a_src[i] + kt * BK, base + i * 1024);
+            glds16(w_src[i] + kt * BK, base + BM * BK * 2 + i * 1024);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // per-lane fragment addressing: row = tile_row + l31, chunk = kk*2 + h, swizzle (row>>1)&7
+    const int sw = (l31 >> 1) & 7;
+    const int a_row_off = (wm * 64 + l31) * 128;
+    const int w_row_off = BM * BK * 2 + (wn * 128 + l31) * 128;
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt landed for every wave; everyone is done reading buffer (kt+1)&1
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* S = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int coff = ((kk * 2 + h) ^ sw) << 4;
+            bf16x8 af[2], wf[4];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(S + a_row_off + mi * 32 * 128 + coff);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const bf16x8*)(S + w_row_off + ni * 32 * 128 + coff);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // epilogue.  acc[mi][ni][4q+r] = C[m0 + wm*64 + mi*32 + l31][n0 + wn*128 + ni*32 + 8q + 4h + r]
+    // ------------------------------------------------------------------------------------------
+    __syncthreads();
+    char* E = smem + w * 16384;  // this wave's [64 rows][128 cols] bf16 staging tile, chunk ^= row&15
+    const int nw0 = n0 + wn * 128;
+    const int mw0 = m0 + wm * 64;
+    {
+        const bf16* bias = (const bf16*)P.bias;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nw0 + ni * 32 + 8 * q + 4 * h;
+                float b[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias != nullptr && n < N) {
+                    const bf16x4 bv = *(const bf16x4*)(bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] = (float)bv[r];
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    bf16x4 y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] + b[r]);
+                    const int row = mi * 32 + l31;
+                    const int c = ni * 4 + q;
+                    *(bf16x4*)(E + row * 256 + ((c ^ (row & 15)) << 4) + h * 8) = y;
+                }
+            }
+    }
+    __syncthreads();
+
+    if constexpr (EPI == EPI_QKV) {
+        const int HD = N / 3;
+        const int section = nw0 / HD;  // wave-uniform: the wave's 128 columns are exactly one head
+        const int head = (nw0 - section * HD) >> 7;
+        const int S_pad = P.S_pad;
+        if (section < 2) {
+            const bf16* nw = (const bf16*)(section == 0 ? P.norm_q_w : P.norm_k_w);
+            bf16* dst = (bf16*)(section == 0 ? P.q_out : P.k_out);
+            const int c = lane & 15;
+            const bf16x8 wv = *(const bf16x8*)(nw + c * 8);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const int m = mw0 + row;
+                const bf16x8 v = *(const bf16x8*)(E + row * 256 + ((c ^ (row & 15)) << 4));
+                float y[8];
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    y[j] = (float)v[j];
+                    ss += y[j] * y[j];
+                }
+                ss += __shfl_xor(ss, 1, 64);
+                ss += __shfl_xor(ss, 2, 64);
+                ss += __shfl_xor(ss, 4, 64);
+                ss += __shfl_xor(ss, 8, 64);
+                // RMSNorm(128, eps 1e-6): models/utils.py:250-257
+                const float rs = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+                if (m < M) {
+                    const f32x4 cs = *(const f32x4*)(P.rope_cos + (size_t)m * 64 + c * 4);
+                    const f32x4 sn = *(const f32x4*)(P.rope_sin + (size_t)m * 64 + c * 4);
+                    bf16x8 o;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float x0 = bf16r(bf16r(y[2 * jj] * rs) * (float)wv[2 * jj]);
+                        const float x1 = bf16r(bf16r(y[2 * jj + 1] * rs) * (float)wv[2 * jj + 1]);
+                        // apply_rotary_emb_qwen: fp32 complex multiply (qwen_image_dit.py:51-57)
+                        o[2 * jj] = (bf16)(x0 * cs[jj] - x1 * sn[jj]);
+                        o[2 * jj + 1] = (bf16)(x0 * sn[jj] + x1 * cs[jj]);
+                    }
+                    *(bf16x8*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
+                }
+            }
+        } else {
+            // V: written TRANSPOSED, Vt[head][d][pos(token)], tokens permuted inside aligned 16-groups
+            // (pos = perm16) so the attention kernel's P.V MFMA needs no cross-lane shuffle.
+            bf16* vt = (bf16*)P.vt_out + (size_t)head * 128 * S_pad;
+            const int seq0 = P.seq_off + mw0;
+            const int valid = min(64, M - mw0);
+            if ((seq0 & 15) == 0) {
+#pragma unroll 2
+                for (int it = 0; it < 16; ++it) {
+                    const int id = it * 64 + lane;
+                    const int d = id >> 3, tg = id & 7;
+                    const int gi = tg >> 1, hh = tg & 1;
+                    unsigned short e[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = gi * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
+                        e[j] = *(const unsigned short*)(E + row * 256 + (((d >> 3) ^ (row & 15)) << 4) + (d & 7) * 2);
+                    }
+                    bf16* dstp = vt + (size_t)d * S_pad + seq0 + gi * 16 + hh * 8;
+                    if (gi * 16 + 16 <= valid) {
+                        u32x4 pk;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+                        *(u32x4*)dstp = pk;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int tok = gi * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
+                            if (tok < valid) ((unsigned short*)dstp)[j] = e[j];
+                        }
+                    }
+                }
+            } else {
+                // unaligned joint offset (text stream behind an odd-sized image stream): element-wise
+                const int s = seq0 + lane;
+                const int pos = (s & ~15) | perm16(s & 15);
+                if (lane < valid) {
+                    for (int d = 0; d < 128; ++d) {
+                        const unsigned short e =
+                            *(const unsigned short*)(E + lane * 256 + (((d >> 3) ^ (lane & 15)) << 4) + (d & 7) * 2);
+                        ((unsigned short*)vt)[(size_t)d * S_pad + pos] = e;
+                    }
+                }
+            }
+        }
+    } else {
+        const int c = lane & 15;
+        const int n = nw0 + c * 8;
+        bf16* out = (bf16*)P.out;
+        float g[8];
+        if constexpr (EPI == EPI_GATE_RES) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = 1.0f;
+            if (P.gate != nullptr && n < N) {
+                const bf16x8 gv = *(const bf16x8*)((const bf16*)P.gate + n);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = (float)gv[j];
+            }
+        }
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = mw0 + row;
+            if (m >= M || n >= N) continue;
+            const bf16x8 v = *(const bf16x8*)(E + row * 256 + ((c ^ (row & 15)) << 4));
+            bf16x8 o;
+            if constexpr (EPI == EPI_BIAS) {
+                o = v;
+            } else if constexpr (EPI == EPI_GELU_SIG) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = (float)v[j];
+                    const float t = bf16r(1.702f * y);
+                    const float sg = bf16r(1.0f / (1.0f + __expf(-t)));
+                    o[j] = (bf16)(y * sg);
+                }
+            } else if constexpr (EPI == EPI_GELU_ERF) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = (float)v[j];
+                    o[j] = (bf16)(0.5f * y * (1.0f + erff(y * 0.70710678118654752440f)));
+                }
+            } else if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = (float)v[j];
+                    o[j] = (bf16)(y / (1.0f + __expf(-y)));
+                }
+            } else if constexpr (EPI == EPI_GATE_RES) {
+                const bf16x8 rv = *(const bf16x8*)((const bf16*)P.res + (size_t)m * P.ldr + n);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)rv[j] + bf16r(g[j] * (float)v[j]));
+            }
+            *(bf16x8*)(out + (size_t)m * P.ldo + n) = o;
+        }
+    }
+}
+
+template <int EPI>
+static int launch_t(const GemmArgs& args, int ntiles, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(ntiles), dim3(GEMM_THREADS), GEMM_LDS, stream, args);
+    return check_launch("gemm_bf16_kernel");
+}
+
+int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream) {
+    PE_REQUIRE(nproblems >= 1 && nproblems <= 2, "gemm: 1 or 2 problems per launch, got %d", nproblems);
+    GemmArgs args;
+    int tiles[2] = {0, 0};
+    for (int i = 0; i < nproblems; ++i) {
+        GemmProblem& p = problems[i];
+        PE_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem %d (M=%d N=%d K=%d)", i, p.M, p.N, p.K);
+        PE_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
+        PE_REQUIRE(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);
+        PE_REQUIRE(p.lda % 8 == 0 && p.lda >= p.K, "gemm: lda=%d must be >= K and a multiple of 8", p.lda);
+        PE_REQUIRE(p.A && p.W, "gemm: null operand");
+        if (epilogue == EPI_QKV) {
+            PE_REQUIRE(p.N % 384 == 0, "gemm(qkv): N=%d must be 3*H*128", p.N);
+            PE_REQUIRE(p.q_out && p.k_out && p.vt_out && p.norm_q_w && p.norm_k_w && p.rope_cos && p.rope_sin,
+                       "gemm(qkv): missing qkv epilogue pointers");
+            PE_REQUIRE(p.S_pad % 64 == 0 && p.seq_off >= 0 && p.seq_off + p.M <= p.S_pad,
+                       "gemm(qkv): bad S_pad=%d seq_off=%d M=%d", p.S_pad, p.seq_off, p.M);
+        } else {
+            PE_REQUIRE(p.out != nullptr && p.ldo % 8 == 0 && p.ldo >= p.N, "gemm: bad out/ldo=%d", p.ldo);
+        }
+        if (epilogue == EPI_GATE_RES)
+            PE_REQUIRE(p.res != nullptr && p.ldr % 8 == 0, "gemm(gate_res): bad residual");
+        p.tilesM = (p.M + BM - 1) / BM;
+        p.tilesN = (p.N + BN - 1) / BN;
+        tiles[i] = p.tilesM * p.tilesN;
+        args.p[i] = p;
+    }
+    if (nproblems == 1) args.p[1] = args.p[0];
+    args.tiles0 = tiles[0];
+    const int ntiles = tiles[0] + tiles[1];
+    switch (epilogue) {
+        case EPI_BIAS: return launch_t<EPI_BIAS>(args, ntiles, stream);
+        case EPI_GELU_SIG: return launch_t<EPI_GELU_SIG>(args, ntiles, stream);
+        case EPI_GELU_ERF: return launch_t<EPI_GELU_ERF>(args, ntiles, stream);
+        case EPI_GATE_RES: return launch_t<EPI_GATE_RES>(args, ntiles, stream);
+        case EPI_QKV: return launch_t<EPI_QKV>(args, ntiles, stream);
+        case EPI_SILU: return launch_t<EPI_SILU>(args, ntiles, stream);
+        default: return set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
+    }
+}
+
+}  // namespace pe

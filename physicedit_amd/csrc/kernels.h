@@ -1,0 +1,71 @@
+// Host-side launcher interface shared by the .hip translation units (internal; the public C-ABI
+// is include/physicedit_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pe {
+
+// ---------------------------------------------------------------------------------------------
+// GEMM:  out[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] )      bf16 in, fp32 accumulate
+// ---------------------------------------------------------------------------------------------
+enum GemmEpilogue {
+    EPI_BIAS = 0,      // y = bf16(acc + bias)
+    EPI_GELU_SIG = 1,  // ApproximateGELU: y * sigmoid(1.702 y), each op rounded (qwen_image_dit.py:47-49)
+    EPI_GELU_ERF = 2,  // nn.GELU() exact erf (helpers.py:127-131)
+    EPI_GATE_RES = 3,  // out = res + gate[n] * y, each op rounded (qwen_image_dit.py:386-387,398-399)
+    EPI_QKV = 4,       // per-head RMSNorm(q,k) + RoPE(q,k), head-major Q/K and transposed V
+    EPI_SILU = 5,      // y -> silu(y) (time MLP linear_1 + SiLU; AdaLN's silu(temb) is a separate tensor)
+};
+
+struct GemmProblem {
+    const void* A;     // [M,K] bf16, row stride lda elements
+    const void* W;     // [N,K] bf16 contiguous (nn.Linear layout)
+    const void* bias;  // [N] bf16 or null
+    void* out;         // [M,N] bf16, row stride ldo (unused by EPI_QKV)
+    int M, N, K;
+    int lda, ldo;
+    // EPI_GATE_RES
+    const void* gate;  // [N] bf16 (null => gate 1)
+    const void* res;   // [M,N] bf16, row stride ldr (may alias out)
+    int ldr;
+    // EPI_QKV: N = 3*H*128; columns [0,HD) q, [HD,2HD) k, [2HD,3HD) v
+    const void* norm_q_w;   // [128] bf16
+    const void* norm_k_w;   // [128] bf16
+    const float* rope_cos;  // [M,64] fp32 (row = token of THIS problem)
+    const float* rope_sin;  // [M,64]
+    void* q_out;            // [H][S_pad][128] bf16
+    void* k_out;            // [H][S_pad][128]
+    void* vt_out;           // [H][128][S_pad], tokens permuted inside 16-groups (see attention.hip)
+    int seq_off;            // joint-sequence row of this problem's row 0
+    int S_pad;
+    int tilesM, tilesN;     // filled by the launcher
+};
+
+int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// flash attention over the joint sequence (no mask), D = 128
+// ---------------------------------------------------------------------------------------------
+int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
+                      int ldo, float scale, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// row kernels / elementwise
+// ---------------------------------------------------------------------------------------------
+// LayerNorm(no affine, eps) -> *(1+scale) -> +shift, rows [0,rows_a) use mod_a, the rest mod_b
+int launch_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
+                       const void* scale_a, const void* shift_b, const void* scale_b, float eps,
+                       hipStream_t stream);
+int launch_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, hipStream_t stream);
+int launch_silu(const void* x, void* out, size_t n, hipStream_t stream);
+int launch_patchify(const void* latents, void* tokens, int C, int H2, int W2, hipStream_t stream);
+int launch_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, hipStream_t stream);
+int launch_gather_rows(const void* src, const int* idx, void* dst, int nrows, int dim, hipStream_t stream);
+int launch_adapter_mix_scatter(const void* dino, const void* vae, float alpha, float one_minus_alpha,
+                               const int* idx, void* prompt_emb, int nrows, int dim, hipStream_t stream);
+int launch_cfg_euler(const void* posi, const void* nega, const void* latents, void* out, size_t n,
+                     float cfg_scale, int use_cfg, float dsigma, hipStream_t stream);
+
+}  // namespace pe

@@ -1,0 +1,293 @@
+"""Device-resident Qwen-Image DiT + visual-thinking adapter, driven through the C-ABI composite.
+
+Host-side mirror of the reference's operator for this path:
+    model_fn_qwen_image(dit=, visual_thinking_adapter=, latents=, timestep=, prompt_emb=, ...)
+        DiffSynth-Studio/diffsynth/pipelines/qwen_image_physical.py:1302-1403
+Weights keep the reference's state-dict names; `params[name]` are torch
+tensors on the GPU.  to_q/to_k/to_v (and add_*_proj) live as row-slices (views) of one fused
+[9216,3072] buffer so the QKV projection is one GEMM, while LoRA merging and `load_state_dict`
+still address them by their original names.
+
+No arithmetic happens in this file except host scalar set-up; all tensor math is HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib, ops
+from ._lib import AdapterWeights, DitBlockWeights, DitCall, DitWeights, check, lib, stream_ptr
+from .rope import RopeCache
+from .scheduler import adapter_alpha, qwen_image_scheduler, timestep_sinusoid
+
+BF = torch.bfloat16
+D = 3072
+
+
+def count_layers(sd: Dict[str, torch.Tensor]) -> int:
+    n = 0
+    while f"transformer_blocks.{n}.img_mod.1.weight" in sd:
+        n += 1
+    return n
+
+
+class QwenImageDiTEngine:
+    """Owns the device weights, the workspace and the prepared per-timestep tables."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], adapter_state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PeError("QwenImageDiTEngine needs a HIP device: physicedit_amd has no CPU path")
+        lib()  # fail loudly now if the .so is missing
+        self.num_layers = count_layers(state_dict)
+        self.params: Dict[str, torch.Tensor] = {}
+        self._fused: Dict[str, torch.Tensor] = {}
+        self._ingest_dit(state_dict)
+        self.adapter: Optional[Dict[str, torch.Tensor]] = None
+        if adapter_state_dict is not None:
+            self.adapter = {k: v.to(device=self.device, dtype=BF).contiguous() for k, v in adapter_state_dict.items()}
+        sch = qwen_image_scheduler()
+        # VisualThinkingDualAdapter(t_min=..., t_max=...) -- qwen_image_physical.py:225
+        self.t_min, self.t_max = sch.timesteps.min().item(), sch.timesteps.max().item()
+        self._handle = C.c_void_p()
+        self._keep = None
+        self._create()
+        self._ws: Optional[torch.Tensor] = None
+        self._bound = (0, 0, 0)
+        self._step_of: Dict[float, int] = {}
+        self.rope = RopeCache(self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def _ingest_dit(self, sd):
+        dev = self.device
+        for i in range(self.num_layers):
+            p = f"transformer_blocks.{i}.attn."
+            for fused_name, parts in ((p + "img_qkv", ("to_q", "to_k", "to_v")),
+                                      (p + "txt_qkv", ("add_q_proj", "add_k_proj", "add_v_proj"))):
+                w = torch.empty((3 * D, D), dtype=BF, device=dev)
+                b = torch.empty((3 * D,), dtype=BF, device=dev)
+                for j, part in enumerate(parts):
+                    w[j * D:(j + 1) * D].copy_(sd[p + part + ".weight"])
+                    b[j * D:(j + 1) * D].copy_(sd[p + part + ".bias"])
+                    self.params[p + part + ".weight"] = w[j * D:(j + 1) * D]
+                    self.params[p + part + ".bias"] = b[j * D:(j + 1) * D]
+                self._fused[fused_name + ".weight"] = w
+                self._fused[fused_name + ".bias"] = b
+        for k, v in sd.items():
+            if k not in self.params:
+                self.params[k] = v.to(device=dev, dtype=BF).contiguous()
+
+    def _create(self):
+        P, F = self.params, self._fused
+        blocks = (DitBlockWeights * max(self.num_layers, 1))()
+        for i in range(self.num_layers):
+            p = f"transformer_blocks.{i}."
+            b = blocks[i]
+            b.img_mod_w, b.img_mod_b = P[p + "img_mod.1.weight"].data_ptr(), P[p + "img_mod.1.bias"].data_ptr()
+            b.img_qkv_w, b.img_qkv_b = F[p + "attn.img_qkv.weight"].data_ptr(), F[p + "attn.img_qkv.bias"].data_ptr()
+            b.norm_q_w, b.norm_k_w = P[p + "attn.norm_q.weight"].data_ptr(), P[p + "attn.norm_k.weight"].data_ptr()
+            b.img_out_w, b.img_out_b = P[p + "attn.to_out.0.weight"].data_ptr(), P[p + "attn.to_out.0.bias"].data_ptr()
+            b.img_mlp_up_w, b.img_mlp_up_b = P[p + "img_mlp.net.0.proj.weight"].data_ptr(), P[p + "img_mlp.net.0.proj.bias"].data_ptr()
+            b.img_mlp_down_w, b.img_mlp_down_b = P[p + "img_mlp.net.2.weight"].data_ptr(), P[p + "img_mlp.net.2.bias"].data_ptr()
+            b.txt_mod_w, b.txt_mod_b = P[p + "txt_mod.1.weight"].data_ptr(), P[p + "txt_mod.1.bias"].data_ptr()
+            b.txt_qkv_w, b.txt_qkv_b = F[p + "attn.txt_qkv.weight"].data_ptr(), F[p + "attn.txt_qkv.bias"].data_ptr()
+            b.norm_added_q_w, b.norm_added_k_w = P[p + "attn.norm_added_q.weight"].data_ptr(), P[p + "attn.norm_added_k.weight"].data_ptr()
+            b.txt_out_w, b.txt_out_b = P[p + "attn.to_add_out.weight"].data_ptr(), P[p + "attn.to_add_out.bias"].data_ptr()
+            b.txt_mlp_up_w, b.txt_mlp_up_b = P[p + "txt_mlp.net.0.proj.weight"].data_ptr(), P[p + "txt_mlp.net.0.proj.bias"].data_ptr()
+            b.txt_mlp_down_w, b.txt_mlp_down_b = P[p + "txt_mlp.net.2.weight"].data_ptr(), P[p + "txt_mlp.net.2.bias"].data_ptr()
+        w = DitWeights()
+        w.num_layers = self.num_layers
+        t = "time_text_embed.timestep_embedder."
+        w.time_w1, w.time_b1 = P[t + "linear_1.weight"].data_ptr(), P[t + "linear_1.bias"].data_ptr()
+        w.time_w2, w.time_b2 = P[t + "linear_2.weight"].data_ptr(), P[t + "linear_2.bias"].data_ptr()
+        w.txt_norm_w = P["txt_norm.weight"].data_ptr()
+        w.img_in_w, w.img_in_b = P["img_in.weight"].data_ptr(), P["img_in.bias"].data_ptr()
+        w.txt_in_w, w.txt_in_b = P["txt_in.weight"].data_ptr(), P["txt_in.bias"].data_ptr()
+        w.norm_out_w, w.norm_out_b = P["norm_out.linear.weight"].data_ptr(), P["norm_out.linear.bias"].data_ptr()
+        w.proj_out_w, w.proj_out_b = P["proj_out.weight"].data_ptr(), P["proj_out.bias"].data_ptr()
+        w.blocks = blocks
+        adp = None
+        if self.adapter is not None:
+            a = AdapterWeights()
+            A = self.adapter
+            a.dino_w0, a.dino_b0 = A["head_dino.0.weight"].data_ptr(), A["head_dino.0.bias"].data_ptr()
+            a.dino_w2, a.dino_b2 = A["head_dino.2.weight"].data_ptr(), A["head_dino.2.bias"].data_ptr()
+            a.vae_w0, a.vae_b0 = A["head_vae.0.weight"].data_ptr(), A["head_vae.0.bias"].data_ptr()
+            a.vae_w2, a.vae_b2 = A["head_vae.2.weight"].data_ptr(), A["head_vae.2.bias"].data_ptr()
+            adp = C.byref(a)
+        if self._handle:
+            lib().pe_dit_destroy(self._handle)
+            self._handle = C.c_void_p()
+        check(lib().pe_dit_create(C.byref(w), adp, C.byref(self._handle)), "pe_dit_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                lib().pe_dit_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    # LoRA merge (GeneralLoRALoader.load, lora/__init__.py:28-45): W <- bf16(W + bf16(alpha * B @ A))
+    # ------------------------------------------------------------------------------------------
+    def load_lora(self, lora_state_dict: Dict[str, torch.Tensor], alpha: float = 1.0) -> int:
+        if alpha != 1.0:
+            raise _lib.PeError("load_lora: only alpha=1.0 is merged on the GPU path (validate.py uses alpha=1)")
+        n = 0
+        for key, up in lora_state_dict.items():
+            if ".lora_B." not in key:
+                continue
+            parts = key.split(".")
+            i = parts.index("lora_B")
+            if len(parts) > i + 2:
+                parts.pop(i + 1)
+            parts.pop(parts.index("lora_B"))
+            if parts[0] == "diffusion_model":
+                parts.pop(0)
+            parts.pop(-1)
+            name = ".".join(parts) + ".weight"
+            if name not in self.params:
+                continue
+            down = lora_state_dict[key.replace(".lora_B.", ".lora_A.")]
+            up = up.to(device=self.device, dtype=BF)
+            down = down.to(device=self.device, dtype=BF)
+            r = up.shape[1]
+            rp = (r + 63) // 64 * 64                    # GEMM K granule; zero padding adds exact zeros
+            a = torch.zeros((up.shape[0], rp), dtype=BF, device=self.device)
+            a[:, :r] = up
+            wt = torch.zeros((down.shape[1], rp), dtype=BF, device=self.device)
+            wt[:, :r] = down.t()
+            W = self.params[name]
+            ops.gemm(a, wt, None, "gate_res", gate=None, res=W, out=W)
+            n += 1
+        return n
+
+    # ------------------------------------------------------------------------------------------
+    def bind(self, S_img_max: int, T_max: int, n_steps: int):
+        if self._bound[0] >= S_img_max and self._bound[1] >= T_max and self._bound[2] >= n_steps and self._ws is not None:
+            return
+        S_img_max = max(S_img_max, self._bound[0]); T_max = max(T_max, self._bound[1]); n_steps = max(n_steps, self._bound[2])
+        nbytes = lib().pe_dit_workspace_bytes(self._handle, S_img_max, T_max, n_steps)
+        self._ws = None
+        self._ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.device)
+        base = (self._ws.data_ptr() + 255) // 256 * 256
+        check(lib().pe_dit_bind_workspace(self._handle, base, nbytes, S_img_max, T_max, n_steps, stream_ptr()),
+              "pe_dit_bind_workspace")
+        self._bound = (S_img_max, T_max, n_steps)
+        self._step_of = {}
+
+    def prepare(self, timesteps_bf16: torch.Tensor):
+        """timesteps_bf16: [n] CPU tensor, scheduler timesteps ALREADY rounded to the pipeline dtype
+        (qwen_image_physical.py:649).  Builds temb / modulation rows for all of them."""
+        assert timesteps_bf16.dim() == 1
+        n = timesteps_bf16.shape[0]
+        if self._ws is None or self._bound[2] < n:
+            raise _lib.PeError("prepare: call bind() with n_steps >= len(timesteps) first")
+        t_scaled = timesteps_bf16.cpu() / 1000          # :1342, in the pipeline dtype
+        sin = timestep_sinusoid(t_scaled).to(BF).to(self.device).contiguous()   # models/utils.py:291
+        check(lib().pe_dit_prepare(self._handle, sin.data_ptr(), n, stream_ptr()), "pe_dit_prepare")
+        self._sin_keep = sin
+        self._step_of = {float(t): i for i, t in enumerate(timesteps_bf16.float().tolist())}
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, latents: torch.Tensor, timestep: torch.Tensor, prompt_emb: torch.Tensor,
+                special_idx: Optional[torch.Tensor] = None, edit_latents=None, step: Optional[int] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One model_fn call.  `timestep`: [1] tensor in the pipeline dtype.  `prompt_emb` [1,T,3584] is
+        MUTATED IN PLACE on `special_idx` rows.  Returns noise_pred [1,16,h8,w8]."""
+        ops._chk(latents, "latents"), ops._chk(prompt_emb, "prompt_emb")
+        h8, w8 = latents.shape[-2:]
+        edits: List[torch.Tensor] = []
+        if edit_latents is not None:
+            edits = list(edit_latents) if isinstance(edit_latents, (list, tuple)) else [edit_latents]
+        img_shapes = [(1, h8 // 2, w8 // 2)] + [(1, e.shape[-2] // 2, e.shape[-1] // 2) for e in edits]
+        S_img = sum(f * h * w for f, h, w in img_shapes)
+        T = prompt_emb.shape[-2]
+        if step is None:
+            key = float(timestep.float().item())
+            if key not in self._step_of or S_img > self._bound[0] or T > self._bound[1]:
+                # ad-hoc call outside a prepared loop: (re)bind and build a 1-row table for this timestep
+                self.bind(S_img, T, 1)
+                self.prepare(timestep.detach().reshape(1).cpu())
+            step = self._step_of[key]
+        elif S_img > self._bound[0] or T > self._bound[1]:
+            raise _lib.PeError(f"forward: sequence ({S_img},{T}) exceeds the bound workspace {self._bound[:2]}; "
+                               "call bind() with the maximum sizes before prepare()")
+        cos_i, sin_i, cos_t, sin_t = self.rope.get(img_shapes, T)
+        if out is None:
+            out = torch.empty((1, 16, h8, w8), dtype=BF, device=self.device)
+        c = DitCall()
+        c.latents, c.h8, c.w8 = latents.data_ptr(), h8, w8
+        c.n_edit = len(edits)
+        for i, e in enumerate(edits):
+            ops._chk(e, "edit_latents")
+            c.edit_latents[i] = e.data_ptr()
+            c.edit_h8[i], c.edit_w8[i] = e.shape[-2], e.shape[-1]
+        c.prompt_emb, c.T = prompt_emb.data_ptr(), T
+        if special_idx is not None and special_idx.numel() > 0:
+            if self.adapter is None:
+                raise _lib.PeError("special tokens given but no visual_thinking_adapter weights loaded")
+            c.special_idx, c.n_special = special_idx.data_ptr(), special_idx.numel()
+            c.alpha, c.one_minus_alpha = adapter_alpha(timestep.detach().cpu(), self.t_min, self.t_max)
+        else:
+            c.special_idx, c.n_special = None, 0
+        c.rope_cos_img, c.rope_sin_img = cos_i.data_ptr(), sin_i.data_ptr()
+        c.rope_cos_txt, c.rope_sin_txt = cos_t.data_ptr(), sin_t.data_ptr()
+        c.step = step
+        c.noise_pred = out.data_ptr()
+        check(lib().pe_dit_forward(self._handle, C.byref(c), stream_ptr()), "pe_dit_forward")
+        return out
+
+    def debug_tensor(self, name: str, shape, dtype=BF) -> torch.Tensor:
+        """Copy of an internal workspace region (tests only)."""
+        ptr = lib().pe_dit_debug_ptr(self._handle, name.encode())
+        if not ptr:
+            raise KeyError(name)
+        off = ptr - self._ws.data_ptr()
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        return self._ws[off:off + nbytes].view(dtype).reshape(shape).clone()
+
+
+def special_indices(special_token_mask: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    """bool mask [1,T] -> int32 device indices (row-major order == boolean-mask gather order)."""
+    if special_token_mask is None:
+        return None
+    idx = torch.nonzero(special_token_mask.reshape(-1).cpu(), as_tuple=False).reshape(-1).to(torch.int32)
+    return idx.to(device)
+
+
+def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=None, visual_thinking_adapter=None,
+                        latents=None, timestep=None, prompt_emb=None, prompt_emb_mask=None, special_token_mask=None,
+                        height=None, width=None, blockwise_controlnet_conditioning=None,
+                        blockwise_controlnet_inputs=None, progress_id=0, num_inference_steps=1,
+                        entity_prompt_emb=None, entity_prompt_emb_mask=None, entity_masks=None, edit_latents=None,
+                        context_latents=None, enable_fp8_attention=False, use_gradient_checkpointing=False,
+                        use_gradient_checkpointing_offload=False, edit_rope_interpolation=False, is_train=True,
+                        pseudo_special_emb_dino=None, pseudo_special_emb_vae=None, **kwargs):
+    """Drop-in for the reference operator of the same name (qwen_image_physical.py:1302-1403),
+    inference subset: returns (noise_pred, 0).  Unsupported reference features raise instead of
+    silently differing."""
+    if blockwise_controlnet_conditioning is not None or entity_prompt_emb is not None:
+        raise _lib.PeError("model_fn_qwen_image: blockwise ControlNet / EliGen entity masks are outside the hot path")
+    if is_train and special_token_mask is not None:
+        raise _lib.PeError("model_fn_qwen_image: is_train=True (special_token_loss) is a training feature; pass is_train=False")
+    if enable_fp8_attention or edit_rope_interpolation:
+        raise _lib.PeError("model_fn_qwen_image: fp8 attention / rope interpolation not implemented")
+    edits = []
+    if context_latents is not None:
+        edits.append(context_latents)      # context tokens come right after the noise tokens (:1348-1351)
+    if edit_latents is not None:
+        edits += list(edit_latents) if isinstance(edit_latents, (list, tuple)) else [edit_latents]
+    idx = None
+    if special_token_mask is not None:
+        idx = getattr(special_token_mask, "_pe_idx", None)
+        if idx is None:
+            idx = special_indices(special_token_mask, prompt_emb.device)
+    pred = dit.forward(latents, timestep, prompt_emb, idx, edits or None)
+    return pred, 0

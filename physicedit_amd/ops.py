@@ -1,0 +1,150 @@
+"""torch-tensor wrappers over the granular C-ABI operators (one HIP kernel launch each).
+
+Tensors must be contiguous bf16 CUDA(HIP) tensors unless stated; nothing here computes on the
+host.  These are what the `-m gpu` parity tests call, and what `physicedit_amd.dit` is made of.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, stream_ptr
+
+BF = torch.bfloat16
+EPI = {"bias": 0, "gelu_sigmoid": 1, "gelu_erf": 2, "gate_res": 3, "silu": 5}
+
+
+def _chk(t: torch.Tensor, name: str, dtype=BF):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA/HIP tensor (physicedit_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: str = "bias",
+         gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epilogue(x @ w.T + bias); x [M,K], w [N,K] (nn.Linear layout)."""
+    _chk(x, "x"), _chk(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), dtype=BF, device=x.device)
+    check(lib().pe_gemm_bf16(EPI[epilogue], x.data_ptr(), K, w.data_ptr(), _ptr(bias), out.data_ptr(), N, M, N, K,
+                             _ptr(gate), _ptr(res), N if res is not None else 0, stream_ptr()), "pe_gemm_bf16")
+    return out
+
+
+def s_pad_of(S: int) -> int:
+    return (S + 63) // 64 * 64
+
+
+def alloc_qkv(H: int, S: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    sp = s_pad_of(S)
+    q = torch.zeros((H, sp, 128), dtype=BF, device=device)
+    k = torch.zeros((H, sp, 128), dtype=BF, device=device)
+    vt = torch.zeros((H, 128, sp), dtype=BF, device=device)
+    return q, k, vt
+
+
+def qkv_rmsnorm_rope(x, wqkv, bqkv, norm_q_w, norm_k_w, rope_cos, rope_sin, q, k, vt, seq_off: int) -> None:
+    _chk(x, "x"), _chk(wqkv, "wqkv")
+    _chk(rope_cos, "rope_cos", torch.float32), _chk(rope_sin, "rope_sin", torch.float32)
+    M, K = x.shape
+    H = wqkv.shape[0] // 384
+    check(lib().pe_qkv_rmsnorm_rope(x.data_ptr(), K, wqkv.data_ptr(), _ptr(bqkv), M, H, K, norm_q_w.data_ptr(),
+                                     norm_k_w.data_ptr(), rope_cos.data_ptr(), rope_sin.data_ptr(), q.data_ptr(),
+                                     k.data_ptr(), vt.data_ptr(), seq_off, q.shape[1], stream_ptr()),
+          "pe_qkv_rmsnorm_rope")
+
+
+_PERM16 = [(j & 3) | ((j & 4) << 1) | ((j & 8) >> 1) for j in range(16)]
+
+
+def vt_positions(S_pad: int, device) -> torch.Tensor:
+    """pos[s] = column of token s inside a Vt row (perm16 inside aligned 16-groups)."""
+    s = torch.arange(S_pad, device=device)
+    perm = torch.tensor(_PERM16, device=device)
+    return (s & ~15) | perm[s & 15]
+
+
+def pack_vt(v: torch.Tensor, S_pad: int) -> torch.Tensor:
+    """[H,S,128] logical V -> the library's Vt layout [H,128,S_pad] (test helper)."""
+    H, S, Dh = v.shape
+    vt = torch.zeros((H, Dh, S_pad), dtype=v.dtype, device=v.device)
+    vt[:, :, vt_positions(S_pad, v.device)[:S]] = v.transpose(1, 2)
+    return vt
+
+
+def unpack_vt(vt: torch.Tensor, S: int) -> torch.Tensor:
+    return vt[:, :, vt_positions(vt.shape[2], vt.device)[:S]].transpose(1, 2).contiguous()
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, S: int,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q,k [H,S_pad,128], vt [H,128,S_pad] -> [S, H*128]."""
+    _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
+    H, sp, _ = q.shape
+    if out is None:
+        out = torch.empty((S, H * 128), dtype=BF, device=q.device)
+    check(lib().pe_flash_attn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128,
+                              1.0 / math.sqrt(128.0), stream_ptr()), "pe_flash_attn")
+    return out
+
+
+def ln_modulate(x, shift_a, scale_a, rows_a: Optional[int] = None, shift_b=None, scale_b=None, eps: float = 1e-6,
+                out=None) -> torch.Tensor:
+    _chk(x, "x")
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    if rows_a is None:
+        rows_a = rows
+    check(lib().pe_ln_modulate(x.data_ptr(), out.data_ptr(), rows, dim, rows_a, shift_a.data_ptr(), scale_a.data_ptr(),
+                               _ptr(shift_b), _ptr(scale_b), eps, stream_ptr()), "pe_ln_modulate")
+    return out
+
+
+def rmsnorm(x, w, eps: float = 1e-6) -> torch.Tensor:
+    _chk(x, "x"), _chk(w, "w")
+    out = torch.empty_like(x)
+    check(lib().pe_rmsnorm(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], eps, stream_ptr()),
+          "pe_rmsnorm")
+    return out
+
+
+def patchify(latents: torch.Tensor) -> torch.Tensor:
+    _chk(latents, "latents")
+    C_, H2, W2 = latents.shape[-3:]
+    out = torch.empty(((H2 // 2) * (W2 // 2), C_ * 4), dtype=BF, device=latents.device)
+    check(lib().pe_patchify(latents.data_ptr(), out.data_ptr(), C_, H2, W2, stream_ptr()), "pe_patchify")
+    return out
+
+
+def unpatchify(tokens: torch.Tensor, C_: int, H2: int, W2: int) -> torch.Tensor:
+    _chk(tokens, "tokens")
+    out = torch.empty((1, C_, H2, W2), dtype=BF, device=tokens.device)
+    check(lib().pe_unpatchify(tokens.data_ptr(), out.data_ptr(), C_, H2, W2, stream_ptr()), "pe_unpatchify")
+    return out
+
+
+def cfg_euler_step(posi, nega, latents, cfg_scale: float, dsigma: float, out=None) -> torch.Tensor:
+    _chk(posi, "posi"), _chk(latents, "latents")
+    if out is None:
+        out = torch.empty_like(latents)
+    use_cfg = 1 if (nega is not None and cfg_scale != 1.0) else 0
+    check(lib().pe_cfg_euler_step(posi.data_ptr(), _ptr(nega) if use_cfg else None, latents.data_ptr(), out.data_ptr(),
+                                  latents.numel(), float(cfg_scale), use_cfg, float(dsigma), stream_ptr()),
+          "pe_cfg_euler_step")
+    return out

@@ -1,0 +1,66 @@
+"""Denoising loop of QwenImagePhysicPipeline on the HIP kernels.
+
+Mirrors DiffSynth-Studio/diffsynth/pipelines/qwen_image_physical.py:
+    :600      scheduler.set_timesteps(steps, dynamic_shift_len=(H//16)*(W//16))
+    :644-661  for each timestep: posi forward, nega forward (cfg != 1), CFG combine, Euler step
+    :664-667  VAE decode (physicedit_amd.vae)
+The prologue (text encoder, tokenizer, physical-reasoning text) is host Python on HF transformers in
+the reference and is outside this path: its outputs (prompt_emb, special_token_mask, edit image) are
+the inputs here.  The loop issues kernels only: no host<->device synchronisation inside it
+(the reference has three per forward: `.tolist()`, boolean-mask gather/scatter, scheduler argmin).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .dit import QwenImageDiTEngine, special_indices
+from .scheduler import qwen_image_scheduler
+
+BF = torch.bfloat16
+
+
+class DenoiseLoop:
+    def __init__(self, dit: QwenImageDiTEngine):
+        self.dit = dit
+        self.device = dit.device
+        self.scheduler = qwen_image_scheduler()
+        self.torch_dtype = BF
+
+    @torch.no_grad()
+    def __call__(self, noise: torch.Tensor, prompt_emb_posi: torch.Tensor, prompt_emb_nega: Optional[torch.Tensor],
+                 special_mask_posi: Optional[torch.Tensor], special_mask_nega: Optional[torch.Tensor],
+                 height: int, width: int, num_inference_steps: int = 30, cfg_scale: float = 4.0,
+                 edit_latents=None, exponential_shift_mu: Optional[float] = None,
+                 denoising_strength: float = 1.0) -> torch.Tensor:
+        """noise [1,16,H/8,W/8]; prompt_emb_* [1,T,3584] DEVICE tensors, mutated in place on their
+        special rows across the steps exactly like `inputs_posi["prompt_emb"]` in the reference."""
+        dev = self.device
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps, denoising_strength=denoising_strength,
+                          dynamic_shift_len=(height // 16) * (width // 16), exponential_shift_mu=exponential_shift_mu)
+        ts = sch.timesteps.to(self.torch_dtype)        # per step: timestep.unsqueeze(0).to(dtype)  (:649)
+        edits: List[torch.Tensor] = []
+        if edit_latents is not None:
+            edits = list(edit_latents) if isinstance(edit_latents, (list, tuple)) else [edit_latents]
+        use_cfg = cfg_scale != 1.0                      # (:654)
+        S_img = (height // 16) * (width // 16) + sum((e.shape[-2] // 2) * (e.shape[-1] // 2) for e in edits)
+        T_max = max(prompt_emb_posi.shape[-2], prompt_emb_nega.shape[-2] if use_cfg else 0)
+        self.dit.bind(S_img, T_max, num_inference_steps)
+        self.dit.prepare(ts)
+        idx_p = special_indices(special_mask_posi, dev)
+        idx_n = special_indices(special_mask_nega, dev) if use_cfg else None
+        latents = noise.to(device=dev, dtype=self.torch_dtype).contiguous().clone()
+        nxt = torch.empty_like(latents)
+        pred_p = torch.empty_like(latents)
+        pred_n = torch.empty_like(latents) if use_cfg else None
+        for i in range(num_inference_steps):
+            t = ts[i:i + 1]
+            self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p)
+            if use_cfg:
+                self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n)
+            ops.cfg_euler_step(pred_p, pred_n, latents, cfg_scale, sch.dsigma(i), out=nxt)
+            latents, nxt = nxt, latents
+        return latents

@@ -1,0 +1,125 @@
+"""CPU (`-m "not gpu"`) checks of the boundary and the host logic: the C-ABI library builds for
+gfx950, loads, and exports exactly the symbols include/physicedit_amd.h declares; host scalar code
+(scheduler, sinusoid, alpha, RoPE tables) equals the oracle bit for bit.  No kernel is launched."""
+import os
+import re
+
+import pytest
+import torch
+
+import oracle.physicedit_oracle as O
+from physicedit_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from physicedit_amd import build, _lib
+    try:
+        build.build(verbose=False)
+    except RuntimeError as e:
+        if not os.path.exists(_lib.LIB_PATH):
+            pytest.fail(f"HIP library could not be built and no prebuilt one exists: {e}")
+    return _lib.lib()
+
+
+def test_header_symbols_exported(built_lib):
+    from physicedit_amd import _lib
+    header = open(os.path.join(ROOT, "include", "physicedit_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pe_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(built_lib, name), name
+    assert built_lib.pe_abi_version() == 1
+    assert built_lib.pe_last_error() == b""
+
+
+def test_invalid_args_fail_loudly_without_gpu(built_lib):
+    """Argument validation happens before any launch: errors are codes + message, not crashes."""
+    from physicedit_amd import _lib
+    rc = built_lib.pe_gemm_bf16(0, None, 64, None, None, None, 64, 8, 8, 64, None, None, 0, None)
+    assert rc == -1 and b"null operand" in built_lib.pe_last_error()
+    rc = built_lib.pe_gemm_bf16(0, 1, 100, 1, None, 1, 64, 8, 8, 100, None, None, 0, None)
+    assert rc == -1 and b"multiple of 64" in built_lib.pe_last_error()
+    rc = built_lib.pe_flash_attn(1, 1, 1, 1, 24, 100, 100, 3072, 0.1, None)
+    assert rc == -1 and b"S_pad" in built_lib.pe_last_error()
+    assert built_lib.pe_dit_workspace_bytes(None, 10, 10, 1) == 0
+    with pytest.raises(_lib.PeError):
+        _lib.check(rc, "x")
+
+
+def test_no_cpu_fallback():
+    from physicedit_amd import ops
+    with pytest.raises(ValueError):
+        ops.gemm(torch.zeros((8, 64), dtype=BF), torch.zeros((8, 64), dtype=BF))
+    from physicedit_amd._lib import PeError
+    from physicedit_amd.dit import QwenImageDiTEngine
+    with pytest.raises(PeError):
+        QwenImageDiTEngine({}, None, device="cpu")
+
+
+def test_product_code_never_imports_oracle():
+    pkg = os.path.join(ROOT, "physicedit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_scheduler_matches_oracle_and_golden(golden):
+    from physicedit_amd.scheduler import qwen_image_scheduler
+    g = golden("G1_scheduler")
+    sch = qwen_image_scheduler()
+    assert torch.equal(sch.timesteps, g["default_timesteps"])
+    for steps, S0 in ((4, 1024), (4, 64), (40, 4096), (50, 6889)):
+        sch.set_timesteps(steps, dynamic_shift_len=S0)
+        assert torch.equal(sch.sigmas, g[f"sigmas_{steps}_{S0}"])
+        assert torch.equal(sch.timesteps, g[f"timesteps_{steps}_{S0}"])
+        gen = torch.Generator().manual_seed(11)
+        x = torch.randn((1, 16, 8, 8), generator=gen).to(BF)
+        v = torch.randn((1, 16, 8, 8), generator=gen).to(BF)
+        outs = torch.stack([sch.step(v, sch.timesteps[i], x) for i in range(steps)])
+        assert torch.equal(outs, g[f"step_{steps}_{S0}"])
+        tab = O.FlowMatchTables(steps, dynamic_shift_len=S0)
+        for i in range(steps):   # the scalar the GPU Euler kernel receives == the oracle's fp32 (sigma' - sigma)
+            sigma = tab.sigmas[i]
+            nxt = tab.sigmas[i + 1] if i + 1 < steps else 0
+            assert sch.dsigma(i) == float((nxt - sigma).item())
+
+
+def test_host_scalars_match_oracle(golden):
+    from physicedit_amd.scheduler import adapter_alpha, timestep_sinusoid, qwen_image_scheduler
+    g = golden("G2_time_embed")
+    sch = qwen_image_scheduler()
+    sch.set_timesteps(40, dynamic_shift_len=4096)
+    ts = sch.timesteps.to(BF)
+    assert torch.equal(timestep_sinusoid(ts / 1000), g["sinusoid_f32"])
+    t_min, t_max = O.adapter_t_range()
+    g9 = golden("G9_adapter")
+    for tv in (1000.0, 748.0, 300.0, 20.0):
+        t = torch.tensor([tv]).to(BF)
+        a, oma = adapter_alpha(t, t_min, t_max)
+        assert a == g9[f"alpha_{int(tv)}"].item()
+        av = O.adapter_alpha(t, t_min, t_max).to(BF)
+        assert oma == (1 - av).float().item()
+
+
+def test_rope_tables_match_oracle():
+    from physicedit_amd.rope import rope_cos_sin
+    for shapes, T in (([(1, 8, 8), (1, 6, 10)], 37), ([(1, 64, 64), (1, 64, 64)], 512), ([(1, 83, 83), (1, 64, 64)], 272)):
+        ci, si, ct, st = rope_cos_sin(shapes, T)
+        vid, txt = O.rope_tables(shapes, T)
+        assert torch.equal(ci, vid.real) and torch.equal(si, vid.imag)
+        assert torch.equal(ct, txt.real) and torch.equal(st, txt.imag)
+
+
+def test_lora_name_mapping_matches_oracle():
+    """Key -> module-name mapping of GeneralLoRALoader.get_name_dict (lora/__init__.py:11-25)."""
+    lora = synth.make_lora(1, 1, 4)
+    sd = {k: torch.zeros(s, dtype=BF) for k, s in synth.dit_layout(1)}
+    assert O.lora_merge(sd, lora) == len(synth.LORA_TARGETS) == 12

@@ -1,0 +1,180 @@
+"""`-m gpu` parity of the DiT composite / sampler loop against reference-generated golden vectors
+(tests/golden/G4..G6, G8, G9) and the oracle.  2-layer full-width DiT, small images: sizes the
+oracle finishes in seconds.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle.physicedit_oracle as O
+from physicedit_amd import synth
+from test_gpu_kernels import report, rnd, ulps
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def eng2():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd.dit import QwenImageDiTEngine
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    return QwenImageDiTEngine(sd, ad, device="cuda")
+
+
+def _model_fn_inputs(h, w, T, n_special, seed):
+    noise = synth.make_noise(seed, h, w)
+    g = torch.Generator().manual_seed(seed + 100)
+    edit = torch.randn((1, 16, h // 8, w // 8), generator=g).to(BF)
+    pe = synth.make_prompt_emb(seed + 7, T)
+    mask = synth.make_special_token_mask(T, n_special)
+    return noise, edit, pe, mask
+
+
+def stats(name, got, ref):
+    d = (got.float().cpu() - ref.float().cpu()).abs()
+    u = ulps(got, ref)
+    print(f"[parity] {name}: max|d| {d.max().item():.4e} mean|d| {d.mean().item():.4e} "
+          f"exact {(d == 0).float().mean().item()*100:.2f}% max {u.max().item():.1f} ulp")
+    return d, u
+
+
+def test_block_G4(golden):
+    """One QwenImageTransformerBlock (qwen_image_dit.py:359-401) composed from the granular C-ABI
+    operators exactly as dit.hip sequences them, vs the reference's own output (G4) and its fp32 run."""
+    from physicedit_amd import ops
+    from physicedit_amd.rope import RopeCache
+    g = golden("G4_block")
+    sd = synth.make_state_dict(synth.dit_block_layout(0), 1234)
+    cu = {k: v.cuda() for k, v in sd.items()}
+    p = "transformer_blocks.0."
+    gen = torch.Generator().manual_seed(44)
+    image = torch.randn((1, 128, 3072), generator=gen).to(BF)
+    text = torch.randn((1, 40, 3072), generator=gen).to(BF)
+    temb = (torch.randn((1, 3072), generator=gen) * 0.5).to(BF)
+    S_img, T, D = 128, 40, 3072
+    S = S_img + T
+    silu_t = F.silu(temb).cuda()                      # host-side tiny op for the test harness only
+    mod_i = ops.gemm(silu_t, cu[p + "img_mod.1.weight"], cu[p + "img_mod.1.bias"])[0]
+    mod_t = ops.gemm(silu_t, cu[p + "txt_mod.1.weight"], cu[p + "txt_mod.1.bias"])[0]
+    ch = lambda m, i: m[i * D:(i + 1) * D].contiguous()
+    x = torch.cat([image[0], text[0]]).cuda().contiguous()       # library order: [image | text]
+    ci, si, ct, stt = RopeCache("cuda").get([(1, 8, 8), (1, 8, 8)], T)
+    wq = lambda names: torch.cat([cu[p + "attn." + n + ".weight"] for n in names]).contiguous()
+    bq = lambda names: torch.cat([cu[p + "attn." + n + ".bias"] for n in names]).contiguous()
+
+    xm = ops.ln_modulate(x, ch(mod_i, 0), ch(mod_i, 1), S_img, ch(mod_t, 0), ch(mod_t, 1))
+    q, k, vt = ops.alloc_qkv(24, S, "cuda")
+    ops.qkv_rmsnorm_rope(xm[:S_img].contiguous(), wq(("to_q", "to_k", "to_v")), bq(("to_q", "to_k", "to_v")),
+                         cu[p + "attn.norm_q.weight"], cu[p + "attn.norm_k.weight"], ci, si, q, k, vt, 0)
+    ops.qkv_rmsnorm_rope(xm[S_img:].contiguous(), wq(("add_q_proj", "add_k_proj", "add_v_proj")),
+                         bq(("add_q_proj", "add_k_proj", "add_v_proj")), cu[p + "attn.norm_added_q.weight"],
+                         cu[p + "attn.norm_added_k.weight"], ct, stt, q, k, vt, S_img)
+    att = ops.flash_attn(q, k, vt, S)
+    xi = ops.gemm(att[:S_img].contiguous(), cu[p + "attn.to_out.0.weight"], cu[p + "attn.to_out.0.bias"], "gate_res",
+                  gate=ch(mod_i, 2), res=x[:S_img].contiguous())
+    xt = ops.gemm(att[S_img:].contiguous(), cu[p + "attn.to_add_out.weight"], cu[p + "attn.to_add_out.bias"], "gate_res",
+                  gate=ch(mod_t, 2), res=x[S_img:].contiguous())
+    x = torch.cat([xi, xt]).contiguous()
+    xm = ops.ln_modulate(x, ch(mod_i, 3), ch(mod_i, 4), S_img, ch(mod_t, 3), ch(mod_t, 4))
+    hi = ops.gemm(xm[:S_img].contiguous(), cu[p + "img_mlp.net.0.proj.weight"], cu[p + "img_mlp.net.0.proj.bias"], "gelu_sigmoid")
+    ht = ops.gemm(xm[S_img:].contiguous(), cu[p + "txt_mlp.net.0.proj.weight"], cu[p + "txt_mlp.net.0.proj.bias"], "gelu_sigmoid")
+    xi = ops.gemm(hi, cu[p + "img_mlp.net.2.weight"], cu[p + "img_mlp.net.2.bias"], "gate_res", gate=ch(mod_i, 5), res=xi)
+    xt = ops.gemm(ht, cu[p + "txt_mlp.net.2.weight"], cu[p + "txt_mlp.net.2.bias"], "gate_res", gate=ch(mod_t, 5), res=xt)
+
+    for name, got, ref, ref32 in (("image", xi, g["image_out"][0], g["image_out_f32"][0]),
+                                  ("text", xt, g["text_out"][0], g["text_out_f32"][0])):
+        d, u = stats(f"block.{name} vs reference bf16", got, ref)
+        e_hip = (got.float().cpu() - ref32).pow(2).mean().sqrt().item()
+        e_ref = (ref.float() - ref32).pow(2).mean().sqrt().item()
+        print(f"[parity] block.{name}: rms distance to the reference's fp32 run: hip {e_hip:.4e}  reference-bf16 {e_ref:.4e}")
+        # the HIP block must be as close to the fp32 truth as the reference's own bf16 run is
+        assert e_hip <= 1.25 * e_ref
+        # and elementwise within a few bf16 ulps of the reference bf16 output
+        assert u.max().item() <= 8.0
+        assert (u > 1.01).float().mean().item() < 0.02
+
+
+def test_model_fn_G5(golden, eng2):
+    """Two successive model_fn calls on the same prompt_emb: pins the in-place special-token
+    accumulation on the GPU path against the reference's outputs."""
+    g = golden("G5_model_fn")
+    noise, edit, pe, mask = _model_fn_inputs(256, 256, 48, 16, 0)
+    from physicedit_amd.dit import model_fn_qwen_image
+    pe_run = pe.cuda().clone()
+    for call, tval in enumerate((986.96, 749.27)):
+        t = torch.tensor([tval]).to(BF)
+        lat, loss = model_fn_qwen_image(dit=eng2, visual_thinking_adapter=True, latents=noise.cuda(), timestep=t,
+                                        prompt_emb=pe_run, prompt_emb_mask=torch.ones((1, 48)), special_token_mask=mask,
+                                        height=256, width=256, edit_latents=edit.cuda(), is_train=False)
+        assert loss == 0
+        m = mask[0]
+        # rows outside the mask must be bit-identical to the input
+        assert torch.equal(pe_run[0, ~m.cuda()].cpu(), pe[0, ~m])
+        d, u = stats(f"model_fn call{call} prompt_emb special rows", pe_run[0, m.cuda()], g[f"prompt_emb_after_call{call}"][0, m])
+        assert u.max().item() <= 4.0 and (u > 0).float().mean().item() < 0.08
+        d, u = stats(f"model_fn call{call} latents", lat, g[f"latents_call{call}"])
+        assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+    lat, _ = model_fn_qwen_image(dit=eng2, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF),
+                                 prompt_emb=pe.cuda().clone(), special_token_mask=None, height=256, width=256,
+                                 edit_latents=None, is_train=False)
+    d, u = stats("model_fn plain (no adapter, no edit)", lat, g["latents_plain"])
+    assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+
+
+@pytest.mark.parametrize("cfg", [1.0, 4.0])
+def test_loop_G6(golden, eng2, cfg):
+    g = golden("G6_loop")
+    from physicedit_amd.pipeline import DenoiseLoop
+    noise, edit, pe_p, mask_p = _model_fn_inputs(128, 128, 40, 16, 0)
+    pe_n = synth.make_prompt_emb(8, 24)
+    mask_n = synth.make_special_token_mask(24, 16)
+    loop = DenoiseLoop(eng2)
+    lat = loop(noise, pe_p.cuda().clone(), pe_n.cuda().clone(), mask_p, mask_n, 128, 128, num_inference_steps=4,
+               cfg_scale=cfg, edit_latents=edit.cuda())
+    d, u = stats(f"4-step loop cfg={cfg} final latents", lat, g[f"latents_cfg{cfg}_step3"])
+    # distance to an fp32 run of the same loop, next to the reference-bf16's own distance
+    sd32 = {k: v.float() for k, v in synth.make_state_dict(synth.dit_layout(2), 1234).items()}
+    ad32 = {k: v.float() for k, v in synth.make_state_dict(synth.adapter_layout(), 4321).items()}
+    lat32 = O.denoise_loop(sd32, ad32, noise.float(), pe_p.float(), pe_n.float(), mask_p, mask_n, 128, 128, 4,
+                           cfg_scale=cfg, edit_latents=edit.float(), dtype=torch.float32)
+    e_hip = (lat.float().cpu() - lat32).abs().max().item()
+    e_ref = (g[f"latents_cfg{cfg}_step3"].float() - lat32).abs().max().item()
+    print(f"[parity] loop cfg={cfg}: max distance to fp32 loop: hip {e_hip:.4e}  reference-bf16 {e_ref:.4e}")
+    assert e_hip <= 2.0 * e_ref + 1e-3
+    assert d.mean().item() <= 6e-3
+
+
+def test_lora_merge_G8(golden):
+    from physicedit_amd.dit import QwenImageDiTEngine
+    g, meta = golden("G8_lora", with_meta=True)
+    eng = QwenImageDiTEngine(synth.make_state_dict(synth.dit_layout(1), 1234), None, device="cuda")
+    before = eng.params["transformer_blocks.0.img_mlp.net.0.proj.weight"].clone()
+    n = eng.load_lora(synth.make_lora(4321, 1, meta["rank"]))
+    assert n == 12
+    for t in synth.LORA_TARGETS:
+        k = f"transformer_blocks.0.{t}.weight"
+        u = ulps(eng.params[k][:64, :256], g[k + ".head"], floor=2.0 ** -12)
+        assert u.max().item() <= 1.01 and (u > 0).float().mean().item() < 0.01, k
+    assert torch.equal(eng.params["transformer_blocks.0.img_mlp.net.0.proj.weight"], before)
+
+
+def test_adapter_G9(golden, eng2):
+    """VisualThinkingDualAdapter through the composite: one forward on a prompt whose 64 special rows
+    are the G9 input; the scattered rows must equal the reference's `mixed`."""
+    g = golden("G9_adapter")
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn((1, 64, 3584), generator=gen).to(BF)
+    T = 80
+    for tv in (1000.0, 748.0, 20.0):
+        pe = synth.make_prompt_emb(3, T)
+        mask = synth.make_special_token_mask(T, 64)
+        pe[0, mask[0]] = x[0]
+        pe_d = pe.cuda().clone()
+        from physicedit_amd.dit import special_indices
+        eng2.forward(synth.make_noise(0, 64, 64).cuda(), torch.tensor([tv]).to(BF), pe_d, special_indices(mask, "cuda"), None)
+        got = pe_d[0, mask[0].cuda()]
+        d, u = stats(f"adapter mixed t={tv}", got, g[f"mixed_{int(tv)}"][0])
+        assert u.max().item() <= 3.0 and (u > 0).float().mean().item() < 0.08

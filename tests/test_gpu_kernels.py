@@ -1,0 +1,211 @@
+"""`-m gpu` parity tests: every HIP kernel, called through the C-ABI, against the CPU oracle on the
+same seeded inputs.  Tolerances are in bf16 ulps of the reference value and are written next to each
+assert; the only legitimate source of difference is fp32 summation order (and device exp/rsqrt
+rounding), which flips a small fraction of bf16 roundings by one ulp.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle.physicedit_oracle as O
+from physicedit_amd import synth
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd import ops as _ops
+    from physicedit_amd._lib import lib
+    lib()  # raises (does not skip) if the HIP library is missing: no silent fallback
+    return _ops
+
+
+def ulps(got: torch.Tensor, ref: torch.Tensor, floor: float = 2.0 ** -6) -> torch.Tensor:
+    """|got-ref| in bf16 ulps of max(|ref|, floor)."""
+    g, r = got.float().cpu(), ref.float().cpu()
+    _, e = torch.frexp(r.abs().clamp_min(floor))
+    return (g - r).abs() / torch.exp2(e.float() - 8)
+
+
+def report(name, got, ref, max_ulp, max_frac, floor=2.0 ** -6):
+    u = ulps(got, ref, floor)
+    frac = (u > 0).float().mean().item()
+    mx = u.max().item()
+    print(f"[parity] {name}: mismatching {frac*100:.3f}% max {mx:.2f} ulp  (limits {max_frac*100:.1f}% / {max_ulp} ulp)")
+    assert torch.isfinite(got.float()).all(), name
+    assert mx <= max_ulp, (name, mx)
+    assert frac <= max_frac, (name, frac)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(BF)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def test_gemm_identity_asymmetric(ops):
+    """A = I against an asymmetric W: catches operand/row-column transposes exactly (no rounding)."""
+    K = 256
+    A = torch.eye(K, dtype=BF)
+    W = (torch.arange(320 * K, dtype=torch.float32).reshape(320, K) % 251 - 125).to(BF)  # exact in bf16
+    out = ops.gemm(A.cuda(), W.cuda())
+    assert torch.equal(out.cpu(), W.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 3072, 3072), (257, 264, 64), (40, 18432, 3072), (64, 64, 3072),
+                                   (1, 3072, 256), (520, 12288, 3072), (272, 3072, 12288)])
+def test_gemm_bias(ops, M, N, K):
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5), rnd((N,), 3, 0.1)
+    ref = F.linear(x, w, b)
+    out = ops.gemm(x.cuda(), w.cuda(), b.cuda())
+    report(f"gemm_bias {M}x{N}x{K}", out, ref, max_ulp=1.01, max_frac=0.03)
+    out2 = ops.gemm(x.cuda(), w.cuda(), None)
+    report(f"gemm_nobias {M}x{N}x{K}", out2, F.linear(x, w), max_ulp=1.01, max_frac=0.03)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 300, 1024, 512
+    x, w, b = rnd((M, K), 4), rnd((N, K), 5, K ** -0.5), rnd((N,), 6, 0.1)
+    y = F.linear(x, w, b)
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    # ApproximateGELU (qwen_image_dit.py:47-49)
+    report("gemm+gelu_sigmoid", ops.gemm(xc, wc, bc, "gelu_sigmoid"), y * torch.sigmoid(1.702 * y), 2.01, 0.05)
+    # nn.GELU() (helpers.py:127-131)
+    report("gemm+gelu_erf", ops.gemm(xc, wc, bc, "gelu_erf"), F.gelu(y), 2.01, 0.05)
+    report("gemm+silu", ops.gemm(xc, wc, bc, "silu"), F.silu(y), 2.01, 0.05)
+    # gated residual (qwen_image_dit.py:386): image + gate * out
+    gate, res = rnd((N,), 7, 0.5), rnd((M, N), 8)
+    ref = res + gate.unsqueeze(0) * y
+    report("gemm+gate_res", ops.gemm(xc, wc, bc, "gate_res", gate=gate.cuda(), res=res.cuda()), ref, 2.01, 0.05)
+    # in place (res aliases out), as the block uses it
+    r2 = res.cuda().clone()
+    ops.gemm(xc, wc, bc, "gate_res", gate=gate.cuda(), res=r2, out=r2)
+    report("gemm+gate_res in place", r2, ref, 2.01, 0.05)
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from physicedit_amd._lib import PeError
+    x, w = rnd((8, 100), 1).cuda(), rnd((16, 100), 2).cuda()
+    with pytest.raises(PeError):
+        ops.gemm(x, w)                      # K % 64 != 0
+    with pytest.raises(ValueError):
+        ops.gemm(rnd((8, 64), 1), rnd((16, 64), 2).cuda())   # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------------
+# QKV epilogue + attention
+# ------------------------------------------------------------------------------------------------
+def _qkv_ref(x, w, b, nq, nk, freqs):
+    y = F.linear(x, w, b)
+    q, k, v = y.chunk(3, dim=-1)
+    hd = lambda t: t.reshape(1, t.shape[0], 24, 128).permute(0, 2, 1, 3)
+    q, k, v = hd(q), hd(k), hd(v)
+    q = O.apply_rope(O.rmsnorm(q, nq), freqs)
+    k = O.apply_rope(O.rmsnorm(k, nk), freqs)
+    return q[0], k[0], v[0]
+
+
+@pytest.mark.parametrize("M,seq_off", [(128, 0), (300, 0), (40, 128), (37, 135)])
+def test_qkv_rmsnorm_rope(ops, M, seq_off):
+    K = 3072
+    x, w, b = rnd((M, K), 11), rnd((9216, K), 12, K ** -0.5), rnd((9216,), 13, 0.1)
+    nq, nk = synth.make_tensor(5, "norm_q.weight", (128,)), synth.make_tensor(5, "norm_k.weight", (128,))
+    _, txt = O.rope_tables([(1, 8, 8)], M)
+    qr, kr, vr = _qkv_ref(x, w, b, nq, nk, txt)
+    S = seq_off + M
+    q, k, vt = ops.alloc_qkv(24, S, "cuda")
+    ops.qkv_rmsnorm_rope(x.cuda(), w.cuda(), b.cuda(), nq.cuda(), nk.cuda(), txt.real.contiguous().cuda(),
+                         txt.imag.contiguous().cuda(), q, k, vt, seq_off)
+    report(f"qkv.q M={M} off={seq_off}", q[:, seq_off:S], qr, 2.01, 0.06)
+    report(f"qkv.k M={M} off={seq_off}", k[:, seq_off:S], kr, 2.01, 0.06)
+    report(f"qkv.v M={M} off={seq_off}", ops.unpack_vt(vt, S)[:, seq_off:S], vr, 1.01, 0.03)
+    # nothing outside the rows of this problem may be touched
+    assert torch.count_nonzero(q[:, :seq_off]).item() == 0 and torch.count_nonzero(q[:, S:]).item() == 0
+    pos = ops.vt_positions(vt.shape[2], "cuda")
+    mask = torch.ones(vt.shape[2], dtype=torch.bool, device="cuda")
+    mask[pos[seq_off:S]] = False
+    assert torch.count_nonzero(vt[:, :, mask]).item() == 0
+
+
+@pytest.mark.parametrize("S", [64, 100, 256, 700, 1093])
+def test_flash_attn(ops, S):
+    H = 24
+    q, k, v = rnd((H, S, 128), 21), rnd((H, S, 128), 22), rnd((H, S, 128), 23)
+    ref = F.scaled_dot_product_attention(q[None], k[None], v[None])[0]           # [H,S,128]
+    ref = ref.permute(1, 0, 2).reshape(S, H * 128)
+    sp = ops.s_pad_of(S)
+    qd = torch.zeros((H, sp, 128), dtype=BF, device="cuda"); qd[:, :S] = q.cuda()
+    kd = torch.full((H, sp, 128), float("nan"), dtype=BF, device="cuda"); kd[:, :S] = k.cuda()   # pad rows are masked
+    out = ops.flash_attn(qd, kd, ops.pack_vt(v.cuda(), sp), S)
+    # fp32 truth for scale: attention outputs are averages, |o| ~ 0.1; compare on an absolute floor
+    report(f"flash_attn S={S}", out, ref, max_ulp=3.01, max_frac=0.35, floor=2.0 ** -4)
+    ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0]
+    ref32 = ref32.permute(1, 0, 2).reshape(S, H * 128)
+    e_gpu = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
+    e_cpu = (ref.float() - ref32).pow(2).mean().sqrt().item()
+    print(f"[parity] flash_attn S={S}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
+    assert e_gpu <= 1.5 * e_cpu + 1e-6
+
+
+def test_flash_attn_peaked(ops):
+    """A spiked key forces large running-max jumps mid-sequence (online-softmax rescale path)."""
+    H, S = 24, 512
+    q, k, v = rnd((H, S, 128), 31), rnd((H, S, 128), 32), rnd((H, S, 128), 33)
+    k[:, 300] = q[:, 7] * 4.0
+    k[:, 470] = q[:, 200] * 6.0
+    ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0]
+    ref32 = ref32.permute(1, 0, 2).reshape(S, H * 128)
+    ref = F.scaled_dot_product_attention(q[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
+    out = ops.flash_attn(q.cuda(), k.cuda(), ops.pack_vt(v.cuda(), S), S)
+    e_gpu = (out.float().cpu() - ref32).abs().max().item()
+    e_cpu = (ref.float() - ref32).abs().max().item()
+    print(f"[parity] flash_attn peaked: max err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
+    assert e_gpu <= 2.0 * e_cpu + 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# row kernels
+# ------------------------------------------------------------------------------------------------
+def test_ln_modulate(ops):
+    rows, D = 333, 3072
+    x = rnd((rows, D), 41, 2.0) + 0.3
+    sa, ca, sb, cb = rnd((D,), 42, 0.3), rnd((D,), 43, 0.3), rnd((D,), 44, 0.3), rnd((D,), 45, 0.3)
+    ln = F.layer_norm(x, (D,), eps=1e-6)
+    ref = torch.cat([ln[:200] * (1 + ca) + sa, ln[200:] * (1 + cb) + sb])
+    out = ops.ln_modulate(x.cuda(), sa.cuda(), ca.cuda(), 200, sb.cuda(), cb.cuda())
+    report("ln_modulate", out, ref, 2.01, 0.02)
+
+
+def test_rmsnorm(ops):
+    x, w = rnd((77, 3584), 51, 1.5), synth.make_tensor(5, "txt_norm.weight", (3584,))
+    report("rmsnorm3584", ops.rmsnorm(x.cuda(), w.cuda()), O.rmsnorm(x, w), 1.01, 0.01)
+
+
+def test_patchify_roundtrip(ops):
+    lat = rnd((1, 16, 24, 40), 61)
+    tok = ops.patchify(lat.cuda())
+    assert torch.equal(tok.cpu(), O.patchify(lat)[0])
+    back = ops.unpatchify(tok, 16, 24, 40)
+    assert torch.equal(back.cpu(), lat)
+
+
+@pytest.mark.parametrize("cfg", [1.0, 4.0])
+def test_cfg_euler(ops, cfg):
+    p, n, x = rnd((1, 16, 32, 32), 71), rnd((1, 16, 32, 32), 72), rnd((1, 16, 32, 32), 73)
+    tab = O.FlowMatchTables(4, dynamic_shift_len=64)
+    from physicedit_amd.scheduler import qwen_image_scheduler
+    sch = qwen_image_scheduler()
+    sch.set_timesteps(4, dynamic_shift_len=64)
+    for i in range(4):
+        pred = n + cfg * (p - n) if cfg != 1.0 else p
+        ref = tab.step(pred, i, x)
+        out = ops.cfg_euler_step(p.cuda(), n.cuda(), x.cuda(), cfg, sch.dsigma(i))
+        assert torch.equal(out.cpu(), ref), (cfg, i)      # pure element-wise: bit exact
