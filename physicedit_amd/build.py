@@ -17,7 +17,11 @@ OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libphysicedit_amd.so")
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "dit.hip", "vae.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "physicedit_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -ffp-contract=off is LOAD-BEARING for parity: with bf16-typed operands LLVM narrows
+# float(bf16(a*b)) + float(c) to bf16 fmul/fadd and the default -ffp-contract=fast then fuses them
+# into one fma, silently deleting a bf16 rounding the reference performs (measured: 29 % of
+# ln_modulate outputs off by one ulp).  Fusion is written explicitly (fmaf) where it is wanted.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

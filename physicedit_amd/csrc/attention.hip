@@ -145,11 +145,11 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[s2][r] * scale_log2 - m_new);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[s2][r], scale_log2, -m_new));
                 st[s2][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
+        l_run = __builtin_fmaf(l_run, alpha, psum);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll

@@ -93,7 +93,7 @@ def test_block_G4(golden):
         # the HIP block must be as close to the fp32 truth as the reference's own bf16 run is
         assert e_hip <= 1.25 * e_ref
         # and elementwise within a few bf16 ulps of the reference bf16 output
-        assert u.max().item() <= 8.0
+        assert u.max().item() <= 4.0
         assert (u > 1.01).float().mean().item() < 0.02
 
 
@@ -114,7 +114,7 @@ def test_model_fn_G5(golden, eng2):
         # rows outside the mask must be bit-identical to the input
         assert torch.equal(pe_run[0, ~m.cuda()].cpu(), pe[0, ~m])
         d, u = stats(f"model_fn call{call} prompt_emb special rows", pe_run[0, m.cuda()], g[f"prompt_emb_after_call{call}"][0, m])
-        assert u.max().item() <= 4.0 and (u > 0).float().mean().item() < 0.08
+        assert u.max().item() <= 4.0 and (u > 0).float().mean().item() < (0.03, 0.25)[call]   # 2nd call compounds the 1st
         d, u = stats(f"model_fn call{call} latents", lat, g[f"latents_call{call}"])
         assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
     lat, _ = model_fn_qwen_image(dit=eng2, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF),
