@@ -167,6 +167,43 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* call, void* stream);
 /* Debug/test taps: device pointers into the bound workspace (valid after pe_dit_forward). */
 const void* pe_dit_debug_ptr(pe_dit_handle h, const char* name);
 
+/* ---------------------------------------------------------------------------------------------
+ * VAE operators (QwenImageVAE.encode/decode, models/qwen_image_vae.py:706-729).  Activations are
+ * NHWC bf16, B = 1, channel count padded to a multiple of 32 with zeros.
+ * ------------------------------------------------------------------------------------------- */
+
+/* 2-D conv = QwenImageCausalConv3d at T=1 (only temporal tap 2 contributes, :40-50) / nn.Conv2d.
+ * w [Cout_p][ksize*ksize][Cin_p] (tap-major, channel-minor), bias [Cout_p], res nullable
+ * [Hout*Wout][Cout_p] added after the conv's own rounding (ResidualBlock `x + h`, :152).
+ * ksize 3: stride 1 pads 1 on every side; stride 2 is ZeroPad2d((0,1,0,1)) + stride-2 conv (:249);
+ * upsample2x reads the input through nearest-exact 2x upsampling (:240) without materialising it.
+ * zero_page: >= 64 B of device zeros (halo reads).  ksize 1: plain 1x1 conv. */
+int pe_conv2d_nhwc(const void* in, const void* w, const void* bias, const void* res, void* out, const void* zero_page,
+                   int Hin, int Win, int Cin_p, int Cout_p, int ksize, int stride, int upsample2x, void* stream);
+
+/* QwenImageRMS_norm (:76-77) over the C valid channels of each pixel, optional fused SiLU. */
+int pe_vae_rmsnorm(const void* x, const void* gamma, void* out, int npix, int C, int Cp, int silu, void* stream);
+
+/* layout converters.  mode 0 copy; mode 1 (decode, :723-724) y = x / tb[c] + ta[c];
+ * mode 2 (encode, :713-714) y = (x - ta[c]) * tb[c]; ta = mean, tb = 1/std, bf16 [C]. */
+int pe_nchw_to_nhwc(const void* in, void* out, int C, int HW, int Cp, int mode, const void* ta, const void* tb,
+                    void* stream);
+int pe_nhwc_to_nchw(const void* in, void* out, int C, int HW, int Cp, int mode, const void* ta, const void* tb,
+                    void* stream);
+
+/* single-head attention, D = 384 (QwenImageAttentionBlock, :173-198): qkv [N][1152] (q|k|v),
+ * vt_scratch >= 384*round_up(N,32) bf16, out [N][384]. */
+int pe_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement: HIP-event timing of sampled launches, recorded on the launch stream.
+ * kind: 0 = MFMA GEMM (work = algorithmic FLOPs 2MNK), 1 = flash attention (4*S*S*128*H FLOPs),
+ *       2 = row kernels (work = algorithmic bytes), 3 = VAE convolutions (FLOPs).
+ * ------------------------------------------------------------------------------------------- */
+int pe_profile_enable(int max_events, int sample_every);
+void pe_profile_disable(void);
+int pe_profile_read(int kind, long long* launches_seen, long long* sampled, double* total_ms, double* total_work);
+
 #ifdef __cplusplus
 }
 #endif

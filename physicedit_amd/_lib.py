@@ -73,6 +73,16 @@ SIGNATURES = {
     "pe_dit_prepare": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "pe_dit_forward": (c_int, [c_void_p, C.POINTER(DitCall), c_void_p]),
     "pe_dit_debug_ptr": (c_void_p, [c_void_p, C.c_char_p]),
+    "pe_conv2d_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_void_p]),
+    "pe_vae_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pe_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pe_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pe_vae_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "pe_profile_enable": (c_int, [c_int, c_int]),
+    "pe_profile_disable": (None, []),
+    "pe_profile_read": (c_int, [c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None

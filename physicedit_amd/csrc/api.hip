@@ -85,4 +85,28 @@ int pe_cfg_euler_step(const void* posi, const void* nega, const void* latents, v
     return launch_cfg_euler(posi, nega, latents, latents_out, n, cfg_scale, use_cfg, dsigma, (hipStream_t)stream);
 }
 
+int pe_conv2d_nhwc(const void* in, const void* w, const void* bias, const void* res, void* out, const void* zero_page,
+                   int Hin, int Win, int Cin_p, int Cout_p, int ksize, int stride, int upsample2x, void* stream) {
+    return launch_conv_nhwc(in, w, bias, res, out, zero_page, Hin, Win, Cin_p, Cout_p, ksize, stride, upsample2x,
+                            (hipStream_t)stream);
+}
+
+int pe_vae_rmsnorm(const void* x, const void* gamma, void* out, int npix, int C, int Cp, int silu, void* stream) {
+    return launch_vae_rmsnorm(x, gamma, out, npix, C, Cp, silu, (hipStream_t)stream);
+}
+
+int pe_nchw_to_nhwc(const void* in, void* out, int C, int HW, int Cp, int mode, const void* ta, const void* tb,
+                    void* stream) {
+    return launch_nchw_to_nhwc(in, out, C, HW, Cp, mode, ta, tb, (hipStream_t)stream);
+}
+
+int pe_nhwc_to_nchw(const void* in, void* out, int C, int HW, int Cp, int mode, const void* ta, const void* tb,
+                    void* stream) {
+    return launch_nhwc_to_nchw(in, out, C, HW, Cp, mode, ta, tb, (hipStream_t)stream);
+}
+
+int pe_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, void* stream) {
+    return launch_vae_attention(qkv, vt_scratch, out, N, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -209,8 +209,10 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     }
     const int nqb = (S + Q_BLOCK - 1) / Q_BLOCK;
     const float scale_log2 = scale * 1.44269504088896340736f;
+    const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);  // QK^T + PV
     hipLaunchKernelGGL(flash_attn_kernel, dim3(H * nqb), dim3(ATT_THREADS), ATT_LDS, stream, (const bf16*)q,
                        (const bf16*)k, (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, nqb);
+    prof_end(slot, stream);
     return check_launch("flash_attn_kernel");
 }
 

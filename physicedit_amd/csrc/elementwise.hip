@@ -72,9 +72,11 @@ int launch_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, 
     PE_REQUIRE(dim == 3072, "ln_modulate: dim=%d unsupported (DiT width 3072 only)", dim);
     if (!shift_b) shift_b = shift_a;
     if (!scale_b) scale_b = scale_a;
+    const int slot = prof_begin(PROF_ROW, 4.0 * (double)rows * dim, stream);  // bytes: read + write bf16
     hipLaunchKernelGGL((ln_modulate_kernel<6>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x,
                        (bf16*)out, rows, dim, rows_a, (const bf16*)shift_a, (const bf16*)scale_a,
                        (const bf16*)shift_b, (const bf16*)scale_b, eps);
+    prof_end(slot, stream);
     return check_launch("ln_modulate_kernel");
 }
 

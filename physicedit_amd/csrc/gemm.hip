@@ -344,15 +344,21 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     if (nproblems == 1) args.p[1] = args.p[0];
     args.tiles0 = tiles[0];
     const int ntiles = tiles[0] + tiles[1];
+    double flops = 0.0;  // algorithmic 2*M*N*K of the launch (what the roofline fraction is quoted on)
+    for (int i = 0; i < nproblems; ++i) flops += 2.0 * problems[i].M * (double)problems[i].N * problems[i].K;
+    const int slot = prof_begin(PROF_GEMM, flops, stream);
+    int rc;
     switch (epilogue) {
-        case EPI_BIAS: return launch_t<EPI_BIAS>(args, ntiles, stream);
-        case EPI_GELU_SIG: return launch_t<EPI_GELU_SIG>(args, ntiles, stream);
-        case EPI_GELU_ERF: return launch_t<EPI_GELU_ERF>(args, ntiles, stream);
-        case EPI_GATE_RES: return launch_t<EPI_GATE_RES>(args, ntiles, stream);
-        case EPI_QKV: return launch_t<EPI_QKV>(args, ntiles, stream);
-        case EPI_SILU: return launch_t<EPI_SILU>(args, ntiles, stream);
-        default: return set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
+        case EPI_BIAS: rc = launch_t<EPI_BIAS>(args, ntiles, stream); break;
+        case EPI_GELU_SIG: rc = launch_t<EPI_GELU_SIG>(args, ntiles, stream); break;
+        case EPI_GELU_ERF: rc = launch_t<EPI_GELU_ERF>(args, ntiles, stream); break;
+        case EPI_GATE_RES: rc = launch_t<EPI_GATE_RES>(args, ntiles, stream); break;
+        case EPI_QKV: rc = launch_t<EPI_QKV>(args, ntiles, stream); break;
+        case EPI_SILU: rc = launch_t<EPI_SILU>(args, ntiles, stream); break;
+        default: rc = set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
     }
+    prof_end(slot, stream);
+    return rc;
 }
 
 }  // namespace pe

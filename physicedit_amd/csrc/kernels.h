@@ -68,4 +68,25 @@ int launch_adapter_mix_scatter(const void* dino, const void* vae, float alpha, f
 int launch_cfg_euler(const void* posi, const void* nega, const void* latents, void* out, size_t n,
                      float cfg_scale, int use_cfg, float dsigma, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// VAE (vae.hip): NHWC bf16 activations, channels padded to a multiple of 32
+// ---------------------------------------------------------------------------------------------
+int launch_conv_nhwc(const void* in, const void* w, const void* bias, const void* res, void* out, const void* zero,
+                     int Hin, int Win, int Cin_p, int Cout_p, int ksize, int stride, int upsample,
+                     hipStream_t stream);
+int launch_vae_rmsnorm(const void* x, const void* gamma, void* out, int npix, int C, int Cp, int silu,
+                       hipStream_t stream);
+int launch_nchw_to_nhwc(const void* in, void* out, int C, int HW, int Cp, int mode, const void* ta, const void* tb,
+                        hipStream_t stream);
+int launch_nhwc_to_nchw(const void* in, void* out, int C, int HW, int Cp, int mode, const void* ta, const void* tb,
+                        hipStream_t stream);
+int launch_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// optional in-library timing (profile.hip): HIP events around sampled launches
+// ---------------------------------------------------------------------------------------------
+enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROW = 2, PROF_CONV = 3, PROF_KINDS = 4 };
+int prof_begin(int kind, double work, hipStream_t stream);  // -> slot or -1
+void prof_end(int slot, hipStream_t stream);
+
 }  // namespace pe
