@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""Benchmark of the PhysicEdit denoising hot path on MI355X.
+
+One "step" = ONE EDITED IMAGE through the whole hot path (BASELINE.json configs[1]):
+    VAE-encode the 1024x1024 edit image  ->  40 flow-match steps x {posi forward (T=512), nega forward
+    (T=272), CFG 4.0 combine, Euler update} on the 60-layer Qwen-Image DiT with a merged rank-128 LoRA
+    and the visual-thinking adapter on 64 special tokens  ->  VAE-decode to 1024x1024.
+Synthetic inputs and random-init weights of the real architecture (no network).  Inputs are resident
+in HBM when the timed region starts.  N > 1: one process per GPU (torchrun), weights replicated,
+images sharded over ranks (weak scaling, no data-path collective; an RCCL all-gather of the decoded
+latents closes the batch, as the north star specifies).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the bf16 MFMA GEMM):
+algorithmic FLOPs / HIP-event time of sampled launches inside the timed region.  `cpu_baseline` times
+the oracle (CPU restatement, validated bit-exact against the reference) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2516.6   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+
+def flops_forward(S_img, T, layers=60):
+    """SURVEY.md section 8(a) / BASELINE.md section 3 FLOP model."""
+    S = S_img + T
+    return layers * (226_492_416 * S + 12_288 * S * S + 226_492_416) + 786_432 * S_img + 22_020_096 * T + 58e6
+
+
+def flops_image(height, width, steps, T_pos, T_neg, cfg, layers=60, edit_hw=(1024, 1024)):
+    S0 = (height // 16) * (width // 16)
+    Se = (edit_hw[0] // 16) * (edit_hw[1] // 16)
+    f = steps * (flops_forward(S0 + Se, T_pos, layers) + (flops_forward(S0 + Se, T_neg, layers) if cfg != 1.0 else 0))
+    f += steps * (2 if cfg != 1.0 else 1) * 19.73e9                       # adapter heads
+    vae = (2.44e12 + 0.41e12) * (edit_hw[0] * edit_hw[1]) / (1024 * 1024) + (4.30e12) * (height * width) / (1024 * 1024) \
+        + 0.41e12 * ((height * width) / (1024 * 1024)) ** 2
+    return f + vae
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1, help="timed images per rank")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed images per rank")
+    ap.add_argument("--layers", type=int, default=60)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--inference-steps", type=int, default=40)
+    ap.add_argument("--cfg", type=float, default=4.0)
+    ap.add_argument("--t-pos", type=int, default=512)
+    ap.add_argument("--t-neg", type=int, default=272)
+    ap.add_argument("--lora-rank", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from physicedit_amd import synth, ops
+    from physicedit_amd._lib import lib
+    from physicedit_amd.dit import QwenImageDiTEngine
+    from physicedit_amd.pipeline import DenoiseLoop
+    from physicedit_amd.vae import QwenImageVAE, preprocess_image
+    import ctypes as C
+
+    BF = torch.bfloat16
+    H, W = args.height, args.width
+    t0 = time.time()
+    # ---- model: random-init weights of the real architecture, generated on the device
+    sd = synth.make_state_dict_device(synth.dit_layout(args.layers), 1234, dev)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    eng = QwenImageDiTEngine(sd, ad, device=dev)
+    del sd
+    torch.cuda.empty_cache()
+    if args.lora_rank > 0:
+        # PhysicEdit LoRA, merged at load like validate.py does (hotload=False), 12 targets x layers
+        n = 0
+        for i in range(args.layers):
+            lora = {k.replace("transformer_blocks.0.", f"transformer_blocks.{i}."): v.to(dev)
+                    for k, v in synth.make_lora(4321 + i, 1, args.lora_rank).items()}
+            n += eng.load_lora(lora)
+        assert n == 12 * args.layers
+    vae = QwenImageVAE(synth.make_state_dict(synth.vae_layout(), 77), device=dev)
+    loop = DenoiseLoop(eng)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] model ready in {time.time()-t0:.1f}s ({args.layers} layers, "
+              f"{torch.cuda.memory_allocated()/2**30:.1f} GiB resident)", file=sys.stderr)
+
+    # ---- inputs (resident in HBM before the timed region)
+    n_img = args.warmup + args.steps
+    edit_img = preprocess_image(synth.make_edit_image_u8(1024, 1024, 0), dev)       # edit image auto-resized to ~1024^2 area
+    pe_p0 = synth.make_prompt_emb(7, args.t_pos).to(dev)
+    pe_n0 = synth.make_prompt_emb(8, args.t_neg).to(dev)
+    mask_p = synth.make_special_token_mask(args.t_pos)
+    mask_n = synth.make_special_token_mask(args.t_neg)
+    noises = [synth.make_noise(1000 * rank + i, H, W).to(dev) for i in range(n_img)]
+    results = []
+
+    def one_image(i):
+        edit_latents = vae.encode(edit_img)
+        lat = loop(noises[i], pe_p0.clone(), pe_n0.clone(), mask_p, mask_n, H, W,
+                   num_inference_steps=args.inference_steps, cfg_scale=args.cfg, edit_latents=edit_latents)
+        img = vae.decode(lat)
+        return lat, img
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        one_image(i)
+    torch.cuda.synchronize()
+    barrier()
+    # sample every 16th GEMM launch: ~1.2k event pairs per image
+    lib().pe_profile_enable(16384, 16)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for i in range(args.warmup, n_img):
+        results.append(one_image(i))
+    torch.cuda.synchronize()
+    barrier()
+    t_end = time.perf_counter()
+    elapsed = t_end - t_start
+    if dist is not None:
+        # close the batch: RCCL all-gather of the decoded latents over xGMI (512 KiB per image)
+        mine = torch.cat([r[0] for r in results], dim=0)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ok = all(torch.isfinite(r[1].float()).all().item() for r in results)
+
+    prof = {}
+    for kind, name in ((0, "gemm"), (1, "attn"), (2, "row"), (3, "conv")):
+        seen, sampled, ms, work = C.c_longlong(), C.c_longlong(), C.c_double(), C.c_double()
+        lib().pe_profile_read(kind, C.byref(seen), C.byref(sampled), C.byref(ms), C.byref(work))
+        prof[name] = dict(launches=seen.value, sampled=sampled.value, ms=ms.value, work=work.value)
+    lib().pe_profile_disable()
+
+    if rank == 0:
+        images = args.steps * world
+        value = images / elapsed
+        fl = flops_image(H, W, args.inference_steps, args.t_pos, args.t_neg, args.cfg, args.layers)
+        g = prof["gemm"]
+        achieved = (g["work"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
+        out = {
+            "metric": "edited images/sec @1024px, 40-step flow-match",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {H}x{W} edit, {args.inference_steps} steps, CFG {args.cfg}, "
+                                   f"{args.layers}-layer Qwen-Image DiT + merged rank-{args.lora_rank} LoRA + "
+                                   f"visual-thinking adapter (64 special tokens), T_pos={args.t_pos} T_neg={args.t_neg}, "
+                                   f"VAE encode(1024x1024 edit image)+decode included",
+                       "images_per_rank": args.steps, "parallelism": f"dp{world} (images sharded, weights replicated)",
+                       "finite_outputs": ok},
+            "whole_path": {"algorithmic_pflop_per_image": fl / 1e15,
+                           "achieved_tflops_per_gpu": fl * value / world / 1e12,
+                           "frac_of_bf16_mfma_peak": fl * value / world / 1e12 / PEAK_BF16_TFLOPS},
+            "roofline": {"kernel": "gemm_bf16_kernel (all epilogues)", "bound": "mfma", "achieved": achieved,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                         "traffic": None,
+                         "launches_in_timed_region": g["launches"], "launches_sampled": g["sampled"],
+                         "avg_launch_ms": g["ms"] / max(g["sampled"], 1),
+                         "avg_algorithmic_gflop_per_launch": g["work"] / max(g["sampled"], 1) / 1e9},
+            "other_kernels": {
+                "flash_attn": {"achieved_tflops": (prof["attn"]["work"] / (prof["attn"]["ms"] * 1e-3) / 1e12) if prof["attn"]["ms"] > 0 else None,
+                               "avg_launch_ms": prof["attn"]["ms"] / max(prof["attn"]["sampled"], 1)},
+                "ln_modulate": {"achieved_GBps": (prof["row"]["work"] / (prof["row"]["ms"] * 1e-3) / 1e9) if prof["row"]["ms"] > 0 else None},
+                "vae_conv": {"achieved_tflops": (prof["conv"]["work"] / (prof["conv"]["ms"] * 1e-3) / 1e12) if prof["conv"]["ms"] > 0 else None},
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args):
+    """The oracle (kind "port": CPU restatement, bit-exact vs the reference on tests/golden) timed on the
+    host cores on a BOUNDED sample of the same workload, extrapolated with the layer/step counts:
+        t_image = steps * layers * (t_block(T_pos) + t_block(T_neg)) + t_vae_enc + t_vae_dec
+    Sample: one full-width DiT block at the full configs[1] sequence (S_img=8192; T=512 and T=272),
+    plus VAE decode at 256x256 scaled by area to 1024x1024 for encode (x2.44/4.30 by FLOPs) and decode."""
+    import torch
+    import oracle.physicedit_oracle as O      # measured as the CPU baseline; never on the product path
+    from physicedit_amd import synth
+    BF = torch.bfloat16
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    S_img = (args.height // 16) * (args.width // 16) + 4096
+    sd = synth.make_state_dict(synth.dit_block_layout(0), 1234)
+    g = torch.Generator().manual_seed(0)
+    temb = (torch.randn((1, 3072), generator=g) * 0.5).to(BF)
+    t_blk = {}
+    with torch.no_grad():
+        for T in (args.t_pos, args.t_neg):
+            image = torch.randn((1, S_img, 3072), generator=g).to(BF)
+            text = torch.randn((1, T, 3072), generator=g).to(BF)
+            rope = O.rope_tables([(1, args.height // 16, args.width // 16), (1, 64, 64)], T)
+            t0 = time.perf_counter()
+            O.block_forward(sd, 0, image, text, temb, rope)
+            t_blk[T] = time.perf_counter() - t0
+        vs = synth.make_state_dict(synth.vae_layout(), 77)
+        lat = torch.randn((1, 16, 32, 32), generator=g).to(BF)
+        O.VAE_CONV_MODE = "2d"
+        try:
+            t0 = time.perf_counter()
+            O.vae_decode(vs, lat)
+            t_dec256 = time.perf_counter() - t0
+        finally:
+            O.VAE_CONV_MODE = "3d"
+    area = (args.height * args.width) / (256 * 256)
+    t_dec = t_dec256 * area
+    t_enc = t_dec256 * (1024 * 1024) / (256 * 256) * (2.85 / 4.71)
+    per_image = args.inference_steps * args.layers * (t_blk[args.t_pos] + (t_blk[args.t_neg] if args.cfg != 1.0 else 0)) + t_enc + t_dec
+    return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 DiT block fwd at full shape S_img={S_img}: T={args.t_pos} {t_blk[args.t_pos]:.2f}s, "
+                      f"T={args.t_neg} {t_blk[args.t_neg]:.2f}s; VAE decode 256x256 {t_dec256:.2f}s (2-D conv form); "
+                      f"extrapolated x{args.inference_steps} steps x{args.layers} layers + VAE scaled by area",
+            "extrapolated_seconds_per_image": per_image}
+
+
+if __name__ == "__main__":
+    main()
