@@ -174,6 +174,7 @@ def main():
         fl = flops_image(H, W, args.inference_steps, args.t_pos, args.t_neg, args.cfg, args.layers)
         g = prof["gemm"]
         achieved = (g["work"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic()
         out = {
             "metric": "edited images/sec @1024px, 40-step flow-match",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,7 +191,7 @@ def main():
                            "frac_of_bf16_mfma_peak": fl * value / world / 1e12 / PEAK_BF16_TFLOPS},
             "roofline": {"kernel": "gemm_bf16_kernel (all epilogues)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "launches_in_timed_region": g["launches"], "launches_sampled": g["sampled"],
                          "avg_launch_ms": g["ms"] / max(g["sampled"], 1),
                          "avg_algorithmic_gflop_per_launch": g["work"] / max(g["sampled"], 1) / 1e9},
@@ -207,6 +208,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the block GEMMs (launch-weighted mean over QKV / out-proj / MLP-up /
+    MLP-down).  PMC counters cannot be collected from inside this process; they come from the committed
+    rocprofv3 --pmc passes of this same command (tools/pmc_traffic_summary.py), or null if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    rows = [r for r in json.load(open(path))["kernels"] if "gemm_bf16_kernel" in r["kernel"] and r["workgroups"] >= 400]
+    n = sum(r["launches"] for r in rows)
+    if not n:
+        return None, None
+    return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n, "profiles/r01_pmc_traffic.json"
 
 
 def cpu_baseline(args):

@@ -35,6 +35,9 @@ extern "C" {
 const char* pe_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int pe_abi_version(void);
+/* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant").
+ * Production callers never need it: the compiled defaults are the validated schedules. */
+int pe_debug_set(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Granular operators (each is one kernel launch; used by the parity tests and by the composites)

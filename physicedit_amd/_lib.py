@@ -55,6 +55,7 @@ class DitCall(C.Structure):
 SIGNATURES = {
     "pe_last_error": (C.c_char_p, []),
     "pe_abi_version": (c_int, []),
+    "pe_debug_set": (c_int, [C.c_char_p, c_int]),
     "pe_gemm_bf16": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_int, c_void_p]),
     "pe_qkv_rmsnorm_rope": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

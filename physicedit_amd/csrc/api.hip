@@ -34,6 +34,13 @@ extern "C" {
 const char* pe_last_error(void) { return g_err; }
 int pe_abi_version(void) { return 1; }
 
+int pe_debug_set(const char* key, int value) {
+    PE_REQUIRE(key != nullptr, "pe_debug_set: null key");
+    if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return PE_OK; }
+    if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
+    return set_error(PE_ERR_INVALID_ARG, "pe_debug_set: unknown key %s", key);
+}
+
 int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
                  int M, int N, int K, const void* gate, const void* res, int ldr, void* stream) {
     PE_REQUIRE(epilogue != EPI_QKV, "pe_gemm_bf16: use pe_qkv_rmsnorm_rope for the QKV epilogue");

@@ -34,6 +34,7 @@ constexpr int KV_TILE = 64;
 constexpr int ATT_STAGE = 2 * KV_TILE * 128 * 2;  // K tile 16 KiB + Vt tile 16 KiB
 constexpr int ATT_LDS = 2 * ATT_STAGE;            // 64 KiB
 constexpr int Q_BLOCK = 256;
+int g_attn_variant = 0;
 
 __global__ void __launch_bounds__(ATT_THREADS, 2)
 flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,

@@ -44,6 +44,8 @@ struct GemmProblem {
 };
 
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream);
+extern int g_gemm_variant;  // experiment knobs (pe_debug_set); production paths use the compiled defaults
+extern int g_attn_variant;
 
 // ---------------------------------------------------------------------------------------------
 // flash attention over the joint sequence (no mask), D = 128
