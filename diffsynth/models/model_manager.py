@@ -1,0 +1,51 @@
+"""Minimal `ModelManager` (reference: models/model_manager.py:350-384): loads checkpoint files and files
+them under the names the pipeline fetches.  The reference detects the model class by an md5 of the sorted
+key/shape list (configs/model_config.py:21-26); the three models of this path are told apart here by a
+characteristic key, which is equivalent for well-formed Qwen-Image checkpoints."""
+from typing import Dict, List, Union
+
+import torch
+
+from .utils import load_state_dict
+
+_SIGNATURES = (
+    ("qwen_image_dit", "transformer_blocks.0.img_mod.1.weight"),
+    ("qwen_image_vae", "decoder.up_blocks.0.resnets.0.conv1.weight"),
+    ("qwen_image_text_encoder", "model.language_model.layers.0.self_attn.q_proj.weight"),
+    ("qwen_image_text_encoder", "model.layers.0.self_attn.q_proj.weight"),
+)
+
+
+def detect_model_name(state_dict: Dict[str, torch.Tensor]) -> str:
+    for name, key in _SIGNATURES:
+        if key in state_dict:
+            return name
+    return "unknown"
+
+
+class ModelManager:
+    def __init__(self, torch_dtype=torch.bfloat16, device="cpu"):
+        self.torch_dtype = torch_dtype
+        self.device = device
+        self.model: List[Dict[str, torch.Tensor]] = []
+        self.model_name: List[str] = []
+        self.model_path: List[Union[str, List[str]]] = []
+
+    def load_model(self, file_path: Union[str, List[str]], device=None, torch_dtype=None):
+        paths = file_path if isinstance(file_path, (list, tuple)) else [file_path]
+        sd: Dict[str, torch.Tensor] = {}
+        for p in sorted(paths):
+            sd.update(load_state_dict(p, torch_dtype=torch_dtype or self.torch_dtype, device="cpu"))
+        self.model.append(sd)
+        self.model_name.append(detect_model_name(sd))
+        self.model_path.append(file_path)
+
+    def load_models(self, file_path_list, **kw):
+        for p in file_path_list:
+            self.load_model(p, **kw)
+
+    def fetch_model(self, model_name, file_path=None, require_model_path=False):
+        for sd, name, path in zip(self.model, self.model_name, self.model_path):
+            if name == model_name and (file_path is None or path == file_path):
+                return (sd, path) if require_model_path else sd
+        return None

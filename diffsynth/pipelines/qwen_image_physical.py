@@ -1,0 +1,296 @@
+"""`diffsynth.pipelines.qwen_image_physical` façade: `QwenImagePhysicPipeline`, `ModelConfig`,
+`model_fn_qwen_image` with the reference's call surface, running the hot path on the MI355X kernels.
+
+Reference: DiffSynth-Studio/diffsynth/pipelines/qwen_image_physical.py (class :183, from_pretrained
+:497-541, load_lora :250-276, __call__ :544-669) and diffsynth/utils/__init__.py (ModelConfig :160-220,
+BasePipeline image helpers :60-83, generate_noise :119-124).
+
+What runs where:
+  * hot path (this repo): noise, edit-image VAE encode, 40-step CFG loop on the DiT + adapter, VAE decode;
+  * prompt prologue (reference / transformers, host Python): `pipe.prompt_encoder(pipe, prompt=..., negative_prompt=...,
+    edit_image=..., cfg=...) -> (posi, nega)` dicts with `prompt_emb [1,T,3584]` and `special_token_mask [1,T]`.
+    `from_pretrained` installs nothing there: wire the reference's QwenImageUnit_PromptEmbedder /
+    PhysicalVerbalEmbedder (qwen_image_physical.py:732-990) or any callable producing the same tensors.
+"""
+from __future__ import annotations
+
+import glob
+import math
+import os
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from physicedit_amd import _lib
+from physicedit_amd.dit import QwenImageDiTEngine, model_fn_qwen_image  # noqa: F401  (re-exported operator)
+from physicedit_amd.pipeline import DenoiseLoop
+from physicedit_amd.scheduler import qwen_image_scheduler
+from physicedit_amd.vae import QwenImageVAE, preprocess_image, vae_output_to_u8
+
+from ..models.model_manager import ModelManager
+from ..models.utils import load_state_dict
+
+SPECIAL_TOKEN_NUM = 64
+
+
+@dataclass
+class ModelConfig:
+    """Same fields as the reference dataclass (utils/__init__.py:160-170).  There is no network here, so
+    `download_if_necessary` only resolves local files: `local_model_path/model_id/origin_file_pattern`."""
+    path: Union[str, List[str]] = None
+    model_id: str = None
+    origin_file_pattern: Union[str, List[str]] = None
+    download_resource: str = "ModelScope"
+    offload_device: Optional[Union[str, torch.device]] = None
+    offload_dtype: Optional[torch.dtype] = None
+    local_model_path: str = None
+    skip_download: bool = False
+
+    def download_if_necessary(self, use_usp=False):
+        if self.path is not None:
+            return
+        if self.model_id is None:
+            raise ValueError('No valid model files. Please use `ModelConfig(path="xxx")` or '
+                             '`ModelConfig(model_id="xxx/yyy", origin_file_pattern="zzz")`.')
+        if self.local_model_path is None:
+            self.local_model_path = "./models"
+        pattern = self.origin_file_pattern or ""
+        base = os.path.join(self.local_model_path, self.model_id)
+        if pattern == "" or (isinstance(pattern, str) and pattern.endswith("/")):
+            self.path = os.path.join(base, pattern)
+        else:
+            self.path = glob.glob(os.path.join(base, pattern))
+            if isinstance(self.path, list) and len(self.path) == 1:
+                self.path = self.path[0]
+        if self.path in ([], None) or (isinstance(self.path, str) and not os.path.exists(self.path)):
+            raise FileNotFoundError(f"ModelConfig: nothing matches {os.path.join(base, pattern)} (no download: offline build)")
+
+
+class _AdapterView:
+    """Stands in for `pipe.visual_thinking_adapter` (an nn.Module in the reference): only its state matters here."""
+
+    def __init__(self):
+        self.state: Dict[str, torch.Tensor] = {}
+
+    def state_dict(self):
+        return dict(self.state)
+
+
+class QwenImagePhysicPipeline:
+    use_special_tokens = True
+
+    def __init__(self, device="cuda", torch_dtype=torch.bfloat16, dinov2_path=None):
+        if torch_dtype != torch.bfloat16:
+            raise _lib.PeError("the MI355X hot path computes in bf16 (the reference's inference dtype)")
+        self.device = torch.device(device)
+        self.torch_dtype = torch_dtype
+        self.height_division_factor = 16
+        self.width_division_factor = 16
+        self.dinov2_path = dinov2_path          # DINOv2 is only executed when is_train=True (training): unused here
+        self.scheduler = qwen_image_scheduler()  # (:192)
+        self.dit: Optional[QwenImageDiTEngine] = None
+        self.vae: Optional[QwenImageVAE] = None
+        self.text_encoder = None
+        self.tokenizer = None
+        self.processor = None
+        self.visual_thinking_adapter = _AdapterView()
+        self.blockwise_controlnet = None
+        self.in_iteration_models = ("dit", "blockwise_controlnet", "visual_thinking_adapter")
+        self.model_fn = model_fn_qwen_image      # same plug point as the reference (:247)
+        self.prompt_encoder: Optional[Callable[..., Any]] = None
+        self.extra_state: Dict[str, torch.Tensor] = {}   # training-only modules' weights (resamplers, time embeds)
+        self._dit_state: Optional[Dict[str, torch.Tensor]] = None
+        self._pending_lora: List[Dict[str, torch.Tensor]] = []
+        self.vram_management_enabled = False
+
+    # ------------------------------------------------------------------------------------------
+    # construction
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def from_pretrained(torch_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
+                        model_configs: List[ModelConfig] = (), tokenizer_config: ModelConfig = None,
+                        processor_config: ModelConfig = None, dinov2_path: str = None) -> "QwenImagePhysicPipeline":
+        """Same signature as the reference (:497-541).  Loads the DiT and VAE checkpoints onto the GPU in the
+        library's layout; text-encoder weights are kept as a raw state-dict for a user-installed prompt_encoder."""
+        mm = ModelManager(torch_dtype=torch_dtype)
+        for cfg in model_configs:
+            cfg.download_if_necessary()
+            mm.load_model(cfg.path, torch_dtype=cfg.offload_dtype or torch_dtype)
+        pipe = QwenImagePhysicPipeline(device=device, torch_dtype=torch_dtype, dinov2_path=dinov2_path)
+        dit_sd = mm.fetch_model("qwen_image_dit")
+        vae_sd = mm.fetch_model("qwen_image_vae")
+        pipe.text_encoder = mm.fetch_model("qwen_image_text_encoder")
+        if dit_sd is not None:
+            pipe.set_dit(dit_sd)
+        if vae_sd is not None:
+            pipe.set_vae(vae_sd)
+        for name, cfg in (("tokenizer", tokenizer_config), ("processor", processor_config)):
+            if cfg is not None:
+                cfg.download_if_necessary()
+                setattr(pipe, name + "_path", cfg.path)
+        return pipe
+
+    def set_dit(self, state_dict: Dict[str, torch.Tensor]):
+        self._dit_state = state_dict
+        self._build_engine()
+
+    def set_vae(self, state_dict: Dict[str, torch.Tensor]):
+        self.vae = QwenImageVAE(state_dict, device=self.device)
+
+    def _build_engine(self):
+        ad = self.visual_thinking_adapter.state if self.visual_thinking_adapter.state else None
+        self.dit = QwenImageDiTEngine(self._dit_state, ad, device=self.device)
+        for lora in self._pending_lora:
+            self.dit.load_lora(lora)
+
+    # ------------------------------------------------------------------------------------------
+    # weights: LoRA + finetuned non-LoRA parameters (validate.py:33-65)
+    # ------------------------------------------------------------------------------------------
+    def load_lora(self, module, lora_config: Union[ModelConfig, str] = None, alpha=1, hotload=False, state_dict=None):
+        """Reference signature (:250-276).  `module` must be `pipe.dit`; the LoRA is merged into the weights
+        (hotload=False is what validate.py uses; the runtime-fused form is not offered)."""
+        if hotload:
+            raise _lib.PeError("load_lora(hotload=True) is not implemented: validate.py merges at load time (hotload=False)")
+        if module is not self.dit:
+            raise _lib.PeError("load_lora: only pipe.dit carries LoRA targets on this path")
+        if state_dict is None:
+            if isinstance(lora_config, str):
+                state_dict = load_state_dict(lora_config, torch_dtype=self.torch_dtype)
+            else:
+                lora_config.download_if_necessary()
+                state_dict = load_state_dict(lora_config.path, torch_dtype=self.torch_dtype)
+        n = self.dit.load_lora(state_dict, alpha=float(alpha))
+        self._pending_lora.append(state_dict)
+        print(f"{n} tensors are updated by LoRA.")
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """nn.Module-style loader for the finetuned non-LoRA parameters (keys `visual_thinking_adapter.*`,
+        `dino_resampler.*`, `vae_resampler.*`, `*_time_embed.weight`; validate.py:55-65).  Only the adapter is
+        on the inference path; the others are training-only and are kept in `extra_state`."""
+        ad = {k[len("visual_thinking_adapter."):]: v for k, v in state_dict.items() if k.startswith("visual_thinking_adapter.")}
+        rest = {k: v for k, v in state_dict.items() if not k.startswith("visual_thinking_adapter.")}
+        known = ("dino_resampler", "vae_resampler", "dino_time_embed", "vae_time_embed", "dinov2")
+        unexpected = [k for k in rest if not k.startswith(known)]
+        if strict and (unexpected or not ad):
+            raise RuntimeError(f"load_state_dict(strict=True): unexpected keys {unexpected[:5]}")
+        self.extra_state.update(rest)
+        if ad:
+            self.visual_thinking_adapter.state.update({k: v.to(self.torch_dtype) for k, v in ad.items()})
+            if self._dit_state is not None:
+                self._build_engine()      # the engine binds adapter pointers at creation
+        return unexpected
+
+    def enable_vram_management(self, *args, **kwargs):
+        """No-op: all weights (41.5 GB) stay resident in the 288 GB of HBM (reference: :375-494)."""
+        self.vram_management_enabled = False
+
+    def load_models_to_device(self, model_names=()):
+        pass
+
+    # ------------------------------------------------------------------------------------------
+    # BasePipeline helpers with the reference's behaviour
+    # ------------------------------------------------------------------------------------------
+    def check_resize_height_width(self, height, width):
+        for name, f in (("height", self.height_division_factor), ("width", self.width_division_factor)):
+            v = height if name == "height" else width
+            if v % f != 0:
+                v = (v + f - 1) // f * f
+                print(f"{name} % {f} != 0. We round it up to {v}.")
+            if name == "height":
+                height = v
+            else:
+                width = v
+        return height, width
+
+    def preprocess_image(self, image, torch_dtype=None, device=None, pattern="B C H W", min_value=-1, max_value=1):
+        assert pattern == "B C H W" and (min_value, max_value) == (-1, 1)
+        return preprocess_image(np.array(image), device or self.device, torch_dtype or self.torch_dtype)
+
+    def vae_output_to_image(self, vae_output, pattern="B C H W", min_value=-1, max_value=1):
+        return Image.fromarray(vae_output_to_u8(vae_output).numpy())
+
+    def generate_noise(self, shape, seed=None, rand_device="cpu", rand_torch_dtype=torch.float32, device=None, torch_dtype=None):
+        generator = None if seed is None else torch.Generator(rand_device).manual_seed(seed)
+        noise = torch.randn(shape, generator=generator, device=rand_device, dtype=rand_torch_dtype)
+        return noise.to(dtype=torch_dtype or self.torch_dtype, device=device or self.device)
+
+    @staticmethod
+    def _auto_resize(edit_image: Image.Image) -> Image.Image:
+        # QwenImageUnit_EditImageEmbedder.edit_image_auto_resize (:1252-1264): ~1024^2 area, /32 rounding, PIL default filter
+        ratio = edit_image.size[0] / edit_image.size[1]
+        width = math.sqrt(1024 * 1024 * ratio)
+        height = width / ratio
+        return edit_image.resize((round(width / 32) * 32, round(height / 32) * 32))
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt: str, negative_prompt: str = "", cfg_scale: float = 4.0,
+                 input_image: Image.Image = None, denoising_strength: float = 1.0,
+                 inpaint_mask: Image.Image = None, inpaint_blur_size: int = None, inpaint_blur_sigma: float = None,
+                 height: int = 1328, width: int = 1328, seed: int = None, rand_device: str = "cpu",
+                 num_inference_steps: int = 30, exponential_shift_mu: float = None,
+                 blockwise_controlnet_inputs=None, eligen_entity_prompts=None, eligen_entity_masks=None,
+                 eligen_enable_on_negative: bool = False, edit_image=None, edit_image_auto_resize: bool = True,
+                 edit_rope_interpolation: bool = False, context_image: Image.Image = None,
+                 enable_fp8_attention: bool = False, tiled: bool = False, tile_size: int = 128, tile_stride: int = 64,
+                 progress_bar_cmd=None, supported_rules=None, contradicted_rules=None, middle_key_frames=None,
+                 stitched_image=None, state: str = None, transition: str = None, triplet: dict = None,
+                 is_train: bool = True, have_text_reasoning: bool = True):
+        """Same keyword surface and defaults as the reference (:545-597); returns a PIL image."""
+        for name, v in (("inpaint_mask", inpaint_mask), ("blockwise_controlnet_inputs", blockwise_controlnet_inputs),
+                        ("eligen_entity_prompts", eligen_entity_prompts)):
+            if v is not None:
+                raise _lib.PeError(f"{name} is outside the accelerated path (SURVEY.md section 8: out of scope)")
+        if enable_fp8_attention or edit_rope_interpolation:
+            raise _lib.PeError("enable_fp8_attention / edit_rope_interpolation are not implemented")
+        if is_train and self.use_special_tokens:
+            raise _lib.PeError("is_train=True runs the DINOv2/resampler training path; inference scripts pass is_train=False")
+        if self.dit is None or self.vae is None:
+            raise _lib.PeError("pipeline has no DiT/VAE weights: use from_pretrained() or set_dit()/set_vae()")
+        if self.prompt_encoder is None:
+            raise _lib.PeError("no prompt_encoder installed: the Qwen2.5-VL prompt prologue is host code outside the hot "
+                               "path; set pipe.prompt_encoder (see INTEGRATION.md)")
+        # ShapeChecker (:673-680)
+        height, width = self.check_resize_height_width(height, width)
+        # NoiseInitializer (:683-689): CPU generator, drawn directly in the pipeline dtype
+        noise = self.generate_noise((1, 16, height // 8, width // 8), seed=seed, rand_device=rand_device,
+                                    rand_torch_dtype=self.torch_dtype)
+        self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength,
+                                     dynamic_shift_len=(height // 16) * (width // 16),
+                                     exponential_shift_mu=exponential_shift_mu)
+        latents = noise
+        if input_image is not None:     # InputImageEmbedder (:693-711)
+            x0 = self.vae.encode(self.preprocess_image(input_image))
+            latents = self.scheduler.add_noise(x0, noise, timestep=self.scheduler.timesteps[0]).to(self.torch_dtype)
+        # EditImageEmbedder (:1244-1283) / ContextImageEmbedder (:1286-1299)
+        edit_latents: List[torch.Tensor] = []
+        resized_edit = edit_image
+        if context_image is not None:
+            edit_latents.append(self.vae.encode(self.preprocess_image(context_image.resize((width, height)))))
+        if edit_image is not None:
+            images = [edit_image] if isinstance(edit_image, Image.Image) else list(edit_image)
+            images = [self._auto_resize(im) if edit_image_auto_resize else im for im in images]
+            resized_edit = images[0] if isinstance(edit_image, Image.Image) else images
+            edit_latents += [self.vae.encode(self.preprocess_image(im)) for im in images]
+        # prompt prologue (PhysicalVerbalEmbedder + PromptEmbedder in the reference, :732-990): host code
+        use_cfg = cfg_scale != 1.0
+        posi, nega = self.prompt_encoder(self, prompt=prompt, negative_prompt=negative_prompt, edit_image=resized_edit,
+                                         cfg=use_cfg, have_text_reasoning=have_text_reasoning)
+        pe_p = posi["prompt_emb"].to(device=self.device, dtype=self.torch_dtype).contiguous()
+        m_p = posi.get("special_token_mask") if self.use_special_tokens else None
+        pe_n = m_n = None
+        if use_cfg:
+            pe_n = nega["prompt_emb"].to(device=self.device, dtype=self.torch_dtype).contiguous()
+            m_n = nega.get("special_token_mask") if self.use_special_tokens else None
+        # denoise loop + decode (:644-667)
+        loop = DenoiseLoop(self.dit)
+        loop.scheduler = self.scheduler
+        latents = loop(latents, pe_p, pe_n, m_p, m_n, height, width, num_inference_steps=num_inference_steps,
+                       cfg_scale=cfg_scale, edit_latents=edit_latents or None, exponential_shift_mu=exponential_shift_mu,
+                       denoising_strength=denoising_strength)
+        self.last_latents = latents
+        image = self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
+        return self.vae_output_to_image(image)

@@ -1,0 +1,87 @@
+"""CPU tests of the `diffsynth` façade's host plumbing (no kernel launches)."""
+import inspect
+import os
+
+import pytest
+import torch
+
+BF = torch.bfloat16
+
+# keyword surface of the reference's QwenImagePhysicPipeline.__call__ (qwen_image_physical.py:545-597)
+REFERENCE_CALL_KWARGS = {
+    "prompt": inspect.Parameter.empty, "negative_prompt": "", "cfg_scale": 4.0, "input_image": None,
+    "denoising_strength": 1.0, "inpaint_mask": None, "inpaint_blur_size": None, "inpaint_blur_sigma": None,
+    "height": 1328, "width": 1328, "seed": None, "rand_device": "cpu", "num_inference_steps": 30,
+    "exponential_shift_mu": None, "blockwise_controlnet_inputs": None, "eligen_entity_prompts": None,
+    "eligen_entity_masks": None, "eligen_enable_on_negative": False, "edit_image": None,
+    "edit_image_auto_resize": True, "edit_rope_interpolation": False, "context_image": None,
+    "enable_fp8_attention": False, "tiled": False, "tile_size": 128, "tile_stride": 64,
+    "supported_rules": None, "contradicted_rules": None, "middle_key_frames": None, "stitched_image": None,
+    "state": None, "transition": None, "triplet": None, "is_train": True, "have_text_reasoning": True,
+}
+
+
+def test_validate_py_imports_resolve():
+    from diffsynth import load_state_dict  # noqa: F401  (validate.py:17)
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline, ModelConfig  # noqa: F401  (:18)
+    from diffsynth.pipelines.qwen_image import QwenImagePipeline  # noqa: F401
+    from diffsynth import ModelManager, FlowMatchScheduler  # noqa: F401
+
+
+def test_call_signature_matches_reference():
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline
+    sig = inspect.signature(QwenImagePhysicPipeline.__call__)
+    for name, default in REFERENCE_CALL_KWARGS.items():
+        assert name in sig.parameters, name
+        assert sig.parameters[name].default == default or (default is inspect.Parameter.empty), name
+    fp = inspect.signature(QwenImagePhysicPipeline.from_pretrained)
+    assert list(fp.parameters) == ["torch_dtype", "device", "model_configs", "tokenizer_config", "processor_config", "dinov2_path"]
+    ll = inspect.signature(QwenImagePhysicPipeline.load_lora)
+    assert list(ll.parameters) == ["self", "module", "lora_config", "alpha", "hotload", "state_dict"]
+
+
+def test_model_config_resolves_local_files(tmp_path):
+    from diffsynth.pipelines.qwen_image_physical import ModelConfig
+    d = tmp_path / "Qwen" / "Qwen-Image" / "vae"
+    d.mkdir(parents=True)
+    (d / "diffusion_pytorch_model.safetensors").write_bytes(b"")
+    c = ModelConfig(model_id="Qwen/Qwen-Image", origin_file_pattern="vae/diffusion_pytorch_model.safetensors", local_model_path=str(tmp_path))
+    c.download_if_necessary()
+    assert c.path == str(d / "diffusion_pytorch_model.safetensors")
+    t = tmp_path / "Qwen" / "Qwen-Image" / "tokenizer"
+    t.mkdir()
+    c = ModelConfig(model_id="Qwen/Qwen-Image", origin_file_pattern="tokenizer/", local_model_path=str(tmp_path))
+    c.download_if_necessary()
+    assert c.path == os.path.join(str(tmp_path), "Qwen/Qwen-Image", "tokenizer/")
+    with pytest.raises(ValueError):
+        ModelConfig().download_if_necessary()
+    with pytest.raises(FileNotFoundError):
+        ModelConfig(model_id="Qwen/None", origin_file_pattern="x*.safetensors", local_model_path=str(tmp_path)).download_if_necessary()
+
+
+def test_load_state_dict_and_model_detection(tmp_path):
+    from safetensors.torch import save_file
+    from diffsynth import load_state_dict, ModelManager
+    sd = {"transformer_blocks.0.img_mod.1.weight": torch.zeros((4, 4), dtype=BF), "x": torch.ones((2,))}
+    p = str(tmp_path / "a.safetensors")
+    save_file(sd, p)
+    got = load_state_dict(p)
+    assert set(got) == set(sd) and got["x"].dtype == torch.float32
+    assert load_state_dict(p, torch_dtype=BF)["x"].dtype == BF
+    mm = ModelManager()
+    mm.load_model(p)
+    assert mm.fetch_model("qwen_image_dit") is not None and mm.fetch_model("qwen_image_vae") is None
+
+
+def test_pipeline_refuses_cpu_and_missing_pieces():
+    from physicedit_amd._lib import PeError
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline
+    pipe = QwenImagePhysicPipeline(device="cuda")
+    with pytest.raises(PeError):
+        pipe("x", is_train=False)              # no weights loaded
+    with pytest.raises(PeError):
+        QwenImagePhysicPipeline(device="cuda", torch_dtype=torch.float16)
+    assert pipe.check_resize_height_width(500, 512) == (512, 512)
+    n1 = pipe.generate_noise((1, 16, 8, 8), seed=3, rand_torch_dtype=BF, device="cpu")
+    from physicedit_amd import synth
+    assert torch.equal(n1, synth.make_noise(3, 64, 64))

@@ -1,0 +1,85 @@
+"""`-m gpu`: BASELINE.json configs[0] (c1) through the `diffsynth` façade exactly as
+scripts/inference/validate.py drives it -- from_pretrained on safetensors files, load_lora(pipe.dit, ...),
+load_state_dict(strict=False) of the adapter, pipe(prompt, edit_image=, seed=, num_inference_steps=4, ...) --
+with a stub prompt encoder (the text-encoder prologue is outside the hot path), against the oracle pipeline."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import oracle.physicedit_oracle as O
+from physicedit_amd import synth
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def test_c1_validate_style_run(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from safetensors.torch import save_file
+    from diffsynth import load_state_dict
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline, ModelConfig
+
+    H = W = 512
+    steps, T, nsp = 4, 128, 64
+    dit_sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    vae_sd = synth.make_state_dict(synth.vae_layout(), 77)
+    ad_sd = synth.make_state_dict(synth.adapter_layout(), 4321)
+    lora = synth.make_lora(4321, 2, 4)
+    base = tmp_path / "base"
+    (base / "Qwen/Qwen-Image-Edit-2509/transformer").mkdir(parents=True)
+    (base / "Qwen/Qwen-Image/vae").mkdir(parents=True)
+    keys = sorted(dit_sd)
+    half = len(keys) // 2   # two shards, like the real checkpoint
+    save_file({k: dit_sd[k] for k in keys[:half]}, str(base / "Qwen/Qwen-Image-Edit-2509/transformer/diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: dit_sd[k] for k in keys[half:]}, str(base / "Qwen/Qwen-Image-Edit-2509/transformer/diffusion_pytorch_model-00002-of-00002.safetensors"))
+    save_file(vae_sd, str(base / "Qwen/Qwen-Image/vae/diffusion_pytorch_model.safetensors"))
+    ckpt = {**lora, **{"pipe.visual_thinking_adapter." + k: v for k, v in ad_sd.items()},
+            "pipe.dino_time_embed.weight": torch.zeros((6, 768), dtype=BF)}
+    save_file(ckpt, str(tmp_path / "finetuned.safetensors"))
+
+    pipe = QwenImagePhysicPipeline.from_pretrained(
+        torch_dtype=torch.bfloat16, device="cuda",
+        model_configs=[
+            ModelConfig(model_id="Qwen/Qwen-Image-Edit-2509", origin_file_pattern="transformer/diffusion_pytorch_model*.safetensors", local_model_path=str(base)),
+            ModelConfig(model_id="Qwen/Qwen-Image", origin_file_pattern="vae/diffusion_pytorch_model.safetensors", local_model_path=str(base)),
+        ], dinov2_path=None)
+    # validate.py:load_finetuned_into_pipe
+    full = load_state_dict(str(tmp_path / "finetuned.safetensors"))
+    lora_state = {k: v for k, v in full.items() if "lora_A" in k or "lora_B" in k}
+    pipe.load_lora(pipe.dit, state_dict=lora_state)
+    rest = {k[len("pipe."):]: v for k, v in full.items() if k not in lora_state and k.startswith("pipe.")}
+    pipe.load_state_dict(rest, strict=False)
+
+    pe = synth.make_prompt_emb(7, T)
+    mask = synth.make_special_token_mask(T, nsp)
+
+    def stub_prompt_encoder(p, prompt, negative_prompt, edit_image, cfg, have_text_reasoning=True):
+        return {"prompt_emb": pe.clone(), "special_token_mask": mask}, None
+    pipe.prompt_encoder = stub_prompt_encoder
+
+    img_u8 = synth.make_edit_image_u8(H, W, 0)
+    out = pipe("turn the ice into water", edit_image=Image.fromarray(img_u8), seed=0, num_inference_steps=steps,
+               height=H, width=W, cfg_scale=1.0, is_train=False, edit_image_auto_resize=False)
+    assert isinstance(out, Image.Image) and out.size == (W, H)
+    got = torch.from_numpy(np.array(out)).float()
+
+    # ---- oracle pipeline on the same inputs (2-D conv form of the VAE: same math, 1/3 of the CPU time)
+    assert O.lora_merge(dit_sd, lora) == 24
+    O.VAE_CONV_MODE = "2d"
+    try:
+        edit_lat = O.vae_encode(vae_sd, O.preprocess_image(img_u8))
+        lat = O.denoise_loop(dit_sd, ad_sd, synth.make_noise(0, H, W), pe, None, mask, None, H, W, steps, cfg_scale=1.0,
+                             edit_latents=edit_lat)
+        ref = O.vae_output_to_u8(O.vae_decode(vae_sd, lat)).float()
+    finally:
+        O.VAE_CONV_MODE = "3d"
+    dl = (pipe.last_latents.float().cpu() - lat.float()).abs()
+    d = (got - ref).abs()
+    print(f"[parity] c1 façade run: latents max|d| {dl.max().item():.4e} mean|d| {dl.mean().item():.4e}; "
+          f"uint8 image max|d| {d.max().item():.0f} mean|d| {d.mean().item():.3f} identical {(d == 0).float().mean().item()*100:.1f}%")
+    assert dl.mean().item() <= 5e-3 and dl.max().item() <= 0.125
+    assert d.mean().item() <= 0.6 and d.max().item() <= 12
