@@ -70,7 +70,11 @@ int pe_qkv_rmsnorm_rope(const void* x, int ldx, const void* Wqkv, const void* bq
 /* softmax(Q K^T * scale) V over the joint sequence, no mask (qwen_image_flash_attention, :14-39).
  * Q,K [H][S_pad][128], Vt [H][128][S_pad] as written by pe_qkv_rmsnorm_rope; out [S][ldo] "s (h d)". */
 int pe_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo,
-                  float scale, void* stream);
+                  float scale, void* workspace, size_t workspace_bytes, void* stream);
+/* Optional scratch for pe_flash_attn (16-B aligned).  With it, the (head, q-block) items that do not fill a
+ * whole round of the 256 CUs are split along KV and merged by a second small kernel (load balance); without
+ * it (NULL) the launch is a single kernel. */
+size_t pe_flash_attn_workspace_bytes(int H, int S);
 
 /* LayerNorm(no affine, eps) * (1 + scale) + shift on rows of width 3072; rows [0,rows_a) use
  * (shift_a, scale_a), the remaining rows (shift_b, scale_b)  (qwen_image_dit.py:355-357,372-376). */

@@ -38,6 +38,8 @@ int pe_debug_set(const char* key, int value) {
     PE_REQUIRE(key != nullptr, "pe_debug_set: null key");
     if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return PE_OK; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
+    if (!strcmp(key, "attn_slots")) { PE_REQUIRE(value > 0 && value <= 256, "attn_slots out of range"); g_attn_slots = value; return PE_OK; }
+    if (!strcmp(key, "attn_force_split")) { g_attn_force_split = value; return PE_OK; }
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set: unknown key %s", key);
 }
 
@@ -66,9 +68,11 @@ int pe_qkv_rmsnorm_rope(const void* x, int ldx, const void* Wqkv, const void* bq
 }
 
 int pe_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo,
-                  float scale, void* stream) {
-    return launch_flash_attn(q, k, vt, out, H, S, S_pad, ldo, scale, (hipStream_t)stream);
+                  float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return launch_flash_attn(q, k, vt, out, H, S, S_pad, ldo, scale, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+size_t pe_flash_attn_workspace_bytes(int H, int S) { return flash_attn_workspace_bytes(H, S); }
 
 int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
                    const void* scale_a, const void* shift_b, const void* scale_b, float eps, void* stream) {

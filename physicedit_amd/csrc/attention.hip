@@ -24,6 +24,8 @@
 //          No permlane / LDS round trip for P.
 // LDS tiles are XOR-swizzled at 16-B granularity (applied on the LDS-DMA source address and on the
 // read) so every ds_read_b128 lane group is bank-conflict free.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -36,9 +38,19 @@ constexpr int ATT_LDS = 2 * ATT_STAGE;            // 64 KiB
 constexpr int Q_BLOCK = 256;
 int g_attn_variant = 0;
 
+// Work decomposition.  total = H * nqb equal (head, q-block) items never divide evenly over the 256 CUs
+// (cfg 2: 816 items = 3.19 rounds -> 4 rounds, 80 % efficiency).  So the first n_full = floor(total/slots)
+// * slots items run whole, and each of the R leftover items is split `split`-ways along the KV sequence
+// (flash-decoding style): the R*split short items write un-normalised partial (O, m, l) to a scratch
+// buffer and attn_combine_kernel merges them.  cfg 2: 768 whole + 48 x 5 short = 3.2 rounds.
+struct AttnPlan {
+    int nqb, n_full, split;   // split == 1: no short items
+};
+
 __global__ void __launch_bounds__(ATT_THREADS, 2)
 flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
-                  bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, int nqb) {
+                  bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
+                  float* __restrict__ part_o, float* __restrict__ part_ml) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
     const int w = wave_id();
@@ -46,9 +58,23 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
 
     // block -> (head, q-block): consecutive remapped ids walk the q-blocks of one head, so the
     // work-groups resident on one XCD share that head's K/V in its L2.
-    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int head = bid / nqb;
-    const int qb = bid - head * nqb;
+    const int nqb = plan.nqb;
+    const int nt_all = (S + KV_TILE - 1) / KV_TILE;
+    int item, t_begin = 0, t_end = nt_all, part_slot = -1;
+    if ((int)blockIdx.x < plan.n_full) {
+        item = xcd_remap((int)blockIdx.x, plan.n_full);
+    } else {
+        const int j = (int)blockIdx.x - plan.n_full;
+        item = plan.n_full + j / plan.split;
+        const int part = j - (j / plan.split) * plan.split;
+        if (plan.split > 1) {
+            t_begin = (int)((long long)nt_all * part / plan.split);
+            t_end = (int)((long long)nt_all * (part + 1) / plan.split);
+            part_slot = j;
+        }
+    }
+    const int head = item / nqb;
+    const int qb = item - head * nqb;
     const int q0 = qb * Q_BLOCK + w * 32;
 
     const bf16* Qh = Q + (size_t)head * S_pad * 128;
@@ -100,28 +126,26 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
     const int v_off = KV_TILE * 256 + l31 * 128;    // Vt row d = l31 (+32 rows per dt)
     const int vsw = (l31 >> 1) & 7;
 
-    const int nt = (S + KV_TILE - 1) / KV_TILE;
-    stage(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+    // One KV tile.  MASK is a compile-time flag so the tail masking costs nothing on full tiles (as a
+    // run-time condition the compiler if-converted it into 32 v_cndmask on EVERY tile).  VALU work is kept
+    // minimal because it is as large as the MFMA work here (PMC: VALU busy ~= MFMA busy): accumulators start
+    // from a constant-zero C operand (no v_mov zeroing), P is packed pairwise with v_cvt_pk (no v_perm), and
+    // the O rescale is skipped when no row's running max moved (alpha == 1 in every lane: same numerics).
+    auto tile = [&](int t, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const char* Sb = smem + (t & 1) * ATT_STAGE;
-
-        // ---- S^T = K . Q^T  (two 32-key sub-tiles)
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 st[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[s2][r] = 0.f;
-#pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const bf16x8 kf = *(const bf16x8*)(Sb + k_off + s2 * 32 * 256 + (((kk * 2 + h) ^ ksw) << 4));
-                st[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[s2], 0, 0, 0);
+                st[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero : st[s2], 0, 0, 0);
             }
         }
         // st[s2][4a+r] = score(q = q0+l31, key = t*64 + s2*32 + 8a + 4h + r)
-        if (t == nt - 1 && (S & (KV_TILE - 1)) != 0) {
+        if constexpr (MASK) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -130,8 +154,6 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
                     if (key >= S) st[s2][r] = -INFINITY;
                 }
         }
-
-        // ---- online softmax, lane-local except one exchange with the partner lane
         float mx = st[0][0];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -139,6 +161,7 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[s2][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * scale_log2);
+        const bool moved = m_new != m_run;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
@@ -151,22 +174,26 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
                 psum += p;
             }
         l_run = __builtin_fmaf(l_run, alpha, psum);
+        if (__any(moved)) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
         // ---- O^T += Vt . P^T
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                bf16x8 pf;
+                u32x4 pk;   // 8 bf16: accumulator quads 2*k2 and 2*k2+1, packed two at a time
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pf[e] = (bf16)st[s2][(2 * k2) * 4 + e];
-                    pf[4 + e] = (bf16)st[s2][(2 * k2 + 1) * 4 + e];
+                    bf16x2 two;
+                    two[0] = (bf16)st[s2][(2 * k2) * 4 + 2 * (e & 1) + 4 * (e >> 1)];
+                    two[1] = (bf16)st[s2][(2 * k2) * 4 + 2 * (e & 1) + 4 * (e >> 1) + 1];
+                    pk[e] = __builtin_bit_cast(uint32_t, two);
                 }
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
                 const int vchunk = s2 * 4 + k2 * 2 + h;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -174,10 +201,47 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
             }
+    };
+
+    const int nt = t_end;
+    // the (only) partially filled tile is peeled out of the loop: one call site inside the loop keeps the
+    // 128 accumulator registers in place (two call sites made the compiler copy them at the join)
+    const bool tail = (S & (KV_TILE - 1)) != 0 && nt == nt_all;
+    const int nt_loop = tail ? nt - 1 : nt;
+    stage(t_begin & 1, t_begin);
+    for (int t = t_begin; t < nt_loop; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        tile(t, std::false_type{});
+    }
+    if (tail) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tile(nt - 1, std::true_type{});
     }
 
     // ---- normalise and store: o[dt][4a+r] = O[q0+l31][dt*32 + 8a + 4h + r]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (part_slot >= 0) {
+        // short item: un-normalised fp32 partial + (running max, row sum) for attn_combine_kernel
+        float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 128 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = o[dt][4 * a + r];
+                *(f32x4*)(po + dt * 32 + 8 * a) = v;
+            }
+        if (h == 0) {
+            float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 2;
+            pm[0] = m_run;
+            pm[1] = l_tot;
+        }
+        return;
+    }
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
     if (q < S) {
@@ -194,8 +258,71 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
     }
 }
 
+// merge the `split` partials of each leftover (head, q-block): O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M)
+__global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o,
+                                                           const float* __restrict__ part_ml, bf16* __restrict__ out,
+                                                           int S, int ldo, AttnPlan plan) {
+    const int r_item = (int)blockIdx.x;
+    const int item = plan.n_full + r_item;
+    const int head = item / plan.nqb;
+    const int qb = item - head * plan.nqb;
+    for (int it = 0; it < 32; ++it) {
+        const int e = it * 256 + (int)threadIdx.x;
+        const int row = e >> 5, c = e & 31;
+        const int q = qb * Q_BLOCK + row;
+        if (q >= S) continue;
+        float M = -INFINITY;
+        for (int i = 0; i < plan.split; ++i)
+            M = fmaxf(M, part_ml[((size_t)(r_item * plan.split + i) * Q_BLOCK + row) * 2]);
+        float L = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < plan.split; ++i) {
+            const size_t base = (size_t)(r_item * plan.split + i) * Q_BLOCK + row;
+            const float wgt = __builtin_amdgcn_exp2f(part_ml[base * 2] - M);
+            L = __builtin_fmaf(part_ml[base * 2 + 1], wgt, L);
+            const f32x4 v = *(const f32x4*)(part_o + base * 128 + c * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v[j], wgt, acc[j]);
+        }
+        const float inv = 1.0f / L;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[j] * inv);
+        *(bf16x4*)(out + (size_t)q * ldo + head * 128 + c * 4) = o;
+    }
+}
+
+int g_attn_slots = 256;      // concurrently resident work-groups (1 per CU at 64 KiB LDS + 173 VGPRs x 8 waves)
+int g_attn_force_split = 0;  // tests: force an R / split decomposition on small problems
+
+static AttnPlan make_plan(int H, int S, bool have_ws) {
+    AttnPlan p;
+    p.nqb = (S + Q_BLOCK - 1) / Q_BLOCK;
+    const int total = H * p.nqb;
+    p.n_full = total;
+    p.split = 1;
+    if (!have_ws) return p;
+    const int nt = (S + KV_TILE - 1) / KV_TILE;
+    int R = total % g_attn_slots;
+    int split = R > 0 ? g_attn_slots / R : 1;
+    if (g_attn_force_split > 1) { R = total < 4 ? total : 4; split = g_attn_force_split; }
+    if (split > 8) split = 8;
+    if (split > nt) split = nt;
+    if (R > 0 && split >= 2) {
+        p.n_full = total - R;
+        p.split = split;
+    }
+    return p;
+}
+
+size_t flash_attn_workspace_bytes(int H, int S) {
+    (void)H; (void)S;
+    // at most (slots - 1) leftover items x 8 partials ... bounded by slots short items in practice; size for the cap
+    return (size_t)g_attn_slots * Q_BLOCK * (128 + 2) * sizeof(float);
+}
+
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
-                      int ldo, float scale, hipStream_t stream) {
+                      int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     PE_REQUIRE(q && k && vt && out, "flash_attn: null pointer");
     PE_REQUIRE(H > 0 && S > 0, "flash_attn: empty problem (H=%d S=%d)", H, S);
     PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
@@ -208,13 +335,27 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
-    const int nqb = (S + Q_BLOCK - 1) / Q_BLOCK;
+    const bool have_ws = workspace != nullptr && workspace_bytes >= flash_attn_workspace_bytes(H, S) &&
+                         ((uintptr_t)workspace & 15) == 0;
+    const AttnPlan plan = make_plan(H, S, have_ws);
+    const int total = H * plan.nqb;
+    const int n_short = (total - plan.n_full) * plan.split;
+    PE_REQUIRE(plan.split == 1 || n_short <= g_attn_slots, "flash_attn: internal plan error");
+    float* part_o = (float*)workspace;
+    float* part_ml = part_o ? part_o + (size_t)g_attn_slots * Q_BLOCK * 128 : nullptr;
     const float scale_log2 = scale * 1.44269504088896340736f;
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);  // QK^T + PV
-    hipLaunchKernelGGL(flash_attn_kernel, dim3(H * nqb), dim3(ATT_THREADS), ATT_LDS, stream, (const bf16*)q,
-                       (const bf16*)k, (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, nqb);
+    const dim3 grid(plan.n_full + (plan.split > 1 ? n_short : 0));
+    hipLaunchKernelGGL(flash_attn_kernel, grid, dim3(ATT_THREADS), ATT_LDS, stream, (const bf16*)q,
+                       (const bf16*)k, (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
+    int rc = check_launch("flash_attn_kernel");
+    if (rc == PE_OK && plan.split > 1) {
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(total - plan.n_full), dim3(256), 0, stream, part_o, part_ml,
+                           (bf16*)out, S, ldo, plan);
+        rc = check_launch("attn_combine_kernel");
+    }
     prof_end(slot, stream);
-    return check_launch("flash_attn_kernel");
+    return rc;
 }
 
 }  // namespace pe

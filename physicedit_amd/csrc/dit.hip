@@ -39,6 +39,8 @@ struct pe_dit {
     char *temb, *silu_temb, *t_hidden, *mod_tab, *final_tab;
     char *x, *xmod, *q, *k, *vt, *attn, *hbuf, *patches, *pe_norm, *proj;
     char *sp_in, *sp_hid, *sp_dino, *sp_vae;
+    char* attn_ws;
+    size_t attn_ws_bytes = 0;
 };
 
 static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
@@ -69,6 +71,8 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->sp_hid, (size_t)MAX_SPECIAL * AD_HID * 2);
     take(&h->sp_dino, (size_t)MAX_SPECIAL * TXT * 2);
     take(&h->sp_vae, (size_t)MAX_SPECIAL * TXT * 2);
+    h->attn_ws_bytes = flash_attn_workspace_bytes(HEADS, (int)S);
+    take(&h->attn_ws, h->attn_ws_bytes);
     return off;
 }
 
@@ -271,7 +275,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         }
         if ((rc = launch_gemm(EPI_QKV, pp, 2, stream))) return rc;
         // joint attention
-        if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, stream))) return rc;
+        if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream))) return rc;
         // output projections + gated residual (in place on x)
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {

@@ -51,7 +51,9 @@ extern int g_attn_variant;
 // flash attention over the joint sequence (no mask), D = 128
 // ---------------------------------------------------------------------------------------------
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
-                      int ldo, float scale, hipStream_t stream);
+                      int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream);
+size_t flash_attn_workspace_bytes(int H, int S);
+extern int g_attn_slots, g_attn_force_split;
 
 // ---------------------------------------------------------------------------------------------
 // row kernels / elementwise

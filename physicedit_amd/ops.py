@@ -92,14 +92,18 @@ def unpack_vt(vt: torch.Tensor, S: int) -> torch.Tensor:
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, S: int,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, workspace: bool = True) -> torch.Tensor:
     """q,k [H,S_pad,128], vt [H,128,S_pad] -> [S, H*128]."""
     _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
     H, sp, _ = q.shape
     if out is None:
         out = torch.empty((S, H * 128), dtype=BF, device=q.device)
+    ws, nbytes = None, 0
+    if workspace:
+        nbytes = lib().pe_flash_attn_workspace_bytes(H, S)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
     check(lib().pe_flash_attn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128,
-                              1.0 / math.sqrt(128.0), stream_ptr()), "pe_flash_attn")
+                              1.0 / math.sqrt(128.0), _ptr(ws), nbytes, stream_ptr()), "pe_flash_attn")
     return out
 
 
