@@ -32,8 +32,9 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 64 KiB
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;        // 128 KiB
+constexpr int GEMM_LDS_V10 = 5 * (STAGE_BYTES / 2);  // A x2 + W x3 = 160 KiB (all of a CU's LDS)
 constexpr int BAND = 8;
-constexpr int GEMM_DEFAULT_VARIANT = 8;   // validated pipelined schedule (see VAR list at the kernel)
+constexpr int GEMM_DEFAULT_VARIANT = 10;  // validated schedule: pipelined clusters + 3-deep W ring (see VAR list)
 
 struct GemmArgs {
     GemmProblem p[2];
@@ -213,6 +214,104 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
             stage_pairs(kt + 2, 0, 2);
             mma(fa1, fw1);
             PE_CLUSTER_SCHED(4);
+        }
+#undef PE_CLUSTER_SCHED
+#undef PE_SGB
+    } else if constexpr (VAR == 10) {
+        // v8 + a THREE-deep W ring: the weight matrix is the cold operand of every block GEMM (each of
+        // the 40 GB of weights is touched once per forward), the activation tile is cache resident.  LDS:
+        // A 2 x 32 KiB + W 3 x 32 KiB = the CU's whole 160 KiB.  W(kt+2) is issued during tile kt, AFTER
+        // A(kt+1) in program order, so the tile barrier can wait with vmcnt(4): everything but the four
+        // newest W pieces (HBM latency then spans ~1.5 K tiles instead of ~0.75).
+        constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+        char* const a_base = smem;
+        char* const w_base = smem + 2 * A_BYTES;
+        auto frag_a = [&](const char* Sa, int kk, bf16x8 (&af)[2]) {
+            const int coff = ((kk * 2 + h) ^ sw) << 4;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(Sa + (wm * 64 + l31) * 128 + mi * 32 * 128 + coff);
+        };
+        auto frag_w = [&](const char* Sw, int kk, bf16x8 (&wf)[4]) {
+            const int coff = ((kk * 2 + h) ^ sw) << 4;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const bf16x8*)(Sw + (wn * 128 + l31) * 128 + ni * 32 * 128 + coff);
+        };
+        auto mma = [&](bf16x8 (&af)[2], bf16x8 (&wf)[4]) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        };
+        auto stage_a = [&](int t, int first, int count) {
+            const int tc = min(t, nk - 1);
+            char* base = a_base + (t & 1) * A_BYTES + w * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i >= first && i < first + count) glds16(a_src[i] + tc * BK, base + i * 1024);
+        };
+        auto stage_w = [&](int t, int slot, int first, int count) {
+            const int tc = min(t, nk - 1);
+            char* base = w_base + slot * W_BYTES + w * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i >= first && i < first + count) glds16(w_src[i] + tc * BK, base + i * 1024);
+        };
+#define PE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define PE_CLUSTER_SCHED(NVMEM)                                    \
+    do {                                                          \
+        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
+        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
+        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
+        for (int v_ = 0; v_ < (NVMEM); ++v_) { PE_SGB(0x008, 1); PE_SGB(0x020, 1); } \
+        PE_SGB(0x008, 5 - (NVMEM));                               \
+    } while (0)
+        // prologue.  The common code above staged tile 0 into the 2-stage layout of the other variants;
+        // wait for it to drain, then restage in this variant's layout (runs once per work-group).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage_a(0, 0, 4);
+        stage_w(0, 0, 0, 4);
+        stage_w(1, 1, 0, 4);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
+        __syncthreads();
+        bf16x8 fa0[2], fw0[4], fa1[2], fw1[4];
+        frag_a(a_base, 0, fa0);
+        frag_w(w_base, 0, fw0);
+        stage_a(1, 0, 2);
+        int ws_cur = 0;                       // W ring slot of tile kt
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* Sa = a_base + (kt & 1) * A_BYTES;
+            const char* San = a_base + ((kt + 1) & 1) * A_BYTES;
+            const int ws_n1 = ws_cur == 2 ? 0 : ws_cur + 1;   // slot of tile kt+1
+            const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;     // slot of tile kt+2 (held tile kt-1: dead)
+            const char* Sw = w_base + ws_cur * W_BYTES;
+            const char* Swn = w_base + ws_n1 * W_BYTES;
+            // cluster 0
+            frag_a(Sa, 1, fa1); frag_w(Sw, 1, fw1);
+            stage_a(kt + 1, 2, 2);
+            mma(fa0, fw0);
+            PE_CLUSTER_SCHED(2);
+            // cluster 1
+            frag_a(Sa, 2, fa0); frag_w(Sw, 2, fw0);
+            stage_w(kt + 2, ws_n2, 0, 2);
+            mma(fa1, fw1);
+            PE_CLUSTER_SCHED(2);
+            // cluster 2
+            frag_a(Sa, 3, fa1); frag_w(Sw, 3, fw1);
+            stage_w(kt + 2, ws_n2, 2, 2);
+            mma(fa0, fw0);
+            PE_CLUSTER_SCHED(2);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // all but the 4 newest (= W(kt+2))
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // cluster 3
+            frag_a(San, 0, fa0); frag_w(Swn, 0, fw0);
+            stage_a(kt + 2, 0, 2);
+            mma(fa1, fw1);
+            PE_CLUSTER_SCHED(2);
+            ws_cur = ws_n1;
         }
 #undef PE_CLUSTER_SCHED
 #undef PE_SGB
@@ -480,17 +579,19 @@ static int launch_v(const GemmArgs& args, int ntiles, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, VAR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, VAR == 10 ? GEMM_LDS_V10 : GEMM_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR>), dim3(ntiles), dim3(GEMM_THREADS), GEMM_LDS, stream, args);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR>), dim3(ntiles), dim3(GEMM_THREADS), VAR == 10 ? GEMM_LDS_V10 : GEMM_LDS,
+                       stream, args);
     return check_launch("gemm_bf16_kernel");
 }
 
 template <int EPI>
 static int launch_t(const GemmArgs& args, int ntiles, hipStream_t stream) {
-    if (g_gemm_variant == 0) return launch_v<EPI, 0>(args, ntiles, stream);   // A/B reference schedule
+    if (g_gemm_variant == 0) return launch_v<EPI, 0>(args, ntiles, stream);   // A/B reference schedules
+    if (g_gemm_variant == 8) return launch_v<EPI, 8>(args, ntiles, stream);
     if constexpr (EPI == EPI_BIAS) {   // further experimental schedules only for the plain epilogue
         switch (g_gemm_variant) {
             case 1: return launch_v<EPI, 1>(args, ntiles, stream);
