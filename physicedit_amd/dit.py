@@ -123,6 +123,23 @@ class QwenImageDiTEngine:
             self._handle = C.c_void_p()
         check(lib().pe_dit_create(C.byref(w), adp, C.byref(self._handle)), "pe_dit_create")
 
+    def fork(self) -> "QwenImageDiTEngine":
+        """A second execution context on the SAME device weights: own C handle, workspace and prepared tables.
+        Lets the positive and the negative forward of a step run concurrently on two streams."""
+        other = object.__new__(QwenImageDiTEngine)
+        other.device = self.device
+        other.num_layers = self.num_layers
+        other.params, other._fused, other.adapter = self.params, self._fused, self.adapter
+        other.t_min, other.t_max = self.t_min, self.t_max
+        other._handle = C.c_void_p()
+        other._keep = None
+        other._create()
+        other._ws = None
+        other._bound = (0, 0, 0)
+        other._step_of = {}
+        other.rope = self.rope
+        return other
+
     def __del__(self):
         try:
             if getattr(self, "_handle", None):

@@ -23,11 +23,17 @@ BF = torch.bfloat16
 
 
 class DenoiseLoop:
-    def __init__(self, dit: QwenImageDiTEngine):
+    def __init__(self, dit: QwenImageDiTEngine, dual_stream: bool = False):
+        """dual_stream: run the positive and the negative forward of each step concurrently on two HIP streams
+        (second workspace on the same weights).  They are independent until the CFG combine (:653-656), and each
+        fills the CUs the other leaves idle in its partial rounds of work-groups."""
         self.dit = dit
         self.device = dit.device
         self.scheduler = qwen_image_scheduler()
         self.torch_dtype = BF
+        self.dual_stream = dual_stream
+        self._dit_n: Optional[QwenImageDiTEngine] = None
+        self._streams = None
 
     @torch.no_grad()
     def __call__(self, noise: torch.Tensor, prompt_emb_posi: torch.Tensor, prompt_emb_nega: Optional[torch.Tensor],
@@ -48,6 +54,15 @@ class DenoiseLoop:
         use_cfg = cfg_scale != 1.0                      # (:654)
         S_img = (height // 16) * (width // 16) + sum((e.shape[-2] // 2) * (e.shape[-1] // 2) for e in edits)
         T_max = max(prompt_emb_posi.shape[-2], prompt_emb_nega.shape[-2] if use_cfg else 0)
+        dual = self.dual_stream and use_cfg
+        dit_n = self.dit
+        if dual:
+            if self._dit_n is None:
+                self._dit_n = self.dit.fork()
+                self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            dit_n = self._dit_n
+            dit_n.bind(S_img, T_max, num_inference_steps)
+            dit_n.prepare(ts)
         self.dit.bind(S_img, T_max, num_inference_steps)
         self.dit.prepare(ts)
         idx_p = special_indices(special_mask_posi, dev)
@@ -56,11 +71,23 @@ class DenoiseLoop:
         nxt = torch.empty_like(latents)
         pred_p = torch.empty_like(latents)
         pred_n = torch.empty_like(latents) if use_cfg else None
+        main = torch.cuda.current_stream(dev)
         for i in range(num_inference_steps):
             t = ts[i:i + 1]
-            self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p)
-            if use_cfg:
-                self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n)
+            if dual:
+                sp, sn = self._streams
+                sp.wait_stream(main)
+                sn.wait_stream(main)
+                with torch.cuda.stream(sp):
+                    self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p)
+                with torch.cuda.stream(sn):
+                    dit_n.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n)
+                main.wait_stream(sp)
+                main.wait_stream(sn)
+            else:
+                self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p)
+                if use_cfg:
+                    self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n)
             ops.cfg_euler_step(pred_p, pred_n, latents, cfg_scale, sch.dsigma(i), out=nxt)
             latents, nxt = nxt, latents
         return latents

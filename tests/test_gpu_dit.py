@@ -124,6 +124,21 @@ def test_model_fn_G5(golden, eng2):
     assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
 
 
+def test_loop_dual_stream_is_bit_identical(eng2):
+    """posi / nega forwards on two streams + two workspaces == the single-stream loop, bit for bit."""
+    from physicedit_amd.pipeline import DenoiseLoop
+    noise, edit, pe_p, mask_p = _model_fn_inputs(128, 128, 40, 16, 0)
+    pe_n = synth.make_prompt_emb(8, 24)
+    mask_n = synth.make_special_token_mask(24, 16)
+    outs = []
+    for dual in (False, True, True):
+        loop = DenoiseLoop(eng2, dual_stream=dual)
+        outs.append(loop(noise, pe_p.cuda().clone(), pe_n.cuda().clone(), mask_p, mask_n, 128, 128, num_inference_steps=4,
+                         cfg_scale=4.0, edit_latents=edit.cuda()).clone())
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
 @pytest.mark.parametrize("cfg", [1.0, 4.0])
 def test_loop_G6(golden, eng2, cfg):
     g = golden("G6_loop")
@@ -131,7 +146,7 @@ def test_loop_G6(golden, eng2, cfg):
     noise, edit, pe_p, mask_p = _model_fn_inputs(128, 128, 40, 16, 0)
     pe_n = synth.make_prompt_emb(8, 24)
     mask_n = synth.make_special_token_mask(24, 16)
-    loop = DenoiseLoop(eng2)
+    loop = DenoiseLoop(eng2, dual_stream=True)
     lat = loop(noise, pe_p.cuda().clone(), pe_n.cuda().clone(), mask_p, mask_n, 128, 128, num_inference_steps=4,
                cfg_scale=cfg, edit_latents=edit.cuda())
     d, u = stats(f"4-step loop cfg={cfg} final latents", lat, g[f"latents_cfg{cfg}_step3"])
@@ -178,3 +193,32 @@ def test_adapter_G9(golden, eng2):
         got = pe_d[0, mask[0].cuda()]
         d, u = stats(f"adapter mixed t={tv}", got, g[f"mixed_{int(tv)}"][0])
         assert u.max().item() <= 3.0 and (u > 0).float().mean().item() < 0.08
+
+
+@pytest.mark.parametrize("hw,edits,T,nsp", [((208, 208), [(256, 256)], 45, 8),        # 13x13 = 169 tokens: odd, unaligned text offset
+                                            ((176, 240), [(208, 144), (96, 96)], 33, 0),  # two edit images, no special tokens
+                                            ((64, 64), [], 19, 4)])                        # tiny, no edit image
+def test_model_fn_odd_geometry(eng2, hw, edits, T, nsp):
+    """Ragged shapes as in BASELINE cfg 5 (1328^2 -> 83x83 tokens): S_img not a multiple of 16/64/256, text
+    stream at an unaligned joint offset (element-wise Vt path), several edit images, vs the oracle."""
+    from physicedit_amd.dit import special_indices
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    t_min, t_max = O.adapter_t_range()
+    h, w = hw
+    noise = synth.make_noise(5, h, w)
+    g = torch.Generator().manual_seed(77)
+    edit = [torch.randn((1, 16, eh // 8, ew // 8), generator=g).to(BF) for eh, ew in edits]
+    pe = synth.make_prompt_emb(11, T)
+    mask = synth.make_special_token_mask(T, nsp, tail=3) if nsp else None
+    t = torch.tensor([612.0]).to(BF)
+    pe_ref = pe.clone()
+    ref = O.model_fn(sd, ad, noise, t, pe_ref, mask, h, w, edit or None, t_min, t_max)
+    pe_d = pe.cuda().clone()
+    got = eng2.forward(noise.cuda(), t, pe_d, special_indices(mask, "cuda") if nsp else None, [e.cuda() for e in edit] or None)
+    d, u = stats(f"model_fn odd geometry {hw} edits={edits} T={T}", got, ref)
+    assert torch.isfinite(got.float()).all()
+    assert u.max().item() <= 4.0 and d.mean().item() <= 1.5e-3
+    if nsp:
+        dp = (pe_d.float().cpu() - pe_ref.float()).abs()
+        assert dp.max().item() <= 2 ** -7
