@@ -150,10 +150,9 @@ class QwenImagePhysicPipeline:
     # weights: LoRA + finetuned non-LoRA parameters (validate.py:33-65)
     # ------------------------------------------------------------------------------------------
     def load_lora(self, module, lora_config: Union[ModelConfig, str] = None, alpha=1, hotload=False, state_dict=None):
-        """Reference signature (:250-276).  `module` must be `pipe.dit`; the LoRA is merged into the weights
-        (hotload=False is what validate.py uses; the runtime-fused form is not offered)."""
-        if hotload:
-            raise _lib.PeError("load_lora(hotload=True) is not implemented: validate.py merges at load time (hotload=False)")
+        """Reference signature (:250-276).  `module` must be `pipe.dit`.  hotload=False merges into the weights
+        (validate.py); hotload=True keeps the pair separate and fuses `x @ A.T @ B.T` into every targeted linear at
+        run time (layers.py:173-181)."""
         if module is not self.dit:
             raise _lib.PeError("load_lora: only pipe.dit carries LoRA targets on this path")
         if state_dict is None:
@@ -162,9 +161,10 @@ class QwenImagePhysicPipeline:
             else:
                 lora_config.download_if_necessary()
                 state_dict = load_state_dict(lora_config.path, torch_dtype=self.torch_dtype)
-        n = self.dit.load_lora(state_dict, alpha=float(alpha))
-        self._pending_lora.append(state_dict)
-        print(f"{n} tensors are updated by LoRA.")
+        n = self.dit.load_lora(state_dict, alpha=float(alpha), hotload=bool(hotload))
+        if not hotload:
+            self._pending_lora.append(state_dict)
+            print(f"{n} tensors are updated by LoRA.")
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         """nn.Module-style loader for the finetuned non-LoRA parameters (keys `visual_thinking_adapter.*`,

@@ -58,6 +58,12 @@ enum {
 int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
                  int M, int N, int K, const void* gate, const void* res, int ldr, void* stream);
 
+/* As pe_gemm_bf16 with a pre-add operand: y = bf16(pre[m][n] + bf16(A@W^T + bias)) and THEN the epilogue.
+ * This is the runtime ("hot") LoRA step `out + x @ lora_A.T @ lora_B.T` of AutoWrappedLinear.forward
+ * (vram_management/layers.py:173-181): pre = the base Linear's output, A = x @ lora_A.T, W = lora_B. */
+int pe_gemm_bf16_pre(int epilogue, const void* A, int lda, const void* W, const void* bias, const void* pre, int ldp,
+                     void* out, int ldo, int M, int N, int K, const void* gate, const void* res, int ldr, void* stream);
+
 /* Fused QKV projection of one stream (QwenDoubleStreamAttention.forward, qwen_image_dit.py:282-302):
  * x[M,K] @ Wqkv[3*H*128,K]^T + b, per-head RMSNorm(q,k) (weights norm_q_w/norm_k_w [128]), RoPE(q,k)
  * with fp32 tables rope_cos/rope_sin [M,64]; writes head-major Q,K [H][S_pad][128] at rows
@@ -148,10 +154,23 @@ typedef struct pe_dit_call {
     void* noise_pred;           /* out: [16,h8,w8] bf16 */
 } pe_dit_call;
 
+/* Runtime ("hot") LoRA operands of one block -- load_lora(hotload=True), qwen_image_physical.py:264-272 +
+ * vram_management/layers.py:173-181: out = linear(x) + (x @ A.T) @ B.T, each op rounded.  r = rank padded to a
+ * multiple of 64 with zeros.  The three attention projections of a stream share one fused pair:
+ * qkv_a = [Aq; Ak; Av] ([3r, 3072]) and qkv_b = blockdiag(Bq, Bk, Bv) ([9216, 3r]).  NULL group = no LoRA there. */
+typedef struct pe_dit_block_lora {
+    const void *img_qkv_a, *img_qkv_b, *img_out_a, *img_out_b, *img_down_a, *img_down_b, *img_mod_a, *img_mod_b;
+    const void *txt_qkv_a, *txt_qkv_b, *txt_out_a, *txt_out_b, *txt_down_a, *txt_down_b, *txt_mod_a, *txt_mod_b;
+} pe_dit_block_lora;
+
 typedef struct pe_dit* pe_dit_handle;
 
 int pe_dit_create(const pe_dit_weights* w, const pe_adapter_weights* adapter /* nullable */, pe_dit_handle* out);
 void pe_dit_destroy(pe_dit_handle h);
+
+/* Install (blocks != NULL, host array [num_layers], copied) or clear (NULL) hot LoRA operands; r <= 128.
+ * Call before pe_dit_prepare: the modulation rows depend on it. */
+int pe_dit_set_hot_lora(pe_dit_handle h, const pe_dit_block_lora* blocks, int r);
 
 /* Bytes of workspace needed for sequences up to (S_img_max image tokens, T_max text tokens) and
  * n_steps prepared timesteps. */

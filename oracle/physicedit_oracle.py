@@ -202,12 +202,12 @@ def _heads(x: torch.Tensor, h: int = 24) -> torch.Tensor:
 def joint_attention(sd: SD, p: str, image, text, rope) -> Tuple[torch.Tensor, torch.Tensor]:
     # QwenDoubleStreamAttention.forward, qwen_image_dit.py:274-316
     a = p + "attn."
-    img_q = F.linear(image, sd[a + "to_q.weight"], sd[a + "to_q.bias"])
-    img_k = F.linear(image, sd[a + "to_k.weight"], sd[a + "to_k.bias"])
-    img_v = F.linear(image, sd[a + "to_v.weight"], sd[a + "to_v.bias"])
-    txt_q = F.linear(text, sd[a + "add_q_proj.weight"], sd[a + "add_q_proj.bias"])
-    txt_k = F.linear(text, sd[a + "add_k_proj.weight"], sd[a + "add_k_proj.bias"])
-    txt_v = F.linear(text, sd[a + "add_v_proj.weight"], sd[a + "add_v_proj.bias"])
+    img_q = _linear(sd, a + "to_q", image)
+    img_k = _linear(sd, a + "to_k", image)
+    img_v = _linear(sd, a + "to_v", image)
+    txt_q = _linear(sd, a + "add_q_proj", text)
+    txt_k = _linear(sd, a + "add_k_proj", text)
+    txt_v = _linear(sd, a + "add_v_proj", text)
     seq_txt = txt_q.shape[1]
     img_q, img_k, img_v = _heads(img_q), _heads(img_k), _heads(img_v)
     txt_q, txt_k, txt_v = _heads(txt_q), _heads(txt_k), _heads(txt_v)
@@ -224,8 +224,8 @@ def joint_attention(sd: SD, p: str, image, text, rope) -> Tuple[torch.Tensor, to
     B, H, S, D = x.shape
     x = x.permute(0, 2, 1, 3).reshape(B, S, H * D).to(q.dtype)
     txt_o, img_o = x[:, :seq_txt, :], x[:, seq_txt:, :]
-    img_o = F.linear(img_o, sd[a + "to_out.0.weight"], sd[a + "to_out.0.bias"])
-    txt_o = F.linear(txt_o, sd[a + "to_add_out.weight"], sd[a + "to_add_out.bias"])
+    img_o = _linear(sd, a + "to_out.0", img_o)
+    txt_o = _linear(sd, a + "to_add_out", txt_o)
     return img_o, txt_o
 
 
@@ -233,7 +233,7 @@ def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     # QwenFeedForward + ApproximateGELU, qwen_image_dit.py:42-49,228-245
     x = F.linear(x, sd[p + "net.0.proj.weight"], sd[p + "net.0.proj.bias"])
     x = x * torch.sigmoid(1.702 * x)
-    return F.linear(x, sd[p + "net.2.weight"], sd[p + "net.2.bias"])
+    return _linear(sd, p + "net.2", x)
 
 
 def block_forward(sd: SD, i: int, image, text, temb, rope) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -241,8 +241,8 @@ def block_forward(sd: SD, i: int, image, text, temb, rope) -> Tuple[torch.Tensor
     p = f"transformer_blocks.{i}."
     D = image.shape[-1]
     st = F.silu(temb)
-    img_mod = F.linear(st, sd[p + "img_mod.1.weight"], sd[p + "img_mod.1.bias"])
-    txt_mod = F.linear(st, sd[p + "txt_mod.1.weight"], sd[p + "txt_mod.1.bias"])
+    img_mod = _linear(sd, p + "img_mod.1", st)
+    txt_mod = _linear(sd, p + "txt_mod.1", st)
     img_mod_attn, img_mod_mlp = img_mod.chunk(2, dim=-1)
     txt_mod_attn, txt_mod_mlp = txt_mod.chunk(2, dim=-1)
 
@@ -374,6 +374,48 @@ def lora_merge(sd: SD, lora: SD, alpha: float = 1.0, dtype=torch.bfloat16) -> in
         sd[target] = sd[target].to(dtype=dtype) + alpha * torch.mm(up, down)
         n += 1
     return n
+
+
+def hot_lora_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                    loras: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor:
+    """AutoWrappedLinear.forward with hot-loaded LoRA (vram_management/layers.py:166-181; filled by
+    load_lora(hotload=True), qwen_image_physical.py:265-272, which stores lora_A * alpha):
+    out = linear(x); for each (A, B): out = out + x @ A.T @ B.T  -- every op rounds to the tensor dtype."""
+    out = F.linear(x, weight, bias)
+    for lora_A, lora_B in loras:
+        out = out + x @ lora_A.T @ lora_B.T
+    return out
+
+
+class HotLoraSD(dict):
+    """A DiT state-dict whose targeted Linear layers additionally carry hot-loaded LoRA pairs:
+    `sd.hot[name] = [(A, B), ...]` with name like 'transformer_blocks.0.attn.to_q'."""
+    hot: Dict[str, List[Tuple[torch.Tensor, torch.Tensor]]]
+
+
+def attach_hot_lora(sd: SD, lora: SD, alpha: float = 1.0) -> "HotLoraSD":
+    out = HotLoraSD(sd)
+    out.hot = {}
+    for key in lora:
+        if ".lora_A." not in key:
+            continue
+        name = key.split(".lora_A.")[0]
+        kb = key.replace(".lora_A.", ".lora_B.")
+        if name + ".weight" in sd and kb in lora:
+            out.hot.setdefault(name, []).append((lora[key] * alpha, lora[kb]))
+    return out
+
+
+_orig_linear = F.linear
+
+
+def _linear(sd, name: str, x: torch.Tensor) -> torch.Tensor:
+    """Linear `name` of the state-dict, with its hot LoRA pairs if the dict carries any."""
+    w, b = sd[name + ".weight"], sd.get(name + ".bias")
+    hot = getattr(sd, "hot", None)
+    if hot and name in hot:
+        return hot_lora_linear(x, w, b, hot[name])
+    return _orig_linear(x, w, b)
 
 
 # ======================================================================================

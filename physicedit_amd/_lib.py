@@ -26,6 +26,12 @@ class DitBlockWeights(C.Structure):
         "txt_out_w", "txt_out_b", "txt_mlp_up_w", "txt_mlp_up_b", "txt_mlp_down_w", "txt_mlp_down_b")]
 
 
+class DitBlockLora(C.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "img_qkv_a", "img_qkv_b", "img_out_a", "img_out_b", "img_down_a", "img_down_b", "img_mod_a", "img_mod_b",
+        "txt_qkv_a", "txt_qkv_b", "txt_out_a", "txt_out_b", "txt_down_a", "txt_down_b", "txt_mod_a", "txt_mod_b")]
+
+
 class DitWeights(C.Structure):
     _fields_ = [("num_layers", c_int)] + [(n, c_void_p) for n in (
         "time_w1", "time_b1", "time_w2", "time_b2", "txt_norm_w", "img_in_w", "img_in_b",
@@ -58,6 +64,8 @@ SIGNATURES = {
     "pe_debug_set": (c_int, [C.c_char_p, c_int]),
     "pe_gemm_bf16": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_int, c_void_p]),
+    "pe_gemm_bf16_pre": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                 c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "pe_qkv_rmsnorm_rope": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_flash_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
@@ -71,6 +79,7 @@ SIGNATURES = {
     "pe_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_void_p]),
     "pe_dit_create": (c_int, [C.POINTER(DitWeights), C.POINTER(AdapterWeights), C.POINTER(c_void_p)]),
     "pe_dit_destroy": (None, [c_void_p]),
+    "pe_dit_set_hot_lora": (c_int, [c_void_p, C.POINTER(DitBlockLora), c_int]),
     "pe_dit_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "pe_dit_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "pe_dit_prepare": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

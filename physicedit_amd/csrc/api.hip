@@ -54,6 +54,17 @@ int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void
     return launch_gemm(epilogue, &p, 1, (hipStream_t)stream);
 }
 
+int pe_gemm_bf16_pre(int epilogue, const void* A, int lda, const void* W, const void* bias, const void* pre, int ldp,
+                     void* out, int ldo, int M, int N, int K, const void* gate, const void* res, int ldr, void* stream) {
+    PE_REQUIRE(epilogue != EPI_QKV, "pe_gemm_bf16_pre: use pe_qkv_rmsnorm_rope for the QKV epilogue");
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.W = W; p.bias = bias; p.out = out; p.pre = pre; p.ldp = ldp;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldo = ldo;
+    p.gate = gate; p.res = res; p.ldr = ldr;
+    return launch_gemm(epilogue, &p, 1, (hipStream_t)stream);
+}
+
 int pe_qkv_rmsnorm_rope(const void* x, int ldx, const void* Wqkv, const void* bqkv, int M, int H, int K,
                         const void* norm_q_w, const void* norm_k_w, const float* rope_cos,
                         const float* rope_sin, void* q_out, void* k_out, void* vt_out, int seq_off, int S_pad,

@@ -41,6 +41,9 @@ struct pe_dit {
     char *sp_in, *sp_hid, *sp_dino, *sp_vae;
     char* attn_ws;
     size_t attn_ws_bytes = 0;
+    char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
+    pe_dit_block_lora* lora = nullptr;  // hot LoRA operands per block, or null
+    int lora_r = 0;
 };
 
 static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
@@ -73,6 +76,7 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->sp_vae, (size_t)MAX_SPECIAL * TXT * 2);
     h->attn_ws_bytes = flash_attn_workspace_bytes(HEADS, (int)S);
     take(&h->attn_ws, h->attn_ws_bytes);
+    take(&h->lora_t, (S > (size_t)n_steps ? S : (size_t)n_steps) * 3 * 128 * 2);
     return off;
 }
 
@@ -97,7 +101,23 @@ int pe_dit_create(const pe_dit_weights* w, const pe_adapter_weights* adapter, pe
 void pe_dit_destroy(pe_dit_handle h) {
     if (!h) return;
     delete[] h->blocks;
+    delete[] h->lora;
     delete h;
+}
+
+int pe_dit_set_hot_lora(pe_dit_handle h, const pe_dit_block_lora* blocks, int r) {
+    PE_REQUIRE(h, "pe_dit_set_hot_lora: null handle");
+    delete[] h->lora;
+    h->lora = nullptr;
+    h->lora_r = 0;
+    h->n_steps = 0;   // modulation rows must be rebuilt
+    if (!blocks) return PE_OK;
+    PE_REQUIRE(r > 0 && r <= 128 && r % 64 == 0, "pe_dit_set_hot_lora: r=%d must be 64 or 128", r);
+    h->lora = new (std::nothrow) pe_dit_block_lora[h->w.num_layers > 0 ? h->w.num_layers : 1];
+    PE_REQUIRE(h->lora, "pe_dit_set_hot_lora: out of host memory");
+    for (int i = 0; i < h->w.num_layers; ++i) h->lora[i] = blocks[i];
+    h->lora_r = r;
+    return PE_OK;
 }
 
 size_t pe_dit_workspace_bytes(pe_dit_handle h, int S_img_max, int T_max, int n_steps) {
@@ -161,6 +181,23 @@ int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void
             pp[s].M = n_steps; pp[s].N = MOD; pp[s].K = D;
         }
         if ((rc = launch_gemm(EPI_BIAS, pp, 2, stream))) return rc;
+        if (h->lora && h->lora[l].img_mod_a && h->lora[l].txt_mod_a) {
+            // mod = Linear(silu) + (silu @ A.T) @ B.T   (img_mod.1 / txt_mod.1 are LoRA targets)
+            const int r = h->lora_r;
+            GemmProblem ta[2], tb[2];
+            memset(ta, 0, sizeof(ta));
+            memset(tb, 0, sizeof(tb));
+            for (int s = 0; s < 2; ++s) {
+                char* t = h->lora_t + (size_t)s * n_steps * r * 2;
+                ta[s].A = h->silu_temb; ta[s].lda = D; ta[s].W = s == 0 ? h->lora[l].img_mod_a : h->lora[l].txt_mod_a;
+                ta[s].out = t; ta[s].ldo = r; ta[s].M = n_steps; ta[s].N = r; ta[s].K = D;
+                tb[s].A = t; tb[s].lda = r; tb[s].W = s == 0 ? h->lora[l].img_mod_b : h->lora[l].txt_mod_b;
+                tb[s].pre = pp[s].out; tb[s].ldp = ld; tb[s].out = pp[s].out; tb[s].ldo = ld;
+                tb[s].M = n_steps; tb[s].N = MOD; tb[s].K = r;
+            }
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, tb, 2, stream))) return rc;
+        }
     }
     memset(&p, 0, sizeof(p));
     p.A = h->silu_temb; p.lda = D; p.W = h->w.norm_out_w; p.bias = h->w.norm_out_b;
@@ -273,6 +310,25 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].q_out = h->q; pp[s].k_out = h->k; pp[s].vt_out = h->vt;
             pp[s].seq_off = s == 0 ? 0 : S_img; pp[s].S_pad = S_pad;
         }
+        const pe_dit_block_lora* LR = h->lora ? &h->lora[l] : nullptr;
+        const int r = h->lora_r;
+        if (LR && LR->img_qkv_a && LR->txt_qkv_a) {
+            // hot LoRA: t = x @ Acat.T ; y1 = x @ W.T + b ; then (t @ Bdiag.T) with pre = y1 and the QKV epilogue
+            GemmProblem ta[2], y1[2];
+            memset(ta, 0, sizeof(ta));
+            memset(y1, 0, sizeof(y1));
+            for (int s = 0; s < 2; ++s) {
+                const size_t row0 = s == 0 ? 0 : (size_t)S_img;
+                ta[s].A = pp[s].A; ta[s].lda = D; ta[s].W = s == 0 ? LR->img_qkv_a : LR->txt_qkv_a;
+                ta[s].out = h->lora_t + row0 * 3 * r * 2; ta[s].ldo = 3 * r; ta[s].M = pp[s].M; ta[s].N = 3 * r; ta[s].K = D;
+                y1[s].A = pp[s].A; y1[s].lda = D; y1[s].W = pp[s].W; y1[s].bias = pp[s].bias;
+                y1[s].out = h->hbuf + row0 * 3 * D * 2; y1[s].ldo = 3 * D; y1[s].M = pp[s].M; y1[s].N = 3 * D; y1[s].K = D;
+                pp[s].A = ta[s].out; pp[s].lda = 3 * r; pp[s].W = s == 0 ? LR->img_qkv_b : LR->txt_qkv_b;
+                pp[s].bias = nullptr; pp[s].K = 3 * r; pp[s].pre = y1[s].out; pp[s].ldp = 3 * D;
+            }
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, y1, 2, stream))) return rc;
+        }
         if ((rc = launch_gemm(EPI_QKV, pp, 2, stream))) return rc;
         // joint attention
         if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream))) return rc;
@@ -286,6 +342,22 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].res = pp[s].out; pp[s].ldr = D;
             pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 0);
             pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = D;
+        }
+        if (LR && LR->img_out_a && LR->txt_out_a) {
+            GemmProblem ta[2], y1[2];
+            memset(ta, 0, sizeof(ta));
+            memset(y1, 0, sizeof(y1));
+            for (int s = 0; s < 2; ++s) {
+                const size_t row0 = s == 0 ? 0 : (size_t)S_img;
+                ta[s].A = pp[s].A; ta[s].lda = D; ta[s].W = s == 0 ? LR->img_out_a : LR->txt_out_a;
+                ta[s].out = h->lora_t + row0 * r * 2; ta[s].ldo = r; ta[s].M = pp[s].M; ta[s].N = r; ta[s].K = D;
+                y1[s].A = pp[s].A; y1[s].lda = D; y1[s].W = pp[s].W; y1[s].bias = pp[s].bias;
+                y1[s].out = h->xmod + row0 * D * 2; y1[s].ldo = D; y1[s].M = pp[s].M; y1[s].N = D; y1[s].K = D;
+                pp[s].A = ta[s].out; pp[s].lda = r; pp[s].W = s == 0 ? LR->img_out_b : LR->txt_out_b;
+                pp[s].bias = nullptr; pp[s].K = r; pp[s].pre = y1[s].out; pp[s].ldp = D;
+            }
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, y1, 2, stream))) return rc;
         }
         if ((rc = launch_gemm(EPI_GATE_RES, pp, 2, stream))) return rc;
         // norm2 + modulate
@@ -312,6 +384,22 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].res = pp[s].out; pp[s].ldr = D;
             pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 1);
             pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = FF;
+        }
+        if (LR && LR->img_down_a && LR->txt_down_a) {
+            GemmProblem ta[2], y1[2];
+            memset(ta, 0, sizeof(ta));
+            memset(y1, 0, sizeof(y1));
+            for (int s = 0; s < 2; ++s) {
+                const size_t row0 = s == 0 ? 0 : (size_t)S_img;
+                ta[s].A = pp[s].A; ta[s].lda = FF; ta[s].W = s == 0 ? LR->img_down_a : LR->txt_down_a;
+                ta[s].out = h->lora_t + row0 * r * 2; ta[s].ldo = r; ta[s].M = pp[s].M; ta[s].N = r; ta[s].K = FF;
+                y1[s].A = pp[s].A; y1[s].lda = FF; y1[s].W = pp[s].W; y1[s].bias = pp[s].bias;
+                y1[s].out = h->attn + row0 * D * 2; y1[s].ldo = D; y1[s].M = pp[s].M; y1[s].N = D; y1[s].K = FF;
+                pp[s].A = ta[s].out; pp[s].lda = r; pp[s].W = s == 0 ? LR->img_down_b : LR->txt_down_b;
+                pp[s].bias = nullptr; pp[s].K = r; pp[s].pre = y1[s].out; pp[s].ldp = D;
+            }
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, y1, 2, stream))) return rc;
         }
         if ((rc = launch_gemm(EPI_GATE_RES, pp, 2, stream))) return rc;
     }

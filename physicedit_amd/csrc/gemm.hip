@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     const int mw0 = m0 + wm * 64;
     {
         const bf16* bias = (const bf16*)P.bias;
+        const bf16* pre = (const bf16*)P.pre;   // hot LoRA: `out + x @ A.T @ B.T` (vram_management/layers.py:179-180)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -420,6 +421,12 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] + b[r]);
                     const int row = mi * 32 + l31;
+                    if (pre != nullptr && n < N && mw0 + row < M) {
+                        // y = pre + y : the linear's own (already rounded) output plus this low-rank product
+                        const bf16x4 pv = *(const bf16x4*)(pre + (size_t)(mw0 + row) * P.ldp + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = (bf16)((float)pv[r] + (float)y[r]);
+                    }
                     const int c = ni * 4 + q;
                     *(bf16x4*)(E + row * 256 + ((c ^ (row & 15)) << 4) + h * 8) = y;
                 }
@@ -627,6 +634,7 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
         }
         if (epilogue == EPI_GATE_RES)
             PE_REQUIRE(p.res != nullptr && p.ldr % 8 == 0, "gemm(gate_res): bad residual");
+        PE_REQUIRE(p.pre == nullptr || (p.ldp % 4 == 0 && p.ldp >= p.N), "gemm: bad pre-add operand (ldp=%d)", p.ldp);
         p.tilesM = (p.M + BM - 1) / BM;
         p.tilesN = (p.N + BN - 1) / BN;
         tiles[i] = p.tilesM * p.tilesN;

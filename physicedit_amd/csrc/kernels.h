@@ -30,6 +30,9 @@ struct GemmProblem {
     const void* gate;  // [N] bf16 (null => gate 1)
     const void* res;   // [M,N] bf16, row stride ldr (may alias out)
     int ldr;
+    // optional for every epilogue: y = bf16(pre[m][n] + bf16(acc + bias)) before the epilogue proper
+    const void* pre;   // [M,N] bf16, row stride ldp, or null
+    int ldp;
     // EPI_QKV: N = 3*H*128; columns [0,HD) q, [HD,2HD) k, [2HD,3HD) v
     const void* norm_q_w;   // [128] bf16
     const void* norm_k_w;   // [128] bf16

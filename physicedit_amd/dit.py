@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import _lib, ops
-from ._lib import AdapterWeights, DitBlockWeights, DitCall, DitWeights, check, lib, stream_ptr
+from ._lib import AdapterWeights, DitBlockLora, DitBlockWeights, DitCall, DitWeights, check, lib, stream_ptr
 from .rope import RopeCache
 from .scheduler import adapter_alpha, qwen_image_scheduler, timestep_sinusoid
 
@@ -134,6 +134,8 @@ class QwenImageDiTEngine:
         other._handle = C.c_void_p()
         other._keep = None
         other._create()
+        other._hot, other._hot_r = getattr(self, "_hot", None), getattr(self, "_hot_r", 0)
+        other._apply_hot()
         other._ws = None
         other._bound = (0, 0, 0)
         other._step_of = {}
@@ -150,7 +152,81 @@ class QwenImageDiTEngine:
     # ------------------------------------------------------------------------------------------
     # LoRA merge (GeneralLoRALoader.load, lora/__init__.py:28-45): W <- bf16(W + bf16(alpha * B @ A))
     # ------------------------------------------------------------------------------------------
-    def load_lora(self, lora_state_dict: Dict[str, torch.Tensor], alpha: float = 1.0) -> int:
+    _HOT_GROUPS = {   # LoRA target -> (fused group, slot inside the group)
+        "attn.to_q": ("img_qkv", 0), "attn.to_k": ("img_qkv", 1), "attn.to_v": ("img_qkv", 2),
+        "attn.add_q_proj": ("txt_qkv", 0), "attn.add_k_proj": ("txt_qkv", 1), "attn.add_v_proj": ("txt_qkv", 2),
+        "attn.to_out.0": ("img_out", 0), "attn.to_add_out": ("txt_out", 0),
+        "img_mlp.net.2": ("img_down", 0), "txt_mlp.net.2": ("txt_down", 0),
+        "img_mod.1": ("img_mod", 0), "txt_mod.1": ("txt_mod", 0),
+    }
+    _HOT_SHAPES = {"qkv": (3 * D, D, 3), "out": (D, D, 1), "down": (D, 4 * D, 1), "mod": (6 * D, D, 1)}
+
+    def load_lora_hot(self, lora_state_dict: Dict[str, torch.Tensor], alpha: float = 1.0) -> int:
+        """load_lora(hotload=True) (qwen_image_physical.py:264-272): the LoRA stays separate and every targeted
+        Linear computes out + x @ (alpha*A).T @ B.T at run time (vram_management/layers.py:173-181).  One LoRA
+        per target; rank <= 128."""
+        found = {}
+        for key, A in lora_state_dict.items():
+            if ".lora_A." not in key:
+                continue
+            name = key.split(".lora_A.")[0]
+            kb = key.replace(".lora_A.", ".lora_B.")
+            parts = name.split(".")
+            if parts[0] == "diffusion_model":
+                parts = parts[1:]
+            if len(parts) < 3 or parts[0] != "transformer_blocks" or kb not in lora_state_dict:
+                raise _lib.PeError(f"load_lora(hotload=True): unsupported LoRA key {key}")
+            blk, target = int(parts[1]), ".".join(parts[2:])
+            if target not in self._HOT_GROUPS:
+                raise _lib.PeError(f"load_lora(hotload=True): {target} is not a hot-loadable Linear of the block")
+            found[(blk, target)] = ((A.to(BF) * alpha).to(self.device), lora_state_dict[kb].to(device=self.device, dtype=BF))
+        if not found:
+            return 0
+        rank = max(a.shape[0] for a, _ in found.values())
+        rp = (rank + 63) // 64 * 64
+        if rp > 128:
+            raise _lib.PeError(f"load_lora(hotload=True): rank {rank} > 128")
+        if getattr(self, "_hot", None) is not None:
+            raise _lib.PeError("load_lora(hotload=True): one hot LoRA per target is supported; clear_lora() first")
+        hot = []
+        for i in range(self.num_layers):
+            blk = {}
+            for g in ("img_qkv", "txt_qkv", "img_out", "txt_out", "img_down", "txt_down", "img_mod", "txt_mod"):
+                n_out, n_in, parts_n = self._HOT_SHAPES[g.split("_")[1]]
+                a = torch.zeros((parts_n * rp, n_in), dtype=BF, device=self.device)
+                b = torch.zeros((n_out, parts_n * rp), dtype=BF, device=self.device)
+                blk[g + "_a"], blk[g + "_b"] = a, b
+            for (bi, target), (A, B) in found.items():
+                if bi != i:
+                    continue
+                g, slot = self._HOT_GROUPS[target]
+                r = A.shape[0]
+                rows = B.shape[0]
+                blk[g + "_a"][slot * rp: slot * rp + r].copy_(A)
+                blk[g + "_b"][slot * rows:(slot + 1) * rows, slot * rp: slot * rp + r].copy_(B)
+            hot.append(blk)
+        self._hot, self._hot_r = hot, rp
+        self._apply_hot()
+        return len(found)
+
+    def clear_lora(self):
+        self._hot, self._hot_r = None, 0
+        check(lib().pe_dit_set_hot_lora(self._handle, None, 0), "pe_dit_set_hot_lora")
+        self._step_of = {}
+
+    def _apply_hot(self):
+        if getattr(self, "_hot", None) is None:
+            return
+        arr = (DitBlockLora * max(self.num_layers, 1))()
+        for i, blk in enumerate(self._hot):
+            for k, t in blk.items():
+                setattr(arr[i], k, t.data_ptr())
+        check(lib().pe_dit_set_hot_lora(self._handle, arr, self._hot_r), "pe_dit_set_hot_lora")
+        self._step_of = {}
+
+    def load_lora(self, lora_state_dict: Dict[str, torch.Tensor], alpha: float = 1.0, hotload: bool = False) -> int:
+        if hotload:
+            return self.load_lora_hot(lora_state_dict, alpha)
         if alpha != 1.0:
             raise _lib.PeError("load_lora: only alpha=1.0 is merged on the GPU path (validate.py uses alpha=1)")
         n = 0

@@ -46,6 +46,23 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def hot_lora_linear(x, w, bias, lora_a, lora_b, epilogue: str = "bias", gate=None, res=None) -> torch.Tensor:
+    """AutoWrappedLinear with one hot-loaded LoRA pair (vram_management/layers.py:173-181), reference rounding:
+    y1 = linear(x); t = x @ A.T; out = epilogue(y1 + t @ B.T).  lora_a [r,K], lora_b [N,r]; r is padded to 64."""
+    r = lora_a.shape[0]
+    rp = (r + 63) // 64 * 64
+    a = torch.zeros((rp, x.shape[1]), dtype=BF, device=x.device); a[:r] = lora_a
+    b = torch.zeros((w.shape[0], rp), dtype=BF, device=x.device); b[:, :r] = lora_b
+    t = gemm(x, a)
+    y1 = gemm(x, w, bias)
+    M, N = y1.shape
+    out = torch.empty_like(y1)
+    check(lib().pe_gemm_bf16_pre(EPI[epilogue], t.data_ptr(), rp, b.data_ptr(), None, y1.data_ptr(), N, out.data_ptr(), N,
+                                 M, N, rp, _ptr(gate), _ptr(res), N if res is not None else 0, stream_ptr()),
+          "pe_gemm_bf16_pre")
+    return out
+
+
 def s_pad_of(S: int) -> int:
     return (S + 63) // 64 * 64
 

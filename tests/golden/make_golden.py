@@ -319,6 +319,37 @@ def G8_lora():
     save("G8_lora", outs, meta={"rank": 8, "seed_lora": 4321, "seed_weights": 1234})
 
 
+def G11_hot_lora():
+    """Runtime LoRA (hotload=True): AutoWrappedLinear with lora_A/B lists (vram_management/layers.py:166-181),
+    on one Linear and through one whole block with all 12 targets hot-loaded."""
+    from diffsynth.vram_management.layers import AutoWrappedLinear
+    from diffsynth.vram_management import enable_vram_management
+    dit, sd = build_dit(1, 1234)
+    enable_vram_management(dit, module_map={torch.nn.Linear: AutoWrappedLinear},
+                           module_config=dict(offload_dtype=BF, offload_device="cpu", onload_dtype=BF, onload_device="cpu",
+                                              computation_dtype=BF, computation_device="cpu"), vram_limit=None)
+    lora = synth.make_lora(4321, 1, 16)
+    alpha = 1
+    n = 0
+    for name, module in dit.named_modules():            # qwen_image_physical.py:264-272 (hotload branch)
+        if isinstance(module, AutoWrappedLinear):
+            a, b = f"{name}.lora_A.default.weight", f"{name}.lora_B.default.weight"
+            if a in lora and b in lora:
+                module.lora_A_weights.append(lora[a] * alpha)
+                module.lora_B_weights.append(lora[b])
+                n += 1
+    assert n == 12
+    g = torch.Generator().manual_seed(55)
+    x = torch.randn((1, 70, 3072), generator=g).to(BF)
+    lin = dit.transformer_blocks[0].attn.to_q
+    outs = {"linear_out": lin(x)}
+    image, text, temb = _block_inputs(128, 40, 44)
+    rope = dit.pos_embed([(1, 8, 8), (1, 8, 8)], [40], device=torch.device("cpu"))
+    text_o, image_o = dit.transformer_blocks[0](image=image, text=text, temb=temb, image_rotary_emb=rope)
+    outs["text_out"], outs["image_out"] = text_o, image_o
+    save("G11_hot_lora", outs, meta={"rank": 16, "seed_lora": 4321})
+
+
 def G9_adapter():
     ad, adsd, (t_min, t_max) = build_adapter(4321)
     g = torch.Generator().manual_seed(9)

@@ -45,7 +45,7 @@ def test_invalid_args_fail_loudly_without_gpu(built_lib):
     assert rc == -1 and b"null operand" in built_lib.pe_last_error()
     rc = built_lib.pe_gemm_bf16(0, 1, 100, 1, None, 1, 64, 8, 8, 100, None, None, 0, None)
     assert rc == -1 and b"multiple of 64" in built_lib.pe_last_error()
-    rc = built_lib.pe_flash_attn(1, 1, 1, 1, 24, 100, 100, 3072, 0.1, None)
+    rc = built_lib.pe_flash_attn(1, 1, 1, 1, 24, 100, 100, 3072, 0.1, None, 0, None)
     assert rc == -1 and b"S_pad" in built_lib.pe_last_error()
     assert built_lib.pe_dit_workspace_bytes(None, 10, 10, 1) == 0
     with pytest.raises(_lib.PeError):

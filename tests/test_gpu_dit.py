@@ -222,3 +222,40 @@ def test_model_fn_odd_geometry(eng2, hw, edits, T, nsp):
     if nsp:
         dp = (pe_d.float().cpu() - pe_ref.float()).abs()
         assert dp.max().item() <= 2 ** -7
+
+
+def test_hot_lora_linear_G11(golden):
+    """One AutoWrappedLinear with a hot-loaded LoRA (layers.py:173-181) vs the reference's output."""
+    from physicedit_amd import ops
+    g, meta = golden("G11_hot_lora", with_meta=True)
+    sd = synth.make_state_dict(synth.dit_block_layout(0), 1234)
+    lora = synth.make_lora(4321, 1, meta["rank"])
+    gen = torch.Generator().manual_seed(55)
+    x = torch.randn((1, 70, 3072), generator=gen).to(BF)
+    n = "transformer_blocks.0.attn.to_q"
+    out = ops.hot_lora_linear(x[0].cuda(), sd[n + ".weight"].cuda(), sd[n + ".bias"].cuda(),
+                              lora[n + ".lora_A.default.weight"].cuda(), lora[n + ".lora_B.default.weight"].cuda())
+    report("hot-lora linear vs reference", out, g["linear_out"][0], 1.01, 0.01)
+
+
+def test_model_fn_hot_lora(eng2):
+    """All 12 targets hot-loaded through the composite (pe_dit_set_hot_lora) vs the oracle's restatement, which is
+    pinned bit-exact on the reference's AutoWrappedLinear (G11).  Also: hot != merged arithmetic, and clear_lora()."""
+    from physicedit_amd.dit import QwenImageDiTEngine, special_indices
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    lora = synth.make_lora(4321, 2, 16, std=0.05)
+    t_min, t_max = O.adapter_t_range()
+    noise, edit, pe, mask = _model_fn_inputs(128, 128, 40, 8, 3)
+    t = torch.tensor([700.0]).to(BF)
+    ref = O.model_fn(O.attach_hot_lora(sd, lora), ad, noise, t, pe.clone(), mask, 128, 128, edit, t_min, t_max)
+    eng = QwenImageDiTEngine(sd, ad, device="cuda")
+    base = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda()).clone()
+    assert eng.load_lora(lora, hotload=True) == 24
+    got = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda()).clone()
+    d, u = stats("model_fn hot LoRA (2 layers, 12 targets/block)", got, ref)
+    assert u.max().item() <= 4.0 and d.mean().item() <= 1.5e-3
+    assert (got.float() - base.float()).abs().max().item() > 0.01      # the LoRA actually does something
+    eng.clear_lora()
+    again = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda())
+    assert torch.equal(again, base)

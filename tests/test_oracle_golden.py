@@ -209,3 +209,23 @@ def test_G10_image(golden):
     ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
     assert_same(O.preprocess_image(ramp), g["pre"], "preprocess")
     assert_same(O.vae_output_to_u8(g["post_in"]), g["post_u8"], "postprocess")
+
+
+def test_G11_hot_lora(golden):
+    """Runtime LoRA (hotload=True), vram_management/layers.py:166-181: one Linear and a whole block."""
+    g, meta = golden("G11_hot_lora", with_meta=True)
+    sd = O.attach_hot_lora(synth.make_state_dict(synth.dit_block_layout(0), 1234), synth.make_lora(4321, 1, meta["rank"]))
+    assert len(sd.hot) == 12
+    gen = torch.Generator().manual_seed(55)
+    x = torch.randn((1, 70, 3072), generator=gen).to(BF)
+    assert_same(O._linear(sd, "transformer_blocks.0.attn.to_q", x), g["linear_out"], "hot-lora linear")
+    image, text, temb = _block_inputs(128, 40, 44)
+    rope = O.rope_tables([(1, 8, 8), (1, 8, 8)], 40)
+    text_o, image_o = O.block_forward(sd, 0, image, text, temb, rope)
+    assert_same(text_o, g["text_out"], "hot-lora block text")
+    assert_same(image_o, g["image_out"], "hot-lora block image")
+    # and it is NOT the same arithmetic as merging the LoRA into the weights
+    merged = synth.make_state_dict(synth.dit_block_layout(0), 1234)
+    O.lora_merge(merged, synth.make_lora(4321, 1, meta["rank"]))
+    _, image_m = O.block_forward(merged, 0, image, text, temb, rope)
+    assert not torch.equal(image_m, image_o)
