@@ -64,6 +64,21 @@ int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void
 int pe_gemm_bf16_pre(int epilogue, const void* A, int lda, const void* W, const void* bias, const void* pre, int ldp,
                      void* out, int ldo, int M, int N, int K, const void* gate, const void* res, int ldr, void* stream);
 
+/* e4m3 ("FP8 computation") Linear: AutoWrappedLinear.fp8_linear, vram_management/layers.py:115-151, reached when the
+ * DiT is stored in float8_e4m3fn and enable_vram_management(enable_dit_fp8_computation=True) is on
+ * (pipelines/qwen_image_physical.py:440-496).  Two launches per Linear:
+ *   pe_quantize_rows_e4m3:  scale[m] = max(bf16(max|x[m,:]| * (1/448)), 1);  out[m,:K] = e4m3fn(x[m,:] / (scale[m] + 1e-8)),
+ *                           out[m,K:Kp] = 0.  x bf16 [M,K] (row stride ldx), out bytes [M,Kp], Kp % 128 == 0, K % 8 == 0.
+ *   pe_gemm_e4m3:           y = bf16(acc * scale_a[m] + bias[n]) with acc = Aq[M,K] . Wq[N,K]^T in fp32 on the
+ *                           block-scaled CDNA4 MFMA (unit block scales), then pre-add / epilogue as pe_gemm_bf16_pre.
+ *                           Aq, Wq are OCP e4m3fn bytes; K % 128 == 0; lda % 16 == 0; bias/pre/gate/res/out bf16.
+ * torch._scaled_mm, which the reference calls here, does not run on CPU with per-row scales: parity of this pair is
+ * pinned only against the CPU restatement in oracle/ ("parity unpinned"). */
+int pe_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, void* stream);
+int pe_gemm_e4m3(int epilogue, const void* Aq, int lda, const float* scale_a, const void* Wq, const void* bias,
+                 const void* pre, int ldp, void* out, int ldo, int M, int N, int K, const void* gate, const void* res,
+                 int ldr, void* stream);
+
 /* Fused QKV projection of one stream (QwenDoubleStreamAttention.forward, qwen_image_dit.py:282-302):
  * x[M,K] @ Wqkv[3*H*128,K]^T + b, per-head RMSNorm(q,k) (weights norm_q_w/norm_k_w [128]), RoPE(q,k)
  * with fp32 tables rope_cos/rope_sin [M,64]; writes head-major Q,K [H][S_pad][128] at rows

@@ -124,9 +124,9 @@ def time_text_embed(sd: SD, timestep: torch.Tensor, dtype: torch.dtype) -> torch
     # models/utils.py:290-293 + _DiffusersCompatibleTimestepProj :260-271
     p = "time_text_embed.timestep_embedder."
     x = timestep_sinusoid(timestep).to(dtype)
-    x = F.linear(x, sd[p + "linear_1.weight"], sd[p + "linear_1.bias"])
+    x = _linear(sd, p + "linear_1", x)
     x = F.silu(x)
-    x = F.linear(x, sd[p + "linear_2.weight"], sd[p + "linear_2.bias"])
+    x = _linear(sd, p + "linear_2", x)
     return x
 
 
@@ -231,7 +231,7 @@ def joint_attention(sd: SD, p: str, image, text, rope) -> Tuple[torch.Tensor, to
 
 def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     # QwenFeedForward + ApproximateGELU, qwen_image_dit.py:42-49,228-245
-    x = F.linear(x, sd[p + "net.0.proj.weight"], sd[p + "net.0.proj.bias"])
+    x = _linear(sd, p + "net.0.proj", x)
     x = x * torch.sigmoid(1.702 * x)
     return _linear(sd, p + "net.2", x)
 
@@ -311,19 +311,19 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
         img_shapes += [(e.shape[0], e.shape[2] // 2, e.shape[3] // 2) for e in edit_list]
         image = torch.cat([image] + [patchify(e) for e in edit_list], dim=1)
 
-    image = F.linear(image, sd["img_in.weight"], sd["img_in.bias"])
+    image = _linear(sd, "img_in", image)
     conditioning = time_text_embed(sd, timestep, image.dtype)
-    text = F.linear(rmsnorm(prompt_emb, sd["txt_norm.weight"]), sd["txt_in.weight"], sd["txt_in.bias"])
+    text = _linear(sd, "txt_in", rmsnorm(prompt_emb, sd["txt_norm.weight"]))
     vid_f, txt_f = rope_tables(img_shapes, T)
 
     for i in range(num_layers_of(sd)):
         text, image = block_forward(sd, i, image, text, conditioning, (vid_f, txt_f))
 
     # AdaLayerNorm(single=True), models/utils.py:304-309
-    emb = F.linear(F.silu(conditioning), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
+    emb = _linear(sd, "norm_out.linear", F.silu(conditioning))
     scale, shift = emb.unsqueeze(1).chunk(2, dim=2)
     image = F.layer_norm(image, (image.shape[-1],), eps=1e-6) * (1 + scale) + shift
-    image = F.linear(image, sd["proj_out.weight"], sd["proj_out.bias"])
+    image = _linear(sd, "proj_out", image)
     image = image[:, :image_seq_len]
     return unpatchify(image, height // 16, width // 16)
 
@@ -410,12 +410,68 @@ _orig_linear = F.linear
 
 
 def _linear(sd, name: str, x: torch.Tensor) -> torch.Tensor:
-    """Linear `name` of the state-dict, with its hot LoRA pairs if the dict carries any."""
+    """Linear `name` of the state-dict (AutoWrappedLinear.forward, vram_management/layers.py:152-186): the e4m3 path
+    when the layer is stored in float8_e4m3fn, then its hot LoRA pairs if the dict carries any."""
     w, b = sd[name + ".weight"], sd.get(name + ".bias")
     hot = getattr(sd, "hot", None)
+    if w.dtype == torch.float8_e4m3fn:
+        out = fp8_linear(x, w, b)
+        if hot and name in hot:
+            for lora_A, lora_B in hot[name]:
+                out = out + x @ lora_A.T @ lora_B.T
+        return out
     if hot and name in hot:
         return hot_lora_linear(x, w, b, hot[name])
     return _orig_linear(x, w, b)
+
+
+# ======================================================================================
+# e4m3 ("FP8 computation") Linear -- PARITY UNPINNED
+# ======================================================================================
+# AutoWrappedLinear.fp8_linear (vram_management/layers.py:115-151) is reached when the DiT is STORED in
+# float8_e4m3fn (ModelConfig(offload_dtype=torch.float8_e4m3fn)) and enable_vram_management(
+# enable_dit_fp8_computation=True) wraps every torch.nn.Linear with computation_dtype = that stored dtype
+# (pipelines/qwen_image_physical.py:440-496).  Its matmul is torch._scaled_mm, which has no CPU implementation for
+# per-row scales, so the reference cannot produce golden vectors for it in the build container: this restatement
+# is PARITY UNPINNED.  What it follows:
+#   * the quantisation arithmetic literally, with the GPU semantics of `bf16_tensor / python_float`
+#     (ATen BinaryDivTrueKernel: x * (1/448) in fp32, one rounding to bf16) because the reference can only run
+#     this path on a GPU;
+#   * for _scaled_mm its documented contract: out = ((A @ B) * scale_a * scale_b + bias).to(out_dtype) with the
+#     product accumulated in fp32.  Products of e4m3 values are exact in fp32; the sum here is taken in float64 so
+#     the oracle carries no accumulation-order noise of its own.
+def fp8_quantize_rows(x2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """layers.py:126-137 -> (xq float8_e4m3fn [M,K], scale_a fp32 [M,1])."""
+    x_max = torch.max(torch.abs(x2), dim=-1, keepdim=True).values
+    inv = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(448.0, dtype=torch.float32)
+    scale_a = torch.clamp((x_max.float() * inv).to(x2.dtype), min=1.0).float()
+    xq = (x2 / (scale_a + 1e-8)).to(torch.float8_e4m3fn)
+    return xq, scale_a
+
+
+def fp8_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    xq, scale_a = fp8_quantize_rows(x2)
+    acc = (xq.to(torch.float64) @ weight.to(torch.float64).T).float()
+    y = acc * scale_a
+    if bias is not None:
+        y = y + bias.to(torch.bfloat16).float()
+    return y.to(x.dtype).reshape(shp[:-1] + (weight.shape[0],))
+
+
+def to_fp8_state_dict(sd: SD) -> SD:
+    """The DiT state-dict as `load_state_dict(..., torch_dtype=float8_e4m3fn)` leaves it: every parameter cast to
+    e4m3fn.  Linear weights and biases stay e4m3 (fp8_linear consumes them); everything else (RMSNorm weights) is
+    what AutoWrappedModule hands to the bf16 computation: bf16(e4m3(w))."""
+    linear = {k[:-len(".weight")] for k, v in sd.items() if k.endswith(".weight") and v.dim() == 2}
+    out = type(sd)(sd) if isinstance(sd, HotLoraSD) else dict(sd)
+    if isinstance(sd, HotLoraSD):
+        out.hot = sd.hot
+    for k, v in sd.items():
+        q = v.to(torch.float8_e4m3fn)
+        out[k] = q if k.rsplit(".", 1)[0] in linear else q.to(v.dtype)
+    return out
 
 
 # ======================================================================================

@@ -65,6 +65,23 @@ int pe_gemm_bf16_pre(int epilogue, const void* A, int lda, const void* W, const 
     return launch_gemm(epilogue, &p, 1, (hipStream_t)stream);
 }
 
+int pe_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, void* stream) {
+    return launch_quantize_rows_e4m3(x, ldx, M, K, out, Kp, scale, (hipStream_t)stream);
+}
+
+int pe_gemm_e4m3(int epilogue, const void* Aq, int lda, const float* scale_a, const void* Wq, const void* bias,
+                 const void* pre, int ldp, void* out, int ldo, int M, int N, int K, const void* gate, const void* res,
+                 int ldr, void* stream) {
+    PE_REQUIRE(epilogue != EPI_QKV, "pe_gemm_e4m3: the QKV epilogue is reached through pe_dit_forward");
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = Aq; p.W = Wq; p.bias = bias; p.out = out; p.pre = pre; p.ldp = ldp;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldo = ldo;
+    p.gate = gate; p.res = res; p.ldr = ldr;
+    p.fp8 = 1; p.scale_a = scale_a;
+    return launch_gemm(epilogue, &p, 1, (hipStream_t)stream);
+}
+
 int pe_qkv_rmsnorm_rope(const void* x, int ldx, const void* Wqkv, const void* bqkv, int M, int H, int K,
                         const void* norm_q_w, const void* norm_k_w, const float* rope_cos,
                         const float* rope_sin, void* q_out, void* k_out, void* vt_out, int seq_off, int S_pad,

@@ -149,6 +149,79 @@ int launch_silu(const void* x, void* out, size_t n, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row quantiser of AutoWrappedLinear.fp8_linear (vram_management/layers.py:126-137), GPU semantics of the reference:
+//   x_max   = max|x[m,:]|                     (bf16, exact)
+//   scale_a = clamp(x_max / 448, min=1)       bf16 tensor / python scalar on the GPU = x * (1/448) in fp32, rounded to bf16
+//   xq      = e4m3fn( float(x) / (float(scale_a) + 1e-8) )     fp32 IEEE division, RNE conversion
+// One 256-thread block per row; a thread keeps up to MAXC 8-element chunks in registers (K <= 2048*MAXC).
+// Columns [K, Kp) of the output are zero-filled (K tile of the e4m3 GEMM is 128).
+// ------------------------------------------------------------------------------------------------
+PE_DEV uint32_t pack4_e4m3(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);   // v_cvt_pk_fp8_f32: OCP e4m3fn on gfx950, RNE
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+
+template <int MAXC>
+__global__ void __launch_bounds__(256) quantize_rows_e4m3_kernel(const bf16* __restrict__ x, int ldx, int K,
+                                                                 uint8_t* __restrict__ out, int Kp,
+                                                                 float* __restrict__ scale) {
+    __shared__ float red[4];
+    const int row = (int)blockIdx.x;
+    const int t = (int)threadIdx.x;
+    const bf16* xr = x + (size_t)row * ldx;
+    const int nch = K >> 3;
+    bf16x8 v[MAXC];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 256 + t;
+        if (c < nch) {
+            v[i] = *(const bf16x8*)(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf((float)v[i][j]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = fmaxf(bf16r(mx * (1.0f / 448.0f)), 1.0f);
+    const float dv = sc + 1e-8f;
+    if (t == 0) scale[row] = sc;
+    uint8_t* orow = out + (size_t)row * Kp;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 256 + t;
+        if (c < nch) {
+            u32x2 o;
+            o[0] = pack4_e4m3((float)v[i][0] / dv, (float)v[i][1] / dv, (float)v[i][2] / dv, (float)v[i][3] / dv);
+            o[1] = pack4_e4m3((float)v[i][4] / dv, (float)v[i][5] / dv, (float)v[i][6] / dv, (float)v[i][7] / dv);
+            *(u32x2*)(orow + c * 8) = o;
+        }
+    }
+    for (int c = nch + t; c < (Kp >> 3); c += 256) *(u32x2*)(orow + c * 8) = u32x2{0u, 0u};
+}
+
+int launch_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, hipStream_t stream) {
+    PE_REQUIRE(x && out && scale, "quantize_rows_e4m3: null pointer");
+    PE_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && K <= 12288, "quantize_rows_e4m3: M=%d K=%d (K: multiple of 8, <= 12288)", M, K);
+    PE_REQUIRE(ldx >= K && ldx % 8 == 0, "quantize_rows_e4m3: ldx=%d", ldx);
+    PE_REQUIRE(Kp >= K && Kp % 128 == 0, "quantize_rows_e4m3: Kp=%d must be >= K and a multiple of 128", Kp);
+    const int slot = prof_begin(PROF_ROW, 3.0 * (double)M * K, stream);   // bytes: read bf16 + write e4m3
+    if (K <= 4096)
+        hipLaunchKernelGGL((quantize_rows_e4m3_kernel<2>), dim3(M), dim3(256), 0, stream, (const bf16*)x, ldx, K,
+                           (uint8_t*)out, Kp, scale);
+    else
+        hipLaunchKernelGGL((quantize_rows_e4m3_kernel<6>), dim3(M), dim3(256), 0, stream, (const bf16*)x, ldx, K,
+                           (uint8_t*)out, Kp, scale);
+    prof_end(slot, stream);
+    return check_launch("quantize_rows_e4m3_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // patchify "C (H P) (W Q) -> (H W) (C P Q)", P=Q=2  (qwen_image_physical.py:1344) and its inverse (:1402)
 // latents [C, H2, W2]; tokens [(H2/2)*(W2/2), C*4].  One thread per (token, channel): 4 elements.
 // ------------------------------------------------------------------------------------------------

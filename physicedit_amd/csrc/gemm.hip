@@ -48,8 +48,18 @@ PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 //   1  fragment double buffering: k-step kk+1's ds_reads are issued before k-step kk's MFMAs
 //   2  = 1 + s_setprio(1) around each MFMA cluster
 //   3  ablation: tiles are staged for kt = 0 only (measures the MFMA + LDS-read loop alone; wrong results)
-template <int EPI, int VAR>
+//
+// FP8 = true: operands are OCP e4m3 bytes (activation rows quantised by quantize_rows_e4m3, weights stored in e4m3),
+// the K tile is 128 elements (the SAME 128-B LDS rows, staging and swizzle), the MFMA is the CDNA4 block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the bf16 rate), and the epilogue starts with
+// y = bf16(acc * scale_a[m] + bias[n])  (AutoWrappedLinear.fp8_linear, vram_management/layers.py:115-151).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+template <int EPI, int VAR, bool FP8>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmArgs args) {
+    constexpr int ES = FP8 ? 1 : 2;        // bytes per operand element
+    constexpr int KT_BYTES = 128;          // one K tile of a row, in bytes (64 bf16 / 128 e4m3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
     const int w = wave_id();
@@ -75,11 +85,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     }
 
     // ---- staging sources: wave w moves pieces w*4..w*4+3 (1 KiB = 8 rows x 128 B) of A and of W
-    const bf16* a_src[4];
-    const bf16* w_src[4];
+    const char* a_src[4];
+    const char* w_src[4];
     {
-        const bf16* A = (const bf16*)P.A;
-        const bf16* W = (const bf16*)P.W;
+        const char* A = (const char*)P.A;
+        const char* W = (const char*)P.W;
         const int rin = lane >> 3, slot = lane & 7;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -87,16 +97,16 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
             const int chunk = slot ^ ((row >> 1) & 7);
             const int gr = min(m0 + row, M - 1);
             const int gn = min(n0 + row, N - 1);
-            a_src[i] = A + (size_t)gr * P.lda + chunk * 8;
-            w_src[i] = W + (size_t)gn * K + chunk * 8;
+            a_src[i] = A + (size_t)gr * P.lda * ES + chunk * 16;
+            w_src[i] = W + (size_t)gn * K * ES + chunk * 16;
         }
     }
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE_BYTES + w * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            glds16(a_src[i] + kt * BK, base + i * 1024);
-            glds16(w_src[i] + kt * BK, base + BM * BK * 2 + i * 1024);
+            glds16(a_src[i] + kt * KT_BYTES, base + i * 1024);
+            glds16(w_src[i] + kt * KT_BYTES, base + BM * BK * 2 + i * 1024);
         }
     };
 
@@ -113,9 +123,107 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     const int a_row_off = (wm * 64 + l31) * 128;
     const int w_row_off = BM * BK * 2 + (wn * 128 + l31) * 128;
 
-    const int nk = K / BK;
-    stage(0, 0);
-    if constexpr (VAR == 0 || VAR == 3 || VAR == 4) {
+    const int nk = K * ES / KT_BYTES;
+    if constexpr (!FP8) stage(0, 0);
+    if constexpr (FP8) {
+        // v10's structure (A 2 x 32 KiB + W 3 x 32 KiB ring, tile barrier with vmcnt(4)) on 64-cycle MFMAs:
+        // four clusters of 4 MFMAs per K tile.  Cluster c covers k-half c>>1 and output column pair c&1:
+        //   c0: A(k0) x W(k0, ni 0,1)   c1: A(k0) x W(k0, ni 2,3)   c2: A(k1) x W(k1, ni 0,1)   c3: A(k1) x W(k1, ni 2,3)
+        // Fragment of one 32-row tile for one MFMA = 32 bytes of k per lane (k = 32*h .. +31) = two 16-B chunks.
+        constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
+        char* const a_base = smem;
+        char* const w_base = smem + 2 * A_BYTES;
+        auto frag = [&](const char* rowp, int k2) -> i32x8 {
+            const int c0 = 4 * k2 + 2 * h;
+            const i32x4 lo = *(const i32x4*)(rowp + ((c0 ^ sw) << 4));
+            const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto frag_a = [&](const char* Sa, int k2, i32x8 (&af)[2]) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = frag(Sa + (wm * 64 + mi * 32 + l31) * 128, k2);
+        };
+        auto frag_w = [&](const char* Sw, int k2, int pair, i32x8 (&wf)[2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = frag(Sw + (wn * 128 + (pair * 2 + j) * 32 + l31) * 128, k2);
+        };
+        const int unit = 0x7f7f7f7f;   // E8M0 block scales = 2^0
+        auto mma = [&](i32x8 (&af)[2], i32x8 (&wf)[2], int pair) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mi][pair * 2 + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                        wf[j], af[mi], acc[mi][pair * 2 + j], 0, 0, 0, unit, 0, unit);
+        };
+        auto stage_a = [&](int t, int first, int count) {
+            const int tc = min(t, nk - 1);
+            char* base = a_base + (t & 1) * A_BYTES + w * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i >= first && i < first + count) glds16(a_src[i] + tc * KT_BYTES, base + i * 1024);
+        };
+        auto stage_w = [&](int t, int slot, int first, int count) {
+            const int tc = min(t, nk - 1);
+            char* base = w_base + slot * W_BYTES + w * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i >= first && i < first + count) glds16(w_src[i] + tc * KT_BYTES, base + i * 1024);
+        };
+#define PE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define PE_CLUSTER8(NDS)                                          \
+    do {                                                          \
+        PE_SGB(0x008, 1); PE_SGB(0x100, (NDS) / 2);               \
+        PE_SGB(0x008, 1); PE_SGB(0x100, (NDS) / 2);               \
+        PE_SGB(0x008, 1); PE_SGB(0x020, 1);                       \
+        PE_SGB(0x008, 1); PE_SGB(0x020, 1);                       \
+    } while (0)
+        stage_a(0, 0, 4);
+        stage_w(0, 0, 0, 4);
+        stage_w(1, 1, 0, 4);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
+        __syncthreads();
+        i32x8 fa0[2], fa1[2], fwp[2], fwq[2];
+        frag_a(a_base, 0, fa0);
+        frag_w(w_base, 0, 0, fwp);
+        stage_a(1, 0, 2);
+        int ws_cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* Sa = a_base + (kt & 1) * A_BYTES;
+            const char* San = a_base + ((kt + 1) & 1) * A_BYTES;
+            const int ws_n1 = ws_cur == 2 ? 0 : ws_cur + 1;
+            const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
+            const char* Sw = w_base + ws_cur * W_BYTES;
+            const char* Swn = w_base + ws_n1 * W_BYTES;
+            // cluster 0
+            frag_w(Sw, 0, 1, fwq); frag_a(Sa, 1, fa1);
+            stage_a(kt + 1, 2, 2);
+            mma(fa0, fwp, 0);
+            PE_CLUSTER8(8);
+            // cluster 1
+            frag_w(Sw, 1, 0, fwp);
+            stage_w(kt + 2, ws_n2, 0, 2);
+            mma(fa0, fwq, 1);
+            PE_CLUSTER8(4);
+            // cluster 2
+            frag_w(Sw, 1, 1, fwq);
+            stage_w(kt + 2, ws_n2, 2, 2);
+            mma(fa1, fwp, 0);
+            PE_CLUSTER8(4);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // all but the 4 newest (= W(kt+2))
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // cluster 3
+            frag_a(San, 0, fa0); frag_w(Swn, 0, 0, fwp);
+            stage_a(kt + 2, 0, 2);
+            mma(fa1, fwq, 1);
+            PE_CLUSTER8(8);
+            ws_cur = ws_n1;
+        }
+#undef PE_CLUSTER8
+#undef PE_SGB
+    } else if constexpr (VAR == 0 || VAR == 3 || VAR == 4) {
         for (int kt = 0; kt < nk; ++kt) {
             if constexpr (VAR == 4) {   // ablation: never wait for the LDS-DMA (racy, timing only)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -169,8 +277,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i >= first && i < first + count) {
-                    glds16(a_src[i] + tc * BK, base + i * 1024);
-                    glds16(w_src[i] + tc * BK, base + BM * BK * 2 + i * 1024);
+                    glds16(a_src[i] + tc * KT_BYTES, base + i * 1024);
+                    glds16(w_src[i] + tc * KT_BYTES, base + BM * BK * 2 + i * 1024);
                 }
             }
         };
@@ -248,14 +356,14 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
             char* base = a_base + (t & 1) * A_BYTES + w * 4096;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (i >= first && i < first + count) glds16(a_src[i] + tc * BK, base + i * 1024);
+                if (i >= first && i < first + count) glds16(a_src[i] + tc * KT_BYTES, base + i * 1024);
         };
         auto stage_w = [&](int t, int slot, int first, int count) {
             const int tc = min(t, nk - 1);
             char* base = w_base + slot * W_BYTES + w * 4096;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (i >= first && i < first + count) glds16(w_src[i] + tc * BK, base + i * 1024);
+                if (i >= first && i < first + count) glds16(w_src[i] + tc * KT_BYTES, base + i * 1024);
         };
 #define PE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define PE_CLUSTER_SCHED(NVMEM)                                    \
@@ -351,8 +459,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i >= first && i < first + count) {
-                    glds16(a_src[i] + kt * BK, base + i * 1024);
-                    glds16(w_src[i] + kt * BK, base + BM * BK * 2 + i * 1024);
+                    glds16(a_src[i] + kt * KT_BYTES, base + i * 1024);
+                    glds16(w_src[i] + kt * KT_BYTES, base + BM * BK * 2 + i * 1024);
                 }
             }
         };
@@ -404,6 +512,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     {
         const bf16* bias = (const bf16*)P.bias;
         const bf16* pre = (const bf16*)P.pre;   // hot LoRA: `out + x @ A.T @ B.T` (vram_management/layers.py:179-180)
+        float sa[2] = {1.f, 1.f};               // FP8: per-row activation scale (fp8_linear's scale_a)
+        if constexpr (FP8) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[min(mw0 + mi * 32 + l31, M - 1)];
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -418,8 +531,13 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     bf16x4 y;
+                    if constexpr (FP8) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] + b[r]);
+                        for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] * sa[mi] + b[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] + b[r]);
+                    }
                     const int row = mi * 32 + l31;
                     if (pre != nullptr && n < N && mw0 + row < M) {
                         // y = pre + y : the linear's own (already rounded) output plus this low-rank product
@@ -581,22 +699,23 @@ static int env_int(const char* name, int dflt) {
 }
 int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 
-template <int EPI, int VAR>
+template <int EPI, int VAR, bool FP8 = false>
 static int launch_v(const GemmArgs& args, int ntiles, hipStream_t stream) {
     static bool configured = false;
+    constexpr int lds = (FP8 || VAR == 10) ? GEMM_LDS_V10 : GEMM_LDS;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, VAR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, VAR == 10 ? GEMM_LDS_V10 : GEMM_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, VAR, FP8>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR>), dim3(ntiles), dim3(GEMM_THREADS), VAR == 10 ? GEMM_LDS_V10 : GEMM_LDS,
-                       stream, args);
-    return check_launch("gemm_bf16_kernel");
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR, FP8>), dim3(ntiles), dim3(GEMM_THREADS), lds, stream, args);
+    return check_launch(FP8 ? "gemm_fp8_kernel" : "gemm_bf16_kernel");
 }
 
 template <int EPI>
-static int launch_t(const GemmArgs& args, int ntiles, hipStream_t stream) {
+static int launch_t(const GemmArgs& args, int ntiles, bool fp8, hipStream_t stream) {
+    if (fp8) return launch_v<EPI, GEMM_DEFAULT_VARIANT, true>(args, ntiles, stream);
     if (g_gemm_variant == 0) return launch_v<EPI, 0>(args, ntiles, stream);   // A/B reference schedules
     if (g_gemm_variant == 8) return launch_v<EPI, 8>(args, ntiles, stream);
     if constexpr (EPI == EPI_BIAS) {   // further experimental schedules only for the plain epilogue
@@ -616,12 +735,20 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     PE_REQUIRE(nproblems >= 1 && nproblems <= 2, "gemm: 1 or 2 problems per launch, got %d", nproblems);
     GemmArgs args;
     int tiles[2] = {0, 0};
+    const bool fp8 = problems[0].fp8 != 0;
     for (int i = 0; i < nproblems; ++i) {
         GemmProblem& p = problems[i];
         PE_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem %d (M=%d N=%d K=%d)", i, p.M, p.N, p.K);
-        PE_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
+        PE_REQUIRE((p.fp8 != 0) == fp8, "gemm: bf16 and e4m3 problems cannot share a launch");
+        if (fp8) {
+            PE_REQUIRE(p.K % 128 == 0, "gemm(fp8): K=%d must be a multiple of 128", p.K);
+            PE_REQUIRE(p.lda % 16 == 0 && p.lda >= p.K, "gemm(fp8): lda=%d must be >= K and a multiple of 16", p.lda);
+            PE_REQUIRE(p.scale_a != nullptr, "gemm(fp8): null scale_a");
+        } else {
+            PE_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
+            PE_REQUIRE(p.lda % 8 == 0 && p.lda >= p.K, "gemm: lda=%d must be >= K and a multiple of 8", p.lda);
+        }
         PE_REQUIRE(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);
-        PE_REQUIRE(p.lda % 8 == 0 && p.lda >= p.K, "gemm: lda=%d must be >= K and a multiple of 8", p.lda);
         PE_REQUIRE(p.A && p.W, "gemm: null operand");
         if (epilogue == EPI_QKV) {
             PE_REQUIRE(p.N % 384 == 0, "gemm(qkv): N=%d must be 3*H*128", p.N);
@@ -648,12 +775,12 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     const int slot = prof_begin(PROF_GEMM, flops, stream);
     int rc;
     switch (epilogue) {
-        case EPI_BIAS: rc = launch_t<EPI_BIAS>(args, ntiles, stream); break;
-        case EPI_GELU_SIG: rc = launch_t<EPI_GELU_SIG>(args, ntiles, stream); break;
-        case EPI_GELU_ERF: rc = launch_t<EPI_GELU_ERF>(args, ntiles, stream); break;
-        case EPI_GATE_RES: rc = launch_t<EPI_GATE_RES>(args, ntiles, stream); break;
-        case EPI_QKV: rc = launch_t<EPI_QKV>(args, ntiles, stream); break;
-        case EPI_SILU: rc = launch_t<EPI_SILU>(args, ntiles, stream); break;
+        case EPI_BIAS: rc = launch_t<EPI_BIAS>(args, ntiles, fp8, stream); break;
+        case EPI_GELU_SIG: rc = launch_t<EPI_GELU_SIG>(args, ntiles, fp8, stream); break;
+        case EPI_GELU_ERF: rc = launch_t<EPI_GELU_ERF>(args, ntiles, fp8, stream); break;
+        case EPI_GATE_RES: rc = launch_t<EPI_GATE_RES>(args, ntiles, fp8, stream); break;
+        case EPI_QKV: rc = launch_t<EPI_QKV>(args, ntiles, fp8, stream); break;
+        case EPI_SILU: rc = launch_t<EPI_SILU>(args, ntiles, fp8, stream); break;
         default: rc = set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
     }
     prof_end(slot, stream);

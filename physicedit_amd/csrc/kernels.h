@@ -44,6 +44,10 @@ struct GemmProblem {
     int seq_off;            // joint-sequence row of this problem's row 0
     int S_pad;
     int tilesM, tilesN;     // filled by the launcher
+    // e4m3 operands (fp8_linear, vram_management/layers.py:115-151): A [M,K] and W [N,K] are OCP e4m3 bytes
+    // (lda in elements = bytes, K % 128 == 0); y = bf16(acc * scale_a[m] + bias[n]) before the epilogue proper
+    int fp8;
+    const float* scale_a;   // [M] fp32
 };
 
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream);
@@ -66,6 +70,9 @@ int launch_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, 
                        const void* scale_a, const void* shift_b, const void* scale_b, float eps,
                        hipStream_t stream);
 int launch_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, hipStream_t stream);
+// fp8_linear's activation quantisation: scale[m] = max(bf16(max|x[m,:]| * (1/448)), 1); out = e4m3(x / (scale + 1e-8)),
+// columns [K, Kp) zero-filled
+int launch_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, hipStream_t stream);
 int launch_silu(const void* x, void* out, size_t n, hipStream_t stream);
 int launch_patchify(const void* latents, void* tokens, int C, int H2, int W2, hipStream_t stream);
 int launch_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, hipStream_t stream);

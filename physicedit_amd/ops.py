@@ -63,6 +63,43 @@ def hot_lora_linear(x, w, bias, lora_a, lora_b, epilogue: str = "bias", gate=Non
     return out
 
 
+F8 = torch.float8_e4m3fn
+
+
+def quantize_rows_e4m3(x: torch.Tensor, Kp: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp8_linear's activation quantisation (vram_management/layers.py:126-137): -> (xq e4m3 [M,Kp], scale_a fp32 [M])."""
+    _chk(x, "x")
+    M, K = x.shape
+    if Kp is None:
+        Kp = (K + 127) // 128 * 128
+    xq = torch.empty((M, Kp), dtype=F8, device=x.device)
+    scale = torch.empty((M,), dtype=torch.float32, device=x.device)
+    check(lib().pe_quantize_rows_e4m3(x.data_ptr(), K, M, K, xq.data_ptr(), Kp, scale.data_ptr(), stream_ptr()),
+          "pe_quantize_rows_e4m3")
+    return xq, scale
+
+
+def gemm_e4m3(xq: torch.Tensor, scale_a: torch.Tensor, wq: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              epilogue: str = "bias", gate=None, res=None, pre=None) -> torch.Tensor:
+    """out = epilogue(bf16((xq @ wq.T) * scale_a[:,None] + bias)); xq [M,K], wq [N,K] e4m3fn, K % 128 == 0."""
+    _chk(xq, "xq", F8), _chk(wq, "wq", F8), _chk(scale_a, "scale_a", torch.float32)
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K
+    out = torch.empty((M, N), dtype=BF, device=xq.device)
+    check(lib().pe_gemm_e4m3(EPI[epilogue], xq.data_ptr(), K, scale_a.data_ptr(), wq.data_ptr(), _ptr(bias), _ptr(pre),
+                             N if pre is not None else 0, out.data_ptr(), N, M, N, K, _ptr(gate), _ptr(res),
+                             N if res is not None else 0, stream_ptr()), "pe_gemm_e4m3")
+    return out
+
+
+def fp8_linear(x: torch.Tensor, wq: torch.Tensor, bias: Optional[torch.Tensor], epilogue: str = "bias", gate=None,
+               res=None) -> torch.Tensor:
+    """AutoWrappedLinear.fp8_linear: quantise rows, e4m3 GEMM.  wq [N,Kp] e4m3fn (zero padded beyond x.shape[1])."""
+    xq, sa = quantize_rows_e4m3(x, wq.shape[1])
+    return gemm_e4m3(xq, sa, wq, bias, epilogue, gate, res)
+
+
 def s_pad_of(S: int) -> int:
     return (S + 63) // 64 * 64
 

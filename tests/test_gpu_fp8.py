@@ -1,0 +1,116 @@
+"""`-m gpu` tests of the e4m3 ("FP8 computation") Linear path: row quantiser and e4m3 GEMM through the C-ABI against the
+oracle's restatement of AutoWrappedLinear.fp8_linear (vram_management/layers.py:115-151).
+
+PARITY UNPINNED for the matmul (torch._scaled_mm has no CPU implementation with per-row scales, so the reference
+cannot emit golden vectors in the build container; see oracle/physicedit_oracle.py).  The quantiser is pure
+element-wise arithmetic and is compared BIT-EXACTLY, both with the oracle and with torch's own device ops.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle.physicedit_oracle as O
+from test_gpu_kernels import BF, report, rnd, ulps
+
+pytestmark = pytest.mark.gpu
+F8 = torch.float8_e4m3fn
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd import ops as _ops
+    from physicedit_amd._lib import lib
+    lib()
+    return _ops
+
+
+def _acts(M, K, seed):
+    """activations with the features that matter: rows above and below the 448 clamp, an all-zero row, denormal-range
+    values after scaling, exact 448 multiples."""
+    x = rnd((M, K), seed, 3.0).float()
+    x[0] = 0.0
+    if M > 1:
+        x[1] *= 400.0                    # x_max far above 448 -> scale > 1
+    if M > 2:
+        x[2] *= 2.0 ** -9                # lands in e4m3's denormal range
+    if M > 3:
+        x[3, 0] = 448.0
+    if M > 4:
+        x[4, 5] = -30000.0
+    return x.to(BF)
+
+
+@pytest.mark.parametrize("M,K", [(5, 64), (33, 256), (300, 3072), (272, 3584), (130, 12288), (7, 8)])
+def test_quantize_rows_bit_exact(ops, M, K):
+    x = _acts(M, K, 11)
+    xq_ref, sa_ref = O.fp8_quantize_rows(x)
+    xq, sa = ops.quantize_rows_e4m3(x.cuda())
+    Kp = xq.shape[1]
+    assert Kp % 128 == 0 and Kp >= K
+    assert torch.equal(sa.cpu(), sa_ref.reshape(-1)), "scale_a"
+    got = xq.view(torch.uint8).cpu()
+    assert torch.equal(got[:, :K], xq_ref.view(torch.uint8)), "e4m3 bytes"
+    assert int(got[:, K:].max().item() if Kp > K else 0) == 0, "pad columns must be zero"
+    # the same arithmetic with torch's device ops (what the reference executes on the GPU)
+    xg = x.cuda()
+    x_max = torch.max(torch.abs(xg), dim=-1, keepdim=True).values
+    scale_t = torch.clamp(x_max / 448.0, min=1.0).float()
+    xq_t = (xg / (scale_t + 1e-8)).to(F8)
+    assert torch.equal(scale_t.reshape(-1), sa), "scale_a vs torch device ops"
+    assert torch.equal(xq_t.view(torch.uint8), xq.view(torch.uint8)[:, :K]), "bytes vs torch device ops"
+
+
+def test_e4m3_conversion_all_values(ops):
+    """every e4m3 value and every rounding midpoint between neighbours goes through the hardware conversion."""
+    vals = torch.arange(0, 256, dtype=torch.uint8).view(F8).float()
+    vals = vals[torch.isfinite(vals)]
+    v = torch.sort(vals).values
+    mids = (v[1:] + v[:-1]) / 2
+    pts = torch.cat([v, mids, torch.nextafter(mids, mids + 1), torch.nextafter(mids, mids - 1)])
+    pts = pts[pts.abs() <= 448].to(BF).float().unique()          # bf16-representable probes, no scaling (max <= 448)
+    K = (pts.numel() + 7) // 8 * 8
+    x = torch.zeros((1, K), dtype=BF)
+    x[0, :pts.numel()] = pts.to(BF)
+    xq, sa = ops.quantize_rows_e4m3(x.cuda())
+    assert sa.item() == 1.0
+    assert torch.equal(xq.view(torch.uint8).cpu()[:, :K], x.float().to(F8).view(torch.uint8))
+
+
+def test_gemm_e4m3_exact_small_integers(ops):
+    """small integers: every product and partial sum is exact in any accumulator -> catches layout errors exactly."""
+    M, N, K = 70, 264, 256
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    sa = torch.ones((M,), dtype=torch.float32)
+    out = ops.gemm_e4m3(a.to(F8).cuda(), sa.cuda(), w.to(F8).cuda())
+    assert torch.equal(out.float().cpu(), (a @ w.t()).to(BF).float())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 3072, 3072), (257, 264, 128), (40, 18432, 3072), (1, 3072, 256),
+                                   (520, 12288, 3072), (272, 3072, 12288)])
+def test_fp8_linear(ops, M, N, K):
+    x = _acts(M, K, 21)
+    w8 = rnd((N, K), 22, K ** -0.5).to(F8)
+    b8 = rnd((N,), 23, 0.1).to(F8)
+    ref = O.fp8_linear(x, w8, b8)
+    out = ops.fp8_linear(x.cuda(), w8.cuda(), b8.to(BF).cuda())
+    # The block-scaled MFMA aligns the 64 products of a block to the largest one before adding (measured: ~2^-14 of
+    # the largest term is dropped), where the oracle's sum is exact.  Bound: 2 bf16 ulp at operand scale, <= 6 % of
+    # the outputs off by one.
+    report(f"fp8_linear {M}x{N}x{K}", out, ref, max_ulp=2.01, max_frac=0.06)
+
+
+def test_fp8_linear_epilogues(ops):
+    M, N, K = 300, 1024, 512
+    x = _acts(M, K, 31)
+    w8, b8 = rnd((N, K), 32, K ** -0.5).to(F8), rnd((N,), 33, 0.1).to(F8)
+    gate, res = rnd((N,), 34), rnd((M, N), 35)
+    y = O.fp8_linear(x, w8, b8)
+    xc, wc, bc = x.cuda(), w8.cuda(), b8.to(BF).cuda()
+    report("fp8 gelu_sigmoid", ops.fp8_linear(xc, wc, bc, "gelu_sigmoid"), y * torch.sigmoid(1.702 * y), 2.01, 0.06)
+    report("fp8 silu", ops.fp8_linear(xc, wc, bc, "silu"), F.silu(y), 2.01, 0.06)
+    report("fp8 gate_res", ops.fp8_linear(xc, wc, bc, "gate_res", gate=gate.cuda(), res=res.cuda()), res + gate * y,
+           2.01, 0.06)
