@@ -144,6 +144,12 @@ typedef struct pe_dit_weights {
     const void *norm_out_w, *norm_out_b; /* norm_out.linear [6144,3072] */
     const void *proj_out_w, *proj_out_b; /* [64,3072] */
     const pe_dit_block_weights* blocks;  /* host array [num_layers]; copied by pe_dit_create */
+    /* 0: every weight is bf16.  1: "FP8 computation" (enable_vram_management(enable_dit_fp8_computation=True) on a DiT
+     * stored in float8_e4m3fn, qwen_image_physical.py:440-496): every *_w of a Linear ([N,K], K padded to a multiple
+     * of 128 with zeros -- only img_in, [3072,128]) is OCP e4m3fn bytes and runs as fp8_linear
+     * (vram_management/layers.py:115-151); biases and RMSNorm weights stay bf16 pointers holding bf16(e4m3(value)).
+     * The adapter (a separate module in the reference) and hot LoRA operands are always bf16. */
+    int weights_e4m3;
 } pe_dit_weights;
 
 typedef struct pe_adapter_weights {    /* VisualThinkingDualAdapter, pipelines/helpers.py:123-140 */

@@ -36,7 +36,7 @@ class DitWeights(C.Structure):
     _fields_ = [("num_layers", c_int)] + [(n, c_void_p) for n in (
         "time_w1", "time_b1", "time_w2", "time_b2", "txt_norm_w", "img_in_w", "img_in_b",
         "txt_in_w", "txt_in_b", "norm_out_w", "norm_out_b", "proj_out_w", "proj_out_b")] + [
-        ("blocks", C.POINTER(DitBlockWeights))]
+        ("blocks", C.POINTER(DitBlockWeights)), ("weights_e4m3", c_int)]
 
 
 class AdapterWeights(C.Structure):

@@ -42,6 +42,8 @@ struct pe_dit {
     char* attn_ws;
     size_t attn_ws_bytes = 0;
     char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
+    char* aq;                           // e4m3 mode: quantised activation rows of the Linear being run [S, FF] bytes
+    float* asc;                         // e4m3 mode: their per-row scales
     pe_dit_block_lora* lora = nullptr;  // hot LoRA operands per block, or null
     int lora_r = 0;
 };
@@ -76,8 +78,42 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->sp_vae, (size_t)MAX_SPECIAL * TXT * 2);
     h->attn_ws_bytes = flash_attn_workspace_bytes(HEADS, (int)S);
     take(&h->attn_ws, h->attn_ws_bytes);
-    take(&h->lora_t, (S > (size_t)n_steps ? S : (size_t)n_steps) * 3 * 128 * 2);
+    const size_t rows = S > (size_t)n_steps ? S : (size_t)n_steps;
+    take(&h->lora_t, rows * 3 * 128 * 2);
+    if (h->w.weights_e4m3) {
+        take(&h->aq, rows * FF);
+        take((char**)&h->asc, rows * sizeof(float));
+    } else {
+        h->aq = nullptr;
+        h->asc = nullptr;
+    }
     return off;
+}
+
+// One Linear of the DiT (1 or 2 streams in one launch).  bf16 weights: the GEMM as is.  e4m3 weights
+// (pe_dit_weights.weights_e4m3; AutoWrappedLinear.fp8_linear, vram_management/layers.py:115-151): quantise the
+// activation rows (per-row scale), then the e4m3 GEMM.  K is padded to the GEMM's 128 granule (only img_in, K = 64:
+// its weight arrives zero-padded to [3072,128]).
+static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t stream) {
+    if (!h->w.weights_e4m3) return launch_gemm(epi, pp, n, stream);
+    int rc;
+    const bool joint = n == 2 && pp[0].K == pp[1].K && pp[0].lda == pp[1].lda &&
+                       (const char*)pp[1].A == (const char*)pp[0].A + (size_t)pp[0].M * pp[0].lda * 2;
+    size_t off = 0, row = 0;
+    for (int s = 0; s < n; ++s) {
+        const int Kp = (int)align_up((size_t)pp[s].K, 128);
+        if (s == 0 || !joint) {
+            const int M = joint ? pp[0].M + pp[1].M : pp[s].M;
+            if ((rc = launch_quantize_rows_e4m3(pp[s].A, pp[s].lda, M, pp[s].K, h->aq + off, Kp, h->asc + row, stream)))
+                return rc;
+        }
+        const int Ms = pp[s].M;
+        pp[s].A = h->aq + off; pp[s].lda = Kp; pp[s].K = Kp;
+        pp[s].scale_a = h->asc + row; pp[s].fp8 = 1;
+        off += (size_t)Ms * Kp;
+        row += Ms;
+    }
+    return launch_gemm(epi, pp, n, stream);
 }
 
 extern "C" {
@@ -162,11 +198,11 @@ int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void
     memset(&p, 0, sizeof(p));
     p.A = sinusoid_bf16; p.lda = 256; p.W = h->w.time_w1; p.bias = h->w.time_b1;
     p.out = h->t_hidden; p.ldo = D; p.M = n_steps; p.N = D; p.K = 256;
-    if ((rc = launch_gemm(EPI_SILU, &p, 1, stream))) return rc;
+    if ((rc = dit_linear(h, EPI_SILU, &p, 1, stream))) return rc;
     memset(&p, 0, sizeof(p));
     p.A = h->t_hidden; p.lda = D; p.W = h->w.time_w2; p.bias = h->w.time_b2;
     p.out = h->temb; p.ldo = D; p.M = n_steps; p.N = D; p.K = D;
-    if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+    if ((rc = dit_linear(h, EPI_BIAS, &p, 1, stream))) return rc;
     if ((rc = launch_silu(h->temb, h->silu_temb, (size_t)n_steps * D, stream))) return rc;
     // modulation rows for every block / stream: [step][layer][stream][18432]
     const int ld = L * 2 * MOD;
@@ -180,7 +216,7 @@ int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void
             pp[s].out = h->mod_tab + ((size_t)l * 2 + s) * MOD * 2; pp[s].ldo = ld;
             pp[s].M = n_steps; pp[s].N = MOD; pp[s].K = D;
         }
-        if ((rc = launch_gemm(EPI_BIAS, pp, 2, stream))) return rc;
+        if ((rc = dit_linear(h, EPI_BIAS, pp, 2, stream))) return rc;
         if (h->lora && h->lora[l].img_mod_a && h->lora[l].txt_mod_a) {
             // mod = Linear(silu) + (silu @ A.T) @ B.T   (img_mod.1 / txt_mod.1 are LoRA targets)
             const int r = h->lora_r;
@@ -202,7 +238,7 @@ int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void
     memset(&p, 0, sizeof(p));
     p.A = h->silu_temb; p.lda = D; p.W = h->w.norm_out_w; p.bias = h->w.norm_out_b;
     p.out = h->final_tab; p.ldo = 2 * D; p.M = n_steps; p.N = 2 * D; p.K = D;
-    if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+    if ((rc = dit_linear(h, EPI_BIAS, &p, 1, stream))) return rc;
     h->n_steps = n_steps;
     return PE_OK;
 }
@@ -270,10 +306,10 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         memset(pp, 0, sizeof(pp));
         pp[0].A = h->patches; pp[0].lda = PATCH; pp[0].W = h->w.img_in_w; pp[0].bias = h->w.img_in_b;
         pp[0].out = h->x; pp[0].ldo = D; pp[0].M = S_img; pp[0].N = D; pp[0].K = PATCH;
-        if ((rc = launch_gemm(EPI_BIAS, &pp[0], 1, stream))) return rc;
+        if ((rc = dit_linear(h, EPI_BIAS, &pp[0], 1, stream))) return rc;
         pp[1].A = h->pe_norm; pp[1].lda = TXT; pp[1].W = h->w.txt_in_w; pp[1].bias = h->w.txt_in_b;
         pp[1].out = h->x + (size_t)S_img * D * 2; pp[1].ldo = D; pp[1].M = T; pp[1].N = D; pp[1].K = TXT;
-        if ((rc = launch_gemm(EPI_BIAS, &pp[1], 1, stream))) return rc;
+        if ((rc = dit_linear(h, EPI_BIAS, &pp[1], 1, stream))) return rc;
     }
 
     char* x_img = h->x;
@@ -312,7 +348,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         }
         const pe_dit_block_lora* LR = h->lora ? &h->lora[l] : nullptr;
         const int r = h->lora_r;
+        bool low_rank = false;   // the launch below is the low-rank product on top of an already computed base Linear
         if (LR && LR->img_qkv_a && LR->txt_qkv_a) {
+            low_rank = true;
             // hot LoRA: t = x @ Acat.T ; y1 = x @ W.T + b ; then (t @ Bdiag.T) with pre = y1 and the QKV epilogue
             GemmProblem ta[2], y1[2];
             memset(ta, 0, sizeof(ta));
@@ -327,9 +365,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                 pp[s].bias = nullptr; pp[s].K = 3 * r; pp[s].pre = y1[s].out; pp[s].ldp = 3 * D;
             }
             if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
-            if ((rc = launch_gemm(EPI_BIAS, y1, 2, stream))) return rc;
+            if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
         }
-        if ((rc = launch_gemm(EPI_QKV, pp, 2, stream))) return rc;
+        if ((rc = low_rank ? launch_gemm(EPI_QKV, pp, 2, stream) : dit_linear(h, EPI_QKV, pp, 2, stream))) return rc;
         // joint attention
         if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream))) return rc;
         // output projections + gated residual (in place on x)
@@ -343,7 +381,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 0);
             pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = D;
         }
+        low_rank = false;
         if (LR && LR->img_out_a && LR->txt_out_a) {
+            low_rank = true;
             GemmProblem ta[2], y1[2];
             memset(ta, 0, sizeof(ta));
             memset(y1, 0, sizeof(y1));
@@ -357,9 +397,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                 pp[s].bias = nullptr; pp[s].K = r; pp[s].pre = y1[s].out; pp[s].ldp = D;
             }
             if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
-            if ((rc = launch_gemm(EPI_BIAS, y1, 2, stream))) return rc;
+            if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
         }
-        if ((rc = launch_gemm(EPI_GATE_RES, pp, 2, stream))) return rc;
+        if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
         // norm2 + modulate
         if ((rc = launch_ln_modulate(h->x, h->xmod, S, D, S_img, sh(mod_img, 1), sc(mod_img, 1), sh(mod_txt, 1),
                                      sc(mod_txt, 1), 1e-6f, stream)))
@@ -373,7 +413,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].out = h->hbuf + (s == 0 ? 0 : (size_t)S_img * FF * 2); pp[s].ldo = FF;
             pp[s].M = s == 0 ? S_img : T; pp[s].N = FF; pp[s].K = D;
         }
-        if ((rc = launch_gemm(EPI_GELU_SIG, pp, 2, stream))) return rc;
+        if ((rc = dit_linear(h, EPI_GELU_SIG, pp, 2, stream))) return rc;
         // MLP down + gated residual
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {
@@ -385,7 +425,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 1);
             pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = FF;
         }
+        low_rank = false;
         if (LR && LR->img_down_a && LR->txt_down_a) {
+            low_rank = true;
             GemmProblem ta[2], y1[2];
             memset(ta, 0, sizeof(ta));
             memset(y1, 0, sizeof(y1));
@@ -399,9 +441,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                 pp[s].bias = nullptr; pp[s].K = r; pp[s].pre = y1[s].out; pp[s].ldp = D;
             }
             if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
-            if ((rc = launch_gemm(EPI_BIAS, y1, 2, stream))) return rc;
+            if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
         }
-        if ((rc = launch_gemm(EPI_GATE_RES, pp, 2, stream))) return rc;
+        if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
     }
 
     // ---- 4. AdaLayerNorm(single) head on the S0 kept rows, proj_out, unpatchify  (:1398-1402)
@@ -414,7 +456,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         memset(&p, 0, sizeof(p));
         p.A = h->xmod; p.lda = D; p.W = h->w.proj_out_w; p.bias = h->w.proj_out_b;
         p.out = h->proj; p.ldo = PATCH; p.M = S0; p.N = PATCH; p.K = D;
-        if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+        if ((rc = dit_linear(h, EPI_BIAS, &p, 1, stream))) return rc;
         if ((rc = launch_unpatchify(h->proj, c->noise_pred, 16, c->h8, c->w8, stream))) return rc;
     }
     return PE_OK;

@@ -23,6 +23,7 @@ from .rope import RopeCache
 from .scheduler import adapter_alpha, qwen_image_scheduler, timestep_sinusoid
 
 BF = torch.bfloat16
+F8 = torch.float8_e4m3fn
 D = 3072
 
 
@@ -43,6 +44,7 @@ class QwenImageDiTEngine:
             raise _lib.PeError("QwenImageDiTEngine needs a HIP device: physicedit_amd has no CPU path")
         lib()  # fail loudly now if the .so is missing
         self.num_layers = count_layers(state_dict)
+        self.fp8 = False
         self.params: Dict[str, torch.Tensor] = {}
         self._fused: Dict[str, torch.Tensor] = {}
         self._ingest_dit(state_dict)
@@ -80,6 +82,48 @@ class QwenImageDiTEngine:
             if k not in self.params:
                 self.params[k] = v.to(device=dev, dtype=BF).contiguous()
 
+    _QKV_PARTS = (("img_qkv", ("to_q", "to_k", "to_v")), ("txt_qkv", ("add_q_proj", "add_k_proj", "add_v_proj")))
+
+    def enable_fp8_computation(self):
+        """The state the reference reaches with ModelConfig(offload_dtype=torch.float8_e4m3fn) +
+        enable_vram_management(enable_dit_fp8_computation=True) (qwen_image_physical.py:440-496): every DiT parameter
+        is stored as float8_e4m3fn, every torch.nn.Linear runs AutoWrappedLinear.fp8_linear
+        (vram_management/layers.py:115-151) and the RMSNorm weights are cast back to bf16 for their computation.
+        Conversion of the stored weights is a one-off dtype cast at load time (torch device op); the per-call
+        activation quantisation and the e4m3 GEMMs are HIP kernels.  A merged LoRA must be loaded BEFORE this call
+        (the merge is a bf16 operation); hot LoRA may come before or after and stays bf16."""
+        if self.fp8:
+            return
+        for name in list(self._fused):
+            t = self._fused[name]
+            self._fused[name] = t.to(F8) if name.endswith(".weight") else t.to(F8).to(BF)
+        fused_views = set()
+        for i in range(self.num_layers):
+            p = f"transformer_blocks.{i}.attn."
+            for fused, parts in self._QKV_PARTS:
+                for j, part in enumerate(parts):
+                    for kind in ("weight", "bias"):
+                        self.params[p + part + "." + kind] = self._fused[p + fused + "." + kind][j * D:(j + 1) * D]
+                        fused_views.add(p + part + "." + kind)
+        linear = {k[:-len(".weight")] for k, v in self.params.items() if k.endswith(".weight") and v.dim() == 2}
+        for k in list(self.params):
+            if k in fused_views:
+                continue
+            v = self.params[k]
+            if k.endswith(".weight") and k[:-len(".weight")] in linear:
+                q = v.to(F8)
+                if q.shape[1] % 128:       # img_in [3072,64]: the e4m3 GEMM's K granule is 128; zero columns add exact zeros
+                    qp = torch.zeros((q.shape[0], (q.shape[1] + 127) // 128 * 128), dtype=F8, device=self.device)
+                    qp[:, :q.shape[1]] = q
+                    q = qp
+                self.params[k] = q.contiguous()
+            else:
+                self.params[k] = v.to(F8).to(BF)
+        self.fp8 = True
+        self._create()
+        self._apply_hot()
+        self._ws, self._bound, self._step_of = None, (0, 0, 0), {}
+
     def _create(self):
         P, F = self.params, self._fused
         blocks = (DitBlockWeights * max(self.num_layers, 1))()
@@ -109,6 +153,7 @@ class QwenImageDiTEngine:
         w.norm_out_w, w.norm_out_b = P["norm_out.linear.weight"].data_ptr(), P["norm_out.linear.bias"].data_ptr()
         w.proj_out_w, w.proj_out_b = P["proj_out.weight"].data_ptr(), P["proj_out.bias"].data_ptr()
         w.blocks = blocks
+        w.weights_e4m3 = 1 if self.fp8 else 0
         adp = None
         if self.adapter is not None:
             a = AdapterWeights()
@@ -129,6 +174,7 @@ class QwenImageDiTEngine:
         other = object.__new__(QwenImageDiTEngine)
         other.device = self.device
         other.num_layers = self.num_layers
+        other.fp8 = self.fp8
         other.params, other._fused, other.adapter = self.params, self._fused, self.adapter
         other.t_min, other.t_max = self.t_min, self.t_max
         other._handle = C.c_void_p()
@@ -229,6 +275,9 @@ class QwenImageDiTEngine:
             return self.load_lora_hot(lora_state_dict, alpha)
         if alpha != 1.0:
             raise _lib.PeError("load_lora: only alpha=1.0 is merged on the GPU path (validate.py uses alpha=1)")
+        if self.fp8:
+            raise _lib.PeError("load_lora: merge the LoRA before enable_fp8_computation() (the merge is a bf16 operation), "
+                               "or use hotload=True")
         n = 0
         for key, up in lora_state_dict.items():
             if ".lora_B." not in key:

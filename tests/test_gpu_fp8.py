@@ -114,3 +114,76 @@ def test_fp8_linear_epilogues(ops):
     report("fp8 silu", ops.fp8_linear(xc, wc, bc, "silu"), F.silu(y), 2.01, 0.06)
     report("fp8 gate_res", ops.fp8_linear(xc, wc, bc, "gate_res", gate=gate.cuda(), res=res.cuda()), res + gate * y,
            2.01, 0.06)
+
+
+# ------------------------------------------------------------------------------------------------
+# the DiT composite in e4m3 mode (pe_dit_weights.weights_e4m3)
+# ------------------------------------------------------------------------------------------------
+def _inputs(h, w, T, n_special, seed):
+    from physicedit_amd import synth
+    noise = synth.make_noise(seed, h, w)
+    g = torch.Generator().manual_seed(seed + 100)
+    edit = torch.randn((1, 16, h // 8, w // 8), generator=g).to(BF)
+    return noise, edit, synth.make_prompt_emb(seed + 7, T), synth.make_special_token_mask(T, n_special)
+
+
+def _dist(name, got, ref):
+    d = (got.float().cpu() - ref.float().cpu()).abs()
+    print(f"[parity] {name}: max|d| {d.max().item():.4e} mean|d| {d.mean().item():.4e} "
+          f"exact {(d == 0).float().mean().item()*100:.2f}%")
+    return d
+
+
+@pytest.mark.parametrize("hot_lora", [False, True])
+def test_model_fn_e4m3(hot_lora):
+    """2-layer full-width DiT with every Linear on the e4m3 path (time MLP, modulation, img_in with its K=64 padded
+    to 128, txt_in, QKV, out, MLP, norm_out, proj_out) and the adapter in bf16, vs the oracle run on the e4m3
+    state-dict.  The yardstick is the effect of the mode itself: |oracle_e4m3 - oracle_bf16|."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd import synth
+    from physicedit_amd.dit import QwenImageDiTEngine, special_indices
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    lora = synth.make_lora(4321, 2, 16, std=0.05) if hot_lora else None
+    t_min, t_max = O.adapter_t_range()
+    noise, edit, pe, mask = _inputs(128, 128, 40, 8, 3)
+    t = torch.tensor([700.0]).to(BF)
+    sd_ref = O.attach_hot_lora(sd, lora) if hot_lora else sd
+    ref_bf16 = O.model_fn(sd_ref, ad, noise, t, pe.clone(), mask, 128, 128, edit, t_min, t_max)
+    ref = O.model_fn(O.to_fp8_state_dict(sd_ref), ad, noise, t, pe.clone(), mask, 128, 128, edit, t_min, t_max)
+    eng = QwenImageDiTEngine(sd, ad, device="cuda")
+    if hot_lora:
+        assert eng.load_lora(lora, hotload=True) == 24
+    eng.enable_fp8_computation()
+    assert eng.fp8 and eng.params["img_in.weight"].dtype == F8 and eng.params["img_in.weight"].shape == (3072, 128)
+    got = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda())
+    mode = _dist(f"e4m3 mode effect (oracle e4m3 vs oracle bf16){' +hot LoRA' if hot_lora else ''}", ref, ref_bf16)
+    d = _dist(f"model_fn e4m3 vs oracle e4m3{' +hot LoRA' if hot_lora else ''}", got, ref)
+    assert torch.isfinite(got.float()).all()
+    # parity error must be well inside the mode's own quantisation effect
+    assert d.mean().item() <= 0.25 * mode.mean().item(), (d.mean().item(), mode.mean().item())
+    assert d.max().item() <= mode.max().item()
+
+
+def test_loop_e4m3_dual_stream_bit_identical():
+    """e4m3 mode through the sampler loop (fork()ed second context shares the e4m3 weights): finite output, and
+    dual-stream == single-stream bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd import synth
+    from physicedit_amd.dit import QwenImageDiTEngine
+    from physicedit_amd.pipeline import DenoiseLoop
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    eng = QwenImageDiTEngine(sd, ad, device="cuda")
+    eng.enable_fp8_computation()
+    noise, edit, pe, mask = _inputs(128, 128, 40, 8, 5)
+    _, _, pe_n, mask_n = _inputs(128, 128, 24, 8, 6)
+    outs = []
+    for dual in (False, True):
+        loop = DenoiseLoop(eng, dual_stream=dual)
+        outs.append(loop(noise, pe.cuda().clone(), pe_n.cuda().clone(), mask, mask_n, 128, 128, num_inference_steps=3,
+                         cfg_scale=4.0, edit_latents=edit.cuda()).clone())
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
