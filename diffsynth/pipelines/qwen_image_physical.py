@@ -104,7 +104,10 @@ class QwenImagePhysicPipeline:
         self.extra_state: Dict[str, torch.Tensor] = {}   # training-only modules' weights (resamplers, time embeds)
         self._dit_state: Optional[Dict[str, torch.Tensor]] = None
         self._pending_lora: List[Dict[str, torch.Tensor]] = []
+        self._pending_hot_lora: List[tuple] = []
         self.vram_management_enabled = False
+        self._dit_stored_dtype = torch_dtype
+        self._dit_fp8_computation = False
 
     # ------------------------------------------------------------------------------------------
     # construction
@@ -135,6 +138,8 @@ class QwenImagePhysicPipeline:
 
     def set_dit(self, state_dict: Dict[str, torch.Tensor]):
         self._dit_state = state_dict
+        # dtype the checkpoint was loaded in (ModelConfig.offload_dtype): the reference keys fp8 computation off it
+        self._dit_stored_dtype = next(iter(state_dict.values())).dtype
         self._build_engine()
 
     def set_vae(self, state_dict: Dict[str, torch.Tensor]):
@@ -145,6 +150,10 @@ class QwenImagePhysicPipeline:
         self.dit = QwenImageDiTEngine(self._dit_state, ad, device=self.device)
         for lora in self._pending_lora:
             self.dit.load_lora(lora)
+        for lora, alpha in self._pending_hot_lora:
+            self.dit.load_lora(lora, alpha=alpha, hotload=True)
+        if self._dit_fp8_computation:
+            self.dit.enable_fp8_computation()
 
     # ------------------------------------------------------------------------------------------
     # weights: LoRA + finetuned non-LoRA parameters (validate.py:33-65)
@@ -162,7 +171,9 @@ class QwenImagePhysicPipeline:
                 lora_config.download_if_necessary()
                 state_dict = load_state_dict(lora_config.path, torch_dtype=self.torch_dtype)
         n = self.dit.load_lora(state_dict, alpha=float(alpha), hotload=bool(hotload))
-        if not hotload:
+        if hotload:
+            self._pending_hot_lora.append((state_dict, float(alpha)))   # replayed if the engine is rebuilt
+        else:
             self._pending_lora.append(state_dict)
             print(f"{n} tensors are updated by LoRA.")
 
@@ -183,9 +194,20 @@ class QwenImagePhysicPipeline:
                 self._build_engine()      # the engine binds adapter pointers at creation
         return unexpected
 
-    def enable_vram_management(self, *args, **kwargs):
-        """No-op: all weights (41.5 GB) stay resident in the 288 GB of HBM (reference: :375-494)."""
+    def enable_vram_management(self, num_persistent_param_in_dit=None, vram_limit=None, vram_buffer=0.5, auto_offload=True,
+                               enable_dit_fp8_computation=False):
+        """Reference signature (:375-494).  Offloading is a no-op here: all weights (41.5 GB in bf16) stay resident in
+        the 288 GB of HBM.  `enable_dit_fp8_computation=True` has the reference's meaning: when the DiT was loaded in
+        float8_e4m3fn (ModelConfig(offload_dtype=torch.float8_e4m3fn)) every DiT Linear runs fp8_linear
+        (vram_management/layers.py:115-151); with a bf16-stored DiT the flag changes nothing (:440-468 wraps the
+        Linears with computation_dtype = the stored dtype)."""
         self.vram_management_enabled = False
+        if enable_dit_fp8_computation and self._dit_stored_dtype == torch.float8_e4m3fn:
+            self._dit_fp8_computation = True
+            if self.dit is not None:
+                self.dit.enable_fp8_computation()
+        elif enable_dit_fp8_computation and self._dit_stored_dtype == torch.float8_e4m3fnuz:
+            raise _lib.PeError("float8_e4m3fnuz is the MI300 encoding; gfx950 computes in OCP float8_e4m3fn")
 
     def load_models_to_device(self, model_names=()):
         pass

@@ -83,3 +83,65 @@ def test_c1_validate_style_run(tmp_path):
           f"uint8 image max|d| {d.max().item():.0f} mean|d| {d.mean().item():.3f} identical {(d == 0).float().mean().item()*100:.1f}%")
     assert dl.mean().item() <= 5e-3 and dl.max().item() <= 0.125
     assert d.mean().item() <= 0.6 and d.max().item() <= 12
+
+
+def test_c3_fp8_computation_through_the_facade(tmp_path):
+    """BASELINE.json configs[2] the way a reference user switches it on: the DiT checkpoint loaded with
+    ModelConfig(offload_dtype=torch.float8_e4m3fn) + pipe.enable_vram_management(enable_dit_fp8_computation=True)
+    (qwen_image_physical.py:440-496), hot-loaded LoRA, adapter; vs the oracle on the e4m3 state-dict
+    (parity unpinned: see oracle/physicedit_oracle.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from safetensors.torch import save_file
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline, ModelConfig
+
+    H = W = 256
+    steps, T, nsp = 2, 64, 16
+    dit_sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    vae_sd = synth.make_state_dict(synth.vae_layout(), 77)
+    ad_sd = synth.make_state_dict(synth.adapter_layout(), 4321)
+    lora = synth.make_lora(4321, 2, 8, std=0.05)
+    base = tmp_path / "base"
+    (base / "Qwen/Qwen-Image-Edit-2509/transformer").mkdir(parents=True)
+    (base / "Qwen/Qwen-Image/vae").mkdir(parents=True)
+    save_file(dit_sd, str(base / "Qwen/Qwen-Image-Edit-2509/transformer/diffusion_pytorch_model.safetensors"))
+    save_file(vae_sd, str(base / "Qwen/Qwen-Image/vae/diffusion_pytorch_model.safetensors"))
+    pipe = QwenImagePhysicPipeline.from_pretrained(
+        torch_dtype=torch.bfloat16, device="cuda",
+        model_configs=[
+            ModelConfig(model_id="Qwen/Qwen-Image-Edit-2509", origin_file_pattern="transformer/diffusion_pytorch_model*.safetensors",
+                        local_model_path=str(base), offload_dtype=torch.float8_e4m3fn),
+            ModelConfig(model_id="Qwen/Qwen-Image", origin_file_pattern="vae/diffusion_pytorch_model.safetensors", local_model_path=str(base)),
+        ], dinov2_path=None)
+    assert not pipe.dit.fp8                                   # stored in e4m3, still computing in bf16
+    pipe.enable_vram_management(enable_dit_fp8_computation=True)
+    assert pipe.dit.fp8
+    pipe.load_lora(pipe.dit, state_dict=lora, hotload=True)
+    pipe.load_state_dict({"visual_thinking_adapter." + k: v for k, v in ad_sd.items()}, strict=False)
+    assert pipe.dit.fp8 and pipe.dit.params["transformer_blocks.1.img_mlp.net.2.weight"].dtype == torch.float8_e4m3fn
+
+    pe = synth.make_prompt_emb(7, T)
+    mask = synth.make_special_token_mask(T, nsp)
+    pipe.prompt_encoder = lambda p, prompt, negative_prompt, edit_image, cfg, have_text_reasoning=True: (
+        {"prompt_emb": pe.clone(), "special_token_mask": mask}, None)
+    img_u8 = synth.make_edit_image_u8(H, W, 0)
+    out = pipe("let the candle burn down", edit_image=Image.fromarray(img_u8), seed=0, num_inference_steps=steps,
+               height=H, width=W, cfg_scale=1.0, is_train=False, edit_image_auto_resize=False)
+    assert isinstance(out, Image.Image) and out.size == (W, H)
+
+    O.VAE_CONV_MODE = "2d"
+    try:
+        edit_lat = O.vae_encode(vae_sd, O.preprocess_image(img_u8))
+        sd_hot = O.attach_hot_lora(dit_sd, lora)
+        lat8 = O.denoise_loop(O.to_fp8_state_dict(sd_hot), ad_sd, synth.make_noise(0, H, W), pe.clone(), None, mask, None, H, W,
+                              steps, cfg_scale=1.0, edit_latents=edit_lat)
+        lat16 = O.denoise_loop(sd_hot, ad_sd, synth.make_noise(0, H, W), pe.clone(), None, mask, None, H, W, steps,
+                               cfg_scale=1.0, edit_latents=edit_lat)
+    finally:
+        O.VAE_CONV_MODE = "3d"
+    dl = (pipe.last_latents.float().cpu() - lat8.float()).abs()
+    mode = (lat8.float() - lat16.float()).abs()
+    print(f"[parity] c3 façade run (e4m3): latents vs oracle-e4m3 max|d| {dl.max().item():.4e} mean|d| {dl.mean().item():.4e}; "
+          f"mode effect (oracle e4m3 vs bf16) mean|d| {mode.mean().item():.4e}")
+    assert torch.isfinite(pipe.last_latents.float()).all()
+    assert dl.mean().item() <= 0.25 * mode.mean().item()
