@@ -31,12 +31,10 @@
 
 namespace pe {
 
-constexpr int ATT_THREADS = 512;
 constexpr int KV_TILE = 64;
 constexpr int ATT_STAGE = 2 * KV_TILE * 128 * 2;  // K tile 16 KiB + Vt tile 16 KiB
 constexpr int ATT_LDS = 2 * ATT_STAGE;            // 64 KiB
-constexpr int Q_BLOCK = 256;
-int g_attn_variant = 0;
+int g_attn_variant = 0;   // 0: 8 waves / 256 query rows per work-group (1 per CU);  1: 4 waves / 128 rows (2 per CU)
 
 // Work decomposition.  total = H * nqb equal (head, q-block) items never divide evenly over the 256 CUs
 // (cfg 2: 816 items = 3.19 rounds -> 4 rounds, 80 % efficiency).  So the first n_full = floor(total/slots)
@@ -47,11 +45,14 @@ struct AttnPlan {
     int nqb, n_full, split;   // split == 1: no short items
 };
 
-__global__ void __launch_bounds__(ATT_THREADS, 2)
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2)
 flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
                   bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
                   float* __restrict__ part_o, float* __restrict__ part_ml) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Q_BLOCK = NW * 32;
+    constexpr int PIECES = 16 / NW;      // 1-KiB LDS-DMA pieces of the K tile (and of the Vt tile) moved by one wave
     const int lane = lane_id();
     const int w = wave_id();
     const int l31 = lane & 31, h = lane >> 5;
@@ -92,11 +93,11 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
 
     // staging: wave w moves K pieces {2w, 2w+1} (4 rows x 256 B each) and Vt pieces {2w, 2w+1}
     // (8 rows x 128 B each)
-    const bf16* k_src[2];
-    const bf16* v_src[2];
+    const bf16* k_src[PIECES];
+    const bf16* v_src[PIECES];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int piece = w * 2 + i;
+    for (int i = 0; i < PIECES; ++i) {
+        const int piece = w * PIECES + i;
         const int krow = piece * 4 + (lane >> 4);
         const int kchunk = (lane & 15) ^ (krow & 15);
         k_src[i] = Kh + (size_t)krow * 128 + kchunk * 8;
@@ -105,9 +106,9 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
         v_src[i] = Vh + (size_t)vrow * S_pad + vchunk * 8;
     }
     auto stage = [&](int buf, int t) {
-        char* base = smem + buf * ATT_STAGE + w * 2048;
+        char* base = smem + buf * ATT_STAGE + w * PIECES * 1024;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PIECES; ++i) {
             glds16(k_src[i] + (size_t)t * KV_TILE * 128, base + i * 1024);
             glds16(v_src[i] + t * KV_TILE, base + KV_TILE * 256 + i * 1024);
         }
@@ -261,12 +262,12 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
 // merge the `split` partials of each leftover (head, q-block): O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M)
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o,
                                                            const float* __restrict__ part_ml, bf16* __restrict__ out,
-                                                           int S, int ldo, AttnPlan plan) {
+                                                           int S, int ldo, AttnPlan plan, int Q_BLOCK) {
     const int r_item = (int)blockIdx.x;
     const int item = plan.n_full + r_item;
     const int head = item / plan.nqb;
     const int qb = item - head * plan.nqb;
-    for (int it = 0; it < 32; ++it) {
+    for (int it = 0; it < Q_BLOCK / 8; ++it) {
         const int e = it * 256 + (int)threadIdx.x;
         const int row = e >> 5, c = e & 31;
         const int q = qb * Q_BLOCK + row;
@@ -292,10 +293,10 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
     }
 }
 
-int g_attn_slots = 256;      // concurrently resident work-groups (1 per CU at 64 KiB LDS + 173 VGPRs x 8 waves)
+int g_attn_slots = 256;      // CUs: concurrently resident work-groups = slots x (8 / waves per work-group)
 int g_attn_force_split = 0;  // tests: force an R / split decomposition on small problems
 
-static AttnPlan make_plan(int H, int S, bool have_ws) {
+static AttnPlan make_plan(int H, int S, bool have_ws, int Q_BLOCK, int slots) {
     AttnPlan p;
     p.nqb = (S + Q_BLOCK - 1) / Q_BLOCK;
     const int total = H * p.nqb;
@@ -303,8 +304,8 @@ static AttnPlan make_plan(int H, int S, bool have_ws) {
     p.split = 1;
     if (!have_ws) return p;
     const int nt = (S + KV_TILE - 1) / KV_TILE;
-    int R = total % g_attn_slots;
-    int split = R > 0 ? g_attn_slots / R : 1;
+    int R = total % slots;
+    int split = R > 0 ? slots / R : 1;
     if (g_attn_force_split > 1) { R = total < 4 ? total : 4; split = g_attn_force_split; }
     if (split > 8) split = 8;
     if (split > nt) split = nt;
@@ -318,7 +319,7 @@ static AttnPlan make_plan(int H, int S, bool have_ws) {
 size_t flash_attn_workspace_bytes(int H, int S) {
     (void)H; (void)S;
     // at most (slots - 1) leftover items x 8 partials ... bounded by slots short items in practice; size for the cap
-    return (size_t)g_attn_slots * Q_BLOCK * (128 + 2) * sizeof(float);
+    return (size_t)g_attn_slots * 256 * (128 + 2) * sizeof(float);   // slots x Q_BLOCK is the same for both variants
 }
 
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
@@ -330,28 +331,37 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<8>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)flash_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
     const bool have_ws = workspace != nullptr && workspace_bytes >= flash_attn_workspace_bytes(H, S) &&
                          ((uintptr_t)workspace & 15) == 0;
-    const AttnPlan plan = make_plan(H, S, have_ws);
+    const int NW = g_attn_variant == 1 ? 4 : 8;
+    const int Q_BLOCK = NW * 32;
+    const int slots = g_attn_slots * (8 / NW);
+    const AttnPlan plan = make_plan(H, S, have_ws, Q_BLOCK, slots);
     const int total = H * plan.nqb;
     const int n_short = (total - plan.n_full) * plan.split;
-    PE_REQUIRE(plan.split == 1 || n_short <= g_attn_slots, "flash_attn: internal plan error");
+    PE_REQUIRE(plan.split == 1 || n_short <= slots, "flash_attn: internal plan error");
     float* part_o = (float*)workspace;
-    float* part_ml = part_o ? part_o + (size_t)g_attn_slots * Q_BLOCK * 128 : nullptr;
+    float* part_ml = part_o ? part_o + (size_t)g_attn_slots * 256 * 128 : nullptr;
     const float scale_log2 = scale * 1.44269504088896340736f;
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);  // QK^T + PV
     const dim3 grid(plan.n_full + (plan.split > 1 ? n_short : 0));
-    hipLaunchKernelGGL(flash_attn_kernel, grid, dim3(ATT_THREADS), ATT_LDS, stream, (const bf16*)q,
-                       (const bf16*)k, (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
+    if (NW == 4)
+        hipLaunchKernelGGL(flash_attn_kernel<4>, grid, dim3(256), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
+    else
+        hipLaunchKernelGGL(flash_attn_kernel<8>, grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
     int rc = check_launch("flash_attn_kernel");
     if (rc == PE_OK && plan.split > 1) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3(total - plan.n_full), dim3(256), 0, stream, part_o, part_ml,
-                           (bf16*)out, S, ldo, plan);
+                           (bf16*)out, S, ldo, plan, Q_BLOCK);
         rc = check_launch("attn_combine_kernel");
     }
     prof_end(slot, stream);
