@@ -263,34 +263,36 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o,
                                                            const float* __restrict__ part_ml, bf16* __restrict__ out,
                                                            int S, int ldo, AttnPlan plan, int Q_BLOCK) {
-    const int r_item = (int)blockIdx.x;
+    // one block = 8 query rows x 32 four-column chunks of one leftover item (grid.x = items * Q_BLOCK/8: the merge is a
+    // short dependent chain per element, so it wants many small blocks, not a loop)
+    const int per_item = Q_BLOCK / 8;
+    const int r_item = (int)blockIdx.x / per_item;
+    const int it = (int)blockIdx.x - r_item * per_item;
     const int item = plan.n_full + r_item;
     const int head = item / plan.nqb;
     const int qb = item - head * plan.nqb;
-    for (int it = 0; it < Q_BLOCK / 8; ++it) {
-        const int e = it * 256 + (int)threadIdx.x;
-        const int row = e >> 5, c = e & 31;
-        const int q = qb * Q_BLOCK + row;
-        if (q >= S) continue;
-        float M = -INFINITY;
-        for (int i = 0; i < plan.split; ++i)
-            M = fmaxf(M, part_ml[((size_t)(r_item * plan.split + i) * Q_BLOCK + row) * 2]);
-        float L = 0.f;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < plan.split; ++i) {
-            const size_t base = (size_t)(r_item * plan.split + i) * Q_BLOCK + row;
-            const float wgt = __builtin_amdgcn_exp2f(part_ml[base * 2] - M);
-            L = __builtin_fmaf(part_ml[base * 2 + 1], wgt, L);
-            const f32x4 v = *(const f32x4*)(part_o + base * 128 + c * 4);
+    const int e = it * 256 + (int)threadIdx.x;
+    const int row = e >> 5, c = e & 31;
+    const int q = qb * Q_BLOCK + row;
+    if (q >= S) return;
+    float M = -INFINITY;
+    for (int i = 0; i < plan.split; ++i)
+        M = fmaxf(M, part_ml[((size_t)(r_item * plan.split + i) * Q_BLOCK + row) * 2]);
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < plan.split; ++i) {
+        const size_t base = (size_t)(r_item * plan.split + i) * Q_BLOCK + row;
+        const float wgt = __builtin_amdgcn_exp2f(part_ml[base * 2] - M);
+        L = __builtin_fmaf(part_ml[base * 2 + 1], wgt, L);
+        const f32x4 v = *(const f32x4*)(part_o + base * 128 + c * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v[j], wgt, acc[j]);
-        }
-        const float inv = 1.0f / L;
-        bf16x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[j] * inv);
-        *(bf16x4*)(out + (size_t)q * ldo + head * 128 + c * 4) = o;
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v[j], wgt, acc[j]);
     }
+    const float inv = 1.0f / L;
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[j] * inv);
+    *(bf16x4*)(out + (size_t)q * ldo + head * 128 + c * 4) = o;
 }
 
 int g_attn_slots = 256;      // CUs: concurrently resident work-groups = slots x (8 / waves per work-group)
@@ -360,7 +362,7 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
                            (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
     int rc = check_launch("flash_attn_kernel");
     if (rc == PE_OK && plan.split > 1) {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(total - plan.n_full), dim3(256), 0, stream, part_o, part_ml,
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((total - plan.n_full) * (Q_BLOCK / 8)), dim3(256), 0, stream, part_o, part_ml,
                            (bf16*)out, S, ldo, plan, Q_BLOCK);
         rc = check_launch("attn_combine_kernel");
     }
