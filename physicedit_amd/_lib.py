@@ -58,6 +58,8 @@ class DitCall(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/physicedit_amd.h declares
+ABI_VERSION = 2   # include/physicedit_amd.h: bumped on any signature / struct change
+
 SIGNATURES = {
     "pe_last_error": (C.c_char_p, []),
     "pe_abi_version": (c_int, []),
