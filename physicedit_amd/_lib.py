@@ -112,6 +112,10 @@ def lib() -> C.CDLL:
             raise PeError(
                 f"{LIB_PATH} is missing: build it with `python -m physicedit_amd.build` "
                 "(hipcc --offload-arch=gfx950).  physicedit_amd has no CPU/PyTorch fallback.")
+        # torch first: the process must hold ONE HIP runtime.  torch ships its own libamdhip64 (same soname as
+        # /opt/rocm's); loaded first, the dynamic linker binds this library to it too.  The other order leaves torch on
+        # a second runtime and every HIP call made here fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
