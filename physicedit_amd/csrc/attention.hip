@@ -32,6 +32,7 @@
 namespace pe {
 
 constexpr int KV_TILE = 64;
+constexpr int KDEPTH = 4;   // K-fragment ds_reads kept in flight ahead of the QK^T MFMAs
 constexpr int ATT_STAGE = 2 * KV_TILE * 128 * 2;  // K tile 16 KiB + Vt tile 16 KiB
 constexpr int ATT_LDS = 2 * ATT_STAGE;            // 64 KiB
 int g_attn_variant = 0;   // 0: 8 waves / 256 query rows per work-group (1 per CU);  1: 4 waves / 128 rows (2 per CU)
@@ -127,74 +128,88 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
     const int v_off = KV_TILE * 256 + l31 * 128;    // Vt row d = l31 (+32 rows per dt)
     const int vsw = (l31 >> 1) & 7;
 
-    // One KV tile.  MASK is a compile-time flag so the tail masking costs nothing on full tiles (as a
-    // run-time condition the compiler if-converted it into 32 v_cndmask on EVERY tile).  VALU work is kept
-    // minimal because it is as large as the MFMA work here (PMC: VALU busy ~= MFMA busy): accumulators start
-    // from a constant-zero C operand (no v_mov zeroing), P is packed pairwise with v_cvt_pk (no v_perm), and
-    // the O rescale is skipped when no row's running max moved (alpha == 1 in every lane: same numerics).
-    auto tile = [&](int t, auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
-        const char* Sb = smem + (t & 1) * ATT_STAGE;
+    // Building blocks of one KV tile.  VALU work is kept minimal because it is as large as the MFMA work here:
+    // accumulators start from a constant-zero C operand (no v_mov zeroing), P is packed pairwise with v_cvt_pk (no
+    // v_perm), the key mask is a compile-time flag (as a run-time condition the compiler if-converted it into 32
+    // v_cndmask on EVERY tile), and the O rescale is skipped when no row's running max moved (alpha == 1 in every
+    // lane: same numerics).
+    // Q: sc[s2][4a+r] = score(q = q0+l31, key = t*64 + s2*32 + 8a + 4h + r)
+    auto qk = [&](auto buf_tag, f32x16 (&sc)[2]) {
+        const char* Sb = smem + decltype(buf_tag)::value * ATT_STAGE;   // compile-time stage: LDS addresses become immediates
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x16 st[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const bf16x8 kf = *(const bf16x8*)(Sb + k_off + s2 * 32 * 256 + (((kk * 2 + h) ^ ksw) << 4));
-                st[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero : st[s2], 0, 0, 0);
+                sc[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero : sc[s2], 0, 0, 0);
             }
         }
-        // st[s2][4a+r] = score(q = q0+l31, key = t*64 + s2*32 + 8a + 4h + r)
+    };
+    // S: online-softmax statistics; sc scores -> probabilities; returns the factor the O accumulated so far must be
+    // multiplied with BEFORE this tile's P.V is added.  No LDS traffic, no MFMA.
+    auto softmax = [&](int t, f32x16 (&sc)[2], auto mask_tag, float& alpha, bool& moved) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         if constexpr (MASK) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    if (key >= S) st[s2][r] = -INFINITY;
+                    if (key >= S) sc[s2][r] = -INFINITY;
                 }
         }
-        float mx = st[0][0];
+        float mx = sc[0][0];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[s2][r]);
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[s2][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * scale_log2);
-        const bool moved = m_new != m_run;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        moved = m_new != m_run;
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[s2][r], scale_log2, -m_new));
-                st[s2][r] = p;
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][r], scale_log2, -m_new));
+                sc[s2][r] = p;
                 psum += p;
             }
         l_run = __builtin_fmaf(l_run, alpha, psum);
+    };
+    auto rescale = [&](float alpha, bool moved) {
         if (__any(moved)) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
-        // ---- O^T += Vt . P^T
+    };
+    // P as the four MFMA B-operand fragments of the tile: pk[s2*2+k2] = 8 bf16 = accumulator quads 2*k2, 2*k2+1 of sc[s2]
+    auto pack = [&](const f32x16 (&sc)[2], u32x4 (&pk)[4]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bf16x2 two;
+                    two[0] = (bf16)sc[s2][(2 * k2) * 4 + 2 * (e & 1) + 4 * (e >> 1)];
+                    two[1] = (bf16)sc[s2][(2 * k2) * 4 + 2 * (e & 1) + 4 * (e >> 1) + 1];
+                    pk[s2 * 2 + k2][e] = __builtin_bit_cast(uint32_t, two);
+                }
+    };
+    // P.V: O^T += Vt . P^T
+    auto pv = [&](auto buf_tag, const u32x4 (&pk)[4]) {
+        const char* Sb = smem + decltype(buf_tag)::value * ATT_STAGE;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                u32x4 pk;   // 8 bf16: accumulator quads 2*k2 and 2*k2+1, packed two at a time
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bf16x2 two;
-                    two[0] = (bf16)st[s2][(2 * k2) * 4 + 2 * (e & 1) + 4 * (e >> 1)];
-                    two[1] = (bf16)st[s2][(2 * k2) * 4 + 2 * (e & 1) + 4 * (e >> 1) + 1];
-                    pk[e] = __builtin_bit_cast(uint32_t, two);
-                }
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk[s2 * 2 + k2]);
                 const int vchunk = s2 * 4 + k2 * 2 + h;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -205,21 +220,59 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
     };
 
     const int nt = t_end;
-    // the (only) partially filled tile is peeled out of the loop: one call site inside the loop keeps the
-    // 128 accumulator registers in place (two call sites made the compiler copy them at the join)
     const bool tail = (S & (KV_TILE - 1)) != 0 && nt == nt_all;
-    const int nt_loop = tail ? nt - 1 : nt;
-    stage(t_begin & 1, t_begin);
-    for (int t = t_begin; t < nt_loop; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-        tile(t, std::false_type{});
-    }
-    if (tail) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        tile(nt - 1, std::true_type{});
+    {
+        f32x16 sc[2];
+        u32x4 pk[4];
+        auto tile = [&](int t, auto buf_tag, auto mask_tag) {
+            float alpha;
+            bool moved;
+            qk(buf_tag, sc);
+            // Left alone, hipcc emits  ds_read, s_waitcnt lgkmcnt(0), MFMA  sixteen times: every MFMA then waits a full
+            // LDS round trip.  Pin a KDEPTH-deep fragment prefetch (reads run KDEPTH MFMAs ahead of their consumer).
+            __builtin_amdgcn_sched_group_barrier(0x100, KDEPTH, 0);
+#pragma unroll
+            for (int i = 0; i < 16 - KDEPTH; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, KDEPTH, 0);
+            softmax(t, sc, mask_tag, alpha, moved);
+            rescale(alpha, moved);
+            pack(sc, pk);
+            pv(buf_tag, pk);
+        };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        auto sync = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        // Tile t lives in stage (t - t_begin) & 1; the loop is unrolled by two so the stage is a compile-time constant
+        // (no per-tile address arithmetic: ~15 VALU instructions per tile, and on this chip ordinary VALU instructions
+        // take MFMA issue slots).  The (only) partially filled tile is peeled out (the key mask is a template flag).
+        const int nt_loop = tail ? nt - 1 : nt;
+        stage(0, t_begin);
+        int t = t_begin;
+        for (; t + 2 <= nt_loop; t += 2) {
+            sync();
+            stage(1, t + 1);                     // t + 1 < nt_loop <= nt
+            tile(t, B0{}, std::false_type{});
+            sync();
+            if (t + 2 < nt) stage(0, t + 2);
+            tile(t + 1, B1{}, std::false_type{});
+        }
+        if (t < nt_loop) {
+            sync();
+            if (t + 1 < nt) stage(1, t + 1);
+            tile(t, B0{}, std::false_type{});
+            ++t;
+        }
+        if (tail) {
+            sync();
+            if ((t - t_begin) & 1) tile(t, B1{}, std::true_type{});
+            else tile(t, B0{}, std::true_type{});
+        }
     }
 
     // ---- normalise and store: o[dt][4a+r] = O[q0+l31][dt*32 + 8a + 4h + r]
@@ -333,8 +386,7 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<8>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -354,12 +406,12 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     const float scale_log2 = scale * 1.44269504088896340736f;
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);  // QK^T + PV
     const dim3 grid(plan.n_full + (plan.split > 1 ? n_short : 0));
-    if (NW == 4)
-        hipLaunchKernelGGL(flash_attn_kernel<4>, grid, dim3(256), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
-                           (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
-    else
-        hipLaunchKernelGGL(flash_attn_kernel<8>, grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
-                           (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
+#define PE_ATTN_LAUNCH(NWV)                                                                                       \
+    hipLaunchKernelGGL((flash_attn_kernel<NWV>), grid, dim3(NWV * 64), ATT_LDS, stream, (const bf16*)q, (const bf16*)k, \
+                       (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml)
+    if (NW == 4) PE_ATTN_LAUNCH(4);
+    else PE_ATTN_LAUNCH(8);
+#undef PE_ATTN_LAUNCH
     int rc = check_launch("flash_attn_kernel");
     if (rc == PE_OK && plan.split > 1) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3((total - plan.n_full) * (Q_BLOCK / 8)), dim3(256), 0, stream, part_o, part_ml,
