@@ -75,6 +75,12 @@ int pe_gemm_bf16_pre(int epilogue, const void* A, int lda, const void* W, const 
  * torch._scaled_mm, which the reference calls here, does not run on CPU with per-row scales: parity of this pair is
  * pinned only against the CPU restatement in oracle/ ("parity unpinned"). */
 int pe_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, void* stream);
+/* pe_ln_modulate followed by pe_quantize_rows_e4m3 in one pass over the row (the form the e4m3 composite uses in front of
+ * the QKV and MLP-up Linears): out_e4m3 [rows,dim] bytes + out_scale [rows]; out_bf16 nullable (skipped when null).
+ * Bit-identical to the two separate calls. */
+int pe_ln_modulate_e4m3(const void* x, void* out_bf16, void* out_e4m3, float* out_scale, int rows, int dim, int rows_a,
+                        const void* shift_a, const void* scale_a, const void* shift_b, const void* scale_b, float eps,
+                        void* stream);
 int pe_gemm_e4m3(int epilogue, const void* Aq, int lda, const float* scale_a, const void* Wq, const void* bias,
                  const void* pre, int ldp, void* out, int ldo, int M, int N, int K, const void* gate, const void* res,
                  int ldr, void* stream);

@@ -68,6 +68,8 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_int, c_void_p]),
     "pe_gemm_bf16_pre": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                  c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "pe_ln_modulate_e4m3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_float, c_void_p]),
     "pe_quantize_rows_e4m3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "pe_gemm_e4m3": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                              c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

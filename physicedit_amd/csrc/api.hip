@@ -65,6 +65,14 @@ int pe_gemm_bf16_pre(int epilogue, const void* A, int lda, const void* W, const 
     return launch_gemm(epilogue, &p, 1, (hipStream_t)stream);
 }
 
+int pe_ln_modulate_e4m3(const void* x, void* out_bf16, void* out_e4m3, float* out_scale, int rows, int dim, int rows_a,
+                        const void* shift_a, const void* scale_a, const void* shift_b, const void* scale_b, float eps,
+                        void* stream) {
+    PE_REQUIRE(out_e4m3 && out_scale, "pe_ln_modulate_e4m3: null e4m3 output");
+    return launch_ln_modulate_quant(x, out_bf16, rows, dim, rows_a, shift_a, scale_a, shift_b, scale_b, eps, out_e4m3,
+                                    out_scale, (hipStream_t)stream);
+}
+
 int pe_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, void* stream) {
     return launch_quantize_rows_e4m3(x, ldx, M, K, out, Kp, scale, (hipStream_t)stream);
 }

@@ -44,6 +44,7 @@ struct pe_dit {
     char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
     char* aq;                           // e4m3 mode: quantised activation rows of the Linear being run [S, FF] bytes
     float* asc;                         // e4m3 mode: their per-row scales
+    const void* aq_src = nullptr;       // bf16 operand whose quantised rows currently sit in aq/asc (fused producer), or null
     pe_dit_block_lora* lora = nullptr;  // hot LoRA operands per block, or null
     int lora_r = 0;
 };
@@ -100,9 +101,11 @@ static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t st
     const bool joint = n == 2 && pp[0].K == pp[1].K && pp[0].lda == pp[1].lda &&
                        (const char*)pp[1].A == (const char*)pp[0].A + (size_t)pp[0].M * pp[0].lda * 2;
     size_t off = 0, row = 0;
+    const bool prequantised = joint && h->aq_src != nullptr && h->aq_src == pp[0].A;   // ln_modulate already wrote aq/asc
+    h->aq_src = nullptr;
     for (int s = 0; s < n; ++s) {
         const int Kp = (int)align_up((size_t)pp[s].K, 128);
-        if (s == 0 || !joint) {
+        if (!prequantised && (s == 0 || !joint)) {
             const int M = joint ? pp[0].M + pp[1].M : pp[s].M;
             if ((rc = launch_quantize_rows_e4m3(pp[s].A, pp[s].lda, M, pp[s].K, h->aq + off, Kp, h->asc + row, stream)))
                 return rc;
@@ -329,9 +332,15 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         auto gt = [&](const char* m, int half) { return m + (size_t)(half * 3 + 2) * D * 2; };
 
         // norm1 + modulate (both streams, one launch)
-        if ((rc = launch_ln_modulate(h->x, h->xmod, S, D, S_img, sh(mod_img, 0), sc(mod_img, 0), sh(mod_txt, 0),
-                                     sc(mod_txt, 0), 1e-6f, stream)))
+        // e4m3 mode: the same kernel also emits the rows as e4m3 + per-row scale (the QKV Linear's operand); the bf16
+        // copy is only needed by hot LoRA (x @ A.T runs in bf16)
+        const bool fuse_q = h->w.weights_e4m3 != 0;
+        const bool need_bf16_qkv = !fuse_q || (h->lora && h->lora[l].img_qkv_a && h->lora[l].txt_qkv_a);
+        if ((rc = launch_ln_modulate_quant(h->x, need_bf16_qkv ? h->xmod : nullptr, S, D, S_img, sh(mod_img, 0), sc(mod_img, 0),
+                                           sh(mod_txt, 0), sc(mod_txt, 0), 1e-6f, fuse_q ? h->aq : nullptr,
+                                           fuse_q ? h->asc : nullptr, stream)))
             return rc;
+        if (fuse_q) h->aq_src = h->xmod;
         // QKV projections + per-head RMSNorm + RoPE, head-major Q/K, transposed V
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {
@@ -401,9 +410,11 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         }
         if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
         // norm2 + modulate
-        if ((rc = launch_ln_modulate(h->x, h->xmod, S, D, S_img, sh(mod_img, 1), sc(mod_img, 1), sh(mod_txt, 1),
-                                     sc(mod_txt, 1), 1e-6f, stream)))
+        if ((rc = launch_ln_modulate_quant(h->x, fuse_q ? nullptr : h->xmod, S, D, S_img, sh(mod_img, 1), sc(mod_img, 1),
+                                           sh(mod_txt, 1), sc(mod_txt, 1), 1e-6f, fuse_q ? h->aq : nullptr,
+                                           fuse_q ? h->asc : nullptr, stream)))   // MLP-up is no LoRA target: no bf16 copy
             return rc;
+        if (fuse_q) h->aq_src = h->xmod;
         // MLP up + ApproximateGELU
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {

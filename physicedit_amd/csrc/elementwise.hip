@@ -6,19 +6,28 @@
 
 namespace pe {
 
+PE_DEV uint32_t pack4_e4m3(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);   // v_cvt_pk_fp8_f32: OCP e4m3fn on gfx950, RNE
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm(elementwise_affine=False, eps) -> x*(1+scale) + shift
 //   QwenImageTransformerBlock._modulate   qwen_image_dit.py:355-357, norms :337,344,351,352
 //   AdaLayerNorm(single)                  models/utils.py:304-309
 // One wave per row (dim = 3072: 6 x 16 B per lane, row kept in registers, two-pass moments in fp32).
 // ------------------------------------------------------------------------------------------------
-template <int VPL>  // 16-B vectors per lane; dim = VPL * 512
+template <int VPL, bool QUANT>  // 16-B vectors per lane; dim = VPL * 512.  QUANT: also emit the row as e4m3 + scale
 __global__ void __launch_bounds__(256) ln_modulate_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
                                                           int rows, int dim, int rows_a,
                                                           const bf16* __restrict__ shift_a,
                                                           const bf16* __restrict__ scale_a,
                                                           const bf16* __restrict__ shift_b,
-                                                          const bf16* __restrict__ scale_b, float eps) {
+                                                          const bf16* __restrict__ scale_b, float eps,
+                                                          uint8_t* __restrict__ q_out, float* __restrict__ q_scale) {
     const int lane = lane_id();
     const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (row >= rows) return;
@@ -59,23 +68,61 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const bf16* __restrict
             const float s1 = bf16r(1.0f + (float)sc[j]);       // 1 + scale
             const float p = bf16r(n * s1);                     // x * (1 + scale)
             o[j] = (bf16)(p + (float)sh[j]);                   // + shift
+            if constexpr (QUANT) v[i][j] = (float)o[j];        // keep the rounded row for the quantiser below
         }
-        *(bf16x8*)(orow + c) = o;
+        if (!QUANT || out != nullptr) *(bf16x8*)(orow + c) = o;
+    }
+    if constexpr (QUANT) {
+        // fp8_linear's activation quantisation of this row (see quantize_rows_e4m3_kernel), fused: the row is still in
+        // registers, so the consumer GEMM's e4m3 operand costs no extra pass over HBM
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(v[i][j]));
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+        const float scq = fmaxf(bf16r(mx * (1.0f / 448.0f)), 1.0f);
+        const float dv = scq + 1e-8f;
+        if (lane == 0) q_scale[row] = scq;
+        uint8_t* qrow = q_out + (size_t)row * dim;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            u32x2 pk;
+            pk[0] = pack4_e4m3(v[i][0] / dv, v[i][1] / dv, v[i][2] / dv, v[i][3] / dv);
+            pk[1] = pack4_e4m3(v[i][4] / dv, v[i][5] / dv, v[i][6] / dv, v[i][7] / dv);
+            *(u32x2*)(qrow + (i * 64 + lane) * 8) = pk;
+        }
     }
 }
 
 int launch_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
                        const void* scale_a, const void* shift_b, const void* scale_b, float eps,
                        hipStream_t stream) {
-    PE_REQUIRE(x && out && shift_a && scale_a, "ln_modulate: null pointer");
+    return launch_ln_modulate_quant(x, out, rows, dim, rows_a, shift_a, scale_a, shift_b, scale_b, eps, nullptr, nullptr,
+                                    stream);
+}
+
+// q_out != null: additionally (out == null: only) emit the row as e4m3 bytes [rows, dim] + per-row scale (fp8_linear)
+int launch_ln_modulate_quant(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
+                             const void* scale_a, const void* shift_b, const void* scale_b, float eps, void* q_out,
+                             float* q_scale, hipStream_t stream) {
+    PE_REQUIRE(x && (out || q_out) && shift_a && scale_a, "ln_modulate: null pointer");
+    PE_REQUIRE(q_out == nullptr || q_scale != nullptr, "ln_modulate: q_out without q_scale");
     PE_REQUIRE(rows > 0, "ln_modulate: rows=%d", rows);
     PE_REQUIRE(dim == 3072, "ln_modulate: dim=%d unsupported (DiT width 3072 only)", dim);
     if (!shift_b) shift_b = shift_a;
     if (!scale_b) scale_b = scale_a;
-    const int slot = prof_begin(PROF_ROW, 4.0 * (double)rows * dim, stream);  // bytes: read + write bf16
-    hipLaunchKernelGGL((ln_modulate_kernel<6>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x,
-                       (bf16*)out, rows, dim, rows_a, (const bf16*)shift_a, (const bf16*)scale_a,
-                       (const bf16*)shift_b, (const bf16*)scale_b, eps);
+    const double bytes = (2.0 + (out ? 2.0 : 0.0) + (q_out ? 1.0 : 0.0)) * (double)rows * dim;
+    const int slot = prof_begin(PROF_ROW, bytes, stream);
+    if (q_out)
+        hipLaunchKernelGGL((ln_modulate_kernel<6, true>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x,
+                           (bf16*)out, rows, dim, rows_a, (const bf16*)shift_a, (const bf16*)scale_a,
+                           (const bf16*)shift_b, (const bf16*)scale_b, eps, (uint8_t*)q_out, q_scale);
+    else
+        hipLaunchKernelGGL((ln_modulate_kernel<6, false>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x,
+                           (bf16*)out, rows, dim, rows_a, (const bf16*)shift_a, (const bf16*)scale_a,
+                           (const bf16*)shift_b, (const bf16*)scale_b, eps, (uint8_t*)nullptr, (float*)nullptr);
     prof_end(slot, stream);
     return check_launch("ln_modulate_kernel");
 }
@@ -156,13 +203,6 @@ int launch_silu(const void* x, void* out, size_t n, hipStream_t stream) {
 // One 256-thread block per row; a thread keeps up to MAXC 8-element chunks in registers (K <= 2048*MAXC).
 // Columns [K, Kp) of the output are zero-filled (K tile of the e4m3 GEMM is 128).
 // ------------------------------------------------------------------------------------------------
-PE_DEV uint32_t pack4_e4m3(float a, float b, float c, float d) {
-    int v = 0;
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);   // v_cvt_pk_fp8_f32: OCP e4m3fn on gfx950, RNE
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-    return (uint32_t)v;
-}
-
 template <int MAXC>
 __global__ void __launch_bounds__(256) quantize_rows_e4m3_kernel(const bf16* __restrict__ x, int ldx, int K,
                                                                  uint8_t* __restrict__ out, int Kp,

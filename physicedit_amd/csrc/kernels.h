@@ -69,6 +69,9 @@ extern int g_attn_slots, g_attn_force_split;
 int launch_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
                        const void* scale_a, const void* shift_b, const void* scale_b, float eps,
                        hipStream_t stream);
+int launch_ln_modulate_quant(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
+                             const void* scale_a, const void* shift_b, const void* scale_b, float eps, void* q_out,
+                             float* q_scale, hipStream_t stream);
 int launch_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, hipStream_t stream);
 // fp8_linear's activation quantisation: scale[m] = max(bf16(max|x[m,:]| * (1/448)), 1); out = e4m3(x / (scale + 1e-8)),
 // columns [K, Kp) zero-filled

@@ -174,6 +174,20 @@ def ln_modulate(x, shift_a, scale_a, rows_a: Optional[int] = None, shift_b=None,
     return out
 
 
+def ln_modulate_e4m3(x, shift_a, scale_a, rows_a: Optional[int] = None, shift_b=None, scale_b=None, eps: float = 1e-6,
+                     want_bf16: bool = True):
+    """ln_modulate + fp8_linear's row quantisation in one kernel -> (bf16 out or None, e4m3 [rows,dim], scale fp32 [rows])."""
+    _chk(x, "x")
+    rows, dim = x.shape
+    out = torch.empty_like(x) if want_bf16 else None
+    q = torch.empty((rows, dim), dtype=F8, device=x.device)
+    sc = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(lib().pe_ln_modulate_e4m3(x.data_ptr(), _ptr(out), q.data_ptr(), sc.data_ptr(), rows, dim,
+                                    rows if rows_a is None else rows_a, shift_a.data_ptr(), scale_a.data_ptr(),
+                                    _ptr(shift_b), _ptr(scale_b), eps, stream_ptr()), "pe_ln_modulate_e4m3")
+    return out, q, sc
+
+
 def rmsnorm(x, w, eps: float = 1e-6) -> torch.Tensor:
     _chk(x, "x"), _chk(w, "w")
     out = torch.empty_like(x)

@@ -62,6 +62,21 @@ def test_quantize_rows_bit_exact(ops, M, K):
     assert torch.equal(xq_t.view(torch.uint8), xq.view(torch.uint8)[:, :K]), "bytes vs torch device ops"
 
 
+def test_ln_modulate_e4m3_fused_is_bit_identical(ops):
+    """the fused LayerNorm-modulate + quantiser == pe_ln_modulate followed by pe_quantize_rows_e4m3, bit for bit."""
+    rows, dim, rows_a = 301, 3072, 200
+    x = _acts(rows, dim, 41).cuda()
+    sh_a, sc_a, sh_b, sc_b = (rnd((dim,), 42 + i, 0.5).cuda() for i in range(4))
+    ref = ops.ln_modulate(x, sh_a, sc_a, rows_a, sh_b, sc_b)
+    q_ref, s_ref = ops.quantize_rows_e4m3(ref)
+    out, q, s = ops.ln_modulate_e4m3(x, sh_a, sc_a, rows_a, sh_b, sc_b)
+    assert torch.equal(out, ref)
+    assert torch.equal(s, s_ref)
+    assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8))
+    none, q2, s2 = ops.ln_modulate_e4m3(x, sh_a, sc_a, rows_a, sh_b, sc_b, want_bf16=False)
+    assert none is None and torch.equal(q2.view(torch.uint8), q.view(torch.uint8)) and torch.equal(s2, s)
+
+
 def test_e4m3_conversion_all_values(ops):
     """every e4m3 value and every rounding midpoint between neighbours goes through the hardware conversion."""
     vals = torch.arange(0, 256, dtype=torch.uint8).view(F8).float()
