@@ -259,3 +259,35 @@ def test_model_fn_hot_lora(eng2):
     eng.clear_lora()
     again = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda())
     assert torch.equal(again, base)
+
+
+def test_model_fn_full_shape_one_layer():
+    """BASELINE configs[1] geometry end to end through the composite (1024x1024 latents + a 1024x1024 edit image:
+    S_img = 8192, T = 512 with 64 special tokens, adapter on), one transformer layer so that the oracle finishes in
+    well under a minute: exercises every full-size launch shape (408 / 1224 / 1632-tile GEMMs with the grouped 512-row
+    text problem, split-KV attention at S = 8704, 8704-row row kernels) against the reference arithmetic."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd.dit import QwenImageDiTEngine, special_indices
+    sd = synth.make_state_dict(synth.dit_layout(1), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    t_min, t_max = O.adapter_t_range()
+    noise, edit, pe, mask = _model_fn_inputs(1024, 1024, 512, 64, 11)
+    t = torch.tensor([860.0]).to(BF)
+    pe_ref = pe.clone()
+    ref = O.model_fn(sd, ad, noise, t, pe_ref, mask, 1024, 1024, edit, t_min, t_max)
+    ref32 = O.model_fn({k: v.float() for k, v in sd.items()}, {k: v.float() for k, v in ad.items()}, noise.float(), t.float(),
+                       pe.clone().float(), mask, 1024, 1024, edit.float(), t_min, t_max)
+    eng = QwenImageDiTEngine(sd, ad, device="cuda")
+    pe_run = pe.cuda().clone()
+    got = eng.forward(noise.cuda(), t, pe_run, special_indices(mask, "cuda"), edit.cuda())
+    d, u = stats("model_fn full shape (S=8704, 1 layer) latents", got, ref)
+    assert torch.equal(pe_run[0, ~mask[0].cuda()].cpu(), pe[0, ~mask[0]])           # untouched rows bit-identical
+    ds, us = stats("model_fn full shape prompt_emb special rows", pe_run[0, mask[0].cuda()], pe_ref[0, mask[0]])
+    assert us.max().item() <= 4.0
+    # distance to the fp32 evaluation of the same graph: the HIP result must be as close as the reference-bf16 run is
+    e_hip = (got.float().cpu() - ref32).pow(2).mean().sqrt().item()
+    e_ref = (ref.float() - ref32).pow(2).mean().sqrt().item()
+    print(f"[parity] full shape: rms distance to fp32 run: hip {e_hip:.4e} reference-bf16 {e_ref:.4e}")
+    assert e_hip <= 1.25 * e_ref
+    assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3

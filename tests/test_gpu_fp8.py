@@ -202,3 +202,26 @@ def test_loop_e4m3_dual_stream_bit_identical():
                          cfg_scale=4.0, edit_latents=edit.cuda()).clone())
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_model_fn_e4m3_full_shape_one_layer():
+    """configs[2] geometry through the e4m3 composite (S_img = 8192, T = 512, 64 special tokens), one layer: every
+    full-size e4m3 launch shape incl. the fused LayerNorm->e4m3 producer, vs the oracle on the e4m3 state-dict."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd import synth
+    from physicedit_amd.dit import QwenImageDiTEngine, special_indices
+    sd = synth.make_state_dict(synth.dit_layout(1), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    t_min, t_max = O.adapter_t_range()
+    noise, edit, pe, mask = _inputs(1024, 1024, 512, 64, 11)
+    t = torch.tensor([860.0]).to(BF)
+    ref16 = O.model_fn(sd, ad, noise, t, pe.clone(), mask, 1024, 1024, edit, t_min, t_max)
+    ref = O.model_fn(O.to_fp8_state_dict(sd), ad, noise, t, pe.clone(), mask, 1024, 1024, edit, t_min, t_max)
+    eng = QwenImageDiTEngine(sd, ad, device="cuda")
+    eng.enable_fp8_computation()
+    got = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda())
+    mode = _dist("full shape: e4m3 mode effect (oracle e4m3 vs oracle bf16)", ref, ref16)
+    d = _dist("full shape: model_fn e4m3 vs oracle e4m3", got, ref)
+    assert torch.isfinite(got.float()).all()
+    assert d.mean().item() <= 0.25 * mode.mean().item() and d.max().item() <= mode.max().item()
