@@ -1,4 +1,5 @@
 """Checkpoint readers with the reference's signatures (DiffSynth-Studio/diffsynth/models/utils.py:65-88)."""
+import hashlib
 import os
 
 import torch
@@ -26,3 +27,22 @@ def load_state_dict_from_folder(file_path, torch_dtype=None):
         if name.rsplit(".", 1)[-1] in ("safetensors", "bin", "ckpt", "pth", "pt"):
             sd.update(load_state_dict(os.path.join(file_path, name), torch_dtype=torch_dtype))
     return sd
+
+
+def hash_state_dict_keys(state_dict, with_shape=True) -> str:
+    """The reference's model fingerprint (models/utils.py:148-182): every tensor contributes the strings "key:d0_d1_..."
+    (when with_shape) and "key", nested dicts contribute "key|<their own string>"; the sorted list is joined with ","
+    and md5-hashed.  `ModelManager` matches it against the detector table (configs/model_config.py:21-24)."""
+    def keys_string(sd):
+        items = []
+        for key, value in sd.items():
+            if not isinstance(key, str):
+                continue
+            if isinstance(value, torch.Tensor):
+                if with_shape:
+                    items.append(key + ":" + "_".join(str(d) for d in value.shape))
+                items.append(key)
+            elif isinstance(value, dict):
+                items.append(key + "|" + keys_string(value))
+        return ",".join(sorted(items))
+    return hashlib.md5(keys_string(state_dict).encode("utf-8")).hexdigest()

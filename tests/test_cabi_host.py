@@ -49,6 +49,17 @@ def test_invalid_args_fail_loudly_without_gpu(built_lib):
     rc = built_lib.pe_flash_attn(1, 1, 1, 1, 24, 100, 100, 3072, 0.1, None, 0, None)
     assert rc == -1 and b"S_pad" in built_lib.pe_last_error()
     assert built_lib.pe_dit_workspace_bytes(None, 10, 10, 1) == 0
+    # e4m3 entry points
+    rc = built_lib.pe_quantize_rows_e4m3(1, 64, 4, 64, 1, 64, 1, None)
+    assert rc == -1 and b"multiple of 128" in built_lib.pe_last_error()
+    rc = built_lib.pe_quantize_rows_e4m3(1, 64, 4, 60, 1, 128, 1, None)
+    assert rc == -1 and b"multiple of 8" in built_lib.pe_last_error()
+    rc = built_lib.pe_gemm_e4m3(0, 1, 64, 1, 1, None, None, 0, 1, 64, 8, 8, 64, None, None, 0, None)
+    assert rc == -1 and b"multiple of 128" in built_lib.pe_last_error()
+    rc = built_lib.pe_gemm_e4m3(0, 1, 128, None, 1, None, None, 0, 1, 64, 8, 8, 128, None, None, 0, None)
+    assert rc == -1 and b"scale_a" in built_lib.pe_last_error()
+    rc = built_lib.pe_ln_modulate_e4m3(1, None, None, None, 4, 3072, 4, 1, 1, None, None, 1e-6, None)
+    assert rc == -1 and b"null e4m3 output" in built_lib.pe_last_error()
     with pytest.raises(_lib.PeError):
         _lib.check(rc, "x")
 

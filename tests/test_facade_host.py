@@ -85,3 +85,21 @@ def test_pipeline_refuses_cpu_and_missing_pieces():
     n1 = pipe.generate_noise((1, 16, 8, 8), seed=3, rand_torch_dtype=BF, device="cpu")
     from physicedit_amd import synth
     assert torch.equal(n1, synth.make_noise(3, 64, 64))
+
+
+def test_layout_fingerprints_match_the_reference_detector_table():
+    """The state-dict layouts the library is built around (physicedit_amd.synth: names + shapes) must BE the official
+    checkpoints' layouts: their md5 fingerprints (the reference's hash_state_dict_keys, models/utils.py:148-182) equal
+    the entries of the reference's detector table (configs/model_config.py:21,24)."""
+    import torch
+    from diffsynth.models.utils import hash_state_dict_keys
+    from diffsynth.models.model_manager import detect_model_name
+    from physicedit_amd import synth
+    dit = {k: torch.empty(shape, device="meta") for k, shape in synth.dit_layout(60)}
+    vae = {k: torch.empty(shape, device="meta") for k, shape in synth.vae_layout()}
+    assert len(dit) == 1933
+    assert hash_state_dict_keys(dit) == "0319a1cb19835fb510907dd3367c95ff"
+    assert hash_state_dict_keys(vae) == "ed4ea5824d55ec3107b09815e318123a"
+    assert detect_model_name(dit) == "qwen_image_dit" and detect_model_name(vae) == "qwen_image_vae"
+    small = {k: torch.empty(shape, device="meta") for k, shape in synth.dit_layout(2)}
+    assert detect_model_name(small) == "qwen_image_dit"          # reduced depth: key-signature fallback
