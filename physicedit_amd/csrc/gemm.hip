@@ -43,11 +43,12 @@ struct GemmArgs {
 
 PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 
-// VAR selects the main-loop schedule (A/B-tested in one process through pe_debug_set("gemm_variant")):
-//   0  loads then MFMAs per 16-deep k-step (compiler-scheduled)
-//   1  fragment double buffering: k-step kk+1's ds_reads are issued before k-step kk's MFMAs
-//   2  = 1 + s_setprio(1) around each MFMA cluster
-//   3  ablation: tiles are staged for kt = 0 only (measures the MFMA + LDS-read loop alone; wrong results)
+// VAR selects the main-loop schedule (A/B-tested in one process through pe_debug_set("gemm_variant"); the full study
+// incl. the ablation variants that no longer live here is profiles/r01_gemm_ablation.md):
+//   0   reference: one barrier per K tile, staging burst, loads then MFMAs per 16-deep k-step (compiler-scheduled)
+//   8   pipelined clusters: fragments double buffered in registers, tile barrier before the LAST cluster, staging
+//       spread over the clusters, MFMA / ds_read / LDS-DMA interleave pinned with sched_group_barrier
+//   10  (default) 8 + three-deep W ring and counted vmcnt
 //
 // FP8 = true: operands are OCP e4m3 bytes (activation rows quantised by quantize_rows_e4m3, weights stored in e4m3),
 // the K tile is 128 elements (the SAME 128-B LDS rows, staging and swizzle), the MFMA is the CDNA4 block-scaled
@@ -223,17 +224,13 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
         }
 #undef PE_CLUSTER8
 #undef PE_SGB
-    } else if constexpr (VAR == 0 || VAR == 3 || VAR == 4) {
+    } else if constexpr (VAR == 0) {
+        // reference schedule: one barrier per K tile, whole next tile staged in a burst, loads-then-MFMAs per k-step
         for (int kt = 0; kt < nk; ++kt) {
-            if constexpr (VAR == 4) {   // ablation: never wait for the LDS-DMA (racy, timing only)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();  // tile kt landed for every wave; everyone is done reading buffer (kt+1)&1
-            }
-            if (VAR != 3 && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-            const char* S = smem + (VAR == 3 ? 0 : (kt & 1)) * STAGE_BYTES;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile kt landed for every wave; everyone is done reading buffer (kt+1)&1
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            const char* S = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int coff = ((kk * 2 + h) ^ sw) << 4;
@@ -249,7 +246,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
             }
         }
-    } else if constexpr (VAR == 8 || VAR == 9) {
+    } else if constexpr (VAR == 8) {
         // Pipelined schedule.  Per K tile four clusters of 8 MFMAs; fragments are double buffered in
         // registers; the tile barrier sits BEFORE the last cluster, so (a) the first fragments of tile
         // kt+1 are read under the last cluster of tile kt, (b) the LDS-DMA of tile kt+2 starts there too.
@@ -263,13 +260,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
             for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const bf16x8*)(S + w_row_off + ni * 32 * 128 + coff);
         };
         auto mma = [&](bf16x8 (&af)[2], bf16x8 (&wf)[4]) {
-            if (VAR == 9) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-            if (VAR == 9) __builtin_amdgcn_s_setprio(0);
         };
         auto stage_pairs = [&](int t, int first, int count) {   // pairs [first, first+count) of tile t
             const int tc = min(t, nk - 1);
@@ -423,83 +418,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
         }
 #undef PE_CLUSTER_SCHED
 #undef PE_SGB
-    } else {
-        auto load_frags = [&](const char* S, int kk, bf16x8 (&af)[2], bf16x8 (&wf)[4]) {
-            const int coff = ((kk * 2 + h) ^ sw) << 4;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(S + a_row_off + mi * 32 * 128 + coff);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const bf16x8*)(S + w_row_off + ni * 32 * 128 + coff);
-        };
-        auto mma = [&](bf16x8 (&af)[2], bf16x8 (&wf)[4]) {
-            if (VAR == 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-            if (VAR == 2) __builtin_amdgcn_s_setprio(0);
-        };
-        // LDS-DMA issue is expensive (~100 cycles per 1-KiB piece): a wave that issues its 8 pieces in one
-        // burst stalls its own MFMA stream, and when both waves of a SIMD burst together (right after the
-        // barrier) the matrix pipe idles (measured: MFMA busy 52 % vs 73 % without staging).  VAR >= 5
-        // issue the pieces in small groups BETWEEN the four 8-MFMA clusters of a K tile, so one wave's
-        // load issue overlaps its SIMD partner's MFMAs; the two wave groups (waves 0-3 / 4-7 share SIMDs
-        // pairwise) may use different slots.  sched[g][c] = piece pairs issued before cluster c.
-        constexpr int SCHED[8][2][4] = {
-            {{4, 0, 0, 0}, {4, 0, 0, 0}}, {{4, 0, 0, 0}, {4, 0, 0, 0}}, {{4, 0, 0, 0}, {4, 0, 0, 0}},   // 0-2 burst at top
-            {{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}},                                 // 3,4 unused here
-            {{4, 0, 0, 0}, {0, 0, 4, 0}},                                                               // 5 group stagger
-            {{2, 1, 1, 0}, {2, 1, 1, 0}},                                                               // 6 spread
-            {{2, 2, 0, 0}, {0, 2, 2, 0}},                                                               // 7 staggered halves
-        };
-        const int grp = w >> 2;
-        auto stage_pairs = [&](int buf, int kt, int first, int count) {
-            char* base = smem + buf * STAGE_BYTES + w * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i >= first && i < first + count) {
-                    glds16(a_src[i] + kt * KT_BYTES, base + i * 1024);
-                    glds16(w_src[i] + kt * KT_BYTES, base + BM * BK * 2 + i * 1024);
-                }
-            }
-        };
-        auto stage_slot = [&](int kt, int c) {
-            if (kt + 1 >= nk) return;
-            const int buf = (kt + 1) & 1;
-            if (grp == 0) {
-                constexpr int n0 = SCHED[VAR][0][0], n1 = SCHED[VAR][0][1], n2 = SCHED[VAR][0][2], n3 = SCHED[VAR][0][3];
-                if (c == 0) stage_pairs(buf, kt + 1, 0, n0);
-                if (c == 1) stage_pairs(buf, kt + 1, n0, n1);
-                if (c == 2) stage_pairs(buf, kt + 1, n0 + n1, n2);
-                if (c == 3) stage_pairs(buf, kt + 1, n0 + n1 + n2, n3);
-            } else {
-                constexpr int n0 = SCHED[VAR][1][0], n1 = SCHED[VAR][1][1], n2 = SCHED[VAR][1][2], n3 = SCHED[VAR][1][3];
-                if (c == 0) stage_pairs(buf, kt + 1, 0, n0);
-                if (c == 1) stage_pairs(buf, kt + 1, n0, n1);
-                if (c == 2) stage_pairs(buf, kt + 1, n0 + n1, n2);
-                if (c == 3) stage_pairs(buf, kt + 1, n0 + n1 + n2, n3);
-            }
-        };
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const char* S = smem + (kt & 1) * STAGE_BYTES;
-            bf16x8 a0[2], w0[4], a1[2], w1[4];
-            load_frags(S, 0, a0, w0);
-            stage_slot(kt, 0);
-            load_frags(S, 1, a1, w1);
-            mma(a0, w0);
-            stage_slot(kt, 1);
-            load_frags(S, 2, a0, w0);
-            mma(a1, w1);
-            stage_slot(kt, 2);
-            load_frags(S, 3, a1, w1);
-            mma(a0, w0);
-            stage_slot(kt, 3);
-            mma(a1, w1);
-        }
     }
+    static_assert(FP8 || VAR == 0 || VAR == 8 || VAR == 10, "unknown GEMM schedule");
 
     // ------------------------------------------------------------------------------------------
     // epilogue.  acc[mi][ni][4q+r] = C[m0 + wm*64 + mi*32 + l31][n0 + wn*128 + ni*32 + 8q + 4h + r]
@@ -718,16 +638,6 @@ static int launch_t(const GemmArgs& args, int ntiles, bool fp8, hipStream_t stre
     if (fp8) return launch_v<EPI, GEMM_DEFAULT_VARIANT, true>(args, ntiles, stream);
     if (g_gemm_variant == 0) return launch_v<EPI, 0>(args, ntiles, stream);   // A/B reference schedules
     if (g_gemm_variant == 8) return launch_v<EPI, 8>(args, ntiles, stream);
-    if constexpr (EPI == EPI_BIAS) {   // further experimental schedules only for the plain epilogue
-        switch (g_gemm_variant) {
-            case 1: return launch_v<EPI, 1>(args, ntiles, stream);
-            case 3: return launch_v<EPI, 3>(args, ntiles, stream);
-            case 4: return launch_v<EPI, 4>(args, ntiles, stream);
-            case 6: return launch_v<EPI, 6>(args, ntiles, stream);
-            case 9: return launch_v<EPI, 9>(args, ntiles, stream);
-            default: break;
-        }
-    }
     return launch_v<EPI, GEMM_DEFAULT_VARIANT>(args, ntiles, stream);
 }
 
