@@ -68,13 +68,28 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_only:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  One process per GPU under
+        # torch.distributed.run on 127.0.0.1 (the same command line the driver uses); rank 0 prints the JSON line.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] spawning {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it spawns the ranks itself)")
+    if not args.cpu_baseline_only and torch.cuda.device_count() < world:
+        raise SystemExit(f"[bench] --gpus {world} but only {torch.cuda.device_count()} visible GPU(s)")
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return
@@ -217,6 +232,8 @@ def main():
                                    f"visual-thinking adapter (64 special tokens), T_pos={args.t_pos} T_neg={args.t_neg}, "
                                    f"VAE encode(1024x1024 edit image)+decode included",
                        "images_per_rank": args.steps, "parallelism": f"dp{world} (images sharded, weights replicated)",
+                       "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+                       "batch_closing_collective": ("one RCCL all_gather of the final latents, inside the timed region" if dist is not None else None),
                        "finite_outputs": ok},
             "whole_path": {"algorithmic_pflop_per_image": fl / 1e15,
                            "achieved_tflops_per_gpu": fl * value / world / 1e12,

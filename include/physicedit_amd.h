@@ -38,6 +38,9 @@ int pe_abi_version(void);
 /* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant").
  * Production callers never need it: the compiled defaults are the validated schedules. */
 int pe_debug_set(const char* key, int value);
+/* Device buffer for a profiling variant's output ("gemm_stamps": long long [work-groups][8] s_memtime stamps of
+ * gemm variant 14); NULL detaches it. */
+int pe_debug_set_ptr(const char* key, void* device_ptr);
 
 /* ---------------------------------------------------------------------------------------------
  * Granular operators (each is one kernel launch; used by the parity tests and by the composites)

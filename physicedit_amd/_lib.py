@@ -64,6 +64,7 @@ SIGNATURES = {
     "pe_last_error": (C.c_char_p, []),
     "pe_abi_version": (c_int, []),
     "pe_debug_set": (c_int, [C.c_char_p, c_int]),
+    "pe_debug_set_ptr": (c_int, [C.c_char_p, c_void_p]),
     "pe_gemm_bf16": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_int, c_void_p]),
     "pe_gemm_bf16_pre": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,

@@ -43,6 +43,12 @@ int pe_debug_set(const char* key, int value) {
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set: unknown key %s", key);
 }
 
+int pe_debug_set_ptr(const char* key, void* p) {
+    PE_REQUIRE(key != nullptr, "pe_debug_set_ptr: null key");
+    if (!strcmp(key, "gemm_stamps")) { g_gemm_dbg = (long long*)p; return PE_OK; }
+    return set_error(PE_ERR_INVALID_ARG, "pe_debug_set_ptr: unknown key %s", key);
+}
+
 int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
                  int M, int N, int K, const void* gate, const void* res, int ldr, void* stream) {
     PE_REQUIRE(epilogue != EPI_QKV, "pe_gemm_bf16: use pe_qkv_rmsnorm_rope for the QKV epilogue");

@@ -23,6 +23,8 @@
 //   * "grouped" launch: up to 2 problems (image stream + text stream) share one grid.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -34,12 +36,22 @@ constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 64 KiB
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;        // 128 KiB
 constexpr int GEMM_LDS_V10 = 5 * (STAGE_BYTES / 2);  // A x2 + W x3 = 160 KiB (all of a CU's LDS)
 constexpr int BAND = 8;
-constexpr int GEMM_DEFAULT_VARIANT = 10;  // validated schedule: pipelined clusters + 3-deep W ring (see VAR list)
+constexpr int GEMM_DEFAULT_VARIANT = 15;  // validated schedule: two staggered wave groups, 2 x 16 MFMAs per K tile (see VAR list)
 
 struct GemmArgs {
     GemmProblem p[2];
     int tiles0;
+    long long* dbg;   // VAR 14 only: per work-group s_memtime stamps [grid][8] (pe_debug_set_ptr("gemm_stamps", p))
 };
+long long* g_gemm_dbg = nullptr;
+
+// VAR 14 = VAR 12 + time stamps of wave 0 (profiling build of the default schedule; never the production variant)
+#define PE_STAMP(k)                                                                                     \
+    do {                                                                                                \
+        if constexpr (VAR == 14 || VAR == 15) {                                                         \
+            if (args.dbg != nullptr && threadIdx.x == 0) args.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); \
+        }                                                                                               \
+    } while (0)
 
 PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 
@@ -48,7 +60,11 @@ PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 //   0   reference: one barrier per K tile, staging burst, loads then MFMAs per 16-deep k-step (compiler-scheduled)
 //   8   pipelined clusters: fragments double buffered in registers, tile barrier before the LAST cluster, staging
 //       spread over the clusters, MFMA / ds_read / LDS-DMA interleave pinned with sched_group_barrier
-//   10  (default) 8 + three-deep W ring and counted vmcnt
+//   10  8 + three-deep W ring and counted vmcnt (round-1 default)
+//   12  "ping-pong": the two wave groups run the same stream one barrier apart, 4 phases x 8 MFMAs per K tile
+//   13  12 with A[mi 0] of the next tile pre-read (balanced ds_read counts per phase)
+//   14  12 + s_memtime stamps (profiling only)
+//   15  (default) ping-pong with 2 phases x 16 MFMAs per K tile, A half tiles staged by the group that reads them
 //
 // FP8 = true: operands are OCP e4m3 bytes (activation rows quantised by quantize_rows_e4m3, weights stored in e4m3),
 // the K tile is 128 elements (the SAME 128-B LDS rows, staging and swizzle), the MFMA is the CDNA4 block-scaled
@@ -67,6 +83,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
 
+    PE_STAMP(0);
     int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int pi = bid >= args.tiles0 ? 1 : 0;
     const GemmProblem& P = args.p[pi];
@@ -94,12 +111,16 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
         const int rin = lane >> 3, slot = lane & 7;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = (w * 4 + i) * 8 + rin;
-            const int chunk = slot ^ ((row >> 1) & 7);
-            const int gr = min(m0 + row, M - 1);
-            const int gn = min(n0 + row, N - 1);
-            a_src[i] = A + (size_t)gr * P.lda * ES + chunk * 16;
-            w_src[i] = W + (size_t)gn * K * ES + chunk * 16;
+            // piece (1 KiB = 8 rows) i of this wave.  VAR 0/8/10: whole tiles, piece 4w + i.  VAR 12-14: 128-row half
+            // tiles, piece = half*16 + 2w + j.  VAR 15: A pieces come from the wave group's OWN half (the only one it
+            // reads), piece = grp*16 + 4(w&3) + i; W pieces 4w + i.
+            const int piece_a = VAR == 15 ? (w >> 2) * 16 + (w & 3) * 4 + i : VAR >= 12 ? (i >> 1) * 16 + w * 2 + (i & 1) : w * 4 + i;
+            const int piece_w = VAR == 15 ? w * 4 + i : piece_a;
+            const int row_a = piece_a * 8 + rin, row_w = piece_w * 8 + rin;
+            const int gr = min(m0 + row_a, M - 1);
+            const int gn = min(n0 + row_w, N - 1);
+            a_src[i] = A + (size_t)gr * P.lda * ES + (slot ^ ((row_a >> 1) & 7)) * 16;
+            w_src[i] = W + (size_t)gn * K * ES + (slot ^ ((row_w >> 1) & 7)) * 16;
         }
     }
     auto stage = [&](int buf, int kt) {
@@ -125,8 +146,221 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     const int w_row_off = BM * BK * 2 + (wn * 128 + l31) * 128;
 
     const int nk = K * ES / KT_BYTES;
-    if constexpr (!FP8) stage(0, 0);
-    if constexpr (FP8) {
+    if constexpr (!FP8 && VAR < 12) stage(0, 0);
+    if constexpr (VAR >= 12) {
+        // "Ping-pong" schedule: the two wave groups (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; waves w and w+4
+        // share a SIMD) run the SAME instruction stream one barrier apart.  Each K tile is four phases per wave, one per
+        // 32x64 quadrant of the wave's 64x128 C tile:
+        //     load part : ds_read the quadrant's missing fragments, issue 2 LDS-DMA pieces (one 128-row half tile per phase
+        //                 and work-group), barrier
+        //     MFMA part : 8 (bf16) / 4 (e4m3) MFMAs under s_setprio 1, barrier
+        // so at any time every SIMD has one wave in its MFMA part and one in its load part: LDS latency, the DMA issue
+        // and the barrier skew of one group hide under the other group's MFMAs (v10 interleaves them inside each wave).
+        //     phase  quadrant (mi, nj)   fragment reads               stages (for tile t+2)
+        //     p0     (0, 0)              A[mi 0] x KS, W[ni 0,1] x KS  W half 0 -> W ring slot (t+2)%3
+        //     p1     (1, 0)              A[mi 1] x KS                  W half 1
+        //     p2     (1, 1)              W[ni 2,3] x KS                A half 0 -> A buffer t&1 (its last read: p1)
+        //     p3     (0, 1)              -                             A half 1 ; then s_waitcnt vmcnt(8)
+        // LDS: A 2 x 32 KiB + W 3 x 32 KiB (v10's rings).  RAW: a wave's pieces of tile t+1 were issued during tile t-1;
+        // vmcnt(8) in p3 of tile t retires them (8 younger pieces = tile t+2's) and both groups pass >= 1 barrier
+        // between that wait and the first ds_read of tile t+1.  WAR: every restaged region was last read >= 2 barriers
+        // earlier (A half g only by group g in p0/p1; W ring slot of tile t-1).
+        using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
+        constexpr int KS = FP8 ? 2 : 4;            // MFMA k-steps per K tile
+        constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
+        char* const a_base = smem;
+        char* const w_base = smem + 2 * A_BYTES;
+        const int grp = w >> 2;
+        const int a_off = (wm * 64 + l31) * 128;
+        const int w_off = (wn * 128 + l31) * 128;
+        auto rd = [&](const char* rowp, int ks) -> FragT {
+            if constexpr (FP8) {
+                const int c0 = 4 * ks + 2 * h;
+                const i32x4 lo = *(const i32x4*)(rowp + ((c0 ^ sw) << 4));
+                const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
+                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+                return *(const bf16x8*)(rowp + (((ks * 2 + h) ^ sw) << 4));
+            }
+        };
+#define PE_BAR()                                   \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+#define PE_MMA(a, mi, nj)                          \
+    do {                                           \
+        PE_BAR();                                  \
+        __builtin_amdgcn_s_setprio(1);             \
+        mma(a, mi, nj);                            \
+        __builtin_amdgcn_s_setprio(0);             \
+        PE_BAR();                                  \
+    } while (0)
+        if constexpr (VAR == 15) {
+            // Two phases of 16 MFMAs per K tile (half the barriers of VAR 12: the ~60-cycle barrier/turn-around cost per
+            // phase is paid per 512 instead of per 256 MFMA cycles).  Phase p = row block mi = p of the wave's C tile
+            // against all four column blocks:
+            //     p0: reads A[mi 0] x KS + W[ni 0..3] x KS (20 ds_read_b128), stages this wave's 4 pieces of A(kt+1)
+            //     p1: reads A[mi 1] x KS                                    , stages its 4 pieces of W(kt+2), vmcnt(4)
+            // A half tiles are staged by the group that reads them (piece_a above), so "every wave of my group passed
+            // the barrier behind its lgkmcnt(0)" is all the WAR protection A's two buffers need: A(kt+1) overwrites
+            // A(kt-1), last read in p1 of tile kt-1.  W(kt+2) overwrites W(kt-1) (3-deep ring), last read by group 1 in
+            // p0 of tile kt-1, i.e. >= 4 barriers earlier.  RAW: vmcnt(4) in p1 retires A(kt+1), W(kt+1); both groups
+            // pass a barrier between that wait and the first read of tile kt+1.
+            FragT fa[KS], fw4[4][KS];
+            auto rd_a1 = [&](const char* Sa, int mi) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
+            };
+            auto rd_w4 = [&](const char* Sw) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) fw4[ni][ks] = rd(Sw + w_off + ni * 4096, ks);
+            };
+            auto mma16 = [&](int mi) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        if constexpr (FP8)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                                fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                        else
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
+                    }
+            };
+            auto st_a4 = [&](int t) {
+                const int tc = min(t, nk - 1);
+                char* base = a_base + (t & 1) * A_BYTES + (grp * 16 + (w & 3) * 4) * 1024;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) glds16(a_src[i] + tc * KT_BYTES, base + i * 1024);
+            };
+            auto st_w4 = [&](int t, int slot) {
+                const int tc = min(t, nk - 1);
+                char* base = w_base + slot * W_BYTES + w * 4096;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) glds16(w_src[i] + tc * KT_BYTES, base + i * 1024);
+            };
+#define PE_MMA16(mi)                               \
+    do {                                           \
+        PE_BAR();                                  \
+        __builtin_amdgcn_s_setprio(1);             \
+        mma16(mi);                                 \
+        __builtin_amdgcn_s_setprio(0);             \
+        PE_BAR();                                  \
+    } while (0)
+            st_a4(0); st_w4(0, 0); st_w4(1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
+            PE_BAR();
+            if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger
+            PE_STAMP(1);
+            int ws = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const char* Sa = a_base + (kt & 1) * A_BYTES;
+                const int ws_n1 = ws == 2 ? 0 : ws + 1;
+                const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
+                // p0
+                rd_a1(Sa, 0); rd_w4(w_base + ws * W_BYTES);
+                st_a4(kt + 1);
+                PE_MMA16(0);
+                // p1
+                rd_a1(Sa, 1);
+                st_w4(kt + 2, ws_n2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's pieces of A(kt+1), W(kt+1) landed
+                PE_MMA16(1);
+                ws = ws_n1;
+            }
+            if (grp == 0) __builtin_amdgcn_s_barrier();        // re-align the two groups
+            PE_STAMP(2);
+#undef PE_MMA16
+        } else {
+            constexpr bool BAL = VAR == 13;   // 13: A[mi 0] of the next tile is pre-read in p3 (reads 8/4/8/4 instead of 12/4/8/0)
+            FragT fa0[KS], fa0b[KS], fa1[KS], fw[2][KS];
+            auto rd_a = [&](const char* Sa, int mi, FragT (&f)[KS]) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) f[ks] = rd(Sa + a_off + mi * 4096, ks);
+            };
+            auto rd_w = [&](const char* Sw, int nj) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) fw[j][ks] = rd(Sw + w_off + (nj * 2 + j) * 4096, ks);
+            };
+            auto mma = [&](FragT (&a)[KS], int mi, int nj) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (FP8)
+                            acc[mi][nj * 2 + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                                fw[j][ks], a[ks], acc[mi][nj * 2 + j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                        else
+                            acc[mi][nj * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j][ks], a[ks], acc[mi][nj * 2 + j], 0, 0, 0);
+                    }
+            };
+            auto st_a = [&](int t, int half) {
+                const int tc = min(t, nk - 1);
+                char* base = a_base + (t & 1) * A_BYTES + (half * 16 + w * 2) * 1024;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) glds16(a_src[half * 2 + j] + tc * KT_BYTES, base + j * 1024);
+            };
+            auto st_w = [&](int t, int slot, int half) {
+                const int tc = min(t, nk - 1);
+                char* base = w_base + slot * W_BYTES + (half * 16 + w * 2) * 1024;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) glds16(w_src[half * 2 + j] + tc * KT_BYTES, base + j * 1024);
+            };
+            st_a(0, 0); st_a(0, 1); st_w(0, 0, 0); st_w(0, 0, 1);
+            st_a(1, 0); st_a(1, 1); st_w(1, 1, 0); st_w(1, 1, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed; tile 1 may still fly
+            PE_BAR();
+            if constexpr (BAL) rd_a(a_base, 0, fa0);
+            if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind group 0
+            PE_STAMP(1);
+            // one K tile; BAL: `cur` holds A[mi 0] of tile kt (read during the previous tile), `nxt` receives tile kt+1's
+            auto tile = [&](int kt, int ws_cur, FragT (&cur)[KS], FragT (&nxt)[KS]) __attribute__((always_inline)) {
+                const char* Sa = a_base + (kt & 1) * A_BYTES;
+                const char* San = a_base + ((kt + 1) & 1) * A_BYTES;
+                const int ws_n1 = ws_cur == 2 ? 0 : ws_cur + 1;
+                const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
+                const char* Sw = w_base + ws_cur * W_BYTES;
+                // p0
+                if constexpr (!BAL) rd_a(Sa, 0, cur);
+                rd_w(Sw, 0);
+                st_w(kt + 2, ws_n2, 0);
+                PE_MMA(cur, 0, 0);
+                // p1
+                rd_a(Sa, 1, fa1);
+                st_w(kt + 2, ws_n2, 1);
+                PE_MMA(fa1, 1, 0);
+                // p2
+                rd_w(Sw, 1);
+                st_a(kt + 2, 0);
+                if constexpr (BAL) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this wave's pieces of tile kt+1 landed
+                PE_MMA(fa1, 1, 1);
+                // p3
+                if constexpr (BAL) rd_a(San, 0, nxt);   // both groups passed a barrier since every wave's vmcnt(6)
+                st_a(kt + 2, 1);
+                if constexpr (!BAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's pieces of tile kt+1 landed
+                PE_MMA(cur, 0, 1);
+            };
+            int ws = 0;
+            int kt = 0;
+            for (; kt + 1 < nk; kt += 2) {
+                tile(kt, ws, fa0, fa0b);
+                ws = ws == 2 ? 0 : ws + 1;
+                if constexpr (BAL) tile(kt + 1, ws, fa0b, fa0); else tile(kt + 1, ws, fa0, fa0b);
+                ws = ws == 2 ? 0 : ws + 1;
+            }
+            if (kt < nk) tile(kt, ws, fa0, fa0b);
+            if (grp == 0) __builtin_amdgcn_s_barrier();        // re-align the two groups
+            PE_STAMP(2);
+        }
+#undef PE_MMA
+#undef PE_BAR
+    } else if constexpr (FP8) {
         // v10's structure (A 2 x 32 KiB + W 3 x 32 KiB ring, tile barrier with vmcnt(4)) on 64-cycle MFMAs:
         // four clusters of 4 MFMAs per K tile.  Cluster c covers k-half c>>1 and output column pair c&1:
         //   c0: A(k0) x W(k0, ni 0,1)   c1: A(k0) x W(k0, ni 2,3)   c2: A(k1) x W(k1, ni 0,1)   c3: A(k1) x W(k1, ni 2,3)
@@ -419,16 +653,24 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
 #undef PE_CLUSTER_SCHED
 #undef PE_SGB
     }
-    static_assert(FP8 || VAR == 0 || VAR == 8 || VAR == 10, "unknown GEMM schedule");
+    static_assert(FP8 || VAR == 0 || VAR == 8 || VAR == 10 || VAR == 12 || VAR == 13 || VAR == 14 || VAR == 15, "unknown GEMM schedule");
 
     // ------------------------------------------------------------------------------------------
     // epilogue.  acc[mi][ni][4q+r] = C[m0 + wm*64 + mi*32 + l31][n0 + wn*128 + ni*32 + 8q + 4h + r]
     // ------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain every LDS-DMA (incl. the clamped tail tiles) before LDS is reused
     __syncthreads();
-    char* E = smem + w * 16384;  // this wave's [64 rows][128 cols] bf16 staging tile, chunk ^= row&15
+    PE_STAMP(3);
+    // this wave's [64 rows][128 cols] bf16 staging tile: 16-B chunk c of row r sits at chunk c ^ (r & 15), and its two 8-B
+    // halves are swapped when r & 8 (rows r and r ^ 8 would otherwise land on the same banks in one ds_write_b64
+    // lane group: measured 7.3k instead of ~3.5k cycles for the 64 writes per lane)
+    char* E = smem + w * 16384;
+    auto unswap = [](bf16x8 v, int row) -> bf16x8 {
+        return (row & 8) ? __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3) : v;
+    };
     const int nw0 = n0 + wn * 128;
     const int mw0 = m0 + wm * 64;
+    bf16x8 rv16[EPI == EPI_GATE_RES ? 16 : 1];   // residual rows of the gated-residual epilogue, prefetched
     {
         const bf16* bias = (const bf16*)P.bias;
         const bf16* pre = (const bf16*)P.pre;   // hot LoRA: `out + x @ A.T @ B.T` (vram_management/layers.py:179-180)
@@ -437,17 +679,32 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[min(mw0 + mi * 32 + l31, M - 1)];
         }
+        // bias first, then (EPI_GATE_RES) all 16 residual rows of this lane: 16-B loads that stay in flight under the LDS
+        // staging below (they used to be issued 4 at a time inside the store loop: 15-21k cycles of exposed latency)
+        bf16x4 bvs[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = nw0 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h;
+            bvs[i] = bf16x4{0, 0, 0, 0};
+            if (bias != nullptr && n < N) bvs[i] = *(const bf16x4*)(bias + n);
+        }
+        if constexpr (EPI == EPI_GATE_RES) {
+            const int n = nw0 + (lane & 15) * 8;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int m = mw0 + it * 4 + (lane >> 4);
+                rv16[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < M && n < N) rv16[it] = *(const bf16x8*)((const bf16*)P.res + (size_t)m * P.ldr + n);
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = nw0 + ni * 32 + 8 * q + 4 * h;
-                float b[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias != nullptr && n < N) {
-                    const bf16x4 bv = *(const bf16x4*)(bias + n);
+                float b[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) b[r] = (float)bv[r];
-                }
+                for (int r = 0; r < 4; ++r) b[r] = (float)bvs[ni * 4 + q][r];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     bf16x4 y;
@@ -466,11 +723,12 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
                         for (int r = 0; r < 4; ++r) y[r] = (bf16)((float)pv[r] + (float)y[r]);
                     }
                     const int c = ni * 4 + q;
-                    *(bf16x4*)(E + row * 256 + ((c ^ (row & 15)) << 4) + h * 8) = y;
+                    *(bf16x4*)(E + row * 256 + ((c ^ (row & 15)) << 4) + ((h ^ ((row >> 3) & 1)) << 3)) = y;
                 }
             }
     }
-    __syncthreads();
+    // no barrier here: a wave reads back only its own staging tile, and one wave's LDS accesses execute in order
+    PE_STAMP(4);
 
     if constexpr (EPI == EPI_QKV) {
         const int HD = N / 3;
@@ -486,7 +744,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
             for (int it = 0; it < 16; ++it) {
                 const int row = it * 4 + (lane >> 4);
                 const int m = mw0 + row;
-                const bf16x8 v = *(const bf16x8*)(E + row * 256 + ((c ^ (row & 15)) << 4));
+                const bf16x8 v = unswap(*(const bf16x8*)(E + row * 256 + ((c ^ (row & 15)) << 4)), it << 2);   // row & 8 == (it << 2) & 8
                 float y[8];
                 float ss = 0.f;
 #pragma unroll
@@ -531,7 +789,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int row = gi * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
-                        e[j] = *(const unsigned short*)(E + row * 256 + (((d >> 3) ^ (row & 15)) << 4) + (d & 7) * 2);
+                        e[j] = *(const unsigned short*)(E + row * 256 + (((d >> 3) ^ (row & 15)) << 4) + ((((d & 7) * 2) ^ (row & 8))));
                     }
                     bf16* dstp = vt + (size_t)d * S_pad + seq0 + gi * 16 + hh * 8;
                     if (gi * 16 + 16 <= valid) {
@@ -554,7 +812,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
                 if (lane < valid) {
                     for (int d = 0; d < 128; ++d) {
                         const unsigned short e =
-                            *(const unsigned short*)(E + lane * 256 + (((d >> 3) ^ (lane & 15)) << 4) + (d & 7) * 2);
+                            *(const unsigned short*)(E + lane * 256 + (((d >> 3) ^ (lane & 15)) << 4) + (((d & 7) * 2) ^ (lane & 8)));
                         ((unsigned short*)vt)[(size_t)d * S_pad + pos] = e;
                     }
                 }
@@ -574,12 +832,12 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
                 for (int j = 0; j < 8; ++j) g[j] = (float)gv[j];
             }
         }
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int row = it * 4 + (lane >> 4);
             const int m = mw0 + row;
             if (m >= M || n >= N) continue;
-            const bf16x8 v = *(const bf16x8*)(E + row * 256 + ((c ^ (row & 15)) << 4));
+            const bf16x8 v = unswap(*(const bf16x8*)(E + row * 256 + ((c ^ (row & 15)) << 4)), it << 2);   // row & 8 == (it << 2) & 8
             bf16x8 o;
             if constexpr (EPI == EPI_BIAS) {
                 o = v;
@@ -604,12 +862,18 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
                     o[j] = (bf16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
                 }
             } else if constexpr (EPI == EPI_GATE_RES) {
-                const bf16x8 rv = *(const bf16x8*)((const bf16*)P.res + (size_t)m * P.ldr + n);
+                const bf16x8 rv = rv16[it];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)rv[j] + bf16r(g[j] * (float)v[j]));
             }
             *(bf16x8*)(out + (size_t)m * P.ldo + n) = o;
         }
+    }
+    PE_STAMP(5);
+    if constexpr (VAR == 14) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PE_STAMP(6);
+        if (args.dbg != nullptr && threadIdx.x == 0) args.dbg[(size_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -622,7 +886,7 @@ int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 template <int EPI, int VAR, bool FP8 = false>
 static int launch_v(const GemmArgs& args, int ntiles, hipStream_t stream) {
     static bool configured = false;
-    constexpr int lds = (FP8 || VAR == 10) ? GEMM_LDS_V10 : GEMM_LDS;
+    constexpr int lds = (FP8 || VAR >= 10) ? GEMM_LDS_V10 : GEMM_LDS;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, VAR, FP8>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -635,9 +899,17 @@ static int launch_v(const GemmArgs& args, int ntiles, hipStream_t stream) {
 
 template <int EPI>
 static int launch_t(const GemmArgs& args, int ntiles, bool fp8, hipStream_t stream) {
-    if (fp8) return launch_v<EPI, GEMM_DEFAULT_VARIANT, true>(args, ntiles, stream);
+    if (fp8) return g_gemm_variant == 12 ? launch_v<EPI, 12, true>(args, ntiles, stream)
+                  : g_gemm_variant == 13 ? launch_v<EPI, 13, true>(args, ntiles, stream)
+                  : g_gemm_variant == 10 ? launch_v<EPI, 10, true>(args, ntiles, stream)
+                                         : launch_v<EPI, 15, true>(args, ntiles, stream);
+    if (g_gemm_variant == 12) return launch_v<EPI, 12>(args, ntiles, stream);
+    if (g_gemm_variant == 13) return launch_v<EPI, 13>(args, ntiles, stream);
+    if (g_gemm_variant == 14) return launch_v<EPI, 14>(args, ntiles, stream);
+    if (g_gemm_variant == 15) return launch_v<EPI, 15>(args, ntiles, stream);
     if (g_gemm_variant == 0) return launch_v<EPI, 0>(args, ntiles, stream);   // A/B reference schedules
     if (g_gemm_variant == 8) return launch_v<EPI, 8>(args, ntiles, stream);
+    if (g_gemm_variant == 10) return launch_v<EPI, 10>(args, ntiles, stream);
     return launch_v<EPI, GEMM_DEFAULT_VARIANT>(args, ntiles, stream);
 }
 
@@ -679,6 +951,7 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     }
     if (nproblems == 1) args.p[1] = args.p[0];
     args.tiles0 = tiles[0];
+    args.dbg = g_gemm_dbg;
     const int ntiles = tiles[0] + tiles[1];
     double flops = 0.0;  // algorithmic 2*M*N*K of the launch (what the roofline fraction is quoted on)
     for (int i = 0; i < nproblems; ++i) flops += 2.0 * problems[i].M * (double)problems[i].N * problems[i].K;

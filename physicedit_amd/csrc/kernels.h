@@ -53,6 +53,7 @@ struct GemmProblem {
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream);
 extern int g_gemm_variant;  // experiment knobs (pe_debug_set); production paths use the compiled defaults
 extern int g_attn_variant;
+extern long long* g_gemm_dbg;   // device buffer for the time stamps of the profiling GEMM variant (14), or null
 
 // ---------------------------------------------------------------------------------------------
 // flash attention over the joint sequence (no mask), D = 128

@@ -60,6 +60,7 @@ class QwenImageDiTEngine:
         self._ws: Optional[torch.Tensor] = None
         self._bound = (0, 0, 0)
         self._step_of: Dict[float, int] = {}
+        self.version = 0          # bumped whenever weights / LoRA state change: forks made from an older version are stale
         self.rope = RopeCache(self.device)
 
     # ------------------------------------------------------------------------------------------
@@ -185,6 +186,7 @@ class QwenImageDiTEngine:
         other._ws = None
         other._bound = (0, 0, 0)
         other._step_of = {}
+        other.version = self.version
         other.rope = self.rope
         return other
 
@@ -259,8 +261,10 @@ class QwenImageDiTEngine:
         self._hot, self._hot_r = None, 0
         check(lib().pe_dit_set_hot_lora(self._handle, None, 0), "pe_dit_set_hot_lora")
         self._step_of = {}
+        self.version += 1
 
     def _apply_hot(self):
+        self.version = getattr(self, "version", 0) + 1
         if getattr(self, "_hot", None) is None:
             return
         arr = (DitBlockLora * max(self.num_layers, 1))()
@@ -305,6 +309,10 @@ class QwenImageDiTEngine:
             W = self.params[name]
             ops.gemm(a, wt, None, "gate_res", gate=None, res=W, out=W)
             n += 1
+        if n:
+            # img_mod.1 / txt_mod.1 are LoRA targets: the prepared modulation rows (host map and the C tables) are stale
+            self._step_of = {}
+            self.version += 1
         return n
 
     # ------------------------------------------------------------------------------------------

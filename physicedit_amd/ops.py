@@ -80,13 +80,14 @@ def quantize_rows_e4m3(x: torch.Tensor, Kp: Optional[int] = None) -> Tuple[torch
 
 
 def gemm_e4m3(xq: torch.Tensor, scale_a: torch.Tensor, wq: torch.Tensor, bias: Optional[torch.Tensor] = None,
-              epilogue: str = "bias", gate=None, res=None, pre=None) -> torch.Tensor:
+              epilogue: str = "bias", gate=None, res=None, pre=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epilogue(bf16((xq @ wq.T) * scale_a[:,None] + bias)); xq [M,K], wq [N,K] e4m3fn, K % 128 == 0."""
     _chk(xq, "xq", F8), _chk(wq, "wq", F8), _chk(scale_a, "scale_a", torch.float32)
     M, K = xq.shape
     N = wq.shape[0]
     assert wq.shape[1] == K
-    out = torch.empty((M, N), dtype=BF, device=xq.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=BF, device=xq.device)
     check(lib().pe_gemm_e4m3(EPI[epilogue], xq.data_ptr(), K, scale_a.data_ptr(), wq.data_ptr(), _ptr(bias), _ptr(pre),
                              N if pre is not None else 0, out.data_ptr(), N, M, N, K, _ptr(gate), _ptr(res),
                              N if res is not None else 0, stream_ptr()), "pe_gemm_e4m3")

@@ -57,7 +57,8 @@ class DenoiseLoop:
         dual = self.dual_stream and use_cfg
         dit_n = self.dit
         if dual:
-            if self._dit_n is None or self._dit_n.fp8 != self.dit.fp8:
+            if self._dit_n is None or self._dit_n.version != self.dit.version or self._dit_n.fp8 != self.dit.fp8:
+                # (re)fork: the fork snapshots the primary's hot-LoRA / e4m3 state at fork time (own C handle)
                 self._dit_n = self.dit.fork()
                 self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             dit_n = self._dit_n

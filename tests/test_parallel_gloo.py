@@ -36,7 +36,9 @@ def _worker_dp(rank, world, port, n_units, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     res = parallel.run_data_parallel(n_units, _unit_result)
-    q.put((rank, [r.float() for r in res]))
+    # numpy, not torch tensors: a tensor travels through mp.Queue as a shared-memory handle that dies with this
+    # process, which races with the parent's q.get(); an ndarray is pickled by value
+    q.put((rank, [r.float().numpy() for r in res]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,7 +60,7 @@ def test_data_parallel_gather_matches_single_process(n_units):
     for rank in range(world):
         assert len(got[rank]) == n_units
         for u in range(n_units):
-            assert torch.equal(got[rank][u], single[u]), (rank, u)   # same seeds, same math: bit-identical
+            assert torch.equal(torch.from_numpy(got[rank][u]), single[u]), (rank, u)   # same seeds, same math: bit-identical
 
 
 def test_shard_units():
@@ -85,7 +87,7 @@ def _worker_cfg(rank, world, port, q):
         pred = O.model_fn(sd, None, lat, t.unsqueeze(0).to(BF), pe, None, 64, 64)
         posi, nega = ex.exchange(pred)
         lat = tab.step(nega + 4.0 * (posi - nega), i, lat)
-    q.put((rank, lat.float()))
+    q.put((rank, lat.float().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -104,4 +106,4 @@ def test_cfg_pair_split_matches_single_process():
     sd = synth.make_state_dict(synth.dit_layout(0), 1234)
     ref = O.denoise_loop(sd, None, synth.make_noise(0, 64, 64), synth.make_prompt_emb(7, 16), synth.make_prompt_emb(8, 12),
                          None, None, 64, 64, 2, cfg_scale=4.0).float()
-    assert torch.equal(got[0], ref) and torch.equal(got[1], ref)
+    assert torch.equal(torch.from_numpy(got[0]), ref) and torch.equal(torch.from_numpy(got[1]), ref)
