@@ -35,12 +35,18 @@ extern "C" {
 const char* pe_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int pe_abi_version(void);
+/* Hash of the kernel sources this library was built from (physicedit_amd/build.py:source_hash). */
+const char* pe_build_id(void);
 /* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant").
  * Production callers never need it: the compiled defaults are the validated schedules. */
 int pe_debug_set(const char* key, int value);
 /* Device buffer for a profiling variant's output ("gemm_stamps": long long [work-groups][8] s_memtime stamps of
  * gemm variant 14); NULL detaches it. */
 int pe_debug_set_ptr(const char* key, void* device_ptr);
+/* Bytes of the optional stream-K workspace of the GEMM (fp32 partial tiles + flags; zero-fill it once).  The DiT composite
+ * carves its own from the bound workspace; the granular operators use the one registered with
+ * pe_debug_set_ptr("gemm_streamk_ws", p), or none (every tile computed whole). */
+size_t pe_gemm_streamk_workspace_bytes(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Granular operators (each is one kernel launch; used by the parity tests and by the composites)

@@ -31,6 +31,21 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources and headers (sorted by name): baked into the library as pe_build_id() so a stale
+    prebuilt .so cannot pass for the current sources (ABI_VERSION only changes with signatures)."""
+    import hashlib
+    hh = hashlib.sha256()
+    names = sorted(SOURCES) + sorted(HEADERS)
+    for n in names:
+        path = os.path.join(CSRC, n)
+        if os.path.exists(path):
+            hh.update(n.encode())
+            with open(path, "rb") as f:
+                hh.update(f.read())
+    return hh.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -43,16 +58,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    src_hash = source_hash()
+    stamp = os.path.join(OBJ, "src_hash.txt")
+    old_hash = open(stamp).read().strip() if os.path.exists(stamp) else ""
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + hdrs):
+        if force or _stale(obj, [src] + hdrs) or (s == "api.hip" and old_hash != src_hash):   # api.hip carries the hash
             jobs.append((src, obj))
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + ([f'-DPE_SRC_HASH="{src_hash}"'] if src.endswith("api.hip") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -65,6 +83,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(f"[physicedit_amd.build] compiling {len(jobs)} file(s) for gfx950 ...", flush=True)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(compile_one, jobs))
+        with open(stamp, "w") as f:
+            f.write(src_hash)
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

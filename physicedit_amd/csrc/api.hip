@@ -32,12 +32,17 @@ using namespace pe;
 extern "C" {
 
 const char* pe_last_error(void) { return g_err; }
-int pe_abi_version(void) { return 2; }
+int pe_abi_version(void) { return 3; }
+#ifndef PE_SRC_HASH
+#define PE_SRC_HASH "unknown"
+#endif
+const char* pe_build_id(void) { return PE_SRC_HASH; }
 
 int pe_debug_set(const char* key, int value) {
     PE_REQUIRE(key != nullptr, "pe_debug_set: null key");
     if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return PE_OK; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
+    if (!strcmp(key, "gemm_streamk")) { g_gemm_streamk = value; return PE_OK; }
     if (!strcmp(key, "attn_slots")) { PE_REQUIRE(value > 0 && value <= 256, "attn_slots out of range"); g_attn_slots = value; return PE_OK; }
     if (!strcmp(key, "attn_force_split")) { g_attn_force_split = value; return PE_OK; }
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set: unknown key %s", key);
@@ -46,8 +51,11 @@ int pe_debug_set(const char* key, int value) {
 int pe_debug_set_ptr(const char* key, void* p) {
     PE_REQUIRE(key != nullptr, "pe_debug_set_ptr: null key");
     if (!strcmp(key, "gemm_stamps")) { g_gemm_dbg = (long long*)p; return PE_OK; }
+    if (!strcmp(key, "gemm_streamk_ws")) { g_gemm_sk_ws = p; return PE_OK; }   // pe_gemm_streamk_workspace_bytes() bytes, zero-filled once
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set_ptr: unknown key %s", key);
 }
+
+size_t pe_gemm_streamk_workspace_bytes(void) { return gemm_streamk_ws_bytes(); }
 
 int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
                  int M, int N, int K, const void* gate, const void* res, int ldr, void* stream) {

@@ -41,6 +41,7 @@ struct pe_dit {
     char *sp_in, *sp_hid, *sp_dino, *sp_vae;
     char* attn_ws;
     size_t attn_ws_bytes = 0;
+    char* sk_ws;                        // stream-K workspace of the GEMMs (fp32 partial tiles + flags), see gemm.hip
     char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
     char* aq;                           // e4m3 mode: quantised activation rows of the Linear being run [S, FF] bytes
     float* asc;                         // e4m3 mode: their per-row scales
@@ -79,6 +80,7 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->sp_vae, (size_t)MAX_SPECIAL * TXT * 2);
     h->attn_ws_bytes = flash_attn_workspace_bytes(HEADS, (int)S);
     take(&h->attn_ws, h->attn_ws_bytes);
+    take(&h->sk_ws, gemm_streamk_ws_bytes());
     const size_t rows = S > (size_t)n_steps ? S : (size_t)n_steps;
     take(&h->lora_t, rows * 3 * 128 * 2);
     if (h->w.weights_e4m3) {
@@ -96,7 +98,7 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
 // activation rows (per-row scale), then the e4m3 GEMM.  K is padded to the GEMM's 128 granule (only img_in, K = 64:
 // its weight arrives zero-padded to [3072,128]).
 static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t stream) {
-    if (!h->w.weights_e4m3) return launch_gemm(epi, pp, n, stream);
+    if (!h->w.weights_e4m3) return launch_gemm(epi, pp, n, stream, h->sk_ws);
     int rc;
     const bool joint = n == 2 && pp[0].K == pp[1].K && pp[0].lda == pp[1].lda &&
                        (const char*)pp[1].A == (const char*)pp[0].A + (size_t)pp[0].M * pp[0].lda * 2;
@@ -116,7 +118,7 @@ static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t st
         off += (size_t)Ms * Kp;
         row += Ms;
     }
-    return launch_gemm(epi, pp, n, stream);
+    return launch_gemm(epi, pp, n, stream, h->sk_ws);
 }
 
 extern "C" {
@@ -186,6 +188,9 @@ int pe_dit_bind_workspace(pe_dit_handle h, void* workspace, size_t bytes, int S_
     // Q/K pad rows only feed masked scores.  Zero all three once.
     hipError_t e = hipMemsetAsync(h->q, 0, (size_t)(h->attn - h->q), (hipStream_t)stream);
     if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
+    // stream-K flags start at "no epoch seen" (the partial slots themselves need no initialisation)
+    e = hipMemsetAsync(h->sk_ws + gemm_streamk_ws_bytes() - 4096, 0, 4096, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
     return PE_OK;
 }
 
@@ -234,8 +239,8 @@ int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void
                 tb[s].pre = pp[s].out; tb[s].ldp = ld; tb[s].out = pp[s].out; tb[s].ldo = ld;
                 tb[s].M = n_steps; tb[s].N = MOD; tb[s].K = r;
             }
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
-            if ((rc = launch_gemm(EPI_BIAS, tb, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, tb, 2, stream, h->sk_ws))) return rc;
         }
     }
     memset(&p, 0, sizeof(p));
@@ -285,11 +290,11 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             memset(&p, 0, sizeof(p));
             p.A = h->sp_in; p.lda = TXT; p.W = w0; p.bias = b0; p.out = h->sp_hid; p.ldo = AD_HID;
             p.M = ns; p.N = AD_HID; p.K = TXT;
-            if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream))) return rc;
+            if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream, h->sk_ws))) return rc;
             memset(&p, 0, sizeof(p));
             p.A = h->sp_hid; p.lda = AD_HID; p.W = w2; p.bias = b2; p.out = head == 0 ? h->sp_dino : h->sp_vae;
             p.ldo = TXT; p.M = ns; p.N = TXT; p.K = AD_HID;
-            if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream, h->sk_ws))) return rc;
         }
         if ((rc = launch_adapter_mix_scatter(h->sp_dino, h->sp_vae, c->alpha, c->one_minus_alpha, c->special_idx,
                                              c->prompt_emb, ns, TXT, stream)))
@@ -373,10 +378,10 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                 pp[s].A = ta[s].out; pp[s].lda = 3 * r; pp[s].W = s == 0 ? LR->img_qkv_b : LR->txt_qkv_b;
                 pp[s].bias = nullptr; pp[s].K = 3 * r; pp[s].pre = y1[s].out; pp[s].ldp = 3 * D;
             }
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
             if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
         }
-        if ((rc = low_rank ? launch_gemm(EPI_QKV, pp, 2, stream) : dit_linear(h, EPI_QKV, pp, 2, stream))) return rc;
+        if ((rc = low_rank ? launch_gemm(EPI_QKV, pp, 2, stream, h->sk_ws) : dit_linear(h, EPI_QKV, pp, 2, stream))) return rc;
         // joint attention
         if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream))) return rc;
         // output projections + gated residual (in place on x)
@@ -405,10 +410,10 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                 pp[s].A = ta[s].out; pp[s].lda = r; pp[s].W = s == 0 ? LR->img_out_b : LR->txt_out_b;
                 pp[s].bias = nullptr; pp[s].K = r; pp[s].pre = y1[s].out; pp[s].ldp = D;
             }
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
             if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
         }
-        if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
+        if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream, h->sk_ws) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
         // norm2 + modulate
         if ((rc = launch_ln_modulate_quant(h->x, fuse_q ? nullptr : h->xmod, S, D, S_img, sh(mod_img, 1), sc(mod_img, 1),
                                            sh(mod_txt, 1), sc(mod_txt, 1), 1e-6f, fuse_q ? h->aq : nullptr,
@@ -451,10 +456,10 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                 pp[s].A = ta[s].out; pp[s].lda = r; pp[s].W = s == 0 ? LR->img_down_b : LR->txt_down_b;
                 pp[s].bias = nullptr; pp[s].K = r; pp[s].pre = y1[s].out; pp[s].ldp = D;
             }
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
             if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
         }
-        if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
+        if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream, h->sk_ws) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
     }
 
     // ---- 4. AdaLayerNorm(single) head on the S0 kept rows, proj_out, unpatchify  (:1398-1402)

@@ -23,6 +23,7 @@
 //   * "grouped" launch: up to 2 problems (image stream + text stream) share one grid.
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -42,13 +43,22 @@ struct GemmArgs {
     GemmProblem p[2];
     int tiles0;
     long long* dbg;   // VAR 14 only: per work-group s_memtime stamps [grid][8] (pe_debug_set_ptr("gemm_stamps", p))
+    // stream-K tail (VAR 15): blocks [0, n_full) compute whole tiles; the last sk_tiles tiles (tile ids n_full ..) are
+    // cut along K into SK_WGS equal ranges of K tiles, one per block of the tail phase (blocks n_full .. n_full+SK_WGS-1)
+    int n_full, sk_tiles;
+    float* sk_ws;          // [SK_WGS][256*256] fp32 partial accumulators (one slot per tail block)
+    unsigned* sk_flags;    // [SK_WGS] epoch of the last launch whose partial in that slot is complete
+    unsigned* sk_status;   // [1] set to 1 if an owner gave up waiting (never in a correct run)
+    unsigned sk_epoch;
 };
+constexpr int SK_WGS = 256;               // one tail block per CU
+constexpr int SK_SLOT_FLOATS = BM * BN;   // 256 KiB per partial
 long long* g_gemm_dbg = nullptr;
 
 // VAR 14 = VAR 12 + time stamps of wave 0 (profiling build of the default schedule; never the production variant)
 #define PE_STAMP(k)                                                                                     \
     do {                                                                                                \
-        if constexpr (VAR == 14 || VAR == 15) {                                                         \
+        if constexpr (VAR == 14 || VAR == 15 || VAR == 16) {                                            \
             if (args.dbg != nullptr && threadIdx.x == 0) args.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); \
         }                                                                                               \
     } while (0)
@@ -65,6 +75,10 @@ PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 //   13  12 with A[mi 0] of the next tile pre-read (balanced ds_read counts per phase)
 //   14  12 + s_memtime stamps (profiling only)
 //   15  (default) ping-pong with 2 phases x 16 MFMAs per K tile, A half tiles staged by the group that reads them
+//   16  15 + stream-K tail (the tiles of a partially filled last round are cut along K into 256 equal ranges, fp32
+//       partials exchanged through a workspace).  Correct and deterministic, but SLOWER on MI355X (profiles/
+//       r02_gemm_notes.md): the ranges of different tiles sit at different K offsets, so the L2 sharing of A/W panels
+//       between the tiles of a band is lost, and 64 MB of partials move twice.  Kept as an experiment knob.
 //
 // FP8 = true: operands are OCP e4m3 bytes (activation rows quantised by quantize_rows_e4m3, weights stored in e4m3),
 // the K tile is 128 elements (the SAME 128-B LDS rows, staging and swizzle), the MFMA is the CDNA4 block-scaled
@@ -73,18 +87,23 @@ PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
+// One output tile (or, in the stream-K tail, the K range [k_lo, k_hi) of one): `bid` = tile id in the banded order.
+// sk_c < 0: a whole tile.  sk_c >= 0: this block is tail block sk_c; a range that does not start at K tile 0 ends
+// with its fp32 accumulators dumped to slot sk_c (+ flag); the range that starts at 0 OWNS the tile: it adds the
+// partials of the blocks sk_c+1.. that cover the rest of the tile's K and runs the epilogue.
 template <int EPI, int VAR, bool FP8>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmArgs args) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int bid, int k_lo, int k_hi, int sk_c) {
     constexpr int ES = FP8 ? 1 : 2;        // bytes per operand element
     constexpr int KT_BYTES = 128;          // one K tile of a row, in bytes (64 bf16 / 128 e4m3)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = lane_id();
+    int lane_ = lane_id();
+    if constexpr (VAR == 16)
+        asm volatile("" : "+v"(lane_));    // opaque per call: keeps LICM from hoisting the epilogue's per-lane address math out
+    const int lane = lane_;                // of the caller's (<= 2 iteration) range loop and spilling it across the main loop
     const int w = wave_id();
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
 
     PE_STAMP(0);
-    int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int pi = bid >= args.tiles0 ? 1 : 0;
     const GemmProblem& P = args.p[pi];
     bid -= pi ? args.tiles0 : 0;
@@ -114,8 +133,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
             // piece (1 KiB = 8 rows) i of this wave.  VAR 0/8/10: whole tiles, piece 4w + i.  VAR 12-14: 128-row half
             // tiles, piece = half*16 + 2w + j.  VAR 15: A pieces come from the wave group's OWN half (the only one it
             // reads), piece = grp*16 + 4(w&3) + i; W pieces 4w + i.
-            const int piece_a = VAR == 15 ? (w >> 2) * 16 + (w & 3) * 4 + i : VAR >= 12 ? (i >> 1) * 16 + w * 2 + (i & 1) : w * 4 + i;
-            const int piece_w = VAR == 15 ? w * 4 + i : piece_a;
+            const int piece_a = VAR >= 15 ? (w >> 2) * 16 + (w & 3) * 4 + i : VAR >= 12 ? (i >> 1) * 16 + w * 2 + (i & 1) : w * 4 + i;
+            const int piece_w = VAR >= 15 ? w * 4 + i : piece_a;
             const int row_a = piece_a * 8 + rin, row_w = piece_w * 8 + rin;
             const int gr = min(m0 + row_a, M - 1);
             const int gn = min(n0 + row_w, N - 1);
@@ -197,7 +216,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
         __builtin_amdgcn_s_setprio(0);             \
         PE_BAR();                                  \
     } while (0)
-        if constexpr (VAR == 15) {
+        if constexpr (VAR >= 15) {
             // Two phases of 16 MFMAs per K tile (half the barriers of VAR 12: the ~60-cycle barrier/turn-around cost per
             // phase is paid per 512 instead of per 256 MFMA cycles).  Phase p = row block mi = p of the wave's C tile
             // against all four column blocks:
@@ -231,17 +250,17 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
                     }
             };
-            auto st_a4 = [&](int t) {
-                const int tc = min(t, nk - 1);
-                char* base = a_base + (t & 1) * A_BYTES + (grp * 16 + (w & 3) * 4) * 1024;
+            auto st_a4 = [&](int i) {          // i = K tile index relative to k_lo
+                const int tc = min(k_lo + i, nk - 1);
+                char* base = a_base + (i & 1) * A_BYTES + (grp * 16 + (w & 3) * 4) * 1024;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) glds16(a_src[i] + tc * KT_BYTES, base + i * 1024);
+                for (int j = 0; j < 4; ++j) glds16(a_src[j] + tc * KT_BYTES, base + j * 1024);
             };
-            auto st_w4 = [&](int t, int slot) {
-                const int tc = min(t, nk - 1);
+            auto st_w4 = [&](int i, int slot) {
+                const int tc = min(k_lo + i, nk - 1);
                 char* base = w_base + slot * W_BYTES + w * 4096;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) glds16(w_src[i] + tc * KT_BYTES, base + i * 1024);
+                for (int j = 0; j < 4; ++j) glds16(w_src[j] + tc * KT_BYTES, base + j * 1024);
             };
 #define PE_MMA16(mi)                               \
     do {                                           \
@@ -257,7 +276,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
             if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger
             PE_STAMP(1);
             int ws = 0;
-            for (int kt = 0; kt < nk; ++kt) {
+            const int nloc = k_hi - k_lo;
+            for (int kt = 0; kt < nloc; ++kt) {
                 const char* Sa = a_base + (kt & 1) * A_BYTES;
                 const int ws_n1 = ws == 2 ? 0 : ws + 1;
                 const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
@@ -653,7 +673,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
 #undef PE_CLUSTER_SCHED
 #undef PE_SGB
     }
-    static_assert(FP8 || VAR == 0 || VAR == 8 || VAR == 10 || VAR == 12 || VAR == 13 || VAR == 14 || VAR == 15, "unknown GEMM schedule");
+    static_assert(FP8 || VAR == 0 || VAR == 8 || VAR == 10 || VAR == 12 || VAR == 13 || VAR == 14 || VAR == 15 || VAR == 16, "unknown GEMM schedule");
 
     // ------------------------------------------------------------------------------------------
     // epilogue.  acc[mi][ni][4q+r] = C[m0 + wm*64 + mi*32 + l31][n0 + wn*128 + ni*32 + 8q + 4h + r]
@@ -661,6 +681,66 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain every LDS-DMA (incl. the clamped tail tiles) before LDS is reused
     __syncthreads();
     PE_STAMP(3);
+    if constexpr (VAR == 16) {
+        if (sk_c >= 0) {
+            // partial layout: [wave][mi][ni][quad][lane] f32x4 -- the accumulator registers as they are, 1 KiB per store
+            auto slot_ptr = [&](int c) { return args.sk_ws + (size_t)c * SK_SLOT_FLOATS + ((size_t)w * 32 * 64 + lane) * 4; };
+            if (k_lo > 0) {
+                // not the owner: publish the partial (cdna guide G16: plain stores, every wave drains, barrier, ONE lane
+                // releases at agent scope and only then stores the flag)
+                float* dst = slot_ptr(sk_c);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r];
+                            *(f32x4*)(dst + (size_t)((mi * 4 + ni) * 4 + q) * 64 * 4) = v;
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(args.sk_flags + sk_c, args.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+            if (k_hi < nk) {
+                // owner: the blocks sk_c+1, sk_c+2, .. cover [k_hi, nk) of this tile, each with its FIRST range
+                const long long total = (long long)args.sk_tiles * nk;
+                const long long tile_end = (long long)(bid - args.n_full + 1) * nk;
+                for (int cc = sk_c + 1; cc < SK_WGS && (long long)cc * total / SK_WGS < tile_end; ++cc) {
+                    if (threadIdx.x == 0) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(args.sk_flags + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != args.sk_epoch) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 22)) {          // ~ 1 s: give up loudly instead of hanging the GPU
+                                __hip_atomic_store(args.sk_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    const float* src = slot_ptr(cc);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = *(const f32x4*)(src + (size_t)((mi * 4 + ni) * 4 + q) * 64 * 4);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[mi][ni][4 * q + r] += v[r];
+                            }
+                }
+            }
+        }
+    }
     // this wave's [64 rows][128 cols] bf16 staging tile: 16-B chunk c of row r sits at chunk c ^ (r & 15), and its two 8-B
     // halves are swapped when r & 8 (rows r and r ^ 8 would otherwise land on the same banks in one ds_write_b64
     // lane group: measured 7.3k instead of ~3.5k cycles for the 64 writes per lane)
@@ -877,6 +957,35 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     }
 }
 
+template <int EPI, int VAR, bool FP8>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nk = args.p[0].K * (FP8 ? 1 : 2) / 128;
+    // whole tile: one "range" [0, nk) of tile xcd_remap(block).  Stream-K tail (VAR 15): block b of the tail phase runs on
+    // XCD b % 8; every XCD gets 32 CONSECUTIVE K ranges so that a tile's partials are (mostly) exchanged through one L2.
+    int c = -1, tile = 0, k0 = 0, n_seg = 1;
+    long long r1 = nk;
+    if (VAR == 16 && args.sk_tiles > 0 && (int)blockIdx.x >= args.n_full) {
+        const int b = (int)blockIdx.x - args.n_full;
+        c = (b & 7) * (SK_WGS / 8) + (b >> 3);
+        const long long total = (long long)args.sk_tiles * nk;
+        const long long r0 = (long long)c * total / SK_WGS;
+        r1 = (long long)(c + 1) * total / SK_WGS;
+        const int t0 = (int)(r0 / nk);
+        k0 = (int)(r0 - (long long)t0 * nk);
+        r1 -= (long long)t0 * nk;                 // relative to the first tile's K tile 0
+        n_seg = r1 > nk ? 2 : 1;
+        tile = args.n_full + t0;
+    } else {
+        tile = xcd_remap((int)blockIdx.x, (VAR == 16 && args.sk_tiles > 0) ? args.n_full : (int)gridDim.x);
+    }
+    for (int seg = 0; seg < n_seg; ++seg) {
+        const int lo = seg == 0 ? k0 : 0;
+        const int hi = (int)min((long long)nk, r1 - (long long)seg * nk);
+        gemm_tile<EPI, VAR, FP8>(args, smem, tile + seg, lo, hi, c);
+    }
+}
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -907,13 +1016,20 @@ static int launch_t(const GemmArgs& args, int ntiles, bool fp8, hipStream_t stre
     if (g_gemm_variant == 13) return launch_v<EPI, 13>(args, ntiles, stream);
     if (g_gemm_variant == 14) return launch_v<EPI, 14>(args, ntiles, stream);
     if (g_gemm_variant == 15) return launch_v<EPI, 15>(args, ntiles, stream);
+    if (g_gemm_variant == 16) return launch_v<EPI, 16>(args, ntiles, stream);
     if (g_gemm_variant == 0) return launch_v<EPI, 0>(args, ntiles, stream);   // A/B reference schedules
     if (g_gemm_variant == 8) return launch_v<EPI, 8>(args, ntiles, stream);
     if (g_gemm_variant == 10) return launch_v<EPI, 10>(args, ntiles, stream);
     return launch_v<EPI, GEMM_DEFAULT_VARIANT>(args, ntiles, stream);
 }
 
-int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream) {
+int g_gemm_streamk = env_int("PE_GEMM_STREAMK", 1);
+void* g_gemm_sk_ws = nullptr;     // tests / granular operators: a registered stream-K workspace (pe_debug_set_ptr)
+static std::atomic<unsigned> g_sk_epoch{0};
+
+size_t gemm_streamk_ws_bytes() { return (size_t)SK_WGS * SK_SLOT_FLOATS * sizeof(float) + 4096; }
+
+int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, void* sk_ws) {
     PE_REQUIRE(nproblems >= 1 && nproblems <= 2, "gemm: 1 or 2 problems per launch, got %d", nproblems);
     GemmArgs args;
     int tiles[2] = {0, 0};
@@ -952,7 +1068,29 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     if (nproblems == 1) args.p[1] = args.p[0];
     args.tiles0 = tiles[0];
     args.dbg = g_gemm_dbg;
-    const int ntiles = tiles[0] + tiles[1];
+    int ntiles = tiles[0] + tiles[1];
+    // stream-K tail: when the last round of work-groups would fill only part of the chip, its tiles are cut along K into
+    // SK_WGS equal ranges instead (gemm_bf16_kernel).  Needs a workspace for the fp32 partials, the default schedule and
+    // one common K; not worth it for a nearly full last round or for very short K.
+    args.n_full = ntiles; args.sk_tiles = 0; args.sk_ws = nullptr; args.sk_flags = nullptr; args.sk_status = nullptr; args.sk_epoch = 0;
+    if (sk_ws == nullptr) sk_ws = g_gemm_sk_ws;
+    {
+        const int nk = problems[0].K / (fp8 ? 128 : BK);
+        const int tail = ntiles % SK_WGS;
+        const bool same_k = nproblems == 1 || problems[0].K == problems[1].K;
+        if (g_gemm_streamk && sk_ws != nullptr && g_gemm_variant == 16 && !fp8 && same_k && tail >= 32 && tail <= 224 &&
+            (long long)tail * nk / SK_WGS >= 6) {
+            args.n_full = ntiles - tail;
+            args.sk_tiles = tail;
+            args.sk_ws = (float*)sk_ws;
+            args.sk_flags = (unsigned*)((char*)sk_ws + (size_t)SK_WGS * SK_SLOT_FLOATS * sizeof(float));
+            args.sk_status = args.sk_flags + SK_WGS;
+            unsigned e = ++g_sk_epoch;
+            if (e == 0) e = ++g_sk_epoch;      // 0 is what a freshly zeroed flag holds
+            args.sk_epoch = e;
+            ntiles = args.n_full + SK_WGS;     // grid: whole tiles, then one tail block per CU
+        }
+    }
     double flops = 0.0;  // algorithmic 2*M*N*K of the launch (what the roofline fraction is quoted on)
     for (int i = 0; i < nproblems; ++i) flops += 2.0 * problems[i].M * (double)problems[i].N * problems[i].K;
     const int slot = prof_begin(PROF_GEMM, flops, stream);

@@ -96,11 +96,12 @@ def build_vae(seed):
         vae = QwenImageVAE()
     sd = synth.make_state_dict(synth.vae_layout(), seed)
     vae.load_state_dict(sd, assign=True, strict=True)
-    # mean/std are plain attributes created under the meta context: rebuild like __init__ (:667-704)
-    ref = QwenImageVAE.__new__(QwenImageVAE)
-    import oracle.physicedit_oracle as O
-    vae.mean = torch.tensor(O._VAE_MEAN).view(1, 16, 1, 1, 1)
-    vae.std = 1 / torch.tensor(O._VAE_STD).view(1, 16, 1, 1, 1)
+    # mean/std are plain attributes created under the meta context: take them from a REFERENCE module constructed on the
+    # CPU (qwen_image_vae.py:667-704), so the fixture pins the reference's tables, not the oracle's copy of them
+    cpu_ref = QwenImageVAE()
+    vae.mean = cpu_ref.mean.clone()
+    vae.std = cpu_ref.std.clone()
+    del cpu_ref
     return vae.eval(), sd
 
 

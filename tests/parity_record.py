@@ -22,8 +22,9 @@ def parity_stats(got: torch.Tensor, ref: torch.Tensor, ref32: torch.Tensor = Non
         "mean_abs_diff": float(d.mean()),
         "ref_abs_mean": float(r.abs().mean()),
     }
-    # bf16 ulp of the reference value (floor 2^-9 so that values near zero do not blow the count up)
-    ulp = torch.clamp(r.abs(), min=2.0 ** -9).log2().floor().exp2() * 2.0 ** -7
+    # bf16 ulp of the reference value, floored at the tensor's own mean magnitude: an end-to-end output near zero is the
+    # difference of O(mean) terms, its absolute error lives at that scale
+    ulp = torch.clamp(r.abs(), min=max(st["ref_abs_mean"], 2.0 ** -9)).log2().floor().exp2() * 2.0 ** -7
     st["max_ulp"] = float((d / ulp).max())
     if ref32 is not None:
         r32 = ref32.detach().float().cpu()
