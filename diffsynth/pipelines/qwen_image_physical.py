@@ -234,6 +234,14 @@ class QwenImagePhysicPipeline:
     def vae_output_to_image(self, vae_output, pattern="B C H W", min_value=-1, max_value=1):
         return Image.fromarray(vae_output_to_u8(vae_output).numpy())
 
+    def _encode_image(self, image: Image.Image) -> torch.Tensor:
+        """vae.encode(preprocess_image(image)) with the uint8 -> [-1, 1] map fused into the VAE's first kernel
+        (pe_vae_encode, PE_IMAGE_U8_HWC): the 3 MiB uint8 image is the only thing that crosses PCIe."""
+        u8 = np.array(image)
+        if u8.dtype != np.uint8 or u8.ndim != 3 or u8.shape[2] != 3:
+            return self.vae.encode(self.preprocess_image(image))       # exotic modes: the stand-alone map
+        return self.vae.encode(torch.from_numpy(np.ascontiguousarray(u8)).to(self.device))
+
     def generate_noise(self, shape, seed=None, rand_device="cpu", rand_torch_dtype=torch.float32, device=None, torch_dtype=None):
         generator = None if seed is None else torch.Generator(rand_device).manual_seed(seed)
         noise = torch.randn(shape, generator=generator, device=rand_device, dtype=rand_torch_dtype)
@@ -285,18 +293,18 @@ class QwenImagePhysicPipeline:
                                      exponential_shift_mu=exponential_shift_mu)
         latents = noise
         if input_image is not None:     # InputImageEmbedder (:693-711)
-            x0 = self.vae.encode(self.preprocess_image(input_image))
+            x0 = self._encode_image(input_image)
             latents = self.scheduler.add_noise(x0, noise, timestep=self.scheduler.timesteps[0]).to(self.torch_dtype)
         # EditImageEmbedder (:1244-1283) / ContextImageEmbedder (:1286-1299)
         edit_latents: List[torch.Tensor] = []
         resized_edit = edit_image
         if context_image is not None:
-            edit_latents.append(self.vae.encode(self.preprocess_image(context_image.resize((width, height)))))
+            edit_latents.append(self._encode_image(context_image.resize((width, height))))
         if edit_image is not None:
             images = [edit_image] if isinstance(edit_image, Image.Image) else list(edit_image)
             images = [self._auto_resize(im) if edit_image_auto_resize else im for im in images]
             resized_edit = images[0] if isinstance(edit_image, Image.Image) else images
-            edit_latents += [self.vae.encode(self.preprocess_image(im)) for im in images]
+            edit_latents += [self._encode_image(im) for im in images]
         # prompt prologue (PhysicalVerbalEmbedder + PromptEmbedder in the reference, :732-990): host code
         use_cfg = cfg_scale != 1.0
         posi, nega = self.prompt_encoder(self, prompt=prompt, negative_prompt=negative_prompt, edit_image=resized_edit,
@@ -314,5 +322,6 @@ class QwenImagePhysicPipeline:
                        cfg_scale=cfg_scale, edit_latents=edit_latents or None, exponential_shift_mu=exponential_shift_mu,
                        denoising_strength=denoising_strength)
         self.last_latents = latents
-        image = self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
-        return self.vae_output_to_image(image)
+        # vae.decode + vae_output_to_image (:664-667) in one composite: the last kernel emits HWC uint8
+        u8 = self.vae.decode(latents, output_u8=True, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
+        return Image.fromarray(u8.cpu().numpy())

@@ -258,6 +258,69 @@ int pe_nhwc_to_nchw(const void* in, void* out, int C, int HW, int Cp, int mode, 
 int pe_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * VAE composites: QwenImageVAE.encode / .decode (models/qwen_image_vae.py:706-717 / :719-729) as ONE call each, B = 1,
+ * single frame.  Weights are a table of device pointers in the repacked layout of pe_conv2d_nhwc (conv weights
+ * [Cout_p][k*k][Cin_p] with only the last temporal tap of the causal conv3d, channels zero-padded to 32; RMS-norm gammas
+ * [C]); the library copies the table, not the weights.  Image I/O of the pipeline is fused into the first / last kernel:
+ *   PE_IMAGE_BF16_NCHW  [3,H,W] bf16 in [-1,1]            (what vae.encode / vae.decode take / return in the reference)
+ *   PE_IMAGE_U8_HWC     [H,W,3] uint8: encode applies BasePipeline.preprocess_image (pipelines/utils/__init__.py:60-66,
+ *                       bf16(bf16(u8) * 2/255) - 1), decode applies vae_output_to_image (:76-83, ((x+1)*127.5).clip(0,255)
+ *                       truncated to uint8), both with the reference's bf16 rounding points.
+ * ------------------------------------------------------------------------------------------- */
+enum { PE_IMAGE_BF16_NCHW = 0, PE_IMAGE_U8_HWC = 1 };
+
+typedef struct pe_vae_conv {       /* QwenImageCausalConv3d at T = 1 / nn.Conv2d */
+    const void *w, *b;             /* [cout_p][ksize*ksize][cin_p], [cout_p] bf16; w == NULL: layer absent */
+    int cin_p, cout_p, ksize;      /* ksize 1 or 3 */
+} pe_vae_conv;
+typedef struct pe_vae_res {        /* QwenImageResidualBlock (:81-152) */
+    pe_vae_conv conv1, conv2, shortcut;   /* shortcut.w == NULL when in_dim == out_dim (nn.Identity) */
+    const void *norm1_g, *norm2_g;        /* QwenImageRMS_norm gamma */
+} pe_vae_res;
+typedef struct pe_vae_attn {       /* QwenImageAttentionBlock (:156-198), dim 384 */
+    const void* norm_g;
+    pe_vae_conv to_qkv, proj;
+} pe_vae_attn;
+typedef struct pe_vae_mid { pe_vae_res res0; pe_vae_attn attn; pe_vae_res res1; } pe_vae_mid;   /* QwenImageMidBlock (:304-340) */
+typedef struct pe_vae_weights {
+    /* encoder (:344-448): conv_in, 4 stages x 2 residual blocks with a stride-2 resample after stages 0..2, mid, head */
+    pe_vae_conv enc_conv_in;
+    pe_vae_res enc_res[8];
+    pe_vae_conv enc_down[3];       /* down_blocks.{2,5,8}.resample.1 */
+    pe_vae_mid enc_mid;
+    const void* enc_norm_out_g;
+    pe_vae_conv enc_conv_out, quant_conv;
+    /* decoder (:522-636): post_quant_conv, conv_in, mid, 4 stages x 3 residual blocks with a 2x upsample+conv after 0..2 */
+    pe_vae_conv post_quant_conv, dec_conv_in;
+    pe_vae_mid dec_mid;
+    pe_vae_res dec_res[12];
+    pe_vae_conv dec_up[3];         /* up_blocks.{0,1,2}.upsamplers.0.resample.1 */
+    const void* dec_norm_out_g;
+    pe_vae_conv dec_conv_out;
+    const void *mean, *inv_std;    /* bf16 [16]: latents mean and 1/std (:667-704) */
+    const void* zero_page;         /* >= 64 B of device zeros */
+} pe_vae_weights;
+typedef struct pe_vae* pe_vae_handle;
+
+int pe_vae_create(const pe_vae_weights* w, pe_vae_handle* out);
+void pe_vae_destroy(pe_vae_handle h);
+/* Scratch for an H x W image (encode) / an (H/8) x (W/8) latent (decode): four activation slots + attention scratch. */
+size_t pe_vae_workspace_bytes(int H, int W);
+/* image ([3,H,W] bf16 or [H,W,3] uint8) -> normalised latents [16,H/8,W/8] bf16. */
+int pe_vae_encode(pe_vae_handle h, const void* image, int input_format, int H, int W, void* latents, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* normalised latents [16,H8,W8] bf16 -> image ([3,8*H8,8*W8] bf16 or [8*H8,8*W8,3] uint8). */
+int pe_vae_decode(pe_vae_handle h, const void* latents, int H8, int W8, void* image, int output_format, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* VisualThinkingDualAdapter.forward (pipelines/helpers.py:152-164) on n rows of width 3584:
+ * out = bf16(alpha * head_dino(x)) + bf16((1-alpha) * head_vae(x)), heads = Linear 3584->10752, exact-erf GELU, Linear
+ * 10752->3584.  alpha / one_minus_alpha are the bf16-rounded mix weights of _get_alpha (:142-150). */
+size_t pe_adapter_workspace_bytes(int n);
+int pe_adapter_forward(const pe_adapter_weights* adapter, const void* x, int n, float alpha, float one_minus_alpha, void* out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement: HIP-event timing of sampled launches, recorded on the launch stream.
  * kind: 0 = MFMA GEMM (work = algorithmic FLOPs 2MNK), 1 = flash attention (4*S*S*128*H FLOPs),
  *       2 = row kernels (work = algorithmic bytes), 3 = VAE convolutions (FLOPs).

@@ -44,6 +44,33 @@ class AdapterWeights(C.Structure):
         "dino_w0", "dino_b0", "dino_w2", "dino_b2", "vae_w0", "vae_b0", "vae_w2", "vae_b2")]
 
 
+class VaeConv(C.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("cin_p", c_int), ("cout_p", c_int), ("ksize", c_int)]
+
+
+class VaeRes(C.Structure):
+    _fields_ = [("conv1", VaeConv), ("conv2", VaeConv), ("shortcut", VaeConv), ("norm1_g", c_void_p), ("norm2_g", c_void_p)]
+
+
+class VaeAttn(C.Structure):
+    _fields_ = [("norm_g", c_void_p), ("to_qkv", VaeConv), ("proj", VaeConv)]
+
+
+class VaeMid(C.Structure):
+    _fields_ = [("res0", VaeRes), ("attn", VaeAttn), ("res1", VaeRes)]
+
+
+class VaeWeights(C.Structure):
+    _fields_ = [("enc_conv_in", VaeConv), ("enc_res", VaeRes * 8), ("enc_down", VaeConv * 3), ("enc_mid", VaeMid),
+                ("enc_norm_out_g", c_void_p), ("enc_conv_out", VaeConv), ("quant_conv", VaeConv),
+                ("post_quant_conv", VaeConv), ("dec_conv_in", VaeConv), ("dec_mid", VaeMid), ("dec_res", VaeRes * 12),
+                ("dec_up", VaeConv * 3), ("dec_norm_out_g", c_void_p), ("dec_conv_out", VaeConv),
+                ("mean", c_void_p), ("inv_std", c_void_p), ("zero_page", c_void_p)]
+
+
+IMAGE_BF16_NCHW, IMAGE_U8_HWC = 0, 1
+
+
 class DitCall(C.Structure):
     _fields_ = [
         ("latents", c_void_p), ("h8", c_int), ("w8", c_int),
@@ -101,6 +128,14 @@ SIGNATURES = {
     "pe_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pe_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pe_vae_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "pe_vae_create": (c_int, [C.POINTER(VaeWeights), C.POINTER(c_void_p)]),
+    "pe_vae_destroy": (None, [c_void_p]),
+    "pe_vae_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pe_vae_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pe_vae_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "pe_adapter_workspace_bytes": (c_size_t, [c_int]),
+    "pe_adapter_forward": (c_int, [C.POINTER(AdapterWeights), c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
     "pe_profile_enable": (c_int, [c_int, c_int]),
     "pe_profile_disable": (None, []),
     "pe_profile_read": (c_int, [c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double),

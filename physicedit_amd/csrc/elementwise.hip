@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256) adapter_mix_scatter_kernel(const bf16* __
     const int r = (int)blockIdx.x;
     const bf16* a = dino + (size_t)r * dim8 * 8;
     const bf16* b = vae + (size_t)r * dim8 * 8;
-    bf16* d = pe + (size_t)idx[r] * dim8 * 8;
+    bf16* d = pe + (size_t)(idx ? idx[r] : r) * dim8 * 8;     // idx == null: identity row map (pe_adapter_forward)
     for (int i = (int)threadIdx.x; i < dim8; i += 256) {
         const bf16x8 av = *(const bf16x8*)(a + i * 8);
         const bf16x8 bv = *(const bf16x8*)(b + i * 8);
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) adapter_mix_scatter_kernel(const bf16* __
 
 int launch_adapter_mix_scatter(const void* dino, const void* vae, float alpha, float one_minus_alpha,
                                const int* idx, void* prompt_emb, int nrows, int dim, hipStream_t stream) {
-    PE_REQUIRE(dino && vae && idx && prompt_emb, "adapter_mix: null pointer");
+    PE_REQUIRE(dino && vae && prompt_emb, "adapter_mix: null pointer");
     PE_REQUIRE(nrows > 0 && dim % 8 == 0, "adapter_mix: bad shape %d x %d", nrows, dim);
     hipLaunchKernelGGL(adapter_mix_scatter_kernel, dim3(nrows), dim3(256), 0, stream, (const bf16*)dino,
                        (const bf16*)vae, alpha, one_minus_alpha, idx, (bf16*)prompt_emb, dim / 8);

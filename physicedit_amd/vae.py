@@ -3,8 +3,9 @@
 API mirror of DiffSynth-Studio/diffsynth/models/qwen_image_vae.py: `QwenImageVAE.encode(x, **kwargs)`
 (:706-717) and `.decode(x, **kwargs)` (:719-729) take/return NCHW bf16 tensors and swallow the
 `tiled/tile_size/tile_stride/device` kwargs exactly like the reference does.
-Weights keep the reference's state-dict names.  The graph below is host sequencing only; every op is
-a kernel from csrc/vae.hip (implicit-GEMM NHWC conv, channel RMS-norm+SiLU, D=384 attention).
+Weights keep the reference's state-dict names.  The launch sequence is the C-ABI composite pe_vae_encode / pe_vae_decode (csrc/vae_graph.hip) over the
+kernels of csrc/vae.hip (implicit-GEMM NHWC conv, channel RMS-norm+SiLU, D=384 attention); the pipeline's uint8 image
+I/O (preprocess_image / vae_output_to_image) is fused into its first / last kernel.
 
 Weight repacking at load (one time): conv weights [Cout,Cin,3,3,3] -> last temporal tap ->
 [Cout_p][3*3][Cin_p] bf16 with both channel counts zero-padded to a multiple of 32.
@@ -15,8 +16,10 @@ from typing import Dict, Optional
 
 import torch
 
+import ctypes as C
+
 from . import _lib
-from ._lib import check, lib, stream_ptr
+from ._lib import VaeConv, VaeMid, VaeRes, VaeWeights, check, lib, stream_ptr
 
 BF = torch.bfloat16
 
@@ -50,6 +53,9 @@ class _Conv:
 
 
 class QwenImageVAE:
+    """Thin caller of the C-ABI composites pe_vae_encode / pe_vae_decode: this class only repacks the weights once
+    (load time) and owns the workspace; the launch sequence lives in csrc/vae_graph.hip."""
+
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -72,124 +78,116 @@ class QwenImageVAE:
         self.std = std.to(BF).reshape(-1).to(self.device)
         self.zero = torch.zeros((256,), dtype=BF, device=self.device)
         self.z_dim = 16
+        self._handle = C.c_void_p()
+        self._ws: Optional[torch.Tensor] = None
+        self._create()
 
     # ------------------------------------------------------------------------------------------
-    def _buf(self, npix: int, cp: int) -> torch.Tensor:
-        return torch.empty((npix, cp), dtype=BF, device=self.device)
-
-    def _conv(self, name, x, H, W, res=None, stride=1, upsample=False):
+    def _cv(self, dst: VaeConv, name: str):
         c = self.convs[name]
-        assert x.shape[1] == c.cin_p, (name, x.shape, c.cin_p)
-        if stride == 2:
-            Ho, Wo = H // 2, W // 2
-        elif upsample:
-            Ho, Wo = H * 2, W * 2
-        else:
-            Ho, Wo = H, W
-        out = self._buf(Ho * Wo, c.cout_p)
-        check(lib().pe_conv2d_nhwc(x.data_ptr(), c.w.data_ptr(), c.b.data_ptr(),
-                                   None if res is None else res.data_ptr(), out.data_ptr(), self.zero.data_ptr(),
-                                   H, W, c.cin_p, c.cout_p, c.k, stride, 1 if upsample else 0, stream_ptr()),
-              "pe_conv2d_nhwc")
-        return out, Ho, Wo
+        dst.w, dst.b, dst.cin_p, dst.cout_p, dst.ksize = c.w.data_ptr(), c.b.data_ptr(), c.cin_p, c.cout_p, c.k
 
-    def _norm(self, name, x, C, silu=True):
-        out = torch.empty_like(x)
-        if x.shape[1] != C:
-            out.zero_()
-        check(lib().pe_vae_rmsnorm(x.data_ptr(), self.gammas[name].data_ptr(), out.data_ptr(), x.shape[0], C,
-                                   x.shape[1], 1 if silu else 0, stream_ptr()), "pe_vae_rmsnorm")
-        return out
-
-    def _res(self, p, x, H, W):
-        """QwenImageResidualBlock.forward (:112-152)."""
-        cin = self.convs[p + "conv1"].cin
-        cout = self.convs[p + "conv1"].cout
-        h = x
+    def _rs(self, dst: VaeRes, p: str):
+        self._cv(dst.conv1, p + "conv1")
+        self._cv(dst.conv2, p + "conv2")
         if (p + "conv_shortcut") in self.convs:
-            h, _, _ = self._conv(p + "conv_shortcut", x, H, W)
-        y = self._norm(p + "norm1", x, cin)
-        y, _, _ = self._conv(p + "conv1", y, H, W)
-        y = self._norm(p + "norm2", y, cout)
-        y, _, _ = self._conv(p + "conv2", y, H, W, res=h)
-        return y
+            self._cv(dst.shortcut, p + "conv_shortcut")
+        dst.norm1_g, dst.norm2_g = self.gammas[p + "norm1"].data_ptr(), self.gammas[p + "norm2"].data_ptr()
 
-    def _attn(self, p, x, H, W):
-        """QwenImageAttentionBlock.forward (:173-198)."""
-        C = 384
-        N = H * W
-        y = self._norm(p + "norm", x, C, silu=False)
-        qkv, _, _ = self._conv(p + "to_qkv", y, H, W)                  # [N,1152]
-        vt = torch.empty((C * ((N + 31) // 32 * 32),), dtype=BF, device=self.device)
-        o = self._buf(N, C)
-        check(lib().pe_vae_attention(qkv.data_ptr(), vt.data_ptr(), o.data_ptr(), N, stream_ptr()), "pe_vae_attention")
-        y, _, _ = self._conv(p + "proj", o, H, W, res=x)               # x + identity (:198)
-        return y
+    def _md(self, dst: VaeMid, p: str):
+        self._rs(dst.res0, p + "resnets.0.")
+        dst.attn.norm_g = self.gammas[p + "attentions.0.norm"].data_ptr()
+        self._cv(dst.attn.to_qkv, p + "attentions.0.to_qkv")
+        self._cv(dst.attn.proj, p + "attentions.0.proj")
+        self._rs(dst.res1, p + "resnets.1.")
 
-    def _mid(self, p, x, H, W):
-        x = self._res(p + "resnets.0.", x, H, W)
-        x = self._attn(p + "attentions.0.", x, H, W)
-        return self._res(p + "resnets.1.", x, H, W)
+    def _create(self):
+        w = VaeWeights()
+        self._cv(w.enc_conv_in, "encoder.conv_in")
+        idx, r, d = 0, 0, 0
+        for i in range(4):                                   # Encoder3d.down_blocks is a flat list (:376-396)
+            for _ in range(2):
+                self._rs(w.enc_res[r], f"encoder.down_blocks.{idx}.")
+                r += 1
+                idx += 1
+            if i != 3:
+                self._cv(w.enc_down[d], f"encoder.down_blocks.{idx}.resample.1")
+                d += 1
+                idx += 1
+        self._md(w.enc_mid, "encoder.mid_block.")
+        w.enc_norm_out_g = self.gammas["encoder.norm_out"].data_ptr()
+        self._cv(w.enc_conv_out, "encoder.conv_out")
+        self._cv(w.quant_conv, "quant_conv")
+        self._cv(w.post_quant_conv, "post_quant_conv")
+        self._cv(w.dec_conv_in, "decoder.conv_in")
+        self._md(w.dec_mid, "decoder.mid_block.")
+        for i in range(4):
+            for j in range(3):
+                self._rs(w.dec_res[i * 3 + j], f"decoder.up_blocks.{i}.resnets.{j}.")
+            if i != 3:
+                self._cv(w.dec_up[i], f"decoder.up_blocks.{i}.upsamplers.0.resample.1")
+        w.dec_norm_out_g = self.gammas["decoder.norm_out"].data_ptr()
+        self._cv(w.dec_conv_out, "decoder.conv_out")
+        w.mean, w.inv_std, w.zero_page = self.mean.data_ptr(), self.std.data_ptr(), self.zero.data_ptr()
+        check(lib().pe_vae_create(C.byref(w), C.byref(self._handle)), "pe_vae_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                lib().pe_vae_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _workspace(self, H: int, W: int):
+        n = lib().pe_vae_workspace_bytes(H, W)
+        if self._ws is None or self._ws.numel() < n + 256:
+            self._ws = None
+            self._ws = torch.empty((n + 256,), dtype=torch.uint8, device=self.device)
+        return (self._ws.data_ptr() + 255) // 256 * 256, n
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
-        """[1,3,H,W] bf16 in [-1,1] -> normalised latents [1,16,H/8,W/8]."""
-        squeeze = x.dim() == 5
-        if squeeze:
-            assert x.shape[2] == 1
-            x = x[:, :, 0]
-        assert x.shape[0] == 1 and x.shape[1] == 3 and x.is_cuda
-        x = x.to(BF).contiguous()
-        H, W = x.shape[2], x.shape[3]
+        """[1,3,H,W] bf16 in [-1,1] -> normalised latents [1,16,H/8,W/8].  A uint8 [H,W,3] device tensor is accepted too:
+        BasePipeline.preprocess_image is then applied inside the first kernel (same bf16 rounding points)."""
+        if x.dtype == torch.uint8:
+            assert x.dim() == 3 and x.shape[2] == 3 and x.is_cuda
+            x = x.contiguous()
+            H, W, fmt, squeeze = x.shape[0], x.shape[1], _lib.IMAGE_U8_HWC, False
+        else:
+            squeeze = x.dim() == 5
+            if squeeze:
+                assert x.shape[2] == 1
+                x = x[:, :, 0]
+            assert x.shape[0] == 1 and x.shape[1] == 3 and x.is_cuda
+            x = x.to(BF).contiguous()
+            H, W, fmt = x.shape[2], x.shape[3], _lib.IMAGE_BF16_NCHW
         assert H % 8 == 0 and W % 8 == 0
-        a = self._buf(H * W, 32)
-        check(lib().pe_nchw_to_nhwc(x.data_ptr(), a.data_ptr(), 3, H * W, 32, 0, None, None, stream_ptr()), "pe_nchw_to_nhwc")
-        a, _, _ = self._conv("encoder.conv_in", a, H, W)
-        idx = 0
-        for i in range(4):
-            for _ in range(2):
-                a = self._res(f"encoder.down_blocks.{idx}.", a, H, W)
-                idx += 1
-            if i != 3:
-                a, H, W = self._conv(f"encoder.down_blocks.{idx}.resample.1", a, H, W, stride=2)
-                idx += 1
-        a = self._mid("encoder.mid_block.", a, H, W)
-        a = self._norm("encoder.norm_out", a, 384)
-        a, _, _ = self._conv("encoder.conv_out", a, H, W)
-        a, _, _ = self._conv("quant_conv", a, H, W)
-        out = torch.empty((1, 16, H, W), dtype=BF, device=self.device)
-        check(lib().pe_nhwc_to_nchw(a.data_ptr(), out.data_ptr(), 16, H * W, a.shape[1], 2, self.mean.data_ptr(),
-                                    self.std.data_ptr(), stream_ptr()), "pe_nhwc_to_nchw")
+        out = torch.empty((1, 16, H // 8, W // 8), dtype=BF, device=self.device)
+        ws, n = self._workspace(H, W)
+        check(lib().pe_vae_encode(self._handle, x.data_ptr(), fmt, H, W, out.data_ptr(), ws, n, stream_ptr()), "pe_vae_encode")
         return out.unsqueeze(2) if squeeze else out
 
     @torch.no_grad()
-    def decode(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
-        """normalised latents [1,16,h,w] -> image [1,3,8h,8w] bf16."""
+    def decode(self, x: torch.Tensor, output_u8: bool = False, **kwargs) -> torch.Tensor:
+        """normalised latents [1,16,h,w] -> image [1,3,8h,8w] bf16; output_u8: [8h,8w,3] uint8 with
+        BasePipeline.vae_output_to_image's map applied inside the last kernel."""
         squeeze = x.dim() == 5
         if squeeze:
             assert x.shape[2] == 1
             x = x[:, :, 0]
         assert x.shape[0] == 1 and x.shape[1] == 16 and x.is_cuda
         x = x.to(BF).contiguous()
-        H, W = x.shape[2], x.shape[3]
-        a = self._buf(H * W, 32)
-        check(lib().pe_nchw_to_nhwc(x.data_ptr(), a.data_ptr(), 16, H * W, 32, 1, self.mean.data_ptr(),
-                                    self.std.data_ptr(), stream_ptr()), "pe_nchw_to_nhwc")
-        a, _, _ = self._conv("post_quant_conv", a, H, W)
-        a, _, _ = self._conv("decoder.conv_in", a, H, W)
-        a = self._mid("decoder.mid_block.", a, H, W)
-        for i in range(4):
-            for j in range(3):
-                a = self._res(f"decoder.up_blocks.{i}.resnets.{j}.", a, H, W)
-            if i != 3:
-                # nearest-exact 2x (exact copy, :213-214) fused into the following conv's gather
-                a, H, W = self._conv(f"decoder.up_blocks.{i}.upsamplers.0.resample.1", a, H, W, upsample=True)
-        a = self._norm("decoder.norm_out", a, 96)
-        a, _, _ = self._conv("decoder.conv_out", a, H, W)
-        out = torch.empty((1, 3, H, W), dtype=BF, device=self.device)
-        check(lib().pe_nhwc_to_nchw(a.data_ptr(), out.data_ptr(), 3, H * W, a.shape[1], 0, None, None, stream_ptr()),
-              "pe_nhwc_to_nchw")
+        h, w = x.shape[2], x.shape[3]
+        ws, n = self._workspace(h * 8, w * 8)
+        if output_u8:
+            out = torch.empty((h * 8, w * 8, 3), dtype=torch.uint8, device=self.device)
+            check(lib().pe_vae_decode(self._handle, x.data_ptr(), h, w, out.data_ptr(), _lib.IMAGE_U8_HWC, ws, n, stream_ptr()),
+                  "pe_vae_decode")
+            return out
+        out = torch.empty((1, 3, h * 8, w * 8), dtype=BF, device=self.device)
+        check(lib().pe_vae_decode(self._handle, x.data_ptr(), h, w, out.data_ptr(), _lib.IMAGE_BF16_NCHW, ws, n, stream_ptr()),
+              "pe_vae_decode")
         return out.unsqueeze(2) if squeeze else out
 
 

@@ -150,3 +150,49 @@ def test_image_io(vae_mod, golden):
     ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
     assert torch.equal(vae_mod.preprocess_image(ramp, "cuda").cpu(), g["pre"])
     assert torch.equal(vae_mod.vae_output_to_u8(g["post_in"].cuda()), g["post_u8"])
+
+
+def test_vae_fused_u8_io(vae_mod):
+    """pe_vae_encode(PE_IMAGE_U8_HWC) / pe_vae_decode(PE_IMAGE_U8_HWC): BasePipeline.preprocess_image /
+    vae_output_to_image fused into the composite's first / last kernel must be bit-identical to the stand-alone maps
+    (themselves pinned on the reference's outputs, G10)."""
+    vs = synth.make_state_dict(synth.vae_layout(), 77)
+    v = vae_mod.QwenImageVAE(vs, device="cuda")
+    u8 = synth.make_edit_image_u8(96, 64, seed=3)                      # H != W on purpose
+    z_ref = v.encode(vae_mod.preprocess_image(u8, "cuda"))
+    z_u8 = v.encode(torch.from_numpy(u8).cuda())
+    assert torch.equal(z_ref, z_u8)
+    gen = torch.Generator().manual_seed(9)
+    lat = (torch.randn((1, 16, 12, 8), generator=gen) * 1.5).to(BF).cuda()   # scaled up so the clip at 0 / 255 is exercised
+    img = v.decode(lat)
+    got = v.decode(lat, output_u8=True)
+    ref = vae_mod.vae_output_to_u8(img)
+    assert got.shape == (96, 64, 3) and got.dtype == torch.uint8
+    assert torch.equal(got.cpu(), ref)
+    assert (ref == 0).any() and (ref == 255).any()
+
+
+def test_adapter_forward_cabi(golden):
+    """pe_adapter_forward (VisualThinkingDualAdapter.forward, helpers.py:152-164) vs the reference's outputs (G9)."""
+    import ctypes as C
+    from physicedit_amd import _lib
+    from physicedit_amd._lib import AdapterWeights, check, lib, stream_ptr
+    from physicedit_amd.scheduler import adapter_alpha
+    g = golden("G9_adapter")
+    ad = {k: t.cuda() for k, t in synth.make_state_dict(synth.adapter_layout(), 4321).items()}
+    a = AdapterWeights()
+    a.dino_w0, a.dino_b0 = ad["head_dino.0.weight"].data_ptr(), ad["head_dino.0.bias"].data_ptr()
+    a.dino_w2, a.dino_b2 = ad["head_dino.2.weight"].data_ptr(), ad["head_dino.2.bias"].data_ptr()
+    a.vae_w0, a.vae_b0 = ad["head_vae.0.weight"].data_ptr(), ad["head_vae.0.bias"].data_ptr()
+    a.vae_w2, a.vae_b2 = ad["head_vae.2.weight"].data_ptr(), ad["head_vae.2.bias"].data_ptr()
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn((1, 64, 3584), generator=gen).to(BF)[0].cuda().contiguous()
+    n = lib().pe_adapter_workspace_bytes(64)
+    ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    t_min, t_max = O.adapter_t_range()
+    for tv in (1000.0, 748.0, 20.0):
+        al, om = adapter_alpha(torch.tensor([tv]).to(BF), t_min, t_max)
+        out = torch.empty_like(x)
+        check(lib().pe_adapter_forward(C.byref(a), x.data_ptr(), 64, al, om, out.data_ptr(), ws.data_ptr(), n, stream_ptr()),
+              "pe_adapter_forward")
+        report(f"pe_adapter_forward t={tv}", out, g[f"mixed_{int(tv)}"][0], 3.0, 0.08)
