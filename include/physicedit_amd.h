@@ -73,6 +73,11 @@ int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void
 int pe_gemm_bf16_pre(int epilogue, const void* A, int lda, const void* W, const void* bias, const void* pre, int ldp,
                      void* out, int ldo, int M, int N, int K, const void* gate, const void* res, int ldr, void* stream);
 
+/* GeneralLoRALoader.load (lora/__init__.py:28-45) for one target Linear, in place and with the reference's roundings:
+ * W[N,K] = bf16(W + bf16(alpha * bf16(up[N,r] @ down[r,K]))).  down_t is down transposed, [K,r]; r is the rank zero-padded
+ * to a multiple of 64 (zero columns add exact zeros); alpha is applied as an fp32 scalar like `alpha * tensor` in torch. */
+int pe_lora_merge(void* W, int N, int K, const void* up, const void* down_t, int r, float alpha, void* stream);
+
 /* e4m3 ("FP8 computation") Linear: AutoWrappedLinear.fp8_linear, vram_management/layers.py:115-151, reached when the
  * DiT is stored in float8_e4m3fn and enable_vram_management(enable_dit_fp8_computation=True) is on
  * (pipelines/qwen_image_physical.py:440-496).  Two launches per Linear:
@@ -204,9 +209,12 @@ typedef struct pe_dit* pe_dit_handle;
 int pe_dit_create(const pe_dit_weights* w, const pe_adapter_weights* adapter /* nullable */, pe_dit_handle* out);
 void pe_dit_destroy(pe_dit_handle h);
 
-/* Install (blocks != NULL, host array [num_layers], copied) or clear (NULL) hot LoRA operands; r <= 128.
- * Call before pe_dit_prepare: the modulation rows depend on it. */
+/* Hot LoRA sets.  pe_dit_set_hot_lora replaces all sets by one (blocks != NULL: host array [num_layers], copied) or clears
+ * them (NULL); pe_dit_add_hot_lora appends another set -- load_lora(hotload=True) called again: AutoWrappedLinear keeps lists
+ * of pairs and adds them in load order (vram_management/layers.py:173-181).  r <= 128, at most 8 sets.  Call before
+ * pe_dit_prepare: the modulation rows depend on them. */
 int pe_dit_set_hot_lora(pe_dit_handle h, const pe_dit_block_lora* blocks, int r);
+int pe_dit_add_hot_lora(pe_dit_handle h, const pe_dit_block_lora* blocks, int r);
 
 /* Bytes of workspace needed for sequences up to (S_img_max image tokens, T_max text tokens) and
  * n_steps prepared timesteps. */

@@ -400,7 +400,8 @@ class HotLoraSD(dict):
 
 def attach_hot_lora(sd: SD, lora: SD, alpha: float = 1.0) -> "HotLoraSD":
     out = HotLoraSD(sd)
-    out.hot = {}
+    # a second hot load APPENDS to the module's lists (qwen_image_physical.py:270-271)
+    out.hot = {k: list(v) for k, v in getattr(sd, "hot", {}).items()}
     for key in lora:
         if ".lora_A." not in key:
             continue

@@ -98,6 +98,7 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_int, c_void_p]),
     "pe_gemm_bf16_pre": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                  c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "pe_lora_merge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "pe_ln_modulate_e4m3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_float, c_void_p]),
     "pe_quantize_rows_e4m3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
@@ -117,6 +118,7 @@ SIGNATURES = {
     "pe_dit_create": (c_int, [C.POINTER(DitWeights), C.POINTER(AdapterWeights), C.POINTER(c_void_p)]),
     "pe_dit_destroy": (None, [c_void_p]),
     "pe_dit_set_hot_lora": (c_int, [c_void_p, C.POINTER(DitBlockLora), c_int]),
+    "pe_dit_add_hot_lora": (c_int, [c_void_p, C.POINTER(DitBlockLora), c_int]),
     "pe_dit_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "pe_dit_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "pe_dit_prepare": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

@@ -79,6 +79,16 @@ int pe_gemm_bf16_pre(int epilogue, const void* A, int lda, const void* W, const 
     return launch_gemm(epilogue, &p, 1, (hipStream_t)stream);
 }
 
+int pe_lora_merge(void* W, int N, int K, const void* up, const void* down_t, int r, float alpha, void* stream) {
+    PE_REQUIRE(W && up && down_t, "pe_lora_merge: null pointer");
+    PE_REQUIRE(r > 0 && r % 64 == 0, "pe_lora_merge: rank %d must be padded to a multiple of 64 (zero columns)", r);
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = up; p.lda = r; p.W = down_t; p.out = W; p.ldo = K; p.M = N; p.N = K; p.K = r;
+    p.res = W; p.ldr = K; p.has_gate_scalar = 1; p.gate_scalar = alpha;
+    return launch_gemm(EPI_GATE_RES, &p, 1, (hipStream_t)stream);
+}
+
 int pe_ln_modulate_e4m3(const void* x, void* out_bf16, void* out_e4m3, float* out_scale, int rows, int dim, int rows_a,
                         const void* shift_a, const void* scale_a, const void* shift_b, const void* scale_b, float eps,
                         void* stream) {

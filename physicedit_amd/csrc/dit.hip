@@ -46,9 +46,24 @@ struct pe_dit {
     char* aq;                           // e4m3 mode: quantised activation rows of the Linear being run [S, FF] bytes
     float* asc;                         // e4m3 mode: their per-row scales
     const void* aq_src = nullptr;       // bf16 operand whose quantised rows currently sit in aq/asc (fused producer), or null
-    pe_dit_block_lora* lora = nullptr;  // hot LoRA operands per block, or null
-    int lora_r = 0;
+    // hot LoRA sets (load_lora(hotload=True) may be called several times: AutoWrappedLinear keeps LISTS of pairs and adds
+    // them one after the other, vram_management/layers.py:173-181); each set: operands per block + its padded rank
+    static constexpr int MAX_LORA_SETS = 8;
+    pe_dit_block_lora* lora[MAX_LORA_SETS] = {};
+    int lora_r[MAX_LORA_SETS] = {};
+    int n_lora = 0;
 };
+
+namespace {
+// operands of LoRA set `s` for Linear group g (0 qkv, 1 out, 2 down, 3 mod) of stream st (0 image, 1 text) in block l
+inline void lora_ops(const pe_dit* h, int s, int l, int g, int st, const void** a, const void** b) {
+    const pe_dit_block_lora& L = h->lora[s][l];
+    const void* tab[2][4][2] = {{{L.img_qkv_a, L.img_qkv_b}, {L.img_out_a, L.img_out_b}, {L.img_down_a, L.img_down_b}, {L.img_mod_a, L.img_mod_b}},
+                                {{L.txt_qkv_a, L.txt_qkv_b}, {L.txt_out_a, L.txt_out_b}, {L.txt_down_a, L.txt_down_b}, {L.txt_mod_a, L.txt_mod_b}}};
+    *a = tab[st][g][0];
+    *b = tab[st][g][1];
+}
+}  // namespace
 
 static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     const int L = h->w.num_layers;
@@ -121,6 +136,68 @@ static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t st
     return launch_gemm(epi, pp, n, stream, h->sk_ws);
 }
 
+// does any hot LoRA set carry group g (0 qkv, 1 out, 2 down, 3 mod) of block l (both streams)?
+static bool has_hot(const pe_dit* h, int l, int g) {
+    for (int ls = 0; ls < h->n_lora; ++ls) {
+        const void *a0, *b0, *a1, *b1;
+        lora_ops(h, ls, l, g, 0, &a0, &b0);
+        lora_ops(h, ls, l, g, 1, &a1, &b1);
+        if (a0 && b0 && a1 && b1) return true;
+    }
+    return false;
+}
+
+// One Linear of a block, both streams in one launch, final epilogue `epi`, plus the hot LoRA sets of group g
+// (AutoWrappedLinear.forward, vram_management/layers.py:166-181):
+//     y = Linear(x);  for every (A, B) in the module's lists:  y = y + (x @ A.T) @ B.T      (every op rounds)
+// The base Linear runs without epilogue into ybuf (row stride ldy); each set is two GEMMs, t = x @ A.T and
+// y = pre(y) + t @ B.T -- in place for all but the last set, which carries the real epilogue.
+static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], char* ybuf, int ldy, hipStream_t stream) {
+    int sets[pe_dit::MAX_LORA_SETS], ns = 0;
+    for (int ls = 0; ls < h->n_lora; ++ls) {
+        const void *a0, *b0, *a1, *b1;
+        lora_ops(h, ls, l, g, 0, &a0, &b0);
+        lora_ops(h, ls, l, g, 1, &a1, &b1);
+        if (a0 && b0 && a1 && b1) sets[ns++] = ls;
+    }
+    if (ns == 0) return dit_linear(h, epi, pp, 2, stream);
+    int rc;
+    const void* xA[2] = {pp[0].A, pp[1].A};
+    const int xlda[2] = {pp[0].lda, pp[1].lda};
+    const int xK[2] = {pp[0].K, pp[1].K};
+    const size_t row0[2] = {0, (size_t)pp[0].M};
+    GemmProblem y1[2];
+    memset(y1, 0, sizeof(y1));
+    for (int s = 0; s < 2; ++s) {
+        y1[s].A = pp[s].A; y1[s].lda = pp[s].lda; y1[s].W = pp[s].W; y1[s].bias = pp[s].bias;
+        y1[s].out = ybuf + row0[s] * ldy * 2; y1[s].ldo = ldy; y1[s].M = pp[s].M; y1[s].N = pp[s].N; y1[s].K = pp[s].K;
+    }
+    if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
+    for (int i = 0; i < ns; ++i) {
+        const int r = h->lora_r[sets[i]];
+        const int nl = (g == 0 ? 3 : 1) * r;
+        const bool last = i == ns - 1;
+        GemmProblem ta[2], tb[2];
+        memset(ta, 0, sizeof(ta));
+        memset(tb, 0, sizeof(tb));
+        for (int s = 0; s < 2; ++s) {
+            const void *la, *lb;
+            lora_ops(h, sets[i], l, g, s, &la, &lb);
+            ta[s].A = xA[s]; ta[s].lda = xlda[s]; ta[s].W = la;
+            ta[s].out = h->lora_t + row0[s] * nl * 2; ta[s].ldo = nl; ta[s].M = pp[s].M; ta[s].N = nl; ta[s].K = xK[s];
+            if (last) tb[s] = pp[s];                  // epilogue operands (gate / residual / rope / q,k,v outputs ...)
+            tb[s].A = ta[s].out; tb[s].lda = nl; tb[s].W = lb; tb[s].bias = nullptr; tb[s].K = nl;
+            tb[s].M = pp[s].M; tb[s].N = pp[s].N;
+            tb[s].pre = ybuf + row0[s] * ldy * 2; tb[s].ldp = ldy;
+            if (!last) { tb[s].out = ybuf + row0[s] * ldy * 2; tb[s].ldo = ldy; }   // in place: a lane reads pre before the tile is stored
+        }
+        if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
+        if ((rc = launch_gemm(last ? epi : EPI_BIAS, tb, 2, stream, h->sk_ws))) return rc;
+    }
+    return PE_OK;
+}
+
+
 extern "C" {
 
 int pe_dit_create(const pe_dit_weights* w, const pe_adapter_weights* adapter, pe_dit_handle* out) {
@@ -142,23 +219,31 @@ int pe_dit_create(const pe_dit_weights* w, const pe_adapter_weights* adapter, pe
 void pe_dit_destroy(pe_dit_handle h) {
     if (!h) return;
     delete[] h->blocks;
-    delete[] h->lora;
+    for (int s = 0; s < h->n_lora; ++s) delete[] h->lora[s];
     delete h;
+}
+
+int pe_dit_add_hot_lora(pe_dit_handle h, const pe_dit_block_lora* blocks, int r) {
+    PE_REQUIRE(h && blocks, "pe_dit_add_hot_lora: null argument");
+    PE_REQUIRE(r > 0 && r <= 128 && r % 64 == 0, "pe_dit_add_hot_lora: r=%d must be 64 or 128", r);
+    PE_REQUIRE(h->n_lora < pe_dit::MAX_LORA_SETS, "pe_dit_add_hot_lora: at most %d hot LoRA sets", pe_dit::MAX_LORA_SETS);
+    pe_dit_block_lora* copy = new (std::nothrow) pe_dit_block_lora[h->w.num_layers > 0 ? h->w.num_layers : 1];
+    PE_REQUIRE(copy, "pe_dit_add_hot_lora: out of host memory");
+    for (int i = 0; i < h->w.num_layers; ++i) copy[i] = blocks[i];
+    h->lora[h->n_lora] = copy;
+    h->lora_r[h->n_lora] = r;
+    ++h->n_lora;
+    h->n_steps = 0;   // modulation rows must be rebuilt
+    return PE_OK;
 }
 
 int pe_dit_set_hot_lora(pe_dit_handle h, const pe_dit_block_lora* blocks, int r) {
     PE_REQUIRE(h, "pe_dit_set_hot_lora: null handle");
-    delete[] h->lora;
-    h->lora = nullptr;
-    h->lora_r = 0;
+    for (int s = 0; s < h->n_lora; ++s) { delete[] h->lora[s]; h->lora[s] = nullptr; }
+    h->n_lora = 0;
     h->n_steps = 0;   // modulation rows must be rebuilt
     if (!blocks) return PE_OK;
-    PE_REQUIRE(r > 0 && r <= 128 && r % 64 == 0, "pe_dit_set_hot_lora: r=%d must be 64 or 128", r);
-    h->lora = new (std::nothrow) pe_dit_block_lora[h->w.num_layers > 0 ? h->w.num_layers : 1];
-    PE_REQUIRE(h->lora, "pe_dit_set_hot_lora: out of host memory");
-    for (int i = 0; i < h->w.num_layers; ++i) h->lora[i] = blocks[i];
-    h->lora_r = r;
-    return PE_OK;
+    return pe_dit_add_hot_lora(h, blocks, r);
 }
 
 size_t pe_dit_workspace_bytes(pe_dit_handle h, int S_img_max, int T_max, int n_steps) {
@@ -225,20 +310,25 @@ int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void
             pp[s].M = n_steps; pp[s].N = MOD; pp[s].K = D;
         }
         if ((rc = dit_linear(h, EPI_BIAS, pp, 2, stream))) return rc;
-        if (h->lora && h->lora[l].img_mod_a && h->lora[l].txt_mod_a) {
-            // mod = Linear(silu) + (silu @ A.T) @ B.T   (img_mod.1 / txt_mod.1 are LoRA targets)
-            const int r = h->lora_r;
+        for (int ls = 0; ls < h->n_lora; ++ls) {
+            // mod = Linear(silu) + (silu @ A.T) @ B.T for every hot set in turn   (img_mod.1 / txt_mod.1 are LoRA targets)
+            const int r = h->lora_r[ls];
             GemmProblem ta[2], tb[2];
             memset(ta, 0, sizeof(ta));
             memset(tb, 0, sizeof(tb));
+            bool have = true;
             for (int s = 0; s < 2; ++s) {
+                const void *la, *lb;
+                lora_ops(h, ls, l, 3, s, &la, &lb);
+                have = have && la && lb;
                 char* t = h->lora_t + (size_t)s * n_steps * r * 2;
-                ta[s].A = h->silu_temb; ta[s].lda = D; ta[s].W = s == 0 ? h->lora[l].img_mod_a : h->lora[l].txt_mod_a;
+                ta[s].A = h->silu_temb; ta[s].lda = D; ta[s].W = la;
                 ta[s].out = t; ta[s].ldo = r; ta[s].M = n_steps; ta[s].N = r; ta[s].K = D;
-                tb[s].A = t; tb[s].lda = r; tb[s].W = s == 0 ? h->lora[l].img_mod_b : h->lora[l].txt_mod_b;
+                tb[s].A = t; tb[s].lda = r; tb[s].W = lb;
                 tb[s].pre = pp[s].out; tb[s].ldp = ld; tb[s].out = pp[s].out; tb[s].ldo = ld;
                 tb[s].M = n_steps; tb[s].N = MOD; tb[s].K = r;
             }
+            if (!have) continue;
             if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
             if ((rc = launch_gemm(EPI_BIAS, tb, 2, stream, h->sk_ws))) return rc;
         }
@@ -340,7 +430,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         // e4m3 mode: the same kernel also emits the rows as e4m3 + per-row scale (the QKV Linear's operand); the bf16
         // copy is only needed by hot LoRA (x @ A.T runs in bf16)
         const bool fuse_q = h->w.weights_e4m3 != 0;
-        const bool need_bf16_qkv = !fuse_q || (h->lora && h->lora[l].img_qkv_a && h->lora[l].txt_qkv_a);
+        const bool need_bf16_qkv = !fuse_q || has_hot(h, l, 0);
         if ((rc = launch_ln_modulate_quant(h->x, need_bf16_qkv ? h->xmod : nullptr, S, D, S_img, sh(mod_img, 0), sc(mod_img, 0),
                                            sh(mod_txt, 0), sc(mod_txt, 0), 1e-6f, fuse_q ? h->aq : nullptr,
                                            fuse_q ? h->asc : nullptr, stream)))
@@ -360,28 +450,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].q_out = h->q; pp[s].k_out = h->k; pp[s].vt_out = h->vt;
             pp[s].seq_off = s == 0 ? 0 : S_img; pp[s].S_pad = S_pad;
         }
-        const pe_dit_block_lora* LR = h->lora ? &h->lora[l] : nullptr;
-        const int r = h->lora_r;
-        bool low_rank = false;   // the launch below is the low-rank product on top of an already computed base Linear
-        if (LR && LR->img_qkv_a && LR->txt_qkv_a) {
-            low_rank = true;
-            // hot LoRA: t = x @ Acat.T ; y1 = x @ W.T + b ; then (t @ Bdiag.T) with pre = y1 and the QKV epilogue
-            GemmProblem ta[2], y1[2];
-            memset(ta, 0, sizeof(ta));
-            memset(y1, 0, sizeof(y1));
-            for (int s = 0; s < 2; ++s) {
-                const size_t row0 = s == 0 ? 0 : (size_t)S_img;
-                ta[s].A = pp[s].A; ta[s].lda = D; ta[s].W = s == 0 ? LR->img_qkv_a : LR->txt_qkv_a;
-                ta[s].out = h->lora_t + row0 * 3 * r * 2; ta[s].ldo = 3 * r; ta[s].M = pp[s].M; ta[s].N = 3 * r; ta[s].K = D;
-                y1[s].A = pp[s].A; y1[s].lda = D; y1[s].W = pp[s].W; y1[s].bias = pp[s].bias;
-                y1[s].out = h->hbuf + row0 * 3 * D * 2; y1[s].ldo = 3 * D; y1[s].M = pp[s].M; y1[s].N = 3 * D; y1[s].K = D;
-                pp[s].A = ta[s].out; pp[s].lda = 3 * r; pp[s].W = s == 0 ? LR->img_qkv_b : LR->txt_qkv_b;
-                pp[s].bias = nullptr; pp[s].K = 3 * r; pp[s].pre = y1[s].out; pp[s].ldp = 3 * D;
-            }
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
-            if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
-        }
-        if ((rc = low_rank ? launch_gemm(EPI_QKV, pp, 2, stream, h->sk_ws) : dit_linear(h, EPI_QKV, pp, 2, stream))) return rc;
+        if ((rc = hot_linear(h, l, 0, EPI_QKV, pp, h->hbuf, 3 * D, stream))) return rc;
         // joint attention
         if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream))) return rc;
         // output projections + gated residual (in place on x)
@@ -395,25 +464,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 0);
             pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = D;
         }
-        low_rank = false;
-        if (LR && LR->img_out_a && LR->txt_out_a) {
-            low_rank = true;
-            GemmProblem ta[2], y1[2];
-            memset(ta, 0, sizeof(ta));
-            memset(y1, 0, sizeof(y1));
-            for (int s = 0; s < 2; ++s) {
-                const size_t row0 = s == 0 ? 0 : (size_t)S_img;
-                ta[s].A = pp[s].A; ta[s].lda = D; ta[s].W = s == 0 ? LR->img_out_a : LR->txt_out_a;
-                ta[s].out = h->lora_t + row0 * r * 2; ta[s].ldo = r; ta[s].M = pp[s].M; ta[s].N = r; ta[s].K = D;
-                y1[s].A = pp[s].A; y1[s].lda = D; y1[s].W = pp[s].W; y1[s].bias = pp[s].bias;
-                y1[s].out = h->xmod + row0 * D * 2; y1[s].ldo = D; y1[s].M = pp[s].M; y1[s].N = D; y1[s].K = D;
-                pp[s].A = ta[s].out; pp[s].lda = r; pp[s].W = s == 0 ? LR->img_out_b : LR->txt_out_b;
-                pp[s].bias = nullptr; pp[s].K = r; pp[s].pre = y1[s].out; pp[s].ldp = D;
-            }
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
-            if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
-        }
-        if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream, h->sk_ws) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
+        if ((rc = hot_linear(h, l, 1, EPI_GATE_RES, pp, h->xmod, D, stream))) return rc;
         // norm2 + modulate
         if ((rc = launch_ln_modulate_quant(h->x, fuse_q ? nullptr : h->xmod, S, D, S_img, sh(mod_img, 1), sc(mod_img, 1),
                                            sh(mod_txt, 1), sc(mod_txt, 1), 1e-6f, fuse_q ? h->aq : nullptr,
@@ -441,25 +492,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 1);
             pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = FF;
         }
-        low_rank = false;
-        if (LR && LR->img_down_a && LR->txt_down_a) {
-            low_rank = true;
-            GemmProblem ta[2], y1[2];
-            memset(ta, 0, sizeof(ta));
-            memset(y1, 0, sizeof(y1));
-            for (int s = 0; s < 2; ++s) {
-                const size_t row0 = s == 0 ? 0 : (size_t)S_img;
-                ta[s].A = pp[s].A; ta[s].lda = FF; ta[s].W = s == 0 ? LR->img_down_a : LR->txt_down_a;
-                ta[s].out = h->lora_t + row0 * r * 2; ta[s].ldo = r; ta[s].M = pp[s].M; ta[s].N = r; ta[s].K = FF;
-                y1[s].A = pp[s].A; y1[s].lda = FF; y1[s].W = pp[s].W; y1[s].bias = pp[s].bias;
-                y1[s].out = h->attn + row0 * D * 2; y1[s].ldo = D; y1[s].M = pp[s].M; y1[s].N = D; y1[s].K = FF;
-                pp[s].A = ta[s].out; pp[s].lda = r; pp[s].W = s == 0 ? LR->img_down_b : LR->txt_down_b;
-                pp[s].bias = nullptr; pp[s].K = r; pp[s].pre = y1[s].out; pp[s].ldp = D;
-            }
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
-            if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
-        }
-        if ((rc = low_rank ? launch_gemm(EPI_GATE_RES, pp, 2, stream, h->sk_ws) : dit_linear(h, EPI_GATE_RES, pp, 2, stream))) return rc;
+        if ((rc = hot_linear(h, l, 2, EPI_GATE_RES, pp, h->attn, D, stream))) return rc;
     }
 
     // ---- 4. AdaLayerNorm(single) head on the S0 kept rows, proj_out, unpatchify  (:1398-1402)

@@ -904,8 +904,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
         bf16* out = (bf16*)P.out;
         float g[8];
         if constexpr (EPI == EPI_GATE_RES) {
+            const float gs = P.has_gate_scalar ? P.gate_scalar : 1.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = 1.0f;
+            for (int j = 0; j < 8; ++j) g[j] = gs;
             if (P.gate != nullptr && n < N) {
                 const bf16x8 gv = *(const bf16x8*)((const bf16*)P.gate + n);
 #pragma unroll

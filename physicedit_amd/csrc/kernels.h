@@ -27,7 +27,9 @@ struct GemmProblem {
     int M, N, K;
     int lda, ldo;
     // EPI_GATE_RES
-    const void* gate;  // [N] bf16 (null => gate 1)
+    const void* gate;  // [N] bf16 (null => the scalar gate below, default 1)
+    int has_gate_scalar;   // gate == null: out = res + bf16(gate_scalar * y) with an fp32 scalar (LoRA merge alpha)
+    float gate_scalar;
     const void* res;   // [M,N] bf16, row stride ldr (may alias out)
     int ldr;
     // optional for every epilogue: y = bf16(pre[m][n] + bf16(acc + bias)) before the epilogue proper

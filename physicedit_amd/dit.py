@@ -181,7 +181,7 @@ class QwenImageDiTEngine:
         other._handle = C.c_void_p()
         other._keep = None
         other._create()
-        other._hot, other._hot_r = getattr(self, "_hot", None), getattr(self, "_hot_r", 0)
+        other._hot_sets = list(getattr(self, "_hot_sets", None) or [])
         other._apply_hot()
         other._ws = None
         other._bound = (0, 0, 0)
@@ -211,8 +211,9 @@ class QwenImageDiTEngine:
 
     def load_lora_hot(self, lora_state_dict: Dict[str, torch.Tensor], alpha: float = 1.0) -> int:
         """load_lora(hotload=True) (qwen_image_physical.py:264-272): the LoRA stays separate and every targeted
-        Linear computes out + x @ (alpha*A).T @ B.T at run time (vram_management/layers.py:173-181).  One LoRA
-        per target; rank <= 128."""
+        Linear computes out + x @ (alpha*A).T @ B.T at run time (vram_management/layers.py:173-181).  Calling it
+        again APPENDS another set, applied after the earlier ones exactly like the reference's lists of pairs;
+        rank <= 128 per set, at most 8 sets."""
         found = {}
         for key, A in lora_state_dict.items():
             if ".lora_A." not in key:
@@ -234,8 +235,6 @@ class QwenImageDiTEngine:
         rp = (rank + 63) // 64 * 64
         if rp > 128:
             raise _lib.PeError(f"load_lora(hotload=True): rank {rank} > 128")
-        if getattr(self, "_hot", None) is not None:
-            raise _lib.PeError("load_lora(hotload=True): one hot LoRA per target is supported; clear_lora() first")
         hot = []
         for i in range(self.num_layers):
             blk = {}
@@ -253,32 +252,35 @@ class QwenImageDiTEngine:
                 blk[g + "_a"][slot * rp: slot * rp + r].copy_(A)
                 blk[g + "_b"][slot * rows:(slot + 1) * rows, slot * rp: slot * rp + r].copy_(B)
             hot.append(blk)
-        self._hot, self._hot_r = hot, rp
+        sets = list(getattr(self, "_hot_sets", None) or [])
+        if len(sets) >= 8:
+            raise _lib.PeError("load_lora(hotload=True): at most 8 hot LoRA sets; clear_lora() first")
+        sets.append((hot, rp))
+        self._hot_sets = sets
         self._apply_hot()
         return len(found)
 
     def clear_lora(self):
-        self._hot, self._hot_r = None, 0
+        self._hot_sets = []
         check(lib().pe_dit_set_hot_lora(self._handle, None, 0), "pe_dit_set_hot_lora")
         self._step_of = {}
         self.version += 1
 
     def _apply_hot(self):
         self.version = getattr(self, "version", 0) + 1
-        if getattr(self, "_hot", None) is None:
-            return
-        arr = (DitBlockLora * max(self.num_layers, 1))()
-        for i, blk in enumerate(self._hot):
-            for k, t in blk.items():
-                setattr(arr[i], k, t.data_ptr())
-        check(lib().pe_dit_set_hot_lora(self._handle, arr, self._hot_r), "pe_dit_set_hot_lora")
+        sets = getattr(self, "_hot_sets", None) or []
+        check(lib().pe_dit_set_hot_lora(self._handle, None, 0), "pe_dit_set_hot_lora")
+        for hot, rp in sets:
+            arr = (DitBlockLora * max(self.num_layers, 1))()
+            for i, blk in enumerate(hot):
+                for k, t in blk.items():
+                    setattr(arr[i], k, t.data_ptr())
+            check(lib().pe_dit_add_hot_lora(self._handle, arr, rp), "pe_dit_add_hot_lora")
         self._step_of = {}
 
     def load_lora(self, lora_state_dict: Dict[str, torch.Tensor], alpha: float = 1.0, hotload: bool = False) -> int:
         if hotload:
             return self.load_lora_hot(lora_state_dict, alpha)
-        if alpha != 1.0:
-            raise _lib.PeError("load_lora: only alpha=1.0 is merged on the GPU path (validate.py uses alpha=1)")
         if self.fp8:
             raise _lib.PeError("load_lora: merge the LoRA before enable_fp8_computation() (the merge is a bf16 operation), "
                                "or use hotload=True")
@@ -307,7 +309,9 @@ class QwenImageDiTEngine:
             wt = torch.zeros((down.shape[1], rp), dtype=BF, device=self.device)
             wt[:, :r] = down.t()
             W = self.params[name]
-            ops.gemm(a, wt, None, "gate_res", gate=None, res=W, out=W)
+            # W <- bf16(W + bf16(alpha * bf16(up @ down)))  (lora/__init__.py:40-44)
+            check(lib().pe_lora_merge(W.data_ptr(), W.shape[0], W.shape[1], a.data_ptr(), wt.data_ptr(), rp, float(alpha),
+                                      stream_ptr()), "pe_lora_merge")
             n += 1
         if n:
             # img_mod.1 / txt_mod.1 are LoRA targets: the prepared modulation rows (host map and the C tables) are stale

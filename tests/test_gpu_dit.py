@@ -291,3 +291,43 @@ def test_model_fn_full_shape_one_layer():
     print(f"[parity] full shape: rms distance to fp32 run: hip {e_hip:.4e} reference-bf16 {e_ref:.4e}")
     assert e_hip <= 1.25 * e_ref
     assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+
+
+def test_model_fn_two_hot_loras():
+    """load_lora(hotload=True) twice: AutoWrappedLinear keeps LISTS of (A, B) pairs and adds them in load order
+    (vram_management/layers.py:173-181).  Two sets with different ranks / alphas vs the oracle's restatement."""
+    from physicedit_amd.dit import QwenImageDiTEngine, special_indices
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    lora1 = synth.make_lora(4321, 2, 16, std=0.05)
+    lora2 = synth.make_lora(999, 2, 72, std=0.03)           # rank 72 -> padded to 128
+    t_min, t_max = O.adapter_t_range()
+    noise, edit, pe, mask = _model_fn_inputs(128, 128, 40, 8, 3)
+    t = torch.tensor([700.0]).to(BF)
+    ref = O.model_fn(O.attach_hot_lora(O.attach_hot_lora(sd, lora1), lora2, alpha=0.5), ad, noise, t, pe.clone(), mask, 128, 128, edit,
+                     t_min, t_max)
+    eng = QwenImageDiTEngine(sd, ad, device="cuda")
+    assert eng.load_lora(lora1, hotload=True) == 24
+    one = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda()).clone()
+    assert eng.load_lora(lora2, alpha=0.5, hotload=True) == 24
+    got = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda()).clone()
+    d, u = stats("model_fn two hot LoRA sets", got, ref)
+    assert u.max().item() <= 4.0 and d.mean().item() <= 1.5e-3
+    assert (got.float() - one.float()).abs().max().item() > 0.005      # the second set does something
+
+
+@pytest.mark.parametrize("alpha", [0.7, 2.0])
+def test_lora_merge_alpha(alpha):
+    """GeneralLoRALoader.load with alpha != 1 (lora/__init__.py:40-44): W + alpha * (B @ A), alpha applied as an fp32
+    scalar to the bf16 product."""
+    from physicedit_amd.dit import QwenImageDiTEngine
+    sd = synth.make_state_dict(synth.dit_layout(1), 1234)
+    lora = synth.make_lora(4321, 1, 32)
+    ref = {k: v.clone() for k, v in sd.items()}
+    assert O.lora_merge(ref, lora, alpha=alpha) == 12
+    eng = QwenImageDiTEngine(sd, None, device="cuda")
+    assert eng.load_lora(lora, alpha=alpha) == 12
+    for tname in synth.LORA_TARGETS:
+        k = f"transformer_blocks.0.{tname}.weight"
+        u = ulps(eng.params[k], ref[k], floor=2.0 ** -12)
+        assert u.max().item() <= 1.01 and (u > 0).float().mean().item() < 0.01, (k, u.max().item())

@@ -225,3 +225,32 @@ def test_model_fn_e4m3_full_shape_one_layer():
     d = _dist("full shape: model_fn e4m3 vs oracle e4m3", got, ref)
     assert torch.isfinite(got.float()).all()
     assert d.mean().item() <= 0.25 * mode.mean().item() and d.max().item() <= mode.max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 3072, 3072), (520, 12288, 3072), (272, 3072, 12288), (8704, 3072, 3072)])
+def test_gemm_e4m3_vs_torch_scaled_mm(ops, M, N, K):
+    """Pin the e4m3 GEMM on what the REFERENCE executes on a GPU: torch._scaled_mm with per-row scale_a, unit scale_b,
+    bf16 bias and bf16 output -- the exact call of AutoWrappedLinear.fp8_linear (vram_management/layers.py:141-148) --
+    on the same e4m3 operands.  Both sides accumulate e4m3 products (exact in fp32) in some order on the device; the
+    comparison is element-wise in bf16 ulps and the histogram goes into the parity record (configs[2])."""
+    from parity_record import record
+    x = _acts(M, K, 31)
+    w8 = rnd((N, K), 32, K ** -0.5).to(F8).cuda()
+    bias = rnd((N,), 33, 0.1).to(F8).to(BF).cuda()
+    xq, sa = ops.quantize_rows_e4m3(x.cuda())
+    assert xq.shape[1] == K
+    try:
+        ref = torch._scaled_mm(xq, w8.t(), scale_a=sa.reshape(M, 1), scale_b=torch.ones((1, N), device="cuda"), bias=bias,
+                               out_dtype=BF)
+    except Exception as e:            # rowwise-scaled fp8 GEMM not available in this torch/hipBLASLt build
+        pytest.skip(f"torch._scaled_mm unavailable here: {type(e).__name__}: {str(e)[:120]}")
+    out = ops.gemm_e4m3(xq, sa, w8, bias)
+    u = ulps(out, ref)
+    hist = {f"<= {k} ulp": float((u <= k).float().mean()) for k in (0, 1, 2)}
+    st = record("configs[2]", f"pe_gemm_e4m3 vs torch._scaled_mm {M}x{N}x{K}", out, ref, ulp_histogram=hist)
+    exact = O.fp8_linear(x, w8.cpu(), bias.cpu().to(F8))          # the oracle's exact (f64-summed) restatement
+    st_t = record("configs[2]", f"torch._scaled_mm vs exact-sum oracle {M}x{N}x{K}", ref, exact)
+    st_h = record("configs[2]", f"pe_gemm_e4m3 vs exact-sum oracle {M}x{N}x{K}", out, exact)
+    assert u.max().item() <= 2.01 and hist["<= 0 ulp"] >= 0.97, (u.max().item(), hist)
+    # and neither side is further from the exact sum than the other by more than a hair
+    assert st_h["mean_abs_diff"] <= 1.5 * st_t["mean_abs_diff"] + 1e-6
