@@ -1,0 +1,335 @@
+"""Prompt prologue of QwenImagePhysicPipeline: host Python over HF `transformers` under PyTorch-ROCm, as the north star
+specifies (the Qwen2.5-VL text encoder is third-party code; nothing here is a HIP kernel of this repository).
+
+Behaviour follows the reference's two units at inference (is_train=False):
+  * QwenImageUnit_PhysicalVerbalEmbedder   DiffSynth-Studio/diffsynth/pipelines/qwen_image_physical.py:837-990
+      chat-template prompt (system = SYSTEM_PROMPT_SAMPLE, user = "Edit Instruction:", prompt, "Edit Image:", image)
+      -> text_encoder.generate(max_new_tokens=1000) -> JSON -> "\\n<key>: <value>" lines (raw text if it is not JSON)
+  * QwenImageUnit_PromptEmbedder           :732-835
+      prompt (+ physical text) in one of three templates -> hidden_states[-1] of the text encoder -> rows under the
+      attention mask, minus the first `drop_idx` template tokens -> prompt_emb [1,T,3584]; with one edit image the 64
+      `<imgN>` tokens between <begin_of_img> / <end_of_img> give special_token_mask [1,T]
+The template strings and the system prompt are DATA the checkpoint was trained with; they are restated here verbatim.
+
+The nega branch of the verbal embedder also generates text in the reference, but PromptEmbedder never reads it
+(input_params_nega has no `physical_txt`, :736-737): it is skipped here.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+from PIL import Image
+
+SPECIAL_TOKEN_NUM = 64     # qwen_image_physical.py:35
+
+# qwen_image_physical.py:764-765, :773-781, :806-809 (templates) and :136-155 (system prompt)
+T2I_TEMPLATE = ("<|im_start|>system\nDescribe the image by detailing the color, shape, size, texture, quantity, text, spatial "
+                "relationships of the objects and background:<|im_end|>\n<|im_start|>user\n{}<|im_end|>\n<|im_start|>assistant\n")
+T2I_DROP = 34
+EDIT_TEMPLATE = ("<|im_start|>system\nDescribe the key features of the input image (color, shape, size, texture, objects, background), "
+                 "then explain how the user's text instruction should alter or modify the image. Generate a new image that meets the "
+                 "user's requirements while maintaining consistency with the original input where appropriate.<|im_end|>\n"
+                 "<|im_start|>user\n<|vision_start|><|image_pad|><|vision_end|>{}<|im_end|>\n<|im_start|>assistant\n")
+EDIT_MULTI_TEMPLATE = ("<|im_start|>system\nDescribe the key features of the input image (color, shape, size, texture, objects, "
+                       "background), then explain how the user's text instruction should alter or modify the image. Generate a new "
+                       "image that meets the user's requirements while maintaining consistency with the original input where "
+                       "appropriate.<|im_end|>\n<|im_start|>user\n{}<|im_end|>\n<|im_start|>assistant\n")
+EDIT_DROP = 64
+PICTURE_TEMPLATE = "Picture {}: <|vision_start|><|image_pad|><|vision_end|>"
+SYSTEM_PROMPT_SAMPLE = """
+You are a physics-aware visual editing assistant.
+You will receive an "Edit Instruction" and an "Edit Image".
+Your task is to generate a detailed description of the edit operations required to transform the image according to the instruction, ensuring all changes strictly follow physical laws.
+
+INPUTS:
+- Edit Instruction: The desired modification.
+- Edit Image: The visual starting point.
+
+REQUIREMENTS:
+1. Physical Plausibility: All operations must respect physics (like gravity, inertia, material properties, light transport, collision, etc.).
+2. Mechanism of Change: Describe *how* the change occurs visually (e.g., "The vase tilts and falls due to gravity," not just "The vase is on the floor").
+3. Material Consistency: Ensure materials behave correctly (liquids flow, solids rigid/deform, cloth wrinkles).
+
+OUTPUT FORMAT:
+Return STRICT JSON ONLY:
+{
+  "middle_transition_prompt": "A multi-clause paragraph describing the step-by-step physical operations and visual transition."
+}
+""".strip()
+
+ACCEPTED_FIELD_SETS = (("Reasoning",), ("physical_reasoning", "middle_transition_prompt", "final_state_prompt"),
+                       ("middle_transition_prompt",))
+
+
+def special_tokens() -> List[str]:
+    """Tokens from_pretrained adds to the processor's tokenizer (:529-536)."""
+    return ["<begin_of_img>", "<end_of_img>"] + [f"<img{i}>" for i in range(SPECIAL_TOKEN_NUM)]
+
+
+def resize_for_vl(image: Image.Image, target_area: int = 384 * 384) -> Image.Image:
+    """calculate_dimensions + resize_image (:749-759): ~target_area pixels, sides rounded to /32, PIL's default filter."""
+    ratio = image.size[0] / image.size[1]
+    width = math.sqrt(target_area * ratio)
+    height = width / ratio
+    return image.resize((round(width / 32) * 32, round(height / 32) * 32))
+
+
+def parse_generation_response(response: str) -> Dict[str, str]:
+    """_parse_generation_response (:876-907): the outermost {...} as JSON with exactly one of the accepted key sets."""
+    start, end = response.find("{"), response.rfind("}")
+    if start == -1 or end == -1 or end <= start:
+        raise ValueError(f"Cannot find JSON in response: {response}")
+    payload = response[start:end + 1]
+    try:
+        data = json.loads(payload)
+    except json.JSONDecodeError as exc:
+        raise ValueError(f"Cannot parse JSON: {payload}") from exc
+    allowed = tuple({f for fields in ACCEPTED_FIELD_SETS for f in fields})
+    result: Dict[str, str] = {}
+    for key in allowed:
+        value = data.get(key)
+        if value is not None:
+            if not isinstance(value, str):
+                raise ValueError(f"Field {key} must be string, got {type(value)}: {data}")
+            result[key] = value.strip()
+    if not any(set(result) == set(fields) for fields in ACCEPTED_FIELD_SETS):
+        raise ValueError(f"Unsupported response format. Expected one of {ACCEPTED_FIELD_SETS}, got keys {sorted(result)}: {data}")
+    return result
+
+
+class MiniQwen2VLProcessor:
+    """The three things the prologue needs from `transformers.Qwen2VLProcessor`, without its torchvision dependency
+    (transformers >= 4.5x wants a video processor, which needs torchvision; this ROCm image has none):
+    `__call__(text=, images=, padding=, return_tensors=)`, `apply_chat_template(...)` and `.tokenizer`.
+    Image patches come from transformers' own Qwen2VLImageProcessor (its PIL backend when torchvision is absent)."""
+
+    image_token = "<|image_pad|>"
+
+    def __init__(self, image_processor, tokenizer, chat_template: str):
+        self.image_processor = image_processor
+        self.tokenizer = tokenizer
+        self.chat_template = chat_template
+
+    def __call__(self, text, images=None, padding=True, return_tensors="pt", **kw):
+        from transformers.feature_extraction_utils import BatchFeature
+        text = [text] if isinstance(text, str) else list(text)
+        data = {}
+        if images is not None:
+            images = [images] if isinstance(images, Image.Image) else list(images)
+            img = self.image_processor(images=images, return_tensors=return_tensors)
+            grid = img["image_grid_thw"]
+            merge = int(self.image_processor.merge_size) ** 2
+            idx = 0
+            for i in range(len(text)):
+                while self.image_token in text[i]:
+                    n = int(grid[idx].prod()) // merge
+                    text[i] = text[i].replace(self.image_token, "<|placeholder|>" * n, 1)
+                    idx += 1
+                text[i] = text[i].replace("<|placeholder|>", self.image_token)
+            data.update({"pixel_values": img["pixel_values"], "image_grid_thw": grid})
+        enc = self.tokenizer(text, padding=padding, return_tensors=return_tensors)
+        return BatchFeature(data={**enc, **data})
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True, add_vision_id=False, **kw):
+        assert not tokenize
+        from jinja2.sandbox import ImmutableSandboxedEnvironment
+        env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+        return env.from_string(self.chat_template).render(messages=messages, add_generation_prompt=add_generation_prompt,
+                                                          add_vision_id=add_vision_id)
+
+
+def load_processor(processor_path: str, tokenizer_path: Optional[str] = None):
+    """Qwen2VLProcessor.from_pretrained(processor_path) (:525-527) when transformers can build it; else the minimal
+    processor above from the same directory's preprocessor_config.json / chat_template.jinja and the tokenizer found in
+    `processor_path` (or `tokenizer_path` when the processor directory ships without vocab/merges)."""
+    try:
+        from transformers import Qwen2VLProcessor
+        return Qwen2VLProcessor.from_pretrained(processor_path)
+    except Exception:
+        pass
+    from transformers import Qwen2Tokenizer, Qwen2VLImageProcessor
+    tok_dir = processor_path if os.path.exists(os.path.join(processor_path, "vocab.json")) else tokenizer_path
+    if tok_dir is None:
+        raise FileNotFoundError(f"{processor_path} has no vocab.json and no tokenizer path was given")
+    tokenizer = Qwen2Tokenizer.from_pretrained(tok_dir)
+    cfg = {}
+    cfg_path = os.path.join(processor_path, "preprocessor_config.json")
+    if os.path.exists(cfg_path):
+        raw = json.load(open(cfg_path))
+        keep = ("do_resize", "do_rescale", "do_normalize", "image_mean", "image_std", "min_pixels", "max_pixels", "patch_size",
+                "temporal_patch_size", "merge_size", "do_convert_rgb", "resample", "rescale_factor", "size")
+        cfg = {k: raw[k] for k in keep if k in raw and raw[k] is not None}
+    template = None
+    for name in ("chat_template.jinja", "chat_template.json"):
+        pth = os.path.join(processor_path, name)
+        if os.path.exists(pth):
+            template = open(pth).read()
+            if name.endswith(".json"):
+                template = json.loads(template)["chat_template"]
+            break
+    if template is None:
+        template = getattr(tokenizer, "chat_template", None)
+    return MiniQwen2VLProcessor(Qwen2VLImageProcessor(**cfg), tokenizer, template)
+
+
+# Qwen2.5-VL-7B architecture of the Qwen-Image text encoder (models/qwen_image_text_encoder_withdecode.py:8-147): data
+TEXT_ENCODER_CONFIG = dict(
+    text_config=dict(hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
+                     vocab_size=152064, max_position_embeddings=128000, rms_norm_eps=1e-6, rope_theta=1000000.0, hidden_act="silu",
+                     rope_scaling={"type": "default", "rope_type": "default", "mrope_section": [16, 24, 24]},
+                     tie_word_embeddings=False, use_sliding_window=False, sliding_window=None, max_window_layers=28,
+                     attention_dropout=0.0, bos_token_id=151643, eos_token_id=151645, pad_token_id=151645),
+    vision_config=dict(depth=32, hidden_size=1280, intermediate_size=3420, num_heads=16, out_hidden_size=3584, patch_size=14,
+                       spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[7, 15, 23, 31],
+                       in_chans=3, hidden_act="silu", tokens_per_second=2),
+    image_token_id=151655, video_token_id=151656, vision_start_token_id=151652, vision_end_token_id=151653,
+    bos_token_id=151643, eos_token_id=151645, tie_word_embeddings=False)
+
+
+def convert_text_encoder_keys(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Checkpoint layout -> transformers' Qwen2_5_VLForConditionalGeneration layout
+    (QwenImageTextEncoderStateDictConverter.from_diffusers, qwen_image_text_encoder_withdecode.py:286-297)."""
+    out = {}
+    for k, v in state_dict.items():
+        if k.startswith("visual."):
+            k = "model." + k
+        elif k.startswith("model.language_model."):
+            pass
+        elif k.startswith("model."):
+            k = k.replace("model.", "model.language_model.", 1)
+        out[k] = v
+    return out
+
+
+def build_text_encoder(state_dict: Dict[str, torch.Tensor], device, torch_dtype=torch.bfloat16, config: Optional[dict] = None):
+    """transformers' Qwen2_5_VLForConditionalGeneration, created directly on `device` in `torch_dtype` (16.6 GB for the
+    7B model: nothing next to 288 GB of HBM) and filled from the checkpoint tensors."""
+    import contextlib
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    cfg = Qwen2_5_VLConfig(**(config or TEXT_ENCODER_CONFIG))
+    try:
+        from transformers.modeling_utils import no_init_weights       # skip the random init: every tensor is overwritten
+        guard = no_init_weights()
+    except Exception:
+        guard = contextlib.nullcontext()
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch_dtype)
+    try:
+        with guard, torch.device(device):
+            model = Qwen2_5_VLForConditionalGeneration(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    missing, unexpected = model.load_state_dict(convert_text_encoder_keys(state_dict), strict=False)
+    missing = [k for k in missing if "rotary_emb" not in k and "inv_freq" not in k]
+    if missing:
+        raise RuntimeError(f"text encoder checkpoint misses {len(missing)} tensors, e.g. {missing[:3]}")
+    return model.eval()
+
+
+class PromptPrologue:
+    """callable installed as `pipe.prompt_encoder`:
+    (pipe, prompt=, negative_prompt=, edit_image=, cfg=, have_text_reasoning=) -> (posi, nega) dicts."""
+
+    def __init__(self, text_encoder, processor, tokenizer=None, device="cuda", torch_dtype=torch.bfloat16):
+        self.text_encoder = text_encoder
+        self.processor = processor
+        self.tokenizer = tokenizer if tokenizer is not None else processor.tokenizer
+        self.device = torch.device(device)
+        self.torch_dtype = torch_dtype
+        tok = processor.tokenizer
+        if tok.convert_tokens_to_ids("<begin_of_img>") in (None, getattr(tok, "unk_token_id", None)):
+            tok.add_special_tokens({"additional_special_tokens": special_tokens()})      # (:529-536)
+        self.boi_token_id = tok.convert_tokens_to_ids("<begin_of_img>")
+        self.eoi_token_id = tok.convert_tokens_to_ids("<end_of_img>")
+        self.last_physical_txt: Optional[str] = None
+
+    # ---- text encoder calls -------------------------------------------------------------------------------
+    def _last_hidden(self, model_inputs) -> torch.Tensor:
+        """text_encoder.edit_forward(...)[-1] (qwen_image_text_encoder_withdecode.py:188-275): the inner model with
+        output_hidden_states=True, last entry."""
+        keys = ("input_ids", "attention_mask", "pixel_values", "image_grid_thw")
+        kwargs = {k: model_inputs[k] for k in keys if k in model_inputs}
+        out = self.text_encoder.model(**kwargs, output_attentions=False, output_hidden_states=True, return_dict=True)
+        return out.hidden_states[-1]
+
+    @staticmethod
+    def _masked_rows(hidden_states: torch.Tensor, mask: torch.Tensor) -> List[torch.Tensor]:
+        """extract_masked_hidden (:742-748)."""
+        bool_mask = mask.bool()[:, :hidden_states.shape[1]]
+        lengths = bool_mask.sum(dim=1)
+        return list(torch.split(hidden_states[bool_mask], lengths.tolist(), dim=0))
+
+    # ---- PhysicalVerbalEmbedder at inference (:943-967, :859-873) -------------------------------------------
+    @torch.no_grad()
+    def physical_text(self, prompt: str, edit_image: Image.Image) -> str:
+        messages = [
+            {"role": "system", "content": SYSTEM_PROMPT_SAMPLE},
+            {"role": "user", "content": [{"type": "input_text", "text": "Edit Instruction:"}, {"type": "input_text", "text": prompt},
+                                         {"type": "input_text", "text": "Edit Image:"}, {"type": "image"}]},
+        ]
+        text = self.processor.apply_chat_template(messages, tokenize=False, add_generation_prompt=True, add_vision_id=True)
+        model_inputs = self.processor(text=[text], images=resize_for_vl(edit_image), padding=True, return_tensors="pt").to(self.device)
+        decoded_ids = self.text_encoder.generate(**model_inputs, max_new_tokens=1000)
+        trimmed = [out_ids[len(in_ids):] for in_ids, out_ids in zip(model_inputs["input_ids"], decoded_ids)]
+        decoded = self.tokenizer.batch_decode(trimmed, skip_special_tokens=True, clean_up_tokenization_spaces=False)[0]
+        try:
+            fields = parse_generation_response(decoded)
+        except ValueError:
+            return decoded
+        return "".join(f"\n{k}: {v}" for k, v in fields.items())
+
+    # ---- PromptEmbedder (:761-835) ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def embed(self, prompt: str, edit_image=None, physical_txt: Optional[str] = None) -> Dict[str, Optional[torch.Tensor]]:
+        if physical_txt is not None:
+            prompt = prompt + physical_txt
+        special_token_mask = None
+        if edit_image is None:
+            txt = [T2I_TEMPLATE.format(prompt)]
+            drop = T2I_DROP
+            mi = self.tokenizer(txt, max_length=4096 + drop, padding=True, truncation=True, return_tensors="pt").to(self.device)
+            if mi["input_ids"].shape[1] >= 1024:
+                print(f"Warning!!! QwenImage model was trained on prompts up to 512 tokens. Current prompt requires "
+                      f"{mi['input_ids'].shape[1] - drop} tokens, which may lead to unpredictable behavior.")
+        elif isinstance(edit_image, Image.Image):
+            suffix = "\n<begin_of_img>" + "".join(f"<img{i}>" for i in range(SPECIAL_TOKEN_NUM)) + "<end_of_img><|im_end|>"
+            txt = [EDIT_TEMPLATE.format(prompt + suffix)]
+            drop = EDIT_DROP
+            mi = self.processor(text=txt, images=resize_for_vl(edit_image), padding=True, return_tensors="pt").to(self.device)
+            ids = mi["input_ids"]
+            boi_pos = torch.where(ids == self.boi_token_id)[1]
+            eoi_pos = torch.where(ids == self.eoi_token_id)[1]
+            special_token_mask = torch.zeros_like(mi["attention_mask"], dtype=torch.bool)
+            special_token_mask[:, int(boi_pos[0]) + 1:int(eoi_pos[0])] = True
+            special_token_mask = special_token_mask[:, drop:]
+        else:
+            images = [resize_for_vl(im) for im in edit_image]
+            pictures = "".join(PICTURE_TEMPLATE.format(i + 1) for i in range(len(images)))
+            txt = [EDIT_MULTI_TEMPLATE.format(pictures + prompt)]
+            drop = EDIT_DROP
+            mi = self.processor(text=txt, images=images, padding=True, return_tensors="pt").to(self.device)
+        hidden = self._last_hidden(mi)
+        rows = [e[drop:] for e in self._masked_rows(hidden, mi["attention_mask"])]
+        max_len = max(e.size(0) for e in rows)
+        prompt_emb = torch.stack([torch.cat([u, u.new_zeros(max_len - u.size(0), u.size(1))]) for u in rows])
+        emb_mask = torch.stack([torch.cat([torch.ones(e.size(0), dtype=torch.long, device=e.device),
+                                           torch.zeros(max_len - e.size(0), dtype=torch.long, device=e.device)]) for e in rows])
+        return {"prompt_emb": prompt_emb.to(dtype=self.torch_dtype, device=self.device), "prompt_emb_mask": emb_mask,
+                "special_token_mask": special_token_mask}
+
+    # ---- the unit runner's separate-CFG protocol (utils/__init__.py:247-283) ----------------------------------
+    def __call__(self, pipe=None, prompt: str = "", negative_prompt: str = "", edit_image=None, cfg: bool = True,
+                 have_text_reasoning: bool = True) -> Tuple[Dict, Dict]:
+        physical_txt = None
+        if have_text_reasoning:
+            if not isinstance(edit_image, Image.Image):
+                raise ValueError("have_text_reasoning=True needs one edit image (encode_physical_prompt_sample, :943-967)")
+            physical_txt = self.physical_text(prompt, edit_image)
+        self.last_physical_txt = physical_txt
+        posi = self.embed(prompt, edit_image, physical_txt)
+        nega = self.embed(negative_prompt, edit_image, None) if cfg else dict(posi)
+        return posi, nega

@@ -9,8 +9,9 @@ What runs where:
   * hot path (this repo): noise, edit-image VAE encode, 40-step CFG loop on the DiT + adapter, VAE decode;
   * prompt prologue (reference / transformers, host Python): `pipe.prompt_encoder(pipe, prompt=..., negative_prompt=...,
     edit_image=..., cfg=...) -> (posi, nega)` dicts with `prompt_emb [1,T,3584]` and `special_token_mask [1,T]`.
-    `from_pretrained` installs nothing there: wire the reference's QwenImageUnit_PromptEmbedder /
-    PhysicalVerbalEmbedder (qwen_image_physical.py:732-990) or any callable producing the same tensors.
+    `from_pretrained` installs `prompt_prologue.PromptPrologue` (this repo's host-Python implementation over transformers'
+    Qwen2.5-VL: PhysicalVerbalEmbedder + PromptEmbedder, :732-990) when it is given the text-encoder checkpoint and the
+    tokenizer / processor directories; any callable producing the same tensors can be plugged instead.
 """
 from __future__ import annotations
 
@@ -116,8 +117,10 @@ class QwenImagePhysicPipeline:
     def from_pretrained(torch_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
                         model_configs: List[ModelConfig] = (), tokenizer_config: ModelConfig = None,
                         processor_config: ModelConfig = None, dinov2_path: str = None) -> "QwenImagePhysicPipeline":
-        """Same signature as the reference (:497-541).  Loads the DiT and VAE checkpoints onto the GPU in the
-        library's layout; text-encoder weights are kept as a raw state-dict for a user-installed prompt_encoder."""
+        """Same signature as the reference (:497-541).  Loads the DiT and VAE checkpoints onto the GPU in the library's
+        layout.  When the text-encoder checkpoint and the tokenizer / processor directories are given (validate.py gives
+        all three), the Qwen2.5-VL text encoder is instantiated with `transformers` on the same device and the prompt
+        prologue (prompt_prologue.PromptPrologue) is installed as `pipe.prompt_encoder`."""
         mm = ModelManager(torch_dtype=torch_dtype)
         for cfg in model_configs:
             cfg.download_if_necessary()
@@ -134,7 +137,28 @@ class QwenImagePhysicPipeline:
             if cfg is not None:
                 cfg.download_if_necessary()
                 setattr(pipe, name + "_path", cfg.path)
+        if isinstance(pipe.text_encoder, dict) and processor_config is not None:
+            pipe.install_prompt_prologue(pipe.text_encoder, getattr(pipe, "processor_path", None), getattr(pipe, "tokenizer_path", None))
         return pipe
+
+    text_encoder_config: Optional[dict] = None      # None = the Qwen2.5-VL-7B architecture of Qwen-Image (tests override it)
+
+    def install_prompt_prologue(self, text_encoder_state: Dict[str, torch.Tensor], processor_path: str, tokenizer_path: Optional[str]):
+        """Builds pipe.text_encoder / pipe.processor / pipe.tokenizer (:520-538) and installs the prologue."""
+        from . import prompt_prologue as PP
+        dev = self._prologue_device()
+        self.text_encoder = PP.build_text_encoder(text_encoder_state, dev, self.torch_dtype, self.text_encoder_config)
+        self.processor = PP.load_processor(processor_path, tokenizer_path)
+        if tokenizer_path is not None:
+            from transformers import Qwen2Tokenizer
+            self.tokenizer = Qwen2Tokenizer.from_pretrained(tokenizer_path)
+        else:
+            self.tokenizer = self.processor.tokenizer
+        self.prompt_encoder = PP.PromptPrologue(self.text_encoder, self.processor, self.tokenizer, device=dev, torch_dtype=self.torch_dtype)
+        self.boi_token_id, self.eoi_token_id = self.prompt_encoder.boi_token_id, self.prompt_encoder.eoi_token_id
+
+    def _prologue_device(self):
+        return self.device
 
     def set_dit(self, state_dict: Dict[str, torch.Tensor]):
         self._dit_state = state_dict
@@ -281,8 +305,9 @@ class QwenImagePhysicPipeline:
         if self.dit is None or self.vae is None:
             raise _lib.PeError("pipeline has no DiT/VAE weights: use from_pretrained() or set_dit()/set_vae()")
         if self.prompt_encoder is None:
-            raise _lib.PeError("no prompt_encoder installed: the Qwen2.5-VL prompt prologue is host code outside the hot "
-                               "path; set pipe.prompt_encoder (see INTEGRATION.md)")
+            raise _lib.PeError("no prompt_encoder installed: from_pretrained() builds the Qwen2.5-VL prompt prologue only when it "
+                               "gets the text-encoder checkpoint and the processor directory; otherwise set "
+                               "pipe.prompt_encoder (see INTEGRATION.md)")
         # ShapeChecker (:673-680)
         height, width = self.check_resize_height_width(height, width)
         # NoiseInitializer (:683-689): CPU generator, drawn directly in the pipeline dtype

@@ -375,6 +375,43 @@ def G10_image():
     save("G10_image", {"pre": x, "post_in": y, "post_u8": torch.from_numpy(np.array(img))})
 
 
+def G12_prologue():
+    """Prompt prologue (QwenImageUnit_PhysicalVerbalEmbedder + QwenImageUnit_PromptEmbedder, qwen_image_physical.py:732-990)
+    run by the REFERENCE's units on the synthetic tiny Qwen2.5-VL stack of tests/tiny_vl.py (byte-level tokenizer, seeded
+    2-layer model; the real 7B checkpoint and vocabulary cannot be used here).  Outputs only."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tiny_vl
+    from diffsynth.models.qwen_image_text_encoder_withdecode import QwenImageTextEncoderWithDecode
+    from diffsynth.pipelines.qwen_image_physical import (QwenImageUnit_PhysicalVerbalEmbedder, QwenImageUnit_PromptEmbedder,
+                                                         SPECIAL_TOKEN_NUM)
+    tmp = tempfile.mkdtemp(prefix="pe_tok_")
+    proc = tiny_vl.make_processor(tmp)
+    # from_pretrained (:529-538)
+    proc.tokenizer.add_special_tokens({"additional_special_tokens": ["<begin_of_img>", "<end_of_img>"]
+                                       + [f"<img{i}>" for i in range(SPECIAL_TOKEN_NUM)]})
+    te = tiny_vl.make_text_encoder(proc.tokenizer, extra_vocab=8)
+    te.edit_forward = types.MethodType(QwenImageTextEncoderWithDecode.edit_forward, te)     # the reference's own method
+    pipe = types.SimpleNamespace(device="cpu", torch_dtype=BF, tokenizer=proc.tokenizer, processor=proc, text_encoder=te,
+                                 boi_token_id=proc.tokenizer.convert_tokens_to_ids("<begin_of_img>"),
+                                 eoi_token_id=proc.tokenizer.convert_tokens_to_ids("<end_of_img>"))
+    img = tiny_vl.make_image(200, 120, 0)
+    img2 = tiny_vl.make_image(64, 96, 1)
+    verbal, embed = QwenImageUnit_PhysicalVerbalEmbedder(), QwenImageUnit_PromptEmbedder()
+    prompt, nega = "make the cup fall off the table", ""
+    phys = verbal.process(pipe, prompt, edit_image=img)["physical_txt"]
+    outs, meta = {}, {"physical_txt": phys, "prompt": prompt}
+    cases = {"edit": dict(prompt=prompt, edit_image=img, physical_txt=phys), "edit_nega": dict(prompt=nega, edit_image=img),
+             "t2i": dict(prompt="a red cube on a glass table"), "multi": dict(prompt="swap them", edit_image=[img, img2])}
+    for name, kw in cases.items():
+        r = embed.process(pipe, **kw)
+        outs[f"{name}.prompt_emb"] = r["prompt_emb"]
+        outs[f"{name}.prompt_emb_mask"] = r["prompt_emb_mask"]
+        if r["special_token_mask"] is not None:
+            outs[f"{name}.special_token_mask"] = r["special_token_mask"].to(torch.uint8)
+    save("G12_prologue", outs, meta=meta)
+
+
 GROUPS = {k: v for k, v in list(globals().items()) if k[0] == "G" and k[1].isdigit()}
 
 if __name__ == "__main__":

@@ -329,5 +329,5 @@ def test_lora_merge_alpha(alpha):
     assert eng.load_lora(lora, alpha=alpha) == 12
     for tname in synth.LORA_TARGETS:
         k = f"transformer_blocks.0.{tname}.weight"
-        u = ulps(eng.params[k], ref[k], floor=2.0 ** -12)
+        u = ulps(eng.params[k], ref[k])          # whole matrix: elements where W and the LoRA term cancel are judged at rms scale
         assert u.max().item() <= 1.01 and (u > 0).float().mean().item() < 0.01, (k, u.max().item())

@@ -145,3 +145,64 @@ def test_c3_fp8_computation_through_the_facade(tmp_path):
           f"mode effect (oracle e4m3 vs bf16) mean|d| {mode.mean().item():.4e}")
     assert torch.isfinite(pipe.last_latents.float()).all()
     assert dl.mean().item() <= 0.25 * mode.mean().item()
+
+
+def test_validate_flow_with_real_prologue(tmp_path):
+    """validate.py's whole argument flow on the REAL kernels, prompt prologue included (no stub): from_pretrained with the five
+    ModelConfigs of validate.py:97-125 (DiT, text encoder, VAE, tokenizer/, processor/), load_finetuned_into_pipe, then
+    pipe(prompt, edit_image=, seed=, num_inference_steps=4, height=, width=, is_train=False) with its defaults (CFG 4.0,
+    have_text_reasoning=True, auto-resized edit image).  The text encoder is the synthetic tiny Qwen2.5-VL of tests/tiny_vl.py
+    (3584 wide).  The hot path is then checked against the oracle fed with the prologue's own embeddings."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from test_validate_flow_host import write_finetuned_ckpt, write_model_tree
+    from diffsynth import load_state_dict
+    import diffsynth.pipelines.qwen_image_physical as Q
+    base = str(tmp_path / "models")
+    te_cfg = write_model_tree(base)
+    ckpt = str(tmp_path / "finetuned.safetensors")
+    write_finetuned_ckpt(ckpt)
+    Q.QwenImagePhysicPipeline.text_encoder_config = te_cfg
+    try:
+        pipe = Q.QwenImagePhysicPipeline.from_pretrained(
+            torch_dtype=torch.bfloat16, device="cuda",
+            model_configs=[
+                Q.ModelConfig(model_id="Qwen/Qwen-Image-Edit-2509", origin_file_pattern="transformer/diffusion_pytorch_model*.safetensors", local_model_path=base),
+                Q.ModelConfig(model_id="Qwen/Qwen-Image", origin_file_pattern="text_encoder/model*.safetensors", local_model_path=base),
+                Q.ModelConfig(model_id="Qwen/Qwen-Image", origin_file_pattern="vae/diffusion_pytorch_model.safetensors", local_model_path=base),
+            ],
+            tokenizer_config=Q.ModelConfig(model_id="Qwen/Qwen-Image", origin_file_pattern="tokenizer/", local_model_path=base),
+            processor_config=Q.ModelConfig(model_id="Qwen/Qwen-Image-Edit", origin_file_pattern="processor/", local_model_path=base),
+            dinov2_path="unused")
+    finally:
+        Q.QwenImagePhysicPipeline.text_encoder_config = None
+    assert pipe.prompt_encoder is not None and pipe.text_encoder is not None
+    full = load_state_dict(ckpt)
+    lora_state = {k: v for k, v in full.items() if "lora_A" in k or "lora_B" in k}
+    pipe.load_lora(pipe.dit, state_dict=lora_state)
+    pipe.load_state_dict({k[len("pipe."):]: v for k, v in full.items() if k not in lora_state and k.startswith("pipe.")}, strict=False)
+
+    img = Image.fromarray(synth.make_edit_image_u8(128, 128, 5))
+    prompt = "make the cup fall off the table"
+    out = pipe(prompt, edit_image=img, seed=3, num_inference_steps=2, height=256, width=256, is_train=False)
+    assert isinstance(out, Image.Image) and out.size == (256, 256)
+    assert torch.isfinite(pipe.last_latents.float()).all()
+    # the hot path vs the oracle on the prologue's own outputs (edit image auto-resized to 1024x1024 -> 4096 edit tokens)
+    posi, nega = pipe.prompt_encoder(pipe, prompt=prompt, negative_prompt="", edit_image=Q.QwenImagePhysicPipeline._auto_resize(img),
+                                     cfg=True, have_text_reasoning=True)
+    assert posi["prompt_emb"].shape[2] == 3584 and int(posi["special_token_mask"].sum()) == 64
+    dit_sd = synth.make_state_dict(synth.dit_layout(1), 1234)
+    assert O.lora_merge(dit_sd, synth.make_lora(4321, 1, 4)) == 12
+    ad_sd = synth.make_state_dict(synth.adapter_layout(), 4321)
+    O.VAE_CONV_MODE = "2d"
+    try:
+        edit_u8 = np.array(Q.QwenImagePhysicPipeline._auto_resize(img))
+        edit_lat = O.vae_encode(synth.make_state_dict(synth.vae_layout(), 77), O.preprocess_image(edit_u8))
+    finally:
+        O.VAE_CONV_MODE = "3d"
+    lat = O.denoise_loop(dit_sd, ad_sd, synth.make_noise(3, 256, 256), posi["prompt_emb"].cpu(), nega["prompt_emb"].cpu(),
+                         posi["special_token_mask"].cpu(), nega["special_token_mask"].cpu(), 256, 256, 2, cfg_scale=4.0,
+                         edit_latents=edit_lat)
+    dl = (pipe.last_latents.float().cpu() - lat.float()).abs()
+    print(f"[parity] validate flow with the real prologue: latents max|d| {dl.max().item():.4e} mean|d| {dl.mean().item():.4e}")
+    assert dl.mean().item() <= 5e-3 and dl.max().item() <= 0.125
