@@ -6,7 +6,7 @@ from typing import Dict, List, Union
 
 import torch
 
-from .utils import hash_state_dict_keys, load_state_dict
+from .utils import LazyStateDict, hash_state_dict_keys, load_state_dict
 
 # fingerprints of the official checkpoints' layouts (configs/model_config.py:21-24)
 _HASHES = {
@@ -43,9 +43,13 @@ class ModelManager:
 
     def load_model(self, file_path: Union[str, List[str]], device=None, torch_dtype=None):
         paths = file_path if isinstance(file_path, (list, tuple)) else [file_path]
-        sd: Dict[str, torch.Tensor] = {}
-        for p in sorted(paths):
-            sd.update(load_state_dict(p, torch_dtype=torch_dtype or self.torch_dtype, device="cpu"))
+        if all(str(p).endswith(".safetensors") for p in paths):
+            # lazily: the consumer (DiT engine, VAE, text encoder) pulls each tensor once, straight onto its device
+            sd = LazyStateDict(list(paths), torch_dtype=torch_dtype or self.torch_dtype, device="cpu")
+        else:
+            sd = {}
+            for p in sorted(paths):
+                sd.update(load_state_dict(p, torch_dtype=torch_dtype or self.torch_dtype, device="cpu"))
         self.model.append(sd)
         self.model_name.append(detect_model_name(sd))
         self.model_path.append(file_path)

@@ -137,7 +137,7 @@ class QwenImagePhysicPipeline:
             if cfg is not None:
                 cfg.download_if_necessary()
                 setattr(pipe, name + "_path", cfg.path)
-        if isinstance(pipe.text_encoder, dict) and processor_config is not None:
+        if pipe.text_encoder is not None and not hasattr(pipe.text_encoder, "forward") and processor_config is not None:
             pipe.install_prompt_prologue(pipe.text_encoder, getattr(pipe, "processor_path", None), getattr(pipe, "tokenizer_path", None))
         return pipe
 
@@ -161,13 +161,18 @@ class QwenImagePhysicPipeline:
         return self.device
 
     def set_dit(self, state_dict: Dict[str, torch.Tensor]):
+        if hasattr(state_dict, "to_device"):
+            state_dict.to_device(self.device)       # LazyStateDict: shards are read straight into HBM, tensor by tensor
         self._dit_state = state_dict
         # dtype the checkpoint was loaded in (ModelConfig.offload_dtype): the reference keys fp8 computation off it
-        self._dit_stored_dtype = next(iter(state_dict.values())).dtype
+        self._dit_stored_dtype = (state_dict.dtype_of_first() if hasattr(state_dict, "dtype_of_first")
+                                  else next(iter(state_dict.values())).dtype)
         self._build_engine()
+        if hasattr(state_dict, "close"):
+            state_dict.close()
 
     def set_vae(self, state_dict: Dict[str, torch.Tensor]):
-        self.vae = QwenImageVAE(state_dict, device=self.device)
+        self.vae = QwenImageVAE(dict(state_dict.items()) if hasattr(state_dict, "to_device") else state_dict, device=self.device)
 
     def _build_engine(self):
         ad = self.visual_thinking_adapter.state if self.visual_thinking_adapter.state else None
@@ -214,8 +219,8 @@ class QwenImagePhysicPipeline:
         self.extra_state.update(rest)
         if ad:
             self.visual_thinking_adapter.state.update({k: v.to(self.torch_dtype) for k, v in ad.items()})
-            if self._dit_state is not None:
-                self._build_engine()      # the engine binds adapter pointers at creation
+            if self.dit is not None:
+                self.dit.set_adapter(self.visual_thinking_adapter.state)   # re-binds 8 pointers; the 41 GB of DiT weights stay put
         return unexpected
 
     def enable_vram_management(self, num_persistent_param_in_dit=None, vram_limit=None, vram_buffer=0.5, auto_offload=True,

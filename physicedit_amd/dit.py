@@ -169,6 +169,16 @@ class QwenImageDiTEngine:
             self._handle = C.c_void_p()
         check(lib().pe_dit_create(C.byref(w), adp, C.byref(self._handle)), "pe_dit_create")
 
+    def set_adapter(self, adapter_state_dict: Optional[Dict[str, torch.Tensor]]):
+        """(Re)bind the visual-thinking adapter weights (pipe.load_state_dict of `visual_thinking_adapter.*`,
+        validate.py:55-65).  Only the C handle's pointer table is rebuilt: DiT weights, merged LoRAs and the e4m3 state are
+        untouched."""
+        self.adapter = None if adapter_state_dict is None else {
+            k: v.to(device=self.device, dtype=BF).contiguous() for k, v in adapter_state_dict.items()}
+        self._create()
+        self._apply_hot()
+        self._ws, self._bound, self._step_of = None, (0, 0, 0), {}
+
     def fork(self) -> "QwenImageDiTEngine":
         """A second execution context on the SAME device weights: own C handle, workspace and prepared tables.
         Lets the positive and the negative forward of a step run concurrently on two streams."""

@@ -330,4 +330,5 @@ def test_lora_merge_alpha(alpha):
     for tname in synth.LORA_TARGETS:
         k = f"transformer_blocks.0.{tname}.weight"
         u = ulps(eng.params[k], ref[k])          # whole matrix: elements where W and the LoRA term cancel are judged at rms scale
-        assert u.max().item() <= 1.01 and (u > 0).float().mean().item() < 0.01, (k, u.max().item())
+        # a one-ulp flip of bf16(B @ A) (fp32 summation order) is scaled by alpha before it meets W
+        assert u.max().item() <= max(1.0, alpha) + 0.01 and (u > 0).float().mean().item() < 0.01, (k, u.max().item())

@@ -87,6 +87,9 @@ def test_reference_validate_py_runs_unchanged_through_the_facade(tmp_path, monke
             Recorder.calls.append(("load_lora", len(sd), alpha, hotload))
             return len(sd) // 2
 
+        def set_adapter(self, ad):
+            Recorder.calls.append(("set_adapter", len(ad)))
+
     class FakeVAE:
         def __init__(self, sd, device):
             Recorder.calls.append(("vae", len(sd)))
@@ -133,8 +136,8 @@ def test_reference_validate_py_runs_unchanged_through_the_facade(tmp_path, monke
     assert kinds.count("engine") >= 1 and "vae" in kinds and "load_lora" in kinds
     lora = [c for c in Recorder.calls if c[0] == "load_lora"][0]
     assert lora[1] == 24 and lora[2] == 1.0 and lora[3] is False           # 12 targets x (A, B), merged (validate.py:52)
-    engines = [c for c in Recorder.calls if c[0] == "engine"]
-    assert engines[-1][2] == 8                                             # rebuilt with the 8 adapter tensors (load_state_dict)
+    assert kinds.count("engine") == 1                                      # the 41 GB engine is built ONCE ...
+    assert [c for c in Recorder.calls if c[0] == "set_adapter"] == [("set_adapter", 8)]   # ... load_state_dict only re-binds the adapter
     loop = [c for c in Recorder.calls if c[0] == "loop"][0]
     # resize_image: 160x96 -> area ~1024^2, /32: width 1312, height 800 (validate.py:20-31)
     assert (loop[6], loop[7]) == (800, 1312) and out.size == (1312, 800)
