@@ -214,9 +214,7 @@ def main():
         fl = flops_image(H, W, args.inference_steps, args.t_pos, args.t_neg, args.cfg, args.layers)
         g = prof["gemm"]
         achieved = (g["work"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic()
-        if args.fp8:
-            traffic, traffic_src = None, "not collected for the e4m3 configuration"
+        traffic, mfma_busy, traffic_src = pmc_traffic(args)
         headline = (H, W, args.inference_steps, args.cfg, args.layers) == (1024, 1024, 40, 4.0, 60)
         cfg_label = f"configs[{2 if args.fp8 else 1}]" if headline else (
             "configs[4] geometry on one GPU" if (H, W, args.inference_steps, args.layers) == (1328, 1328, 50, 60) else "non-headline geometry")
@@ -237,10 +235,13 @@ def main():
                        "finite_outputs": ok},
             "whole_path": {"algorithmic_pflop_per_image": fl / 1e15,
                            "achieved_tflops_per_gpu": fl * value / world / 1e12,
-                           "frac_of_bf16_mfma_peak": fl * value / world / 1e12 / PEAK_BF16_TFLOPS},
+                           "frac_of_bf16_mfma_peak": fl * value / world / 1e12 / PEAK_BF16_TFLOPS,
+                           "frac_of_operand_dtype_mfma_peak": fl * value / world / 1e12 / peak,
+                           "note": ("e4m3 Linears run on the 2x-rate block-scaled MFMA (peak %.0f TF/s), attention stays bf16: the "
+                                    "bf16 fraction can exceed what a bf16 path could reach" % PEAK_FP8_TFLOPS) if args.fp8 else None},
             "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "mfma_busy": mfma_busy, "traffic_source": traffic_src,
                          "launches_in_timed_region": g["launches"], "launches_sampled": g["sampled"],
                          "avg_launch_ms": g["ms"] / max(g["sampled"], 1),
                          "avg_algorithmic_gflop_per_launch": g["work"] / max(g["sampled"], 1) / 1e9,
@@ -265,18 +266,30 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the block GEMMs (launch-weighted mean over QKV / out-proj / MLP-up /
-    MLP-down).  PMC counters cannot be collected from inside this process; they come from the committed
-    rocprofv3 --pmc passes of this same command (tools/pmc_traffic_summary.py), or null if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(args):
+    """HBM-side (L2-miss) bytes per launch and matrix-pipe utilisation of the block GEMMs, launch-weighted over QKV / out-proj /
+    MLP-up / MLP-down.  PMC counters cannot be collected from inside this process: they come from the committed rocprofv3 --pmc
+    passes of tools/pmc_collect.sh (profiles/r02_pmc.json, which records its own command line).  They are per-launch properties
+    of (kernel, shape), so they are reported ONLY when this run launches the same kernels on the same shapes -- same layer count,
+    geometry, prompt lengths, operand dtype and stream count as the recorded command -- and are null otherwise."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
     if not os.path.exists(path):
-        return None, None
-    rows = [r for r in json.load(open(path))["kernels"] if "gemm_bf16_kernel" in r["kernel"] and r["workgroups"] >= 400]
+        return None, None, None
+    rec = json.load(open(path))
+    c = rec.get("config", {})
+    same = (c.get("layers") == args.layers and c.get("height") == args.height and c.get("width") == args.width and
+            c.get("t_pos") == args.t_pos and c.get("t_neg") == args.t_neg and bool(c.get("fp8")) == bool(args.fp8) and
+            bool(c.get("dual_stream")) == bool(args.dual_stream))
+    if not same:
+        return None, None, f"profiles/r02_pmc.json was collected for another configuration ({rec.get('command')}): not reported"
+    rows = [r for r in rec["kernels"] if "gemm_bf16_kernel" in r["kernel"] and r["workgroups"] >= 400]
     n = sum(r["launches"] for r in rows)
     if not n:
-        return None, None
-    return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n, "profiles/r01_pmc_traffic.json"
+        return None, None, None
+    traffic = sum(r["traffic_bytes_per_launch"] * r["launches"] for r in rows) / n
+    busy = [r for r in rows if r.get("mfma_busy") is not None]
+    mfma = sum(r["mfma_busy"] * r["launches"] for r in busy) / sum(r["launches"] for r in busy) if busy else None
+    return traffic, mfma, f"profiles/r02_pmc.json ({rec.get('command')})"
 
 
 def cpu_baseline(args):

@@ -80,11 +80,12 @@ def main():
         pipe, out["from_pretrained_seconds_page_cache_dropped"] = load()
     out["ingest_gb_per_s_warm"] = out["checkpoint_gb"] / out["from_pretrained_seconds_page_cache_warm"]
     # ---- validate.py:load_finetuned_into_pipe: LoRA merge of 12 targets x layers at rank 128, adapter state
+    # (the synthetic LoRA is generated and uploaded BEFORE the clock starts: a real run reads it from one safetensors file)
+    base = {k: v.to(dev) for k, v in synth.make_lora(4321, 1, 128).items()}
+    loras = [{k.replace("transformer_blocks.0.", f"transformer_blocks.{i}."): v for k, v in base.items()} for i in range(a.layers)]
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 0
-    for i in range(a.layers):
-        lora = {k.replace("transformer_blocks.0.", f"transformer_blocks.{i}."): v for k, v in synth.make_lora(4321 + i, 1, 128).items()}
-        n += pipe.dit.load_lora({k: v.to(dev) for k, v in lora.items()})
+    n = sum(pipe.dit.load_lora(lora) for lora in loras)
     torch.cuda.synchronize()
     out["lora_merge_tensors"] = n
     out["lora_merge_seconds"] = time.perf_counter() - t0
