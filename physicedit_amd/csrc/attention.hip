@@ -620,6 +620,289 @@ flash_attn_pp_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 3: four waves, ONE wave per SIMD, 64 query rows per wave (two 32-row blocks A and B) -- the structure
+// MI355X_MICROARCH.md / cdna_hip_programming.md (Appendix B) report as the fastest on this chip.  Each wave owns its
+// SIMD's whole 512-entry register file (O 128 + Q 64 + scores 64 + P 32 + K fragments 64 + Vt fragments 64), every K / Vt
+// fragment read from LDS feeds TWO MFMAs (half the LDS traffic per MFMA of the 8-wave kernels), and the softmax of
+// one block is software-pipelined under the other block's MFMAs inside the single instruction stream:
+//     phase 1   QK^T(A)   16 MFMA
+//     phase 2   QK^T(B)   16 MFMA  ||  softmax(A)  ||  Vt fragment reads of this tile
+//     phase 3   P.V(A)    16 MFMA  ||  softmax(B)
+//     -- s_waitcnt vmcnt(8) (own pieces of tile i+1) + the tile barrier --
+//     phase 4   P.V(B)    16 MFMA  ||  K fragment reads of tile i+1  ||  LDS-DMA of tile i+3 (ring slot of tile i-1)
+// Same arithmetic and summation order as flash_attn_kernel (bit-identical output).  One barrier per KV tile, 4-deep ring.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 1)
+flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
+                     bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
+                     float* __restrict__ part_o, float* __restrict__ part_ml) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Q_BLOCK = 256;
+    constexpr int KT_BYTES = KV_TILE * 256;        // 16 KiB
+    constexpr int V_BASE = PP_STAGES * KT_BYTES;   // K ring [0, 64 KiB), Vt ring [64 KiB, 128 KiB)
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int nqb = plan.nqb;
+    const int nt_all = (S + KV_TILE - 1) / KV_TILE;
+    int item, t_begin = 0, t_end = nt_all, part_slot = -1;
+    if ((int)blockIdx.x < plan.n_full) {
+        item = xcd_remap((int)blockIdx.x, plan.n_full);
+    } else {
+        const int j = (int)blockIdx.x - plan.n_full;
+        item = plan.n_full + j / plan.split;
+        const int part = j - (j / plan.split) * plan.split;
+        if (plan.split > 1) {
+            t_begin = (int)((long long)nt_all * part / plan.split);
+            t_end = (int)((long long)nt_all * (part + 1) / plan.split);
+            part_slot = j;
+        }
+    }
+    const int head = item / nqb;
+    const int qb = item - head * nqb;
+    const int q0 = qb * Q_BLOCK + w * 64;
+    const bf16* Qh = Q + (size_t)head * S_pad * 128;
+    const bf16* Kh = K + (size_t)head * S_pad * 128;
+    const bf16* Vh = Vt + (size_t)head * 128 * S_pad;
+
+    bf16x8 qf[2][8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int qrow = min(q0 + b * 32 + l31, S - 1);
+        const bf16* qp = Qh + (size_t)qrow * 128 + h * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[b][kk] = *(const bf16x8*)(qp + kk * 16);
+    }
+    // staging: wave w moves K pieces 4w..4w+3 (4 rows x 256 B each) and Vt pieces 4w..4w+3 (8 rows x 128 B each)
+    const bf16* k_src[4];
+    const bf16* v_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int krow = piece * 4 + (lane >> 4);
+        k_src[i] = Kh + (size_t)krow * 128 + ((lane & 15) ^ (krow & 15)) * 8;
+        const int vrow = piece * 8 + (lane >> 3);
+        v_src[i] = Vh + (size_t)vrow * S_pad + ((lane & 7) ^ ((vrow >> 1) & 7)) * 8;
+    }
+    const int n = t_end - t_begin;
+    auto stage = [&](int st, int i) {
+        const int t = t_begin + min(i, n - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(k_src[j] + (size_t)t * KV_TILE * 128, smem + st * KT_BYTES + w * 4096 + j * 1024);
+            glds16(v_src[j] + t * KV_TILE, smem + V_BASE + st * KT_BYTES + w * 4096 + j * 1024);
+        }
+    };
+
+    f32x16 o[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][dt][r] = 0.f;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    int kaddr[8], vaddr[4];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) kaddr[kk] = l31 * 256 + (((kk * 2 + h) ^ (l31 & 15)) << 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vaddr[c] = V_BASE + l31 * 128 + (((c * 2 + h) ^ ((l31 >> 1) & 7)) << 4);
+    const bool tail = (S & (KV_TILE - 1)) != 0 && t_end == nt_all;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    f32x16 sc[2][2];
+    u32x4 pk[2][4];
+    bf16x8 kf[16], vf[16];
+    auto k_frag = [&](int st, int idx) -> bf16x8 {      // idx = s2*8 + kk
+        return *(const bf16x8*)(smem + kaddr[idx & 7] + st * KT_BYTES + (idx >> 3) * 32 * 256);
+    };
+    auto v_frag = [&](int st, int idx) -> bf16x8 {      // idx = (s2*2 + k2)*4 + dt
+        return *(const bf16x8*)(smem + vaddr[idx >> 2] + st * KT_BYTES + (idx & 3) * 32 * 128);
+    };
+    // softmax of block b on sc[b] -> pk[b]; updates m_run / l_run / o[b]   (VALU only)
+    auto softmax = [&](auto b_tag, auto mask_tag, int t) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_tag)::value;
+        constexpr bool MASK = decltype(mask_tag)::value;
+        if constexpr (MASK) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (key >= S) sc[b][s2][r] = -INFINITY;
+                }
+        }
+        float mx = sc[b][0][0];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[b][s2][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[b], mx * scale_log2);
+        const bool moved = m_new != m_run[b];
+        const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+        m_run[b] = m_new;
+        if (__any(moved)) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][dt][r] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                float pr[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pr[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[b][s2][k2 * 8 + e], scale_log2, -m_new));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) psum += pr[e];
+                asm volatile("" : "+v"(psum));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bf16x2 two;
+                    two[0] = (bf16)pr[2 * e];
+                    two[1] = (bf16)pr[2 * e + 1];
+                    pk[b][s2 * 2 + k2][e] = __builtin_bit_cast(uint32_t, two);
+                }
+            }
+        l_run[b] = __builtin_fmaf(l_run[b], alpha, psum);
+    };
+    auto qk = [&](auto b_tag) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_tag)::value;
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx)
+            sc[b][idx >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[idx], qf[b][idx & 7], (idx & 7) == 0 ? zero : sc[b][idx >> 3], 0, 0, 0);
+    };
+    auto pv = [&](auto b_tag) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_tag)::value;
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx)
+            o[b][idx & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[idx], __builtin_bit_cast(bf16x8, pk[b][idx >> 2]), o[b][idx & 3], 0, 0, 0);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+
+    auto tile = [&](auto st_tag, auto mask_tag, int i) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_tag)::value;
+        const int t = t_begin + i;
+        // phase 1: QK^T(A) (K fragments: read in phase 4 of the previous tile / in the prologue)
+        qk(B0{});
+        W4_SB();
+        // phase 2: QK^T(B) || softmax(A) || Vt fragment reads
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) vf[idx] = v_frag(ST, idx);
+        qk(B1{});
+        softmax(B0{}, mask_tag, t);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
+        }
+        W4_SB();
+        // phase 3: P.V(A) || softmax(B)
+        pv(B0{});
+        softmax(B1{}, mask_tag, t);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
+        }
+        W4_SB();
+        // this wave's pieces of tile i+1 landed (tile i+2's 8 may still fly), then everyone's; every wave is also done
+        // reading tile i's K and Vt (and tile i-1's), so the ring slot of tile i-1 can be refilled
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        W4_SB();
+        __builtin_amdgcn_s_barrier();
+        W4_SB();
+        // phase 4: P.V(B) || K fragment reads of tile i+1 || LDS-DMA of tile i+3
+        stage((ST + 3) & 3, i + 3);
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) kf[idx] = k_frag((ST + 1) & 3, idx);
+        pv(B1{});
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        W4_SB();
+    };
+
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
+    using NM = std::false_type;
+    using MK = std::true_type;
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) kf[idx] = k_frag(0, idx);
+    const int n_plain = tail ? n - 1 : n;
+    int i = 0;
+    for (; i + 4 <= n_plain; i += 4) {
+        tile(T0{}, NM{}, i); tile(T1{}, NM{}, i + 1); tile(T2{}, NM{}, i + 2); tile(T3{}, NM{}, i + 3);
+    }
+    if (i < n_plain) tile(T0{}, NM{}, i);
+    if (i + 1 < n_plain) tile(T1{}, NM{}, i + 1);
+    if (i + 2 < n_plain) tile(T2{}, NM{}, i + 2);
+    if (tail) {
+        switch ((n - 1) & 3) {
+            case 0: tile(T0{}, MK{}, n - 1); break;
+            case 1: tile(T1{}, MK{}, n - 1); break;
+            case 2: tile(T2{}, MK{}, n - 1); break;
+            default: tile(T3{}, MK{}, n - 1); break;
+        }
+    }
+#undef W4_SB
+
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+        if (part_slot >= 0) {
+            float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 32 + l31) * 128 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = o[b][dt][4 * a + r];
+                    *(f32x4*)(po + dt * 32 + 8 * a) = v;
+                }
+            if (h == 0) {
+                float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 32 + l31) * 2;
+                pm[0] = m_run[b];
+                pm[1] = l_tot;
+            }
+            continue;
+        }
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + b * 32 + l31;
+        if (q < S) {
+            bf16* op = out + (size_t)q * ldo + head * 128 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[b][dt][4 * a + r] * inv);
+                    *(bf16x4*)(op + dt * 32 + 8 * a) = v;
+                }
+        }
+    }
+}
+
 // merge the `split` partials of each leftover (head, q-block): O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M)
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o,
                                                            const float* __restrict__ part_ml, bf16* __restrict__ out,
@@ -699,6 +982,8 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
             e = hipFuncSetAttribute((const void*)flash_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
@@ -719,7 +1004,10 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
 #define PE_ATTN_LAUNCH(NWV)                                                                                       \
     hipLaunchKernelGGL((flash_attn_kernel<NWV>), grid, dim3(NWV * 64), ATT_LDS, stream, (const bf16*)q, (const bf16*)k, \
                        (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml)
-    if (g_attn_variant == 2)
+    if (g_attn_variant == 3)
+        hipLaunchKernelGGL(flash_attn_w4_kernel, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                           (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
+    else if (g_attn_variant == 2)
         hipLaunchKernelGGL(flash_attn_pp_kernel, grid, dim3(512), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                            (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
     else if (NW == 4) PE_ATTN_LAUNCH(4);
