@@ -21,7 +21,7 @@ HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "physice
 # float(bf16(a*b)) + float(c) to bf16 fmul/fadd and the default -ffp-contract=fast then fuses them
 # into one fma, silently deleting a bf16 rounding the reference performs (measured: 29 % of
 # ln_modulate outputs off by one ulp).  Fusion is written explicitly (fmaf) where it is wanted.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

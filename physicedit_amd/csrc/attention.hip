@@ -25,6 +25,7 @@
 // LDS tiles are XOR-swizzled at 16-B granularity (applied on the LDS-DMA source address and on the
 // read) so every ds_read_b128 lane group is bank-conflict free.
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "kernels.h"
@@ -623,17 +624,78 @@ flash_attn_pp_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
 
 // ---------------------------------------------------------------------------------------------------------------
 // Variant 3: four waves, ONE wave per SIMD, 64 query rows per wave (two 32-row blocks A and B) -- the structure
-// MI355X_MICROARCH.md / cdna_hip_programming.md (Appendix B) report as the fastest on this chip.  Each wave owns its
-// SIMD's whole 512-entry register file (O 128 + Q 64 + scores 64 + P 32 + K fragments 64 + Vt fragments 64), every K / Vt
-// fragment read from LDS feeds TWO MFMAs (half the LDS traffic per MFMA of the 8-wave kernels), and the softmax of
-// one block is software-pipelined under the other block's MFMAs inside the single instruction stream:
+// MI355X_MICROARCH.md / cdna_hip_programming.md (Appendix B) report as the fastest on this chip.  Each wave owns its SIMD's
+// whole 512-entry register file.  The split between its two halves is fixed by hand, through the register-class
+// constraints of the MFMA statements (hipcc's own assignment of a 512-register kernel shuttles accumulators between the
+// halves: ~240 v_accvgpr copies per tile and spills):
+//     accumulator half (256):  O 128  |  Q fragments 64  |  K fragments of one tile 64      -- touched by MFMAs only
+//     arch half       (256):  scores 64  |  packed P 32  |  Vt fragments 64  |  softmax temporaries, addresses
+// Every K / Vt fragment read from LDS feeds TWO MFMAs (half the LDS traffic per MFMA of the 8-wave kernels), and the softmax
+// of one block is sliced into the 16 MFMA gaps of the other block's matrix phase, in source order:
 //     phase 1   QK^T(A)   16 MFMA
-//     phase 2   QK^T(B)   16 MFMA  ||  softmax(A)  ||  Vt fragment reads of this tile
-//     phase 3   P.V(A)    16 MFMA  ||  softmax(B)
+//     phase 2   QK^T(B)   16 MFMA  ||  softmax(A) slices  ||  Vt fragment reads of this tile
+//     phase 3   P.V(A)    16 MFMA  ||  softmax(B) slices
 //     -- s_waitcnt vmcnt(8) (own pieces of tile i+1) + the tile barrier --
 //     phase 4   P.V(B)    16 MFMA  ||  K fragment reads of tile i+1  ||  LDS-DMA of tile i+3 (ring slot of tile i-1)
 // Same arithmetic and summation order as flash_attn_kernel (bit-identical output).  One barrier per KV tile, 4-deep ring.
+// MFMAs are asm statements: the compiler neither pads their hazards nor counts them -- the s_nop statements below are the
+// "XDL write -> VALU read" wait states (cdna guide 5.7 item 2); LDS reads stay C++ loads (the compiler's lgkmcnt covers them).
 // ---------------------------------------------------------------------------------------------------------------
+template <int OFF> PE_DEV void lds_read_to_a(u32x4& d, int addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "i"(OFF));
+}
+template <int OFF> PE_DEV void lds_read_to_v(u32x4& d, int addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+// the compiler does not count asm LDS reads: the wait names the register it makes valid, so no use can move above it
+template <int N> PE_DEV void lds_wait_v(u32x4& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+template <int N> PE_DEV void lds_wait_a(u32x4& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(d) : "n"(N)); }
+PE_DEV void mfma_qk(f32x16& d, const u32x4& k_frag, const u32x4& q_frag, bool first) {   // d (arch) = K(acc) . Q(acc) (+ d)
+    if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(k_frag), "a"(q_frag));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(k_frag), "a"(q_frag));
+}
+PE_DEV void mfma_pv(f32x16& d, const u32x4& v_frag, const u32x4& p_frag) {               // d (acc) += Vt(acc) . P(arch)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(v_frag), "v"(p_frag));
+}
+// x (op) x-of-lane^32 on every lane, by v_permlane32_swap (no LDS traffic: the LDS queue is counted by hand below).  After the swap
+// of two copies, one register holds the low half's value on all lanes and the other the high half's.  A VALU write needs two
+// wait states before v_permlane32_swap reads it.
+PE_DEV float max_with_lane_xor32(float x) {
+    float y;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(x), "=&v"(y));
+    return x;
+}
+PE_DEV float sum_with_lane_xor32(float x) {
+    float y;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_add_f32 %0, %0, %1" : "+v"(x), "=&v"(y));
+    return x;
+}
+
+// Variant 3: 4 waves x 64 query rows, ONE wave per SIMD with the whole 512-register file, software-pipelined across KV tiles.
+//   accumulator half: O (128) + Q fragments (64) + rolling windows of K and Vt fragments (~24 + ~16); arch half: the scores
+//   of two tiles (128), P (32), addresses.  Every MFMA is an asm statement whose constraints name the
+//   half each operand lives in, so nothing is copied across; all LDS reads are asm with hand-counted lgkmcnt.
+//   iteration i = two phases of 32 MFMAs, one barrier:
+//     phase 1  QK^T(tile i+1)  ||  K(i+1) fragment reads 2 k-steps ahead, second part of softmax(i): remaining exp2, row
+//                                  sums, bf16 packs; O rescale if the max moved
+//     phase 2  P.V(tile i)     ||  Vt(i) fragment reads 3 ahead, LDS-DMA of tile i+3,
+//                                  first part of softmax(i+1): mask, row max, m / alpha, the first SM_EARLY exp2 per block
+//   every (MFMA, fillers) pair is fenced with sched_barrier(0): source order is the schedule (~5 fillers per MFMA gap).
+//   The arithmetic (and its order) is that of flash_attn_kernel: results are bit-identical.
+namespace w4 {
+constexpr int SM_EARLY = 12;      // exp2 of a block's first SM_EARLY scores run in phase 2 (of the iteration before)
+// softmax(i) is cut in PAIRS of scores (one bf16x2 of P each; 16 per block): the first SM_EARLY / 2 pairs of a block run in
+// phase 2 of the iteration before (slices 10..31), the rest in phase 1 (slices 0..29).  pair index e: block e & 1
+constexpr int early_lo(int g) { return g < 10 ? 0 : ((g - 10) * SM_EARLY) / 22; }
+constexpr int late_lo(int g) { return g >= 30 ? 32 - SM_EARLY : (g * (32 - SM_EARLY)) / 30; }
+static_assert(early_lo(32) == SM_EARLY && late_lo(0) == 0 && late_lo(32) == 32 - SM_EARLY, "softmax slices must cover every pair");
+// LDS queue (all reads are asm, in issue order): phase 1  [K0..K3 of the tile, issued at the end of the phase 2 before]  K4 K5 (gaps 0, 1)
+// K6 K7 (gaps 4, 5) ... K14 K15 (gaps 20, 21), Vt0..Vt2 (gaps 29..31); phase 2  Vt(f+3) in gap 2f, K0..K3 of the next tile in gaps
+// 28..31.  lgkmcnt(N) before a fragment's first use = the number of reads issued after it by then.
+constexpr int k_wait(int j) { return j <= 12 ? 3 : 15 - j; }
+constexpr int v_wait(int f) { return f == 14 ? 1 : 2; }
+}  // namespace w4
+
 __global__ void __launch_bounds__(256, 1)
 flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
                      bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
@@ -641,7 +703,7 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Q_BLOCK = 256;
     constexpr int KT_BYTES = KV_TILE * 256;        // 16 KiB
-    constexpr int V_BASE = PP_STAGES * KT_BYTES;   // K ring [0, 64 KiB), Vt ring [64 KiB, 128 KiB)
+    constexpr int V_BASE = PP_STAGES * KT_BYTES;   // K ring [0, 64 KiB), Vt ring [64 KiB, 128 KiB); tile t sits in slot t & 3
     const int lane = lane_id();
     const int w = wave_id();
     const int l31 = lane & 31, h = lane >> 5;
@@ -668,33 +730,46 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
     const bf16* Kh = K + (size_t)head * S_pad * 128;
     const bf16* Vh = Vt + (size_t)head * 128 * S_pad;
 
-    bf16x8 qf[2][8];
+    u32x4 qf[2][8];          // Q fragments: defined in the accumulator half by asm, never moved again
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int qrow = min(q0 + b * 32 + l31, S - 1);
         const bf16* qp = Qh + (size_t)qrow * 128 + h * 8;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[b][kk] = *(const bf16x8*)(qp + kk * 16);
+        for (int kk = 0; kk < 8; ++kk) {
+            const u32x4 tq = *(const u32x4*)(qp + kk * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(qf[b][kk][e]) : "v"(tq[e]));
+        }
     }
-    // staging: wave w moves K pieces 4w..4w+3 (4 rows x 256 B each) and Vt pieces 4w..4w+3 (8 rows x 128 B each)
-    const bf16* k_src[4];
-    const bf16* v_src[4];
+    // staging: wave w moves K pieces 4w..4w+3 (4 rows x 256 B each) and Vt pieces 4w..4w+3 (8 rows x 128 B each); the source is a
+    // wave-uniform tile base plus a 32-bit per-lane byte offset (64-bit per-lane pointers would not fit the register budget)
+    uint32_t k_off[4], v_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = w * 4 + i;
         const int krow = piece * 4 + (lane >> 4);
-        k_src[i] = Kh + (size_t)krow * 128 + ((lane & 15) ^ (krow & 15)) * 8;
+        k_off[i] = (uint32_t)(krow * 128 + ((lane & 15) ^ (krow & 15)) * 8) * 2u;
         const int vrow = piece * 8 + (lane >> 3);
-        v_src[i] = Vh + (size_t)vrow * S_pad + ((lane & 7) ^ ((vrow >> 1) & 7)) * 8;
+        v_off[i] = (uint32_t)(vrow * S_pad + ((lane & 7) ^ ((vrow >> 1) & 7)) * 8) * 2u;
     }
     const int n = t_end - t_begin;
-    auto stage = [&](int st, int i) {
+    // buffer-addressed LDS-DMA: SGPR descriptor of the head + SGPR tile offset + the lane's 32-bit offset (no 64-bit VALU math)
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, 0x7fffffff, 0x00020000);
+    auto stage_k = [&](int st, int i, int j) {
         const int t = t_begin + min(i, n - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(smem + st * KT_BYTES + w * 4096 + j * 1024),
+                                                 16, (int)k_off[j], t * (KV_TILE * 256), 0, 0);
+    };
+    auto stage_v = [&](int st, int i, int j) {
+        const int t = t_begin + min(i, n - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(smem + V_BASE + st * KT_BYTES + w * 4096 + j * 1024),
+                                                 16, (int)v_off[j], t * (KV_TILE * 2), 0, 0);
+    };
+    auto stage = [&](int st, int i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(k_src[j] + (size_t)t * KV_TILE * 128, smem + st * KT_BYTES + w * 4096 + j * 1024);
-            glds16(v_src[j] + t * KV_TILE, smem + V_BASE + st * KT_BYTES + w * 4096 + j * 1024);
-        }
+        for (int j = 0; j < 4; ++j) { stage_k(st, i, j); stage_v(st, i, j); }
     };
 
     f32x16 o[2][4];
@@ -703,7 +778,7 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[b][dt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(o[b][dt][r]));
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
     int kaddr[8], vaddr[4];
 #pragma unroll
@@ -711,163 +786,194 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
 #pragma unroll
     for (int c = 0; c < 4; ++c) vaddr[c] = V_BASE + l31 * 128 + (((c * 2 + h) ^ ((l31 >> 1) & 7)) << 4);
     const bool tail = (S & (KV_TILE - 1)) != 0 && t_end == nt_all;
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    f32x16 sc[2][2];
-    u32x4 pk[2][4];
-    bf16x8 kf[16], vf[16];
-    auto k_frag = [&](int st, int idx) -> bf16x8 {      // idx = s2*8 + kk
-        return *(const bf16x8*)(smem + kaddr[idx & 7] + st * KT_BYTES + (idx >> 3) * 32 * 256);
+    f32x16 sc[2][2][2];      // [tile parity][q block][key half]
+    u32x4 pk[2][2][4];       // P, bf16 pairs: [tile parity][q block][16-key chunk]
+    u32x4 kf[16], vf[16];    // K / Vt fragments, accumulator half: ~6 / ~4 live at a time
+    float sm_mx[2], sm_sub[2], sm_alpha[2], sm_psum[2];
+    bool sm_moved[2];
+
+    auto k_read = [&](auto slot_tag, auto idx_tag) __attribute__((always_inline)) {      // idx = kk*2 + s2 (order of first use)
+        constexpr int st = decltype(slot_tag)::value, idx = decltype(idx_tag)::value;
+        lds_read_to_a<st * KT_BYTES + (idx & 1) * 32 * 256>(kf[idx], kaddr[idx >> 1]);
     };
-    auto v_frag = [&](int st, int idx) -> bf16x8 {      // idx = (s2*2 + k2)*4 + dt
-        return *(const bf16x8*)(smem + vaddr[idx >> 2] + st * KT_BYTES + (idx & 3) * 32 * 128);
+    auto v_read = [&](auto slot_tag, auto idx_tag) __attribute__((always_inline)) {      // idx = c*4 + dt
+        constexpr int st = decltype(slot_tag)::value, idx = decltype(idx_tag)::value;
+        lds_read_to_a<st * KT_BYTES + (idx & 3) * 32 * 128>(vf[idx], vaddr[idx >> 2]);
     };
-    // softmax of block b on sc[b] -> pk[b]; updates m_run / l_run / o[b]   (VALU only)
-    auto softmax = [&](auto b_tag, auto mask_tag, int t) __attribute__((always_inline)) {
-        constexpr int b = decltype(b_tag)::value;
-        constexpr bool MASK = decltype(mask_tag)::value;
-        if constexpr (MASK) {
+    // the 32 QK^T MFMAs of one tile in issue order g: kk = g >> 2, q block = (g >> 1) & 1, key half = g & 1
+    auto qk_mfma = [&](auto p_tag, auto g_tag) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_tag)::value, g = decltype(g_tag)::value;
+        if constexpr (((g >> 1) & 1) == 0) lds_wait_a<w4::k_wait((g >> 2) * 2 + (g & 1))>(kf[(g >> 2) * 2 + (g & 1)]);
+        mfma_qk(sc[P][(g >> 1) & 1][g & 1], kf[(g >> 2) * 2 + (g & 1)], qf[(g >> 1) & 1][g >> 2], (g >> 2) == 0);
+    };
+    // K fragment read that rides in gap g of a QK^T phase (tile in ring slot `slot`): fragments 4.. in gaps 4kk, 4kk+1
+    auto k_ahead = [&](auto slot_tag, auto g_tag) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_tag)::value;
+        if constexpr ((g & 3) < 2 && (g >> 2) <= 5) k_read(slot_tag, std::integral_constant<int, ((g >> 2) + 2) * 2 + (g & 1)>{});
+    };
+
+    // scores 2q, 2q+1 of block b -> exp2, row sum (score order, as in flash_attn_kernel), one packed bf16 pair of P
+    // One asm statement per pair: it stays in its slice (pure arithmetic is otherwise free to float across the MFMA statements
+    // when the block is linearised, long before the fences are looked at) and is exactly 7 instructions.  v_exp_f32 results are
+    // first read two instructions later (trans-use hazard).
+    auto sm_pair = [&](auto p_tag, int b, int q) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_tag)::value;
+        const int f = 2 * q, s2 = f >> 4, r0 = f & 15;
+        float t0, t1;
+        uint32_t packed;
+        asm volatile("v_fma_f32 %2, %4, %6, -%7\n\t"
+                     "v_fma_f32 %3, %5, %6, -%7\n\t"
+                     "v_exp_f32 %2, %2\n\t"
+                     "v_exp_f32 %3, %3\n\t"
+                     "v_add_f32 %0, %0, %2\n\t"
+                     "v_add_f32 %0, %0, %3\n\t"
+                     "v_cvt_pk_bf16_f32 %1, %2, %3"
+                     : "+v"(sm_psum[b]), "=v"(packed), "=&v"(t0), "=&v"(t1)
+                     : "v"(sc[P][b][s2][r0]), "v"(sc[P][b][s2][r0 + 1]), "s"(scale_log2), "v"(sm_sub[b]));
+        pk[P][b][s2 * 2 + (r0 >> 3)][(r0 & 7) >> 1] = packed;
+    };
+    // ---- first part of softmax(tile in score buffer P), slice g of 32 (phase 2 of the iteration before)
+    // `live` = the tile exists (iterations are issued in fours: a tile past the end contributes P = 0 and leaves m, l alone);
+    // `mask` = it is the ragged last tile of the sequence.  Both are wave-uniform.
+    auto sm_start = [&](auto p_tag, auto g_tag, bool live, bool mask, int t) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_tag)::value, g = decltype(g_tag)::value;
+        if constexpr (g < 8) {                      // running max over scores 4g .. 4g+3 of both blocks
+            if (mask) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    if (key >= S) sc[b][s2][r] = -INFINITY;
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = g * 4 + e, s2 = f >> 4, r = f & 15;
+                        const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                        if (key >= S) sc[P][b][s2][r] = -INFINITY;
+                    }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                constexpr int s2 = (g * 4) >> 4, r = (g * 4) & 15;
+                if constexpr (g == 0)
+                    asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4"
+                                 : "=&v"(sm_mx[b]) : "v"(sc[P][b][0][0]), "v"(sc[P][b][0][1]), "v"(sc[P][b][0][2]), "v"(sc[P][b][0][3]));
+                else
+                    asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4"
+                                 : "+v"(sm_mx[b]) : "v"(sc[P][b][s2][r]), "v"(sc[P][b][s2][r + 1]), "v"(sc[P][b][s2][r + 2]), "v"(sc[P][b][s2][r + 3]));
+            }
+        } else if constexpr (g < 10) {
+            constexpr int b = g - 8;
+            const float mx = max_with_lane_xor32(sm_mx[b]);
+            const float m_new = live ? fmaxf(m_run[b], mx * scale_log2) : m_run[b];
+            sm_moved[b] = __any(m_new != m_run[b]);
+            sm_alpha[b] = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+            m_run[b] = m_new;
+            sm_sub[b] = live ? m_new : INFINITY;    // exp2(s - inf) = 0
+            sm_psum[b] = 0.f;
+            asm volatile("" : "+v"(sm_alpha[b]), "+v"(sm_sub[b]), "+v"(m_run[b]));
+        } else {                                    // early pairs
+#pragma unroll
+            for (int e = w4::early_lo(g); e < w4::early_lo(g + 1); ++e) sm_pair(p_tag, e & 1, e >> 1);
         }
-        float mx = sc[b][0][0];
+    };
+    // ---- second part of softmax(tile in score buffer P), slice g of 32 (phase 1)
+    auto sm_finish = [&](auto p_tag, auto g_tag) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_tag)::value;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int e = w4::late_lo(g); e < w4::late_lo(g + 1); ++e) sm_pair(p_tag, e & 1, w4::SM_EARLY / 2 + (e >> 1));
+        if constexpr (g == 31) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[b][s2][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[b], mx * scale_log2);
-        const bool moved = m_new != m_run[b];
-        const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
-        m_run[b] = m_new;
-        if (__any(moved)) {
+            for (int b = 0; b < 2; ++b) l_run[b] = __builtin_fmaf(l_run[b], sm_alpha[b], sm_psum[b]);
+        }
+    };
+    auto rescale = [&](int b) __attribute__((always_inline)) {     // O(block b) *= alpha, after the P.V of the tile before is done
+        if (sm_moved[b]) {
+            const float alpha = sm_alpha[b];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[b][dt][r] *= alpha;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                float pr[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pr[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[b][s2][k2 * 8 + e], scale_log2, -m_new));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) psum += pr[e];
-                asm volatile("" : "+v"(psum));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bf16x2 two;
-                    two[0] = (bf16)pr[2 * e];
-                    two[1] = (bf16)pr[2 * e + 1];
-                    pk[b][s2 * 2 + k2][e] = __builtin_bit_cast(uint32_t, two);
+                for (int r = 0; r < 16; ++r) {
+                    float tmp;
+                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                                 : "+a"(o[b][dt][r]), "=&v"(tmp) : "v"(alpha));
                 }
-            }
-        l_run[b] = __builtin_fmaf(l_run[b], alpha, psum);
+        }
     };
-    auto qk = [&](auto b_tag) __attribute__((always_inline)) {
-        constexpr int b = decltype(b_tag)::value;
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx)
-            sc[b][idx >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[idx], qf[b][idx & 7], (idx & 7) == 0 ? zero : sc[b][idx >> 3], 0, 0, 0);
-    };
-    auto pv = [&](auto b_tag) __attribute__((always_inline)) {
-        constexpr int b = decltype(b_tag)::value;
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx)
-            o[b][idx & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[idx], __builtin_bit_cast(bf16x8, pk[b][idx >> 2]), o[b][idx & 3], 0, 0, 0);
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-#define W4_SB() __builtin_amdgcn_sched_barrier(0)
 
-    auto tile = [&](auto st_tag, auto mask_tag, int i) __attribute__((always_inline)) {
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // iteration i: tile i (ring slot ST = i & 3, score buffer ST & 1) gets its P.V, tile i+1 its QK^T.  ONE body per ring slot:
+    // more instantiations (peeled / masked variants) cost the register allocator its footing (lane-constant addresses get
+    // spilled, and a scratch reload's vmcnt(0) would serialise the LDS-DMA).
+    auto iter = [&](auto st_tag, int i) __attribute__((always_inline)) {
         constexpr int ST = decltype(st_tag)::value;
-        const int t = t_begin + i;
-        // phase 1: QK^T(A) (K fragments: read in phase 4 of the previous tile / in the prologue)
-        qk(B0{});
-        W4_SB();
-        // phase 2: QK^T(B) || softmax(A) || Vt fragment reads
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx) vf[idx] = v_frag(ST, idx);
-        qk(B1{});
-        softmax(B0{}, mask_tag, t);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
-        }
-        W4_SB();
-        // phase 3: P.V(A) || softmax(B)
-        pv(B0{});
-        softmax(B1{}, mask_tag, t);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
-        }
-        W4_SB();
-        // this wave's pieces of tile i+1 landed (tile i+2's 8 may still fly), then everyone's; every wave is also done
-        // reading tile i's K and Vt (and tile i-1's), so the ring slot of tile i-1 can be refilled
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        W4_SB();
+        using PC = std::integral_constant<int, ST & 1>;            // scores of tile i
+        using PN = std::integral_constant<int, (ST & 1) ^ 1>;      // scores of tile i+1
+        using SLOT_V = std::integral_constant<int, ST>;            // Vt(i)
+        using SLOT_K1 = std::integral_constant<int, (ST + 1) & 3>; // K(i+1)
+        using SLOT_K2 = std::integral_constant<int, (ST + 2) & 3>; // K(i+2)
+        constexpr int SLOT_D = (ST + 3) & 3;                       // destination of tile i+3
+        const int t_next = t_begin + i + 1;
+        const bool live_next = i + 1 < n;
+        const bool mask_next = tail && i + 1 == n - 1;
+        // ---- phase 1
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            ((qk_mfma(PN{}, std::integral_constant<int, G>{}), k_ahead(SLOT_K1{}, std::integral_constant<int, G>{}),
+              (G == 2 ? rescale(0) : G == 3 ? rescale(1) : (void)0),
+              sm_finish(PC{}, std::integral_constant<int, G>{}),
+              (G >= 29 ? v_read(SLOT_V{}, std::integral_constant<int, (G >= 29 ? G - 29 : 0)>{}) : (void)0),
+              W4_FENCE()), ...);
+        }(std::make_integer_sequence<int, 32>{});
+        // own pieces of tile i+2 landed (issued one iteration ago), then everyone's; every wave is past its reads of
+        // tile i-1's Vt and K, so slot (i+3) & 3 can be refilled
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4_FENCE();
         __builtin_amdgcn_s_barrier();
-        W4_SB();
-        // phase 4: P.V(B) || K fragment reads of tile i+1 || LDS-DMA of tile i+3
-        stage((ST + 3) & 3, i + 3);
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx) kf[idx] = k_frag((ST + 1) & 3, idx);
-        pv(B1{});
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        W4_SB();
+        W4_FENCE();
+        // ---- phase 2: MFMA g: Vt fragment f = g >> 1 (chunk c = f >> 2, dt = f & 3), q block g & 1
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            ((((G & 1) == 0 ? lds_wait_a<w4::v_wait(G >> 1)>(vf[G >> 1]) : (void)0),
+              mfma_pv(o[G & 1][(G >> 1) & 3], vf[G >> 1], pk[ST & 1][G & 1][G >> 3]),
+              ((G & 1) == 0 && (G >> 1) + 3 < 16 ? v_read(SLOT_V{}, std::integral_constant<int, ((G >> 1) + 3) & 15>{}) : (void)0),
+              (G >= 28 ? k_read(SLOT_K2{}, std::integral_constant<int, (G >= 28 ? G - 28 : 0)>{}) : (void)0),
+              ((G & 3) == 1 ? (((G >> 2) & 1) ? stage_v(SLOT_D, i + 3, G >> 3) : stage_k(SLOT_D, i + 3, G >> 3)) : (void)0),
+              sm_start(PN{}, std::integral_constant<int, G>{}, live_next, mask_next, t_next),
+              W4_FENCE()), ...);
+        }(std::make_integer_sequence<int, 32>{});
     };
 
-    using T0 = std::integral_constant<int, 0>;
-    using T1 = std::integral_constant<int, 1>;
-    using T2 = std::integral_constant<int, 2>;
-    using T3 = std::integral_constant<int, 3>;
-    using NM = std::false_type;
-    using MK = std::true_type;
+    // ---- prologue: tiles 0..2 in flight, QK^T(0), K(1) fragments, first part of softmax(0)
     stage(0, 0); stage(1, 1); stage(2, 2);
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed
-    __builtin_amdgcn_sched_barrier(0);
+    W4_FENCE();
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int idx = 0; idx < 16; ++idx) kf[idx] = k_frag(0, idx);
-    const int n_plain = tail ? n - 1 : n;
-    int i = 0;
-    for (; i + 4 <= n_plain; i += 4) {
-        tile(T0{}, NM{}, i); tile(T1{}, NM{}, i + 1); tile(T2{}, NM{}, i + 2); tile(T3{}, NM{}, i + 3);
+    W4_FENCE();
+    k_read(I0{}, I0{}); k_read(I0{}, I1{}); k_read(I0{}, I2{}); k_read(I0{}, I3{});
+    W4_FENCE();
+    [&]<int... G>(std::integer_sequence<int, G...>) {
+        ((qk_mfma(I0{}, std::integral_constant<int, G>{}), k_ahead(I0{}, std::integral_constant<int, G>{}), W4_FENCE()), ...);
+    }(std::make_integer_sequence<int, 32>{});
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // tile 1 landed
+    W4_FENCE();
+    __builtin_amdgcn_s_barrier();
+    W4_FENCE();
+    k_read(I1{}, I0{}); k_read(I1{}, I1{}); k_read(I1{}, I2{}); k_read(I1{}, I3{});
+    asm volatile("s_nop 15");                           // last QK^T MFMAs -> the score reads below
+    W4_FENCE();
+    {
+        const bool mask0 = tail && n == 1;
+        [&]<int... G>(std::integer_sequence<int, G...>) { ((sm_start(I0{}, std::integral_constant<int, G>{}, true, mask0, t_begin), W4_FENCE()), ...); }(std::make_integer_sequence<int, 32>{});
     }
-    if (i < n_plain) tile(T0{}, NM{}, i);
-    if (i + 1 < n_plain) tile(T1{}, NM{}, i + 1);
-    if (i + 2 < n_plain) tile(T2{}, NM{}, i + 2);
-    if (tail) {
-        switch ((n - 1) & 3) {
-            case 0: tile(T0{}, MK{}, n - 1); break;
-            case 1: tile(T1{}, MK{}, n - 1); break;
-            case 2: tile(T2{}, MK{}, n - 1); break;
-            default: tile(T3{}, MK{}, n - 1); break;
-        }
+    for (int i = 0; i < n; i += 4) {
+        iter(I0{}, i); iter(I1{}, i + 1); iter(I2{}, i + 2); iter(I3{}, i + 3);
     }
-#undef W4_SB
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // stray DMA / K reads; last P.V -> reads of O
 
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+        const float l_tot = sum_with_lane_xor32(l_run[b]);
         if (part_slot >= 0) {
             float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 32 + l31) * 128 + 4 * h;
 #pragma unroll
