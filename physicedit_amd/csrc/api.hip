@@ -51,6 +51,7 @@ int pe_debug_set(const char* key, int value) {
 int pe_debug_set_ptr(const char* key, void* p) {
     PE_REQUIRE(key != nullptr, "pe_debug_set_ptr: null key");
     if (!strcmp(key, "gemm_stamps")) { g_gemm_dbg = (long long*)p; return PE_OK; }
+    if (!strcmp(key, "attn_stamps")) { g_attn_dbg = (long long*)p; return PE_OK; }
     if (!strcmp(key, "gemm_streamk_ws")) { g_gemm_sk_ws = p; return PE_OK; }   // pe_gemm_streamk_workspace_bytes() bytes, zero-filled once
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set_ptr: unknown key %s", key);
 }

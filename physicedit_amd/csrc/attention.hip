@@ -36,6 +36,7 @@ constexpr int KV_TILE = 64;
 constexpr int KDEPTH = 4;   // K-fragment ds_reads kept in flight ahead of the QK^T MFMAs
 constexpr int ATT_STAGE = 2 * KV_TILE * 128 * 2;  // K tile 16 KiB + Vt tile 16 KiB
 constexpr int ATT_LDS = 2 * ATT_STAGE;            // 64 KiB
+long long* g_attn_dbg = nullptr;   // device buffer for the s_memtime stamps of variant 3 / 4 (10 per work-group), or null
 int g_attn_variant = 0;   // 0: 8 waves / 256 query rows per work-group (1 per CU);  1: 4 waves / 128 rows (2 per CU)
 
 // Work decomposition.  total = H * nqb equal (head, q-block) items never divide evenly over the 256 CUs
@@ -647,15 +648,24 @@ template <int OFF> PE_DEV void lds_read_to_a(u32x4& d, int addr) {
 template <int OFF> PE_DEV void lds_read_to_v(u32x4& d, int addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
 }
-// the compiler does not count asm LDS reads: the wait names the register it makes valid, so no use can move above it
-template <int N> PE_DEV void lds_wait_v(u32x4& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
-template <int N> PE_DEV void lds_wait_a(u32x4& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(d) : "n"(N)); }
-PE_DEV void mfma_qk(f32x16& d, const u32x4& k_frag, const u32x4& q_frag, bool first) {   // d (arch) = K(acc) . Q(acc) (+ d)
-    if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(k_frag), "a"(q_frag));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(k_frag), "a"(q_frag));
+// WAIT >= 0: the statement opens with s_waitcnt lgkmcnt(WAIT) -- the fragment operands come from asm LDS reads the compiler does not
+// count; `also` is the second fragment that wait covers (named so that no use of it can be placed above this statement)
+template <int WAIT>
+PE_DEV void mfma_qk(f32x16& d, const u32x4& k_frag, const u32x4& q_frag, bool first, u32x4& also) {   // d (arch) = K(acc) . Q(acc) (+ d)
+    if constexpr (WAIT >= 0) {
+        if (first) asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, 0" : "=&v"(d), "+a"(also) : "a"(k_frag), "a"(q_frag), "n"(WAIT));
+        else asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0" : "+v"(d), "+a"(also) : "a"(k_frag), "a"(q_frag), "n"(WAIT));
+    } else {
+        if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(k_frag), "a"(q_frag));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(k_frag), "a"(q_frag));
+    }
 }
-PE_DEV void mfma_pv(f32x16& d, const u32x4& v_frag, const u32x4& p_frag) {               // d (acc) += Vt(acc) . P(arch)
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(v_frag), "v"(p_frag));
+template <int WAIT>
+PE_DEV void mfma_pv(f32x16& d, const u32x4& v_frag, const u32x4& p_frag, u32x4& also) {               // d (acc) += Vt(acc) . P(arch)
+    if constexpr (WAIT >= 0)
+        asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0" : "+a"(d), "+a"(also) : "a"(v_frag), "v"(p_frag), "n"(WAIT));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(v_frag), "v"(p_frag));
 }
 // x (op) x-of-lane^32 on every lane, by v_permlane32_swap (no LDS traffic: the LDS queue is counted by hand below).  After the swap
 // of two copies, one register holds the low half's value on all lanes and the other the high half's.  A VALU write needs two
@@ -690,20 +700,23 @@ constexpr int early_lo(int g) { return g < 10 ? 0 : ((g - 10) * SM_EARLY) / 22; 
 constexpr int late_lo(int g) { return g >= 30 ? 32 - SM_EARLY : (g * (32 - SM_EARLY)) / 30; }
 static_assert(early_lo(32) == SM_EARLY && late_lo(0) == 0 && late_lo(32) == 32 - SM_EARLY, "softmax slices must cover every pair");
 // LDS queue (all reads are asm, in issue order): phase 1  [K0..K3 of the tile, issued at the end of the phase 2 before]  K4 K5 (gaps 0, 1)
-// K6 K7 (gaps 4, 5) ... K14 K15 (gaps 20, 21), Vt0..Vt2 (gaps 29..31); phase 2  Vt(f+3) in gap 2f, K0..K3 of the next tile in gaps
-// 28..31.  lgkmcnt(N) before a fragment's first use = the number of reads issued after it by then.
-constexpr int k_wait(int j) { return j <= 12 ? 3 : 15 - j; }
-constexpr int v_wait(int f) { return f == 14 ? 1 : 2; }
+// K6 K7 (gaps 4, 5) ... K14 K15 (gaps 20, 21), Vt0..Vt3 (gaps 28..31); phase 2  Vt(f+4) in gap 2f, K0..K3 of the next tile in gaps
+// 28..31.  One wait per two fragments, folded into the MFMA statement that first uses them: lgkmcnt(N), N = the reads issued after
+// the second fragment by then.
+constexpr int k_wait2(int kk) { return kk <= 6 ? 2 : 0; }      // before MFMA 4kk: fragments 2kk, 2kk+1
+constexpr int v_wait2(int f) { return f <= 12 ? 2 : 0; }       // before MFMA 2f (f even): fragments f, f+1
 }  // namespace w4
 
 __global__ void __launch_bounds__(256, 1)
 flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
                      bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
-                     float* __restrict__ part_o, float* __restrict__ part_ml) {
+                     float* __restrict__ part_o, float* __restrict__ part_ml, float tau, long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Q_BLOCK = 256;
     constexpr int KT_BYTES = KV_TILE * 256;        // 16 KiB
     constexpr int V_BASE = PP_STAGES * KT_BYTES;   // K ring [0, 64 KiB), Vt ring [64 KiB, 128 KiB); tile t sits in slot t & 3
+    const long long stamp_begin = (long long)__builtin_readcyclecounter();
+    long long stamp_it[4] = {0, 0, 0, 0};
     const int lane = lane_id();
     const int w = wave_id();
     const int l31 = lane & 31, h = lane >> 5;
@@ -757,13 +770,13 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
     // buffer-addressed LDS-DMA: SGPR descriptor of the head + SGPR tile offset + the lane's 32-bit offset (no 64-bit VALU math)
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, 0x7fffffff, 0x00020000);
-    auto stage_k = [&](int st, int i, int j) {
-        const int t = t_begin + min(i, n - 1);
+    auto stage_k = [&](int st, int i, int j) {      // i: tile index relative to t_begin, clamped (a tile past the end re-reads the last)
+        const int t = __builtin_amdgcn_readfirstlane(t_begin + min(i, n - 1));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(smem + st * KT_BYTES + w * 4096 + j * 1024),
                                                  16, (int)k_off[j], t * (KV_TILE * 256), 0, 0);
     };
     auto stage_v = [&](int st, int i, int j) {
-        const int t = t_begin + min(i, n - 1);
+        const int t = __builtin_amdgcn_readfirstlane(t_begin + min(i, n - 1));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(smem + V_BASE + st * KT_BYTES + w * 4096 + j * 1024),
                                                  16, (int)v_off[j], t * (KV_TILE * 2), 0, 0);
     };
@@ -793,96 +806,33 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
     float sm_mx[2], sm_sub[2], sm_alpha[2], sm_psum[2];
     bool sm_moved[2];
 
-    auto k_read = [&](auto slot_tag, auto idx_tag) __attribute__((always_inline)) {      // idx = kk*2 + s2 (order of first use)
-        constexpr int st = decltype(slot_tag)::value, idx = decltype(idx_tag)::value;
-        lds_read_to_a<st * KT_BYTES + (idx & 1) * 32 * 256>(kf[idx], kaddr[idx >> 1]);
+    // raises block b's running max (only when some row exceeds it by more than tau, see below) and derives what the exp2 slices
+    // and the O rescale need.  `live` = the tile exists: iterations are issued in fours, a tile past the end contributes P = 0
+    // (exp2(s - inf)) and leaves m, l alone.
+    auto sm_state = [&](int b, bool live) __attribute__((always_inline)) {
+        const float mx = max_with_lane_xor32(sm_mx[b]);
+        // the running max is only raised (and O rescaled) when some row of the block exceeds it by more than tau (log2 units):
+        // P = exp2(s - m) then stays <= 2^tau, and O / l does not depend on which m was used.  tau = 0 is the textbook
+        // update, bit-identical to flash_attn_kernel.
+        const float m_cand = fmaxf(m_run[b], mx * scale_log2);
+        sm_moved[b] = live && __any(m_cand - m_run[b] > tau);
+        const float m_new = sm_moved[b] ? m_cand : m_run[b];
+        sm_alpha[b] = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+        m_run[b] = m_new;
+        sm_sub[b] = live ? m_new : INFINITY;
+        sm_psum[b] = 0.f;
+        asm volatile("" : "+v"(sm_alpha[b]), "+v"(sm_sub[b]), "+v"(m_run[b]), "+v"(sm_psum[b]));
     };
-    auto v_read = [&](auto slot_tag, auto idx_tag) __attribute__((always_inline)) {      // idx = c*4 + dt
-        constexpr int st = decltype(slot_tag)::value, idx = decltype(idx_tag)::value;
-        lds_read_to_a<st * KT_BYTES + (idx & 3) * 32 * 128>(vf[idx], vaddr[idx >> 2]);
-    };
-    // the 32 QK^T MFMAs of one tile in issue order g: kk = g >> 2, q block = (g >> 1) & 1, key half = g & 1
-    auto qk_mfma = [&](auto p_tag, auto g_tag) __attribute__((always_inline)) {
-        constexpr int P = decltype(p_tag)::value, g = decltype(g_tag)::value;
-        if constexpr (((g >> 1) & 1) == 0) lds_wait_a<w4::k_wait((g >> 2) * 2 + (g & 1))>(kf[(g >> 2) * 2 + (g & 1)]);
-        mfma_qk(sc[P][(g >> 1) & 1][g & 1], kf[(g >> 2) * 2 + (g & 1)], qf[(g >> 1) & 1][g >> 2], (g >> 2) == 0);
-    };
-    // K fragment read that rides in gap g of a QK^T phase (tile in ring slot `slot`): fragments 4.. in gaps 4kk, 4kk+1
-    auto k_ahead = [&](auto slot_tag, auto g_tag) __attribute__((always_inline)) {
-        constexpr int g = decltype(g_tag)::value;
-        if constexpr ((g & 3) < 2 && (g >> 2) <= 5) k_read(slot_tag, std::integral_constant<int, ((g >> 2) + 2) * 2 + (g & 1)>{});
-    };
-
-    // scores 2q, 2q+1 of block b -> exp2, row sum (score order, as in flash_attn_kernel), one packed bf16 pair of P
-    // One asm statement per pair: it stays in its slice (pure arithmetic is otherwise free to float across the MFMA statements
-    // when the block is linearised, long before the fences are looked at) and is exactly 7 instructions.  v_exp_f32 results are
-    // first read two instructions later (trans-use hazard).
-    auto sm_pair = [&](auto p_tag, int b, int q) __attribute__((always_inline)) {
+    auto mask_scores = [&](auto p_tag, int t) __attribute__((always_inline)) {      // keys past S of the ragged last tile -> -inf
         constexpr int P = decltype(p_tag)::value;
-        const int f = 2 * q, s2 = f >> 4, r0 = f & 15;
-        float t0, t1;
-        uint32_t packed;
-        asm volatile("v_fma_f32 %2, %4, %6, -%7\n\t"
-                     "v_fma_f32 %3, %5, %6, -%7\n\t"
-                     "v_exp_f32 %2, %2\n\t"
-                     "v_exp_f32 %3, %3\n\t"
-                     "v_add_f32 %0, %0, %2\n\t"
-                     "v_add_f32 %0, %0, %3\n\t"
-                     "v_cvt_pk_bf16_f32 %1, %2, %3"
-                     : "+v"(sm_psum[b]), "=v"(packed), "=&v"(t0), "=&v"(t1)
-                     : "v"(sc[P][b][s2][r0]), "v"(sc[P][b][s2][r0 + 1]), "s"(scale_log2), "v"(sm_sub[b]));
-        pk[P][b][s2 * 2 + (r0 >> 3)][(r0 & 7) >> 1] = packed;
-    };
-    // ---- first part of softmax(tile in score buffer P), slice g of 32 (phase 2 of the iteration before)
-    // `live` = the tile exists (iterations are issued in fours: a tile past the end contributes P = 0 and leaves m, l alone);
-    // `mask` = it is the ragged last tile of the sequence.  Both are wave-uniform.
-    auto sm_start = [&](auto p_tag, auto g_tag, bool live, bool mask, int t) __attribute__((always_inline)) {
-        constexpr int P = decltype(p_tag)::value, g = decltype(g_tag)::value;
-        if constexpr (g < 8) {                      // running max over scores 4g .. 4g+3 of both blocks
-            if (mask) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int f = g * 4 + e, s2 = f >> 4, r = f & 15;
-                        const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                        if (key >= S) sc[P][b][s2][r] = -INFINITY;
-                    }
+            for (int f = 0; f < 32; ++f) {
+                const int s2 = f >> 4, r = f & 15;
+                const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (key >= S) sc[P][b][s2][r] = -INFINITY;
             }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                constexpr int s2 = (g * 4) >> 4, r = (g * 4) & 15;
-                if constexpr (g == 0)
-                    asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4"
-                                 : "=&v"(sm_mx[b]) : "v"(sc[P][b][0][0]), "v"(sc[P][b][0][1]), "v"(sc[P][b][0][2]), "v"(sc[P][b][0][3]));
-                else
-                    asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4"
-                                 : "+v"(sm_mx[b]) : "v"(sc[P][b][s2][r]), "v"(sc[P][b][s2][r + 1]), "v"(sc[P][b][s2][r + 2]), "v"(sc[P][b][s2][r + 3]));
-            }
-        } else if constexpr (g < 10) {
-            constexpr int b = g - 8;
-            const float mx = max_with_lane_xor32(sm_mx[b]);
-            const float m_new = live ? fmaxf(m_run[b], mx * scale_log2) : m_run[b];
-            sm_moved[b] = __any(m_new != m_run[b]);
-            sm_alpha[b] = __builtin_amdgcn_exp2f(m_run[b] - m_new);
-            m_run[b] = m_new;
-            sm_sub[b] = live ? m_new : INFINITY;    // exp2(s - inf) = 0
-            sm_psum[b] = 0.f;
-            asm volatile("" : "+v"(sm_alpha[b]), "+v"(sm_sub[b]), "+v"(m_run[b]));
-        } else {                                    // early pairs
-#pragma unroll
-            for (int e = w4::early_lo(g); e < w4::early_lo(g + 1); ++e) sm_pair(p_tag, e & 1, e >> 1);
-        }
-    };
-    // ---- second part of softmax(tile in score buffer P), slice g of 32 (phase 1)
-    auto sm_finish = [&](auto p_tag, auto g_tag) __attribute__((always_inline)) {
-        constexpr int g = decltype(g_tag)::value;
-#pragma unroll
-        for (int e = w4::late_lo(g); e < w4::late_lo(g + 1); ++e) sm_pair(p_tag, e & 1, w4::SM_EARLY / 2 + (e >> 1));
-        if constexpr (g == 31) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) l_run[b] = __builtin_fmaf(l_run[b], sm_alpha[b], sm_psum[b]);
-        }
     };
     auto rescale = [&](int b) __attribute__((always_inline)) {     // O(block b) *= alpha, after the P.V of the tile before is done
         if (sm_moved[b]) {
@@ -890,85 +840,34 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float tmp;
-                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
-                                 : "+a"(o[b][dt][r]), "=&v"(tmp) : "v"(alpha));
+                for (int r = 0; r < 16; r += 8) {
+                    float t0, t1, t2, t3, t4, t5, t6, t7;
+                    f32x16& acc = o[b][dt];
+                    asm volatile("v_accvgpr_read_b32 %8, %0\n\tv_accvgpr_read_b32 %9, %1\n\tv_accvgpr_read_b32 %10, %2\n\tv_accvgpr_read_b32 %11, %3\n\t"
+                                 "v_accvgpr_read_b32 %12, %4\n\tv_accvgpr_read_b32 %13, %5\n\tv_accvgpr_read_b32 %14, %6\n\tv_accvgpr_read_b32 %15, %7\n\t"
+                                 "v_mul_f32 %8, %8, %16\n\tv_mul_f32 %9, %9, %16\n\tv_mul_f32 %10, %10, %16\n\tv_mul_f32 %11, %11, %16\n\t"
+                                 "v_mul_f32 %12, %12, %16\n\tv_mul_f32 %13, %13, %16\n\tv_mul_f32 %14, %14, %16\n\tv_mul_f32 %15, %15, %16\n\t"
+                                 "v_accvgpr_write_b32 %0, %8\n\tv_accvgpr_write_b32 %1, %9\n\tv_accvgpr_write_b32 %2, %10\n\tv_accvgpr_write_b32 %3, %11\n\t"
+                                 "v_accvgpr_write_b32 %4, %12\n\tv_accvgpr_write_b32 %5, %13\n\tv_accvgpr_write_b32 %6, %14\n\tv_accvgpr_write_b32 %7, %15"
+                                 : "+a"(acc[r]), "+a"(acc[r + 1]), "+a"(acc[r + 2]), "+a"(acc[r + 3]), "+a"(acc[r + 4]), "+a"(acc[r + 5]),
+                                   "+a"(acc[r + 6]), "+a"(acc[r + 7]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5),
+                                   "=&v"(t6), "=&v"(t7)
+                                 : "v"(alpha));
                 }
         }
     };
 
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-
-    // iteration i: tile i (ring slot ST = i & 3, score buffer ST & 1) gets its P.V, tile i+1 its QK^T.  ONE body per ring slot:
-    // more instantiations (peeled / masked variants) cost the register allocator its footing (lane-constant addresses get
-    // spilled, and a scratch reload's vmcnt(0) would serialise the LDS-DMA).
-    auto iter = [&](auto st_tag, int i) __attribute__((always_inline)) {
-        constexpr int ST = decltype(st_tag)::value;
-        using PC = std::integral_constant<int, ST & 1>;            // scores of tile i
-        using PN = std::integral_constant<int, (ST & 1) ^ 1>;      // scores of tile i+1
-        using SLOT_V = std::integral_constant<int, ST>;            // Vt(i)
-        using SLOT_K1 = std::integral_constant<int, (ST + 1) & 3>; // K(i+1)
-        using SLOT_K2 = std::integral_constant<int, (ST + 2) & 3>; // K(i+2)
-        constexpr int SLOT_D = (ST + 3) & 3;                       // destination of tile i+3
-        const int t_next = t_begin + i + 1;
-        const bool live_next = i + 1 < n;
-        const bool mask_next = tail && i + 1 == n - 1;
-        // ---- phase 1
-        [&]<int... G>(std::integer_sequence<int, G...>) {
-            ((qk_mfma(PN{}, std::integral_constant<int, G>{}), k_ahead(SLOT_K1{}, std::integral_constant<int, G>{}),
-              (G == 2 ? rescale(0) : G == 3 ? rescale(1) : (void)0),
-              sm_finish(PC{}, std::integral_constant<int, G>{}),
-              (G >= 29 ? v_read(SLOT_V{}, std::integral_constant<int, (G >= 29 ? G - 29 : 0)>{}) : (void)0),
-              W4_FENCE()), ...);
-        }(std::make_integer_sequence<int, 32>{});
-        // own pieces of tile i+2 landed (issued one iteration ago), then everyone's; every wave is past its reads of
-        // tile i-1's Vt and K, so slot (i+3) & 3 can be refilled
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W4_FENCE();
-        __builtin_amdgcn_s_barrier();
-        W4_FENCE();
-        // ---- phase 2: MFMA g: Vt fragment f = g >> 1 (chunk c = f >> 2, dt = f & 3), q block g & 1
-        [&]<int... G>(std::integer_sequence<int, G...>) {
-            ((((G & 1) == 0 ? lds_wait_a<w4::v_wait(G >> 1)>(vf[G >> 1]) : (void)0),
-              mfma_pv(o[G & 1][(G >> 1) & 3], vf[G >> 1], pk[ST & 1][G & 1][G >> 3]),
-              ((G & 1) == 0 && (G >> 1) + 3 < 16 ? v_read(SLOT_V{}, std::integral_constant<int, ((G >> 1) + 3) & 15>{}) : (void)0),
-              (G >= 28 ? k_read(SLOT_K2{}, std::integral_constant<int, (G >= 28 ? G - 28 : 0)>{}) : (void)0),
-              ((G & 3) == 1 ? (((G >> 2) & 1) ? stage_v(SLOT_D, i + 3, G >> 3) : stage_k(SLOT_D, i + 3, G >> 3)) : (void)0),
-              sm_start(PN{}, std::integral_constant<int, G>{}, live_next, mask_next, t_next),
-              W4_FENCE()), ...);
-        }(std::make_integer_sequence<int, 32>{});
-    };
-
-    // ---- prologue: tiles 0..2 in flight, QK^T(0), K(1) fragments, first part of softmax(0)
-    stage(0, 0); stage(1, 1); stage(2, 2);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed
-    W4_FENCE();
-    __builtin_amdgcn_s_barrier();
-    W4_FENCE();
-    k_read(I0{}, I0{}); k_read(I0{}, I1{}); k_read(I0{}, I2{}); k_read(I0{}, I3{});
-    W4_FENCE();
-    [&]<int... G>(std::integer_sequence<int, G...>) {
-        ((qk_mfma(I0{}, std::integral_constant<int, G>{}), k_ahead(I0{}, std::integral_constant<int, G>{}), W4_FENCE()), ...);
-    }(std::make_integer_sequence<int, 32>{});
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // tile 1 landed
-    W4_FENCE();
-    __builtin_amdgcn_s_barrier();
-    W4_FENCE();
-    k_read(I1{}, I0{}); k_read(I1{}, I1{}); k_read(I1{}, I2{}); k_read(I1{}, I3{});
-    asm volatile("s_nop 15");                           // last QK^T MFMAs -> the score reads below
-    W4_FENCE();
-    {
-        const bool mask0 = tail && n == 1;
-        [&]<int... G>(std::integer_sequence<int, G...>) { ((sm_start(I0{}, std::integral_constant<int, G>{}, true, mask0, t_begin), W4_FENCE()), ...); }(std::make_integer_sequence<int, 32>{});
-    }
+#ifndef PE_W4_STAMPS
+#define PE_W4_STAMPS 0
+#endif
+    // the instruction schedule: lambdas iter0..iter3 (one per ring slot) and the prologue, generated by tools/gen_attn_w4.py
+#include "attention_w4_body.inc"
+    const long long stamp_loop = (long long)__builtin_readcyclecounter();
     for (int i = 0; i < n; i += 4) {
-        iter(I0{}, i); iter(I1{}, i + 1); iter(I2{}, i + 2); iter(I3{}, i + 3);
+        iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
     }
+    const long long stamp_loop_end = (long long)__builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // stray DMA / K reads; last P.V -> reads of O
 
 #pragma unroll
@@ -1006,6 +905,11 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
                     *(bf16x4*)(op + dt * 32 + 8 * a) = v;
                 }
         }
+    }
+    if (dbg != nullptr && threadIdx.x == 0) {      // profiling only (pe_debug_set_ptr("attn_stamps")): s_memtime of wave 0
+        long long* d = dbg + (size_t)blockIdx.x * 10;
+        d[0] = stamp_begin; d[1] = stamp_loop; d[2] = stamp_loop_end; d[3] = (long long)__builtin_readcyclecounter();
+        d[4] = stamp_it[0]; d[5] = stamp_it[1]; d[6] = stamp_it[2]; d[7] = stamp_it[3]; d[8] = n; d[9] = 0;
     }
 }
 
@@ -1110,9 +1014,9 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
 #define PE_ATTN_LAUNCH(NWV)                                                                                       \
     hipLaunchKernelGGL((flash_attn_kernel<NWV>), grid, dim3(NWV * 64), ATT_LDS, stream, (const bf16*)q, (const bf16*)k, \
                        (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml)
-    if (g_attn_variant == 3)
+    if (g_attn_variant == 3 || g_attn_variant == 4)
         hipLaunchKernelGGL(flash_attn_w4_kernel, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                           (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
+                           (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, g_attn_variant == 4 ? 8.0f : 0.0f, g_attn_dbg);
     else if (g_attn_variant == 2)
         hipLaunchKernelGGL(flash_attn_pp_kernel, grid, dim3(512), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                            (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);

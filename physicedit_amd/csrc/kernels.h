@@ -60,6 +60,7 @@ extern int g_gemm_streamk;
 extern void* g_gemm_sk_ws;
 extern int g_gemm_variant;  // experiment knobs (pe_debug_set); production paths use the compiled defaults
 extern int g_attn_variant;
+extern long long* g_attn_dbg;
 extern long long* g_gemm_dbg;   // device buffer for the time stamps of the profiling GEMM variant (14), or null
 
 // ---------------------------------------------------------------------------------------------

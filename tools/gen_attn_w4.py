@@ -1,0 +1,323 @@
+#!/usr/bin/env python
+"""Generates physicedit_amd/csrc/attention_w4_body.inc: the instruction schedule of flash_attn_w4_kernel (attention variants 3/4).
+
+The kernel runs ONE wave per SIMD, so nothing hides an instruction's issue slot except the MFMA that is executing: every
+MFMA "gap" (32 cycles of matrix pipe) has room for ~5 other instructions of the same wave.  The schedule is therefore written
+down explicitly, one asm statement per gap (MFMA + its LDS read + its slice of the softmax), with a scheduling fence after
+each; statement boundaries cost padding instructions, so a gap is never split into several statements.  The tables below
+say which work rides in which gap; the C++ around the statements (register arrays, rescale, state update) is in attention.hip.
+
+    python tools/gen_attn_w4.py          # rewrites the .inc; the build does not run this (the .inc is committed)
+
+Iteration i of the KV loop (ring slot ST = i & 3, score buffer P = ST & 1 holds tile i, P^1 tile i+1):
+  phase 1, gap g: QK^T MFMA g of tile i+1  | K(i+1) fragment reads two k-steps ahead (gaps 4kk, 4kk+1), Vt(i) fragments
+                  0..3 (gaps 28..31)       | the LATE score pairs of softmax(i): exp2 in gap G, row sum + bf16 pack a gap later
+                                           | O rescale of blocks 0 / 1 in gaps 2 / 3 when the running max was raised
+  phase 2, gap g: P.V MFMA g of tile i     | Vt(i) fragment f+4 in gap 2f, K(i+2) fragments 0..3 (gaps 28..31), LDS-DMA of
+                  tile i+3 (gaps 4j+1)     | softmax(i+1): row max (gaps 0..7), m / alpha (gaps 8, 9), the EARLY pairs
+LDS reads are asm and not counted by the compiler; the queue is, in issue order: phase 1  [K0..K3 issued at the end of the
+phase 2 before] K4 K5 (gaps 0,1) K6 K7 (4,5) .. K14 K15 (20,21) Vt0..Vt3 (28..31); phase 2  Vt(f+4) in gap 2f (f = 0..11),
+K0..K3 of the next tile (28..31).  One wait per two fragments opens the MFMA statement that first uses them: lgkmcnt(N) with
+N = the reads issued after the second fragment by then (2, or 0 at the end of the queue).
+"""
+import os
+
+EARLY_PAIRS = 5          # per block: pairs 0..4 of softmax(i+1) run in phase 2 of iteration i, pairs 5..15 in phase 1 of i+1
+KT_BYTES = 64 * 256
+
+
+def distribute(n_items, first_gap, last_gap):
+    """gap of item k when n_items are spread evenly over first_gap..last_gap (inclusive)"""
+    span = last_gap - first_gap + 1
+    return [first_gap + (k * span) // n_items for k in range(n_items)]
+
+
+class Stmt:
+    def __init__(self):
+        self.lines, self.outs, self.ins, self.after = [], [], [], []
+
+    def emit(self, ind):
+        if not self.lines:
+            return [ind + a for a in self.after]
+        body = [ind + 'asm volatile("' + self.lines[0] + ('\\n\\t"' if len(self.lines) > 1 else '"')]
+        for k, ln in enumerate(self.lines[1:]):
+            last = k == len(self.lines) - 2
+            body.append(ind + '             "' + ln + ('"' if last else '\\n\\t"'))
+        body.append(ind + "             : " + ", ".join(self.outs))
+        body.append(ind + "             : " + ", ".join(self.ins) + ");")
+        return body + [ind + a for a in self.after]
+
+
+def score(P, b, f):
+    return f"sc[{P}][{b}][{f >> 4}][{f & 15}]"
+
+
+def pk_slot(P, b, q):
+    f = 2 * q
+    s2, r0 = f >> 4, f & 15
+    return f"pk[{P}][{b}][{s2 * 2 + (r0 >> 3)}][{(r0 & 7) >> 1}]"
+
+
+def add_read(st, kind, slot, idx):
+    """kind 'k': fragment idx = kk*2 + s2 of the K tile in ring slot `slot`; 'v': idx = c*4 + dt of the Vt tile"""
+    if kind == "k":
+        off, dst, addr = slot * KT_BYTES + (idx & 1) * 32 * 256, f"kf[{idx}]", f"kaddr[{idx >> 1}]"
+    else:
+        off, dst, addr = slot * KT_BYTES + (idx & 3) * 32 * 128, f"vf[{idx}]", f"vaddr[{idx >> 2}]"
+    st.lines.append(f"ds_read_b128 %[rd], %[ra] offset:{off}")
+    st.outs.append(f'[rd] "=a"({dst})')
+    st.ins.append(f'[ra] "v"({addr})')
+
+
+def add_pair_a(st, P, b, q, tag):
+    """exp2 of scores 2q, 2q+1 of block b into fresh temporaries"""
+    st.lines += [f"v_fma_f32 %[t0], %[s0], %[sl], -%[suba]", f"v_fma_f32 %[t1], %[s1], %[sl], -%[suba]"]
+    st.tail_a = [f"v_exp_f32 %[t0], %[t0]", f"v_exp_f32 %[t1], %[t1]"]
+    st.outs += [f'[t0] "=&v"(e0_{tag})', f'[t1] "=&v"(e1_{tag})']
+    st.ins += [f'[s0] "v"({score(P, b, 2 * q)})', f'[s1] "v"({score(P, b, 2 * q + 1)})', '[sl] "s"(scale_log2)',
+               f'[suba] "v"(sm_sub[{b}])']
+
+
+def add_pair_b(st, P, b, q, tag):
+    """row sum (score order) and bf16 pack of a pair whose exp2 ran in an earlier gap"""
+    st.lines_b = [f"v_add_f32 %[ps], %[ps], %[u0]", f"v_add_f32 %[ps], %[ps], %[u1]", f"v_cvt_pk_bf16_f32 %[pkd], %[u0], %[u1]"]
+    st.outs += [f'[ps] "+v"(sm_psum[{b}])', f'[pkd] "=v"(pw_{tag})']
+    st.ins += [f'[u0] "v"(e0_{tag})', f'[u1] "v"(e1_{tag})']
+    st.after.append(f"{pk_slot(P, b, q)} = pw_{tag};")
+
+
+def finish_pairs(st):
+    """interleave the two halves so that no instruction reads a result produced by the instruction right before it"""
+    a = getattr(st, "tail_a", [])
+    b = getattr(st, "lines_b", [])
+    if a and b:            # fma fma (already in lines) | add exp add exp cvt
+        st.lines += [b[0], a[0], b[1], a[1], b[2]]
+    else:
+        st.lines += a + b
+
+
+def add_max(st, P, g):
+    """running max over scores 4g..4g+3 of both blocks"""
+    for b in (0, 1):
+        e = [score(P, b, 4 * g + k) for k in range(4)]
+        if g == 0:
+            st.outs.append(f'[mx{b}] "=&v"(sm_mx[{b}])')
+        else:
+            st.outs.append(f'[mx{b}] "+v"(sm_mx[{b}])')
+        st.ins += [f'[m{b}{k}] "v"({e[k]})' for k in range(4)]
+    if g == 0:
+        st.lines += ["v_max3_f32 %[mx0], %[m00], %[m01], %[m02]", "v_max3_f32 %[mx1], %[m10], %[m11], %[m12]",
+                     "v_max_f32 %[mx0], %[mx0], %[m03]", "v_max_f32 %[mx1], %[mx1], %[m13]"]
+    else:
+        st.lines += ["v_max3_f32 %[mx0], %[mx0], %[m00], %[m01]", "v_max3_f32 %[mx1], %[mx1], %[m10], %[m11]",
+                     "v_max3_f32 %[mx0], %[mx0], %[m02], %[m03]", "v_max3_f32 %[mx1], %[mx1], %[m12], %[m13]"]
+
+
+def qk_stmt(P, g, slot_k, ahead=True):
+    """QK^T MFMA g of the tile whose K sits in ring slot slot_k: kk = g >> 2, q block (g >> 1) & 1, key half g & 1"""
+    st = Stmt()
+    kk, b, s2 = g >> 2, (g >> 1) & 1, g & 1
+    if g & 3 == 0:
+        st.lines.append(f"s_waitcnt lgkmcnt({2 if kk <= 6 else 0})")
+    acc = f"sc[{P}][{b}][{s2}]"
+    if kk == 0:
+        st.lines.append("v_mfma_f32_32x32x16_bf16 %[acc], %[fa], %[fb], 0")
+        st.outs.append(f'[acc] "=&v"({acc})')
+    else:
+        st.lines.append("v_mfma_f32_32x32x16_bf16 %[acc], %[fa], %[fb], %[acc]")
+        st.outs.append(f'[acc] "+v"({acc})')
+    st.ins += [f'[fa] "a"(kf[{kk * 2 + s2}])', f'[fb] "a"(qf[{b}][{kk}])']
+    if ahead and (g & 3) < 2 and kk <= 5:
+        add_read(st, "k", slot_k, (kk + 2) * 2 + (g & 1))
+    return st
+
+
+def pv_stmt(PC, g):
+    """P.V MFMA g: Vt fragment f = g >> 1 (key chunk f >> 2, dt = f & 3), q block g & 1"""
+    st = Stmt()
+    f, b = g >> 1, g & 1
+    if g & 3 == 0:
+        st.lines.append(f"s_waitcnt lgkmcnt({2 if f <= 12 else 0})")
+    st.lines.append("v_mfma_f32_32x32x16_bf16 %[acc], %[fa], %[fb], %[acc]")
+    st.outs.append(f'[acc] "+a"(o[{b}][{f & 3}])')
+    st.ins += [f'[fa] "a"(vf[{f}])', f'[fb] "v"(pk[{PC}][{b}][{f >> 2}])']
+    return st
+
+
+def pair_list(lo, hi):
+    return [(b, q) for q in range(lo, hi) for b in (0, 1)]
+
+
+def schedule_pairs(pairs, first_gap, last_gap):
+    """gap of the exp2 half and of the sum/pack half of every pair; the sum/pack half is one gap behind"""
+    ga = distribute(len(pairs), first_gap, last_gap - 1)
+    return ga, [g + 1 for g in ga]
+
+
+def gen_iter(ST, out):
+    PC, PN = ST & 1, (ST & 1) ^ 1
+    slot_v, slot_k1, slot_k2, slot_d = ST, (ST + 1) & 3, (ST + 2) & 3, (ST + 3) & 3
+    ind = "        "
+    w = out.append
+    w(f"    auto iter{ST} = [&](int i) __attribute__((always_inline)) {{")
+    w(ind + f"// tile i: ring slot {slot_v}, scores sc[{PC}], P pk[{PC}];  tile i+1: K in slot {slot_k1}, scores sc[{PN}]")
+    w(ind + "const int t_next = t_begin + i + 1;")
+    w(ind + "const bool live_next = i + 1 < n;")
+    w(ind + "const bool mask_next = tail && i + 1 == n - 1;")
+    if ST == 0:
+        w("#if PE_W4_STAMPS")
+        w(ind + "const bool stamp = i == 8;")
+        w(ind + "if (stamp) stamp_it[0] = (long long)__builtin_readcyclecounter();")
+        w("#endif")
+    late = pair_list(EARLY_PAIRS, 16)
+    ga, gb = schedule_pairs(late, 0, 31)
+    w(ind + "float " + ", ".join(f"e0_l{k}, e1_l{k}" for k in range(len(late))) + ";")
+    w(ind + "uint32_t " + ", ".join(f"pw_l{k}" for k in range(len(late))) + ";")
+    w(ind + "// ---- phase 1")
+    for g in range(32):
+        st = qk_stmt(PN, g, slot_k1)
+        if g >= 28:
+            add_read(st, "v", slot_v, g - 28)
+        for k, (b, q) in enumerate(late):
+            if ga[k] == g:
+                add_pair_a(st, PC, b, q, f"l{k}")
+        for k, (b, q) in enumerate(late):
+            if gb[k] == g:
+                add_pair_b(st, PC, b, q, f"l{k}")
+        finish_pairs(st)
+        out.extend(st.emit(ind))
+        if g == 2:
+            w(ind + "rescale(0);")
+        if g == 3:
+            w(ind + "rescale(1);")
+        if g == 31:
+            w(ind + "l_run[0] = __builtin_fmaf(l_run[0], sm_alpha[0], sm_psum[0]);")
+            w(ind + "l_run[1] = __builtin_fmaf(l_run[1], sm_alpha[1], sm_psum[1]);")
+        w(ind + "W4_FENCE();")
+    if ST == 0:
+        w("#if PE_W4_STAMPS")
+        w(ind + "if (stamp) stamp_it[1] = (long long)__builtin_readcyclecounter();")
+        w("#endif")
+    w(ind + "// own pieces of tile i+2 landed (issued one iteration ago), then everyone's; every wave is past its reads of")
+    w(ind + "// tile i-1's Vt and K, so ring slot (i+3) & 3 can be refilled")
+    w(ind + 'asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+    w(ind + "W4_FENCE();")
+    w(ind + "__builtin_amdgcn_s_barrier();")
+    w(ind + "W4_FENCE();")
+    if ST == 0:
+        w("#if PE_W4_STAMPS")
+        w(ind + "if (stamp) stamp_it[2] = (long long)__builtin_readcyclecounter();")
+        w("#endif")
+    early = pair_list(0, EARLY_PAIRS)
+    ga, gb = schedule_pairs(early, 11, 31)
+    w(ind + "float " + ", ".join(f"e0_e{k}, e1_e{k}" for k in range(len(early))) + ";")
+    w(ind + "uint32_t " + ", ".join(f"pw_e{k}" for k in range(len(early))) + ";")
+    w(ind + "// ---- phase 2")
+    for g in range(32):
+        st = pv_stmt(PC, g)
+        f = g >> 1
+        if g & 1 == 0 and f + 4 < 16:
+            add_read(st, "v", slot_v, f + 4)
+        if g >= 28:
+            add_read(st, "k", slot_k2, g - 28)
+        if g == 0:
+            w(ind + f"if (mask_next) mask_scores(std::integral_constant<int, {PN}>{{}}, t_next);")
+        if g < 8:
+            add_max(st, PN, g)
+        for k, (b, q) in enumerate(early):
+            if ga[k] == g:
+                add_pair_a(st, PN, b, q, f"e{k}")
+        for k, (b, q) in enumerate(early):
+            if gb[k] == g:
+                add_pair_b(st, PN, b, q, f"e{k}")
+        finish_pairs(st)
+        out.extend(st.emit(ind))
+        if g & 3 == 1:
+            j = g >> 3
+            w(ind + (f"stage_v({slot_d}, i + 3, {j});" if (g >> 2) & 1 else f"stage_k({slot_d}, i + 3, {j});"))
+        if g in (8, 9):
+            w(ind + f"sm_state({g - 8}, live_next);")
+        w(ind + "W4_FENCE();")
+    if ST == 0:
+        w("#if PE_W4_STAMPS")
+        w(ind + "if (stamp) stamp_it[3] = (long long)__builtin_readcyclecounter();")
+        w("#endif")
+    w("    };")
+    w("")
+
+
+def gen_prologue(out):
+    ind = "    "
+    w = out.append
+    w(ind + "// ---- prologue: tiles 0..2 in flight, QK^T(0), first K(1) fragments, first part of softmax(0)")
+    w(ind + "stage(0, 0); stage(1, 1); stage(2, 2);")
+    w(ind + 'asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed')
+    w(ind + "W4_FENCE();")
+    w(ind + "__builtin_amdgcn_s_barrier();")
+    w(ind + "W4_FENCE();")
+    for idx in range(4):
+        st = Stmt()
+        add_read(st, "k", 0, idx)
+        out.extend(st.emit(ind))
+    w(ind + "W4_FENCE();")
+    for g in range(32):
+        out.extend(qk_stmt(0, g, 0).emit(ind))
+        w(ind + "W4_FENCE();")
+    w(ind + 'asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // tile 1 landed')
+    w(ind + "W4_FENCE();")
+    w(ind + "__builtin_amdgcn_s_barrier();")
+    w(ind + "W4_FENCE();")
+    for idx in range(4):
+        st = Stmt()
+        add_read(st, "k", 1, idx)
+        out.extend(st.emit(ind))
+    w(ind + 'asm volatile("s_nop 15");                           // last QK^T MFMAs -> the score reads below')
+    w(ind + "W4_FENCE();")
+    w(ind + "if (tail && n == 1) mask_scores(std::integral_constant<int, 0>{}, t_begin);")
+    early = pair_list(0, EARLY_PAIRS)
+    w(ind + "{")
+    ind2 = ind + "    "
+    w(ind2 + "float " + ", ".join(f"e0_p{k}, e1_p{k}" for k in range(len(early))) + ";")
+    w(ind2 + "uint32_t " + ", ".join(f"pw_p{k}" for k in range(len(early))) + ";")
+    for g in range(8):
+        st = Stmt()
+        add_max(st, 0, g)
+        out.extend(st.emit(ind2))
+        w(ind2 + "W4_FENCE();")
+    w(ind2 + "sm_state(0, true);")
+    w(ind2 + "sm_state(1, true);")
+    w(ind2 + "W4_FENCE();")
+    for k, (b, q) in enumerate(early):
+        st = Stmt()
+        add_pair_a(st, 0, b, q, f"p{k}")
+        finish_pairs(st)
+        out.extend(st.emit(ind2))
+        if k > 0:
+            st = Stmt()
+            add_pair_b(st, 0, early[k - 1][0], early[k - 1][1], f"p{k - 1}")
+            finish_pairs(st)
+            out.extend(st.emit(ind2))
+        w(ind2 + "W4_FENCE();")
+    st = Stmt()
+    add_pair_b(st, 0, early[-1][0], early[-1][1], f"p{len(early) - 1}")
+    finish_pairs(st)
+    out.extend(st.emit(ind2))
+    w(ind2 + "W4_FENCE();")
+    w(ind + "}")
+    w("")
+
+
+def main():
+    out = ["// GENERATED by tools/gen_attn_w4.py -- do not edit; the schedule tables and their rationale are in that script.",
+           "// Included inside flash_attn_w4_kernel (attention.hip), which declares every name used here.", ""]
+    for st in range(4):
+        gen_iter(st, out)
+    gen_prologue(out)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "physicedit_amd", "csrc", "attention_w4_body.inc")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    print(f"wrote {os.path.normpath(path)}: {len(out)} lines")
+
+
+if __name__ == "__main__":
+    main()
