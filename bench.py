@@ -64,6 +64,12 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[2]: DiT stored in e4m3 + enable_dit_fp8_computation (every DiT Linear runs "
                          "fp8_linear); NOT the headline configuration, reported with dtype fp8")
+    ap.add_argument("--attn-variant", type=int, default=0, choices=[0, 3, 4],
+                    help="flash-attention kernel: 0 = default (8 waves x 32 rows; the textbook online-softmax update, P rounded at "
+                         "the same scale as the reference's SDPA); 3 = 4 waves x 64 rows, one wave per SIMD, bit-identical to 0; "
+                         "4 = 3 with the running max raised only when a row outgrows it by 2^8 (faster; same distance to fp32, "
+                         "fewer bf16 outputs identical to the reference's: profiles/r02_attention_notes.md).  Non-zero values are "
+                         "reported in config.attn_variant and are not the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     args = ap.parse_args()
@@ -131,6 +137,9 @@ def main():
         torch.cuda.empty_cache()
     vae = QwenImageVAE(synth.make_state_dict(synth.vae_layout(), 77), device=dev)
     loop = DenoiseLoop(eng, dual_stream=args.dual_stream)
+    if args.attn_variant:
+        from physicedit_amd._lib import lib
+        assert lib().pe_debug_set(b"attn_variant", args.attn_variant) == 0
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] model ready in {time.time()-t0:.1f}s ({args.layers} layers, "
@@ -231,6 +240,7 @@ def main():
                                    f"VAE encode(1024x1024 edit image)+decode included",
                        "images_per_rank": args.steps, "parallelism": f"dp{world} (images sharded, weights replicated)",
                        "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+                       "attn_variant": args.attn_variant,
                        "batch_closing_collective": ("one RCCL all_gather of the final latents, inside the timed region" if dist is not None else None),
                        "finite_outputs": ok},
             "whole_path": {"algorithmic_pflop_per_image": fl / 1e15,

@@ -798,7 +798,6 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
     for (int kk = 0; kk < 8; ++kk) kaddr[kk] = l31 * 256 + (((kk * 2 + h) ^ (l31 & 15)) << 4);
 #pragma unroll
     for (int c = 0; c < 4; ++c) vaddr[c] = V_BASE + l31 * 128 + (((c * 2 + h) ^ ((l31 >> 1) & 7)) << 4);
-    const bool tail = (S & (KV_TILE - 1)) != 0 && t_end == nt_all;
 
     f32x16 sc[2][2][2];      // [tile parity][q block][key half]
     u32x4 pk[2][2][4];       // P, bf16 pairs: [tile parity][q block][16-key chunk]
@@ -823,7 +822,9 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
         sm_psum[b] = 0.f;
         asm volatile("" : "+v"(sm_alpha[b]), "+v"(sm_sub[b]), "+v"(m_run[b]), "+v"(sm_psum[b]));
     };
-    auto mask_scores = [&](auto p_tag, int t) __attribute__((always_inline)) {      // keys past S of the ragged last tile -> -inf
+    // keys past S -> -inf: the ragged last tile, and every tile past the end of the sequence (iterations are issued in fours; such a
+    // tile re-reads the last one, whose pad rows may hold anything, NaN included)
+    auto mask_scores = [&](auto p_tag, int t) __attribute__((always_inline)) {
         constexpr int P = decltype(p_tag)::value;
 #pragma unroll
         for (int b = 0; b < 2; ++b)

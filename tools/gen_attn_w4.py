@@ -60,6 +60,8 @@ def pk_slot(P, b, q):
 
 def add_read(st, kind, slot, idx):
     """kind 'k': fragment idx = kk*2 + s2 of the K tile in ring slot `slot`; 'v': idx = c*4 + dt of the Vt tile"""
+    if os.environ.get("W4_NO_READS"):       # timing experiment only
+        return
     if kind == "k":
         off, dst, addr = slot * KT_BYTES + (idx & 1) * 32 * 256, f"kf[{idx}]", f"kaddr[{idx >> 1}]"
     else:
@@ -71,6 +73,8 @@ def add_read(st, kind, slot, idx):
 
 def add_pair_a(st, P, b, q, tag):
     """exp2 of scores 2q, 2q+1 of block b into fresh temporaries"""
+    if os.environ.get("W4_NO_PAIRS"):       # timing experiment only
+        return
     st.lines += [f"v_fma_f32 %[t0], %[s0], %[sl], -%[suba]", f"v_fma_f32 %[t1], %[s1], %[sl], -%[suba]"]
     st.tail_a = [f"v_exp_f32 %[t0], %[t0]", f"v_exp_f32 %[t1], %[t1]"]
     st.outs += [f'[t0] "=&v"(e0_{tag})', f'[t1] "=&v"(e1_{tag})']
@@ -80,6 +84,8 @@ def add_pair_a(st, P, b, q, tag):
 
 def add_pair_b(st, P, b, q, tag):
     """row sum (score order) and bf16 pack of a pair whose exp2 ran in an earlier gap"""
+    if os.environ.get("W4_NO_PAIRS"):
+        return
     st.lines_b = [f"v_add_f32 %[ps], %[ps], %[u0]", f"v_add_f32 %[ps], %[ps], %[u1]", f"v_cvt_pk_bf16_f32 %[pkd], %[u0], %[u1]"]
     st.outs += [f'[ps] "+v"(sm_psum[{b}])', f'[pkd] "=v"(pw_{tag})']
     st.ins += [f'[u0] "v"(e0_{tag})', f'[u1] "v"(e1_{tag})']
@@ -163,7 +169,7 @@ def gen_iter(ST, out):
     w(ind + f"// tile i: ring slot {slot_v}, scores sc[{PC}], P pk[{PC}];  tile i+1: K in slot {slot_k1}, scores sc[{PN}]")
     w(ind + "const int t_next = t_begin + i + 1;")
     w(ind + "const bool live_next = i + 1 < n;")
-    w(ind + "const bool mask_next = tail && i + 1 == n - 1;")
+    w(ind + "const bool mask_next = (t_next + 1) * KV_TILE > S;      // ragged last tile, or past the end: no key of it may count")
     if ST == 0:
         w("#if PE_W4_STAMPS")
         w(ind + "const bool stamp = i == 8;")
@@ -232,7 +238,7 @@ def gen_iter(ST, out):
                 add_pair_b(st, PN, b, q, f"e{k}")
         finish_pairs(st)
         out.extend(st.emit(ind))
-        if g & 3 == 1:
+        if g & 3 == 1 and not os.environ.get("W4_NO_DMA"):       # W4_NO_DMA: timing experiment only (results are garbage)
             j = g >> 3
             w(ind + (f"stage_v({slot_d}, i + 3, {j});" if (g >> 2) & 1 else f"stage_k({slot_d}, i + 3, {j});"))
         if g in (8, 9):
@@ -273,7 +279,7 @@ def gen_prologue(out):
         out.extend(st.emit(ind))
     w(ind + 'asm volatile("s_nop 15");                           // last QK^T MFMAs -> the score reads below')
     w(ind + "W4_FENCE();")
-    w(ind + "if (tail && n == 1) mask_scores(std::integral_constant<int, 0>{}, t_begin);")
+    w(ind + "if ((t_begin + 1) * KV_TILE > S) mask_scores(std::integral_constant<int, 0>{}, t_begin);")
     early = pair_list(0, EARLY_PAIRS)
     w(ind + "{")
     ind2 = ind + "    "

@@ -5,9 +5,10 @@ shape, L2-miss (fabric-side) traffic per launch, L2 hit rate, and matrix-pipe ut
   * FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B for wide coalesced reads -- MI355X_MICROARCH.md section
     HBM) and converted KiB -> bytes; WRITE_SIZE is uncalibrated and reported as it is.  Infinity-Cache hits are counted,
     so `traffic` is what leaves the XCD's L2, an upper bound on HBM bytes.
-  * mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed
-    over the chip's SIMDs (32 per v_mfma_f32_32x32x16_bf16); the JSON also carries counter / (algorithmic MFMA count x 32)
-    as a calibration of that reading.
+  * mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed
+    over the chip's SIMDs (32 per v_mfma_f32_32x32x16_bf16); GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (5.99 M for a
+    0.37 ms launch = 8 x 2.0 GHz), hence the / 8.  The JSON also carries counter / (algorithmic MFMA count x 32) as a
+    calibration of the numerator (1.014 measured: the counter is trustworthy).
 
     python tools/pmc_summary.py gpurun_out/pmc_r02 profiles/r02_pmc.json
 """
@@ -19,6 +20,7 @@ import os
 import sys
 
 SIMDS = 256 * 4
+XCDS = 8
 
 
 def load(root, name):
@@ -56,7 +58,7 @@ def main(root, out):
                "fetch_bytes_per_launch_corrected": 2 * f * 1024, "write_bytes_per_launch": None if w is None else w * 1024,
                "traffic_bytes_per_launch": (2 * f + (w or 0)) * 1024, "l2_hit_rate": h / (h + m) if h + m else None,
                "sq_valu_mfma_busy_cycles": busy, "grbm_gui_active": gui,
-               "mfma_busy": busy / (gui * SIMDS) if busy and gui else None}
+               "mfma_busy": busy / (gui / XCDS * SIMDS) if busy and gui else None}
         for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
             row[c.lower()] = mean(sq.get(key, {}).get(c, []))
         for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS"):
