@@ -292,7 +292,9 @@ def pmc_traffic(args):
             bool(c.get("dual_stream")) == bool(args.dual_stream))
     if not same:
         return None, None, f"profiles/r02_pmc.json was collected for another configuration ({rec.get('command')}): not reported"
-    rows = [r for r in rec["kernels"] if "gemm_bf16_kernel" in r["kernel"] and r["workgroups"] >= 400]
+    # the block GEMMs only (QKV 1224, MLP-up 1632, out-proj / MLP-down 408 work-groups at this geometry): the hoisted modulation
+    # GEMMs of pe_dit_prepare (M = steps) share the kernel name but are not what `roofline` is about
+    rows = [r for r in rec["kernels"] if "gemm_bf16_kernel" in r["kernel"] and r.get("algorithmic_gflop_per_launch")]
     n = sum(r["launches"] for r in rows)
     if not n:
         return None, None, None

@@ -37,11 +37,15 @@ const char* pe_last_error(void);
 int pe_abi_version(void);
 /* Hash of the kernel sources this library was built from (physicedit_amd/build.py:source_hash). */
 const char* pe_build_id(void);
-/* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant").
- * Production callers never need it: the compiled defaults are the validated schedules. */
+/* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant", ...).
+ * Production callers never need it: the compiled defaults are the validated schedules.
+ * "attn_variant": 0 default (8 waves x 32 query rows); 3 = 4 waves x 64 rows, one wave per SIMD, bit-identical to 0;
+ * 4 = 3 with the running softmax max raised only when a row outgrows it by 2^8 (faster; same distance to an fp32 result,
+ * fewer bf16 outputs identical to the reference SDPA's -- opt-in, see profiles/r02_attention_notes.md). */
 int pe_debug_set(const char* key, int value);
 /* Device buffer for a profiling variant's output ("gemm_stamps": long long [work-groups][8] s_memtime stamps of
- * gemm variant 14); NULL detaches it. */
+ * gemm variant 14; "attn_stamps": long long [work-groups][10] of attention variants 3 / 4 built with -DPE_W4_STAMPS=1);
+ * NULL detaches it. */
 int pe_debug_set_ptr(const char* key, void* device_ptr);
 /* Bytes of the optional stream-K workspace of the GEMM (fp32 partial tiles + flags; zero-fill it once).  The DiT composite
  * carves its own from the bound workspace; the granular operators use the one registered with
@@ -86,8 +90,9 @@ int pe_lora_merge(void* W, int N, int K, const void* up, const void* down_t, int
  *   pe_gemm_e4m3:           y = bf16(acc * scale_a[m] + bias[n]) with acc = Aq[M,K] . Wq[N,K]^T in fp32 on the
  *                           block-scaled CDNA4 MFMA (unit block scales), then pre-add / epilogue as pe_gemm_bf16_pre.
  *                           Aq, Wq are OCP e4m3fn bytes; K % 128 == 0; lda % 16 == 0; bias/pre/gate/res/out bf16.
- * torch._scaled_mm, which the reference calls here, does not run on CPU with per-row scales: parity of this pair is
- * pinned only against the CPU restatement in oracle/ ("parity unpinned"). */
+ * torch._scaled_mm, which the reference calls here, does not run on CPU with per-row scales, so there is no CPU fixture; the
+ * pair is pinned on the GPU: the quantiser bit-exact against torch's device ops, pe_gemm_e4m3 bit-identical to
+ * torch._scaled_mm on the same operands (tests/test_gpu_fp8.py, profiles/r02_parity.json). */
 int pe_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, void* stream);
 /* pe_ln_modulate followed by pe_quantize_rows_e4m3 in one pass over the row (the form the e4m3 composite uses in front of
  * the QKV and MLP-up Linears): out_e4m3 [rows,dim] bytes + out_scale [rows]; out_bf16 nullable (skipped when null).

@@ -20,10 +20,13 @@ pinned against outputs of the reference itself, imported in the build container 
 `tests/golden/make_golden.py`, which wrote the fixtures `tests/golden/*.safetensors`;
 `tests/test_oracle_golden.py` replays them (CPU, `-m "not gpu"`).
 
-PARITY UNPINNED for one optional branch: the e4m3 "FP8 computation" Linear (`fp8_linear`, `fp8_quantize_rows`,
-`to_fp8_state_dict` below; BASELINE.json configs[2]).  The reference's implementation ends in torch._scaled_mm, which
-does not run on CPU with per-row scales, so no golden vector can be generated for it here; see the section comment.
-Everything else in this file is pinned bit-exact by the G1..G11 fixtures.
+One optional branch cannot be pinned by CPU fixtures: the e4m3 "FP8 computation" Linear (`fp8_linear`, `fp8_quantize_rows`,
+`to_fp8_state_dict` below; BASELINE.json configs[2]).  The reference's implementation ends in torch._scaled_mm, which does
+not run on CPU with per-row scales, so no golden vector can be generated for it in the build container.  It is pinned on the
+GPU instead, against the very call the reference makes: tests/test_gpu_fp8.py compares pe_quantize_rows_e4m3 with torch's own
+device ops (bit-exact) and pe_gemm_e4m3 with torch._scaled_mm on the same operands (bit-identical on every tested shape,
+profiles/r02_parity.json); this file's restatement of _scaled_mm (exact sum) is only the CPU-side cross-check.
+Everything else in this file is pinned bit-exact by the G1..G12 fixtures.
 
 `dtype=torch.float32` runs the same graph in fp32 (used for the "distance to fp32 truth" parity
 bound in tests; never a reference behaviour).
@@ -432,14 +435,14 @@ def _linear(sd, name: str, x: torch.Tensor) -> torch.Tensor:
 
 
 # ======================================================================================
-# e4m3 ("FP8 computation") Linear -- PARITY UNPINNED
+# e4m3 ("FP8 computation") Linear -- not pinnable on CPU; pinned on the GPU against torch._scaled_mm (tests/test_gpu_fp8.py)
 # ======================================================================================
 # AutoWrappedLinear.fp8_linear (vram_management/layers.py:115-151) is reached when the DiT is STORED in
 # float8_e4m3fn (ModelConfig(offload_dtype=torch.float8_e4m3fn)) and enable_vram_management(
 # enable_dit_fp8_computation=True) wraps every torch.nn.Linear with computation_dtype = that stored dtype
 # (pipelines/qwen_image_physical.py:440-496).  Its matmul is torch._scaled_mm, which has no CPU implementation for
-# per-row scales, so the reference cannot produce golden vectors for it in the build container: this restatement
-# is PARITY UNPINNED.  What it follows:
+# per-row scales, so the reference cannot produce golden vectors for it in the build container: this restatement has no
+# CPU fixture (the HIP kernels are compared with torch._scaled_mm itself on the GPU box).  What it follows:
 #   * the quantisation arithmetic literally, with the GPU semantics of `bf16_tensor / python_float`
 #     (ATen BinaryDivTrueKernel: x * (1/448) in fp32, one rounding to bf16) because the reference can only run
 #     this path on a GPU;

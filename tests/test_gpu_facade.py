@@ -89,7 +89,7 @@ def test_c3_fp8_computation_through_the_facade(tmp_path):
     """BASELINE.json configs[2] the way a reference user switches it on: the DiT checkpoint loaded with
     ModelConfig(offload_dtype=torch.float8_e4m3fn) + pipe.enable_vram_management(enable_dit_fp8_computation=True)
     (qwen_image_physical.py:440-496), hot-loaded LoRA, adapter; vs the oracle on the e4m3 state-dict
-    (parity unpinned: see oracle/physicedit_oracle.py)."""
+    (the e4m3 Linear itself is pinned against torch._scaled_mm in tests/test_gpu_fp8.py)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from safetensors.torch import save_file

@@ -1,9 +1,10 @@
 """`-m gpu` tests of the e4m3 ("FP8 computation") Linear path: row quantiser and e4m3 GEMM through the C-ABI against the
 oracle's restatement of AutoWrappedLinear.fp8_linear (vram_management/layers.py:115-151).
 
-PARITY UNPINNED for the matmul (torch._scaled_mm has no CPU implementation with per-row scales, so the reference
-cannot emit golden vectors in the build container; see oracle/physicedit_oracle.py).  The quantiser is pure
-element-wise arithmetic and is compared BIT-EXACTLY, both with the oracle and with torch's own device ops.
+torch._scaled_mm has no CPU implementation with per-row scales, so the reference cannot emit golden vectors for the matmul
+in the build container; it is pinned HERE, on the device, against the call the reference makes: pe_gemm_e4m3 must equal
+torch._scaled_mm on the same e4m3 operands and scales (measured bit-identical, test_gemm_e4m3_vs_torch_scaled_mm).  The
+quantiser is pure element-wise arithmetic and is compared BIT-EXACTLY, both with the oracle and with torch's own device ops.
 """
 import pytest
 import torch
