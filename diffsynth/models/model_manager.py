@@ -18,6 +18,7 @@ _HASHES = {
 _SIGNATURES = (
     ("qwen_image_dit", "transformer_blocks.0.img_mod.1.weight"),
     ("qwen_image_vae", "decoder.up_blocks.0.resnets.0.conv1.weight"),
+    ("qwen_image_blockwise_controlnet", "controlnet_blocks.0.x_rms.weight"),
     ("qwen_image_text_encoder", "model.language_model.layers.0.self_attn.q_proj.weight"),
     ("qwen_image_text_encoder", "model.layers.0.self_attn.q_proj.weight"),
 )
@@ -58,8 +59,11 @@ class ModelManager:
         for p in file_path_list:
             self.load_model(p, **kw)
 
-    def fetch_model(self, model_name, file_path=None, require_model_path=False):
-        for sd, name, path in zip(self.model, self.model_name, self.model_path):
-            if name == model_name and (file_path is None or path == file_path):
-                return (sd, path) if require_model_path else sd
-        return None
+    def fetch_model(self, model_name, file_path=None, require_model_path=False, index=None):
+        """`index="all"` returns every loaded model of that name as a list (the reference fetches its block-wise ControlNets
+        this way, qwen_image_physical.py:521); otherwise the first match or None."""
+        found = [((sd, path) if require_model_path else sd) for sd, name, path in zip(self.model, self.model_name, self.model_path)
+                 if name == model_name and (file_path is None or path == file_path)]
+        if index == "all":
+            return found
+        return found[0] if found else None

@@ -26,6 +26,8 @@ import torch
 from PIL import Image
 
 from physicedit_amd import _lib
+from physicedit_amd.controlnet import (ControlNetInput, QwenImageBlockWiseControlNet,  # noqa: F401  (re-exported)
+                                        QwenImageBlockwiseMultiControlNet)
 from physicedit_amd.dit import QwenImageDiTEngine, model_fn_qwen_image  # noqa: F401  (re-exported operator)
 from physicedit_amd.pipeline import DenoiseLoop
 from physicedit_amd.scheduler import qwen_image_scheduler
@@ -133,6 +135,10 @@ class QwenImagePhysicPipeline:
             pipe.set_dit(dit_sd)
         if vae_sd is not None:
             pipe.set_vae(vae_sd)
+        controlnets = mm.fetch_model("qwen_image_blockwise_controlnet", index="all")       # (:521)
+        if controlnets:
+            pipe.blockwise_controlnet = QwenImageBlockwiseMultiControlNet(
+                [QwenImageBlockWiseControlNet(dict(sd.items()), device=device) for sd in controlnets])
         for name, cfg in (("tokenizer", tokenizer_config), ("processor", processor_config)):
             if cfg is not None:
                 cfg.download_if_necessary()
@@ -271,6 +277,32 @@ class QwenImagePhysicPipeline:
             return self.vae.encode(self.preprocess_image(image))       # exotic modes: the stand-alone map
         return self.vae.encode(torch.from_numpy(np.ascontiguousarray(u8)).to(self.device))
 
+    # ---- QwenImageUnit_BlockwiseControlNet (:1201-1241): host-side image / mask arithmetic around one VAE encode per input
+    def apply_controlnet_mask_on_latents(self, latents: torch.Tensor, mask: Image.Image) -> torch.Tensor:
+        m = (self.preprocess_image(mask) + 1) / 2
+        m = m.mean(dim=1, keepdim=True)
+        m = 1 - torch.nn.functional.interpolate(m, size=latents.shape[-2:])
+        return torch.concat([latents, m], dim=1)
+
+    def apply_controlnet_mask_on_image(self, image: Image.Image, mask: Image.Image) -> Image.Image:
+        mask = mask.resize(image.size)
+        m = self.preprocess_image(mask).mean(dim=[0, 1]).cpu()
+        out = np.array(image)
+        out[(m > 0).numpy()] = 0
+        return Image.fromarray(out)
+
+    def controlnet_conditionings(self, blockwise_controlnet_inputs) -> List[torch.Tensor]:
+        conditionings = []
+        for ci in blockwise_controlnet_inputs:
+            image = ci.image
+            if ci.inpaint_mask is not None:
+                image = self.apply_controlnet_mask_on_image(image, ci.inpaint_mask)
+            lat = self._encode_image(image)
+            if ci.inpaint_mask is not None:
+                lat = self.apply_controlnet_mask_on_latents(lat, ci.inpaint_mask)
+            conditionings.append(lat)
+        return conditionings
+
     def generate_noise(self, shape, seed=None, rand_device="cpu", rand_torch_dtype=torch.float32, device=None, torch_dtype=None):
         generator = None if seed is None else torch.Generator(rand_device).manual_seed(seed)
         noise = torch.randn(shape, generator=generator, device=rand_device, dtype=rand_torch_dtype)
@@ -299,10 +331,11 @@ class QwenImagePhysicPipeline:
                  stitched_image=None, state: str = None, transition: str = None, triplet: dict = None,
                  is_train: bool = True, have_text_reasoning: bool = True):
         """Same keyword surface and defaults as the reference (:545-597); returns a PIL image."""
-        for name, v in (("inpaint_mask", inpaint_mask), ("blockwise_controlnet_inputs", blockwise_controlnet_inputs),
-                        ("eligen_entity_prompts", eligen_entity_prompts)):
+        for name, v in (("inpaint_mask", inpaint_mask), ("eligen_entity_prompts", eligen_entity_prompts)):
             if v is not None:
                 raise _lib.PeError(f"{name} is outside the accelerated path (SURVEY.md section 8: out of scope)")
+        if blockwise_controlnet_inputs is not None and self.blockwise_controlnet is None:
+            raise _lib.PeError("blockwise_controlnet_inputs given but no block-wise ControlNet checkpoint was loaded")
         if enable_fp8_attention or edit_rope_interpolation:
             raise _lib.PeError("enable_fp8_attention / edit_rope_interpolation are not implemented")
         if is_train and self.use_special_tokens:
@@ -345,12 +378,15 @@ class QwenImagePhysicPipeline:
         if use_cfg:
             pe_n = nega["prompt_emb"].to(device=self.device, dtype=self.torch_dtype).contiguous()
             m_n = nega.get("special_token_mask") if self.use_special_tokens else None
+        # BlockwiseControlNet unit (:1201-1241)
+        ctl_cond = self.controlnet_conditionings(blockwise_controlnet_inputs) if blockwise_controlnet_inputs is not None else None
         # denoise loop + decode (:644-667)
         loop = DenoiseLoop(self.dit)
         loop.scheduler = self.scheduler
         latents = loop(latents, pe_p, pe_n, m_p, m_n, height, width, num_inference_steps=num_inference_steps,
                        cfg_scale=cfg_scale, edit_latents=edit_latents or None, exponential_shift_mu=exponential_shift_mu,
-                       denoising_strength=denoising_strength)
+                       denoising_strength=denoising_strength, blockwise_controlnet=self.blockwise_controlnet,
+                       blockwise_controlnet_inputs=blockwise_controlnet_inputs, blockwise_controlnet_conditioning=ctl_cond)
         self.last_latents = latents
         # vae.decode + vae_output_to_image (:664-667) in one composite: the last kernel emits HWC uint8
         u8 = self.vae.decode(latents, output_u8=True, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)

@@ -129,6 +129,10 @@ int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, cons
 
 /* RMSNorm with weight over rows of width 3584 (txt_norm; models/utils.py:250-257). */
 int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, void* stream);
+/* BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18): out = bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of
+ * dim = 3072, each RMSNorm with the roundings of models/utils.py:250-257. */
+int pe_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,
+                        void* stream);
 
 /* "C (H 2) (W 2) -> (H W) (C 2 2)" and back (qwen_image_physical.py:1344,1402); latents [C,H2,W2]. */
 int pe_patchify(const void* latents, void* tokens, int C, int H2, int W2, void* stream);
@@ -182,6 +186,21 @@ typedef struct pe_adapter_weights {    /* VisualThinkingDualAdapter, pipelines/h
     const void *vae_w0, *vae_b0, *vae_w2, *vae_b2;
 } pe_adapter_weights;
 
+/* One BlockWiseControlBlock (models/qwen_image_controlnet.py:6-27): rms(x) + rms(y) -> Linear -> exact-erf GELU -> Linear. */
+typedef struct pe_controlnet_block {
+    const void *x_rms_w, *y_rms_w;             /* [3072] bf16 */
+    const void *in_w, *in_b, *out_w, *out_b;   /* [3072,3072], [3072] bf16 */
+} pe_controlnet_block;
+
+/* One ControlNetInput that is ACTIVE for this call (the progress gate of QwenImageBlockwiseMultiControlNet.blockwise_forward,
+ * pipelines/qwen_image_physical.py:172-180, is host logic).  After every transformer block l the first S0 (noise) rows of the
+ * image stream become  image + sum_i bf16(controlnet_i.blocks[l](image, conditioning_i) * scale_i)  (:1389-1396). */
+typedef struct pe_control_input {
+    const pe_controlnet_block* blocks;  /* HOST array [num_layers of the DiT] of device pointers; read during the call only */
+    const void* conditioning;           /* [S0,3072] bf16 = controlnet.img_in(patchify(conditioning latents)), :164-170 */
+    float scale;
+} pe_control_input;
+
 /* geometry + per-call inputs of one model_fn_qwen_image call */
 typedef struct pe_dit_call {
     const void* latents;        /* [16,h8,w8] bf16 (B = 1) */
@@ -198,6 +217,8 @@ typedef struct pe_dit_call {
     const float *rope_cos_txt, *rope_sin_txt; /* [T,64]     fp32, QwenEmbedRope txt_freqs */
     int step;                   /* row of the tables built by pe_dit_prepare */
     void* noise_pred;           /* out: [16,h8,w8] bf16 */
+    int n_control;              /* 0..4 active block-wise ControlNet inputs (bf16 weights only) */
+    pe_control_input control[4];
 } pe_dit_call;
 
 /* Runtime ("hot") LoRA operands of one block -- load_lora(hotload=True), qwen_image_physical.py:264-272 +

@@ -298,12 +298,57 @@ def num_layers_of(sd: SD) -> int:
     return n
 
 
+# ---- block-wise ControlNet (models/qwen_image_controlnet.py, pipelines/qwen_image_physical.py:157-180, :1373-1396) ----------
+def controlnet_preprocess(cs: SD, conditioning_latents: torch.Tensor) -> torch.Tensor:
+    """QwenImageBlockwiseMultiControlNet.preprocess for one input (:164-170): patchify ("B C (H P) (W Q) -> B (H W) (C P Q)",
+    C = 16, or 17 with the inpaint mask channel) + QwenImageBlockWiseControlNet.img_in."""
+    B, Cc, H, W = conditioning_latents.shape
+    x = conditioning_latents.reshape(B, Cc, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 2) * (W // 2), Cc * 4)
+    return F.linear(x, cs["img_in.weight"], cs["img_in.bias"])
+
+
+def controlnet_block(cs: SD, block_id: int, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """BlockWiseControlBlock.forward (qwen_image_controlnet.py:16-21): rms(x) + rms(y) -> Linear -> exact-erf GELU -> Linear."""
+    p = f"controlnet_blocks.{block_id}."
+    x, y = rmsnorm(x, cs[p + "x_rms.weight"]), rmsnorm(y, cs[p + "y_rms.weight"])
+    x = F.linear(x + y, cs[p + "input_proj.weight"], cs[p + "input_proj.bias"])
+    x = F.gelu(x)
+    return F.linear(x, cs[p + "output_proj.weight"], cs[p + "output_proj.bias"])
+
+
+def controlnet_active(progress_id: int, num_inference_steps: int, start: float, end: float) -> bool:
+    """the gate of QwenImageBlockwiseMultiControlNet.blockwise_forward (:175-177); ControlNetInput defaults start=1, end=0"""
+    progress = (num_inference_steps - 1 - progress_id) / max(num_inference_steps - 1, 1)
+    return not (progress > start + 1e-4 or progress < end - 1e-4)
+
+
+def controlnet_mask_on_image(image_u8_hwc, mask_u8_hwc, dtype=torch.bfloat16):
+    """QwenImageUnit_BlockwiseControlNet.apply_controlnet_mask_on_image (:1218-1222) for a mask already resized to the image:
+    pixels whose mask mean (taken over all three channels of preprocess_image's [-1,1] values) is > 0 become black."""
+    import numpy as np
+    m = preprocess_image(mask_u8_hwc, dtype).mean(dim=[0, 1])
+    out = np.array(image_u8_hwc).copy()
+    out[(m > 0).numpy()] = 0
+    return out
+
+
+def controlnet_mask_on_latents(latents: torch.Tensor, mask_u8_hwc, dtype=torch.bfloat16) -> torch.Tensor:
+    """apply_controlnet_mask_on_latents (:1211-1216): channel 17 = 1 - nearest-resized((mask + 1) / 2 averaged over RGB)."""
+    m = (preprocess_image(mask_u8_hwc, dtype) + 1) / 2
+    m = m.mean(dim=1, keepdim=True)
+    m = 1 - torch.nn.functional.interpolate(m, size=latents.shape[-2:])
+    return torch.concat([latents, m], dim=1)
+
+
 def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Tensor,
              prompt_emb: torch.Tensor, special_token_mask: Optional[torch.Tensor],
              height: int, width: int, edit_latents=None,
-             t_min: float = 20.0, t_max: float = 1000.0) -> torch.Tensor:
+             t_min: float = 20.0, t_max: float = 1000.0, controlnets=None, progress_id: int = 0,
+             num_inference_steps: int = 1) -> torch.Tensor:
     """One DiT forward at inference (is_train=False).  MUTATES `prompt_emb` IN PLACE on the
-    special-token rows exactly as the reference does (:1336)."""
+    special-token rows exactly as the reference does (:1336).
+    `controlnets`: list of dicts {"sd": controlnet state dict, "conditioning": latents [1,16|17,h8,w8], "scale", "start", "end"}
+    (one per ControlNetInput; the unit that VAE-encodes the control image is outside this function)."""
     if special_token_mask is not None:
         special = prompt_emb[special_token_mask].view(prompt_emb.shape[0], -1, prompt_emb.size(-1))
         special, _, _ = adapter_forward(ad, special, timestep, t_min, t_max)
@@ -324,8 +369,18 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
     text = _linear(sd, "txt_in", rmsnorm(prompt_emb, sd["txt_norm.weight"]))
     vid_f, txt_f = rope_tables(img_shapes, T)
 
+    processed = [controlnet_preprocess(c["sd"], c["conditioning"]) for c in controlnets] if controlnets else None
+
     for i in range(num_layers_of(sd)):
         text, image = block_forward(sd, i, image, text, conditioning, (vid_f, txt_f))
+        if processed is not None:                          # :1389-1396
+            image_slice = image[:, :image_seq_len].clone()
+            res = 0
+            for c, cond in zip(controlnets, processed):
+                if not controlnet_active(progress_id, num_inference_steps, c.get("start", 1.0), c.get("end", 0.0)):
+                    continue
+                res = res + controlnet_block(c["sd"], i, image_slice, cond) * c.get("scale", 1.0)
+            image[:, :image_seq_len] = image_slice + res
 
     # AdaLayerNorm(single=True), models/utils.py:304-309
     emb = _linear(sd, "norm_out.linear", F.silu(conditioning))
@@ -339,7 +394,7 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
 def denoise_loop(sd: SD, ad: Optional[SD], noise: torch.Tensor, prompt_emb_posi: torch.Tensor,
                  prompt_emb_nega: Optional[torch.Tensor], mask_posi, mask_nega,
                  height: int, width: int, num_inference_steps: int, cfg_scale: float = 4.0,
-                 edit_latents=None, dtype=torch.bfloat16) -> torch.Tensor:
+                 edit_latents=None, dtype=torch.bfloat16, controlnets=None) -> torch.Tensor:
     """QwenImagePhysicPipeline.__call__ lines 600 + 644-661 (loop only; prologue outputs are the
     arguments).  prompt_emb_* are cloned once here and then mutated across steps like the
     reference's `inputs_posi` / `inputs_nega` dict entries."""
@@ -350,9 +405,10 @@ def denoise_loop(sd: SD, ad: Optional[SD], noise: torch.Tensor, prompt_emb_posi:
     pe_n = prompt_emb_nega.clone() if prompt_emb_nega is not None else None
     for progress_id, timestep in enumerate(tab.timesteps):
         t = timestep.unsqueeze(0).to(dtype=dtype)
-        pred = model_fn(sd, ad, latents, t, pe_p, mask_posi, height, width, edit_latents, t_min, t_max)
+        kw = dict(controlnets=controlnets, progress_id=progress_id, num_inference_steps=num_inference_steps)
+        pred = model_fn(sd, ad, latents, t, pe_p, mask_posi, height, width, edit_latents, t_min, t_max, **kw)
         if cfg_scale != 1.0:
-            pred_n = model_fn(sd, ad, latents, t, pe_n, mask_nega, height, width, edit_latents, t_min, t_max)
+            pred_n = model_fn(sd, ad, latents, t, pe_n, mask_nega, height, width, edit_latents, t_min, t_max, **kw)
             pred = pred_n + cfg_scale * (pred - pred_n)
         latents = tab.step(pred, progress_id, latents)
     return latents

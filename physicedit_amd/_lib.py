@@ -71,6 +71,14 @@ class VaeWeights(C.Structure):
 IMAGE_BF16_NCHW, IMAGE_U8_HWC = 0, 1
 
 
+class ControlNetBlock(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("x_rms_w", "y_rms_w", "in_w", "in_b", "out_w", "out_b")]
+
+
+class ControlInput(C.Structure):
+    _fields_ = [("blocks", C.POINTER(ControlNetBlock)), ("conditioning", c_void_p), ("scale", c_float)]
+
+
 class DitCall(C.Structure):
     _fields_ = [
         ("latents", c_void_p), ("h8", c_int), ("w8", c_int),
@@ -81,11 +89,12 @@ class DitCall(C.Structure):
         ("rope_cos_img", c_void_p), ("rope_sin_img", c_void_p),
         ("rope_cos_txt", c_void_p), ("rope_sin_txt", c_void_p),
         ("step", c_int), ("noise_pred", c_void_p),
+        ("n_control", c_int), ("control", ControlInput * 4),
     ]
 
 
 # name -> (restype, argtypes); every symbol include/physicedit_amd.h declares
-ABI_VERSION = 3   # include/physicedit_amd.h: bumped on any signature / struct change
+ABI_VERSION = 4   # include/physicedit_amd.h: bumped on any signature / struct change
 
 SIGNATURES = {
     "pe_last_error": (C.c_char_p, []),
@@ -112,6 +121,7 @@ SIGNATURES = {
     "pe_ln_modulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_float, c_void_p]),
     "pe_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "pe_dual_rmsnorm_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "pe_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pe_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pe_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_void_p]),

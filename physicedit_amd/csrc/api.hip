@@ -32,7 +32,7 @@ using namespace pe;
 extern "C" {
 
 const char* pe_last_error(void) { return g_err; }
-int pe_abi_version(void) { return 3; }
+int pe_abi_version(void) { return 4; }
 #ifndef PE_SRC_HASH
 #define PE_SRC_HASH "unknown"
 #endif
@@ -142,6 +142,11 @@ int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, cons
 
 int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, void* stream) {
     return launch_rmsnorm(x, w, out, rows, dim, eps, (hipStream_t)stream);
+}
+
+int pe_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,
+                        void* stream) {
+    return launch_dual_rmsnorm_add(x, wx, y, wy, out, rows, dim, eps, (hipStream_t)stream);
 }
 
 int pe_patchify(const void* latents, void* tokens, int C, int H2, int W2, void* stream) {

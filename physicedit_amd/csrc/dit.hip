@@ -353,6 +353,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
     PE_REQUIRE(c->rope_cos_img && c->rope_sin_img && c->rope_cos_txt && c->rope_sin_txt, "pe_dit_forward: null rope table");
     PE_REQUIRE(c->n_special >= 0 && c->n_special <= MAX_SPECIAL, "pe_dit_forward: n_special=%d", c->n_special);
     PE_REQUIRE(c->n_special == 0 || (h->has_adapter && c->special_idx), "pe_dit_forward: special tokens without adapter");
+    PE_REQUIRE(c->n_control >= 0 && c->n_control <= 4, "pe_dit_forward: n_control=%d", c->n_control);
+    for (int i = 0; i < c->n_control; ++i)
+        PE_REQUIRE(c->control[i].blocks && c->control[i].conditioning, "pe_dit_forward: control input %d has a null pointer", i);
     hipStream_t stream = (hipStream_t)stream_;
     const int L = h->w.num_layers;
     const int S0 = (c->h8 / 2) * (c->w8 / 2);
@@ -493,6 +496,32 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = FF;
         }
         if ((rc = hot_linear(h, l, 2, EPI_GATE_RES, pp, h->attn, D, stream))) return rc;
+
+        // block-wise ControlNet on the noise rows (:1389-1396): image[:S0] += sum_i bf16(block_i(image[:S0], cond_i) * scale_i).
+        // One input: folded into the second Linear's epilogue (0 + v is exact).  Several: the sum is formed first, as the
+        // reference does (`res = res + out * scale`), in a zeroed scratch, then added.
+        if (c->n_control > 0) {
+            const bool single = c->n_control == 1;
+            char* acc = single ? x_img : h->hbuf;
+            if (!single) {
+                const hipError_t e = hipMemsetAsync(acc, 0, (size_t)S0 * D * 2, stream);
+                if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_forward: hipMemsetAsync: %s", hipGetErrorString(e));
+            }
+            for (int ci = 0; ci < c->n_control; ++ci) {
+                const pe_controlnet_block& cb = c->control[ci].blocks[l];
+                if ((rc = launch_dual_rmsnorm_add(x_img, cb.x_rms_w, c->control[ci].conditioning, cb.y_rms_w, h->xmod, S0, D, 1e-6f,
+                                                  stream)))
+                    return rc;
+                memset(&p, 0, sizeof(p));
+                p.A = h->xmod; p.lda = D; p.W = cb.in_w; p.bias = cb.in_b; p.out = h->attn; p.ldo = D; p.M = S0; p.N = D; p.K = D;
+                if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream, h->sk_ws))) return rc;
+                memset(&p, 0, sizeof(p));
+                p.A = h->attn; p.lda = D; p.W = cb.out_w; p.bias = cb.out_b; p.out = acc; p.ldo = D; p.res = acc; p.ldr = D;
+                p.has_gate_scalar = 1; p.gate_scalar = c->control[ci].scale; p.M = S0; p.N = D; p.K = D;
+                if ((rc = launch_gemm(EPI_GATE_RES, &p, 1, stream, h->sk_ws))) return rc;
+            }
+            if (!single && (rc = launch_add_inplace(x_img, acc, (size_t)S0 * D, stream))) return rc;
+        }
     }
 
     // ---- 4. AdaLayerNorm(single) head on the S0 kept rows, proj_out, unpatchify  (:1398-1402)

@@ -171,6 +171,78 @@ int launch_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18): x_rms(x) + y_rms(y) over 3072, each RMSNorm rounded as
+// models/utils.py:250-257 (x * rsqrt -> bf16, * weight -> bf16), then the bf16 add.  One wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dual_rmsnorm_add_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wx,
+                                                               const bf16* __restrict__ y, const bf16* __restrict__ wy,
+                                                               bf16* __restrict__ out, int rows, float eps) {
+    constexpr int VPL = 6, DIM = 3072;
+    const int lane = lane_id();
+    const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16* xr = x + (size_t)row * DIM;
+    const bf16* yr = y + (size_t)row * DIM;
+    float vx[VPL][8], vy[VPL][8];
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const bf16x8 tx = *(const bf16x8*)(xr + (i * 64 + lane) * 8);
+        const bf16x8 ty = *(const bf16x8*)(yr + (i * 64 + lane) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            vx[i][j] = (float)tx[j];
+            vy[i][j] = (float)ty[j];
+            sx += vx[i][j] * vx[i][j];
+            sy += vy[i][j] * vy[i][j];
+        }
+    }
+    const float rx = rsqrtf(wave_sum(sx) / (float)DIM + eps);
+    const float ry = rsqrtf(wave_sum(sy) / (float)DIM + eps);
+    bf16* orow = out + (size_t)row * DIM;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        const bf16x8 wxv = *(const bf16x8*)(wx + c);
+        const bf16x8 wyv = *(const bf16x8*)(wy + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = (bf16)(bf16r(bf16r(vx[i][j] * rx) * (float)wxv[j]) + bf16r(bf16r(vy[i][j] * ry) * (float)wyv[j]));
+        *(bf16x8*)(orow + c) = o;
+    }
+}
+
+int launch_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,
+                            hipStream_t stream) {
+    PE_REQUIRE(x && wx && y && wy && out, "dual_rmsnorm_add: null pointer");
+    PE_REQUIRE(rows > 0, "dual_rmsnorm_add: rows=%d", rows);
+    PE_REQUIRE(dim == 3072, "dual_rmsnorm_add: dim=%d unsupported (DiT width 3072 only)", dim);
+    hipLaunchKernelGGL(dual_rmsnorm_add_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (const bf16*)wx,
+                       (const bf16*)y, (const bf16*)wy, (bf16*)out, rows, eps);
+    return check_launch("dual_rmsnorm_add_kernel");
+}
+
+// x[i] = bf16(x[i] + y[i]) over n elements (n % 8 == 0)
+__global__ void __launch_bounds__(256) add_inplace_kernel(bf16* __restrict__ x, const bf16* __restrict__ y, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        bf16x8 a = *(const bf16x8*)(x + i * 8);
+        const bf16x8 b = *(const bf16x8*)(y + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (bf16)((float)a[j] + (float)b[j]);
+        *(bf16x8*)(x + i * 8) = a;
+    }
+}
+
+int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream) {
+    PE_REQUIRE(x && y && n % 8 == 0, "add_inplace: null pointer or n %% 8 != 0");
+    const size_t n8 = n / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, (bf16*)x, (const bf16*)y, n8);
+    return check_launch("add_inplace_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // SiLU (torch.nn.SiLU on bf16: fp32 inside, one rounding)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, size_t n8) {

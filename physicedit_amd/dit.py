@@ -359,9 +359,11 @@ class QwenImageDiTEngine:
     # ------------------------------------------------------------------------------------------
     def forward(self, latents: torch.Tensor, timestep: torch.Tensor, prompt_emb: torch.Tensor,
                 special_idx: Optional[torch.Tensor] = None, edit_latents=None, step: Optional[int] = None,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, controls=None) -> torch.Tensor:
         """One model_fn call.  `timestep`: [1] tensor in the pipeline dtype.  `prompt_emb` [1,T,3584] is
-        MUTATED IN PLACE on `special_idx` rows.  Returns noise_pred [1,16,h8,w8]."""
+        MUTATED IN PLACE on `special_idx` rows.  Returns noise_pred [1,16,h8,w8].
+        `controls`: active block-wise ControlNet inputs, [(QwenImageBlockWiseControlNet, processed conditioning [S0,3072], scale)]
+        (physicedit_amd.controlnet)."""
         ops._chk(latents, "latents"), ops._chk(prompt_emb, "prompt_emb")
         h8, w8 = latents.shape[-2:]
         edits: List[torch.Tensor] = []
@@ -402,6 +404,22 @@ class QwenImageDiTEngine:
         c.rope_cos_txt, c.rope_sin_txt = cos_t.data_ptr(), sin_t.data_ptr()
         c.step = step
         c.noise_pred = out.data_ptr()
+        c.n_control = 0
+        if controls:
+            if self.fp8:
+                raise _lib.PeError("block-wise ControlNet with the e4m3 DiT is not implemented (its Linears would be fp8_linear too)")
+            if len(controls) > 4:
+                raise _lib.PeError("at most 4 active ControlNet inputs per call")
+            S0 = (h8 // 2) * (w8 // 2)
+            for i, (net, cond, scale) in enumerate(controls):
+                ops._chk(cond, "controlnet conditioning")
+                if net.num_layers < self.num_layers or tuple(cond.shape) != (S0, 3072):
+                    raise _lib.PeError(f"controlnet input {i}: {net.num_layers} blocks / conditioning {tuple(cond.shape)} for a "
+                                       f"{self.num_layers}-layer DiT with {S0} noise tokens")
+                c.control[i].blocks = net.block_table
+                c.control[i].conditioning = cond.data_ptr()
+                c.control[i].scale = float(scale)
+            c.n_control = len(controls)
         check(lib().pe_dit_forward(self._handle, C.byref(c), stream_ptr()), "pe_dit_forward")
         return out
 
@@ -437,8 +455,8 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
     """Drop-in for the reference operator of the same name (qwen_image_physical.py:1302-1403),
     inference subset: returns (noise_pred, 0).  Unsupported reference features raise instead of
     silently differing."""
-    if blockwise_controlnet_conditioning is not None or entity_prompt_emb is not None:
-        raise _lib.PeError("model_fn_qwen_image: blockwise ControlNet / EliGen entity masks are outside the hot path")
+    if entity_prompt_emb is not None:
+        raise _lib.PeError("model_fn_qwen_image: EliGen entity masks are outside the hot path")
     if is_train and special_token_mask is not None:
         raise _lib.PeError("model_fn_qwen_image: is_train=True (special_token_loss) is a training feature; pass is_train=False")
     if enable_fp8_attention or edit_rope_interpolation:
@@ -453,5 +471,15 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
         idx = getattr(special_token_mask, "_pe_idx", None)
         if idx is None:
             idx = special_indices(special_token_mask, prompt_emb.device)
-    pred = dit.forward(latents, timestep, prompt_emb, idx, edits or None)
+    controls = None
+    if blockwise_controlnet_conditioning is not None:
+        # :1373-1375 (img_in of every conditioning, every call) and the per-block hook :1389-1396 with its progress gate :175-177.
+        # A conditioning that is already [S0,3072] was pre-processed by the caller (the result is the same every step).
+        if blockwise_controlnet is None or blockwise_controlnet_inputs is None:
+            raise _lib.PeError("model_fn_qwen_image: blockwise_controlnet_conditioning without blockwise_controlnet / inputs")
+        processed = [c if (c.dim() == 2 and c.shape[-1] == 3072) else
+                     blockwise_controlnet.models[ci.controlnet_id].process_controlnet_conditioning(c)
+                     for ci, c in zip(blockwise_controlnet_inputs, blockwise_controlnet_conditioning)]
+        controls = blockwise_controlnet.active_controls(blockwise_controlnet_inputs, processed, progress_id, num_inference_steps)
+    pred = dit.forward(latents, timestep, prompt_emb, idx, edits or None, controls=controls)
     return pred, 0

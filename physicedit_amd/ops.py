@@ -197,6 +197,15 @@ def rmsnorm(x, w, eps: float = 1e-6) -> torch.Tensor:
     return out
 
 
+def dual_rmsnorm_add(x, wx, y, wy, eps: float = 1e-6) -> torch.Tensor:
+    """BlockWiseControlBlock input: bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of 3072."""
+    _chk(x, "x"), _chk(y, "y"), _chk(wx, "wx"), _chk(wy, "wy")
+    out = torch.empty_like(x)
+    check(lib().pe_dual_rmsnorm_add(x.data_ptr(), wx.data_ptr(), y.data_ptr(), wy.data_ptr(), out.data_ptr(), x.shape[0],
+                                    x.shape[1], eps, stream_ptr()), "pe_dual_rmsnorm_add")
+    return out
+
+
 def patchify(latents: torch.Tensor) -> torch.Tensor:
     _chk(latents, "latents")
     C_, H2, W2 = latents.shape[-3:]

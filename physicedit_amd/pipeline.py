@@ -40,7 +40,8 @@ class DenoiseLoop:
                  special_mask_posi: Optional[torch.Tensor], special_mask_nega: Optional[torch.Tensor],
                  height: int, width: int, num_inference_steps: int = 30, cfg_scale: float = 4.0,
                  edit_latents=None, exponential_shift_mu: Optional[float] = None,
-                 denoising_strength: float = 1.0) -> torch.Tensor:
+                 denoising_strength: float = 1.0, blockwise_controlnet=None, blockwise_controlnet_inputs=None,
+                 blockwise_controlnet_conditioning=None) -> torch.Tensor:
         """noise [1,16,H/8,W/8]; prompt_emb_* [1,T,3584] DEVICE tensors, mutated in place on their
         special rows across the steps exactly like `inputs_posi["prompt_emb"]` in the reference."""
         dev = self.device
@@ -73,22 +74,29 @@ class DenoiseLoop:
         pred_p = torch.empty_like(latents)
         pred_n = torch.empty_like(latents) if use_cfg else None
         main = torch.cuda.current_stream(dev)
+        # block-wise ControlNet (:1373-1396): img_in of each conditioning once (the reference redoes it every call with the same
+        # result), then per step the inputs whose progress window contains the step
+        processed = None
+        if blockwise_controlnet_conditioning is not None:
+            processed = blockwise_controlnet.preprocess(blockwise_controlnet_inputs, blockwise_controlnet_conditioning)
         for i in range(num_inference_steps):
             t = ts[i:i + 1]
+            ctl = (blockwise_controlnet.active_controls(blockwise_controlnet_inputs, processed, i, num_inference_steps)
+                   if processed is not None else None)
             if dual:
                 sp, sn = self._streams
                 sp.wait_stream(main)
                 sn.wait_stream(main)
                 with torch.cuda.stream(sp):
-                    self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p)
+                    self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl)
                 with torch.cuda.stream(sn):
-                    dit_n.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n)
+                    dit_n.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl)
                 main.wait_stream(sp)
                 main.wait_stream(sn)
             else:
-                self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p)
+                self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl)
                 if use_cfg:
-                    self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n)
+                    self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl)
             ops.cfg_euler_step(pred_p, pred_n, latents, cfg_scale, sch.dsigma(i), out=nxt)
             latents, nxt = nxt, latents
         return latents

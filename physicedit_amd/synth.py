@@ -87,6 +87,19 @@ def dit_layout(num_layers: int) -> List[Tuple[str, Shape]]:
     return out
 
 
+def controlnet_layout(num_layers: int, additional_in_dim: int = 0) -> List[Tuple[str, Shape]]:
+    """QwenImageBlockWiseControlNet(num_layers, in_dim=64, additional_in_dim, dim=3072) -- models/qwen_image_controlnet.py:6-57
+    (additional_in_dim = 4 is the inpaint variant: the conditioning latents carry one mask channel, x 2 x 2 patch)."""
+    d = DIT_DIM
+    out: List[Tuple[str, Shape]] = [("img_in.weight", (d, PATCH_DIM + additional_in_dim)), ("img_in.bias", (d,))]
+    for i in range(num_layers):
+        p = f"controlnet_blocks.{i}."
+        out += [(p + "x_rms.weight", (d,)), (p + "y_rms.weight", (d,)),
+                (p + "input_proj.weight", (d, d)), (p + "input_proj.bias", (d,)),
+                (p + "output_proj.weight", (d, d)), (p + "output_proj.bias", (d,))]
+    return out
+
+
 def adapter_layout() -> List[Tuple[str, Shape]]:
     out: List[Tuple[str, Shape]] = []
     for head in ("head_dino", "head_vae"):

@@ -351,6 +351,64 @@ def G11_hot_lora():
     save("G11_hot_lora", outs, meta={"rank": 16, "seed_lora": 4321})
 
 
+def G13_controlnet():
+    """Block-wise ControlNet through the reference's model_fn (qwen_image_physical.py:1373-1396): one plain and one inpaint
+    (additional_in_dim = 4) ControlNet, scales 0.7 / 0.5, the second gated to the first half of the schedule."""
+    from diffsynth.models.qwen_image_controlnet import QwenImageBlockWiseControlNet
+    from diffsynth.pipelines.qwen_image_physical import QwenImageBlockwiseMultiControlNet
+    from diffsynth.pipelines.qwen_image_physical import ControlNetInput
+    dit, sd = build_dit(2, 1234)
+    nets = []
+    for seed, add in ((555, 0), (556, 4)):
+        with torch.device("meta"):
+            net = QwenImageBlockWiseControlNet(num_layers=2, additional_in_dim=add)
+        net.load_state_dict(synth.make_state_dict(synth.controlnet_layout(2, add), seed), assign=True, strict=True)
+        nets.append(net.eval())
+    multi = QwenImageBlockwiseMultiControlNet(nets)
+    h = w = 128
+    T = 24
+    noise, edit, pe, _ = _model_fn_inputs(h, w, T, 0, 3)
+    g = torch.Generator().manual_seed(77)
+    conds = [torch.randn((1, 16, h // 8, w // 8), generator=g).to(BF), torch.randn((1, 17, h // 8, w // 8), generator=g).to(BF)]
+    inputs = [ControlNetInput(controlnet_id=0, scale=0.7), ControlNetInput(controlnet_id=1, scale=0.5, start=1.0, end=0.5)]
+    pm = torch.ones((1, T), dtype=torch.long)
+    outs = {"conditioning0": conds[0], "conditioning1": conds[1]}
+    steps = 4
+    for pid, tval in ((0, 986.96), (3, 300.0)):           # progress 1.0: both active; progress 0.0: the second is gated out
+        lat, _ = model_fn_qwen_image(dit=dit, blockwise_controlnet=multi, visual_thinking_adapter=None, latents=noise,
+                                     timestep=torch.tensor([tval]).to(BF), prompt_emb=pe.clone(), prompt_emb_mask=pm,
+                                     special_token_mask=None, height=h, width=w, edit_latents=edit,
+                                     blockwise_controlnet_conditioning=[c.clone() for c in conds],
+                                     blockwise_controlnet_inputs=inputs, progress_id=pid, num_inference_steps=steps,
+                                     is_train=False)
+        outs[f"latents_progress{pid}"] = lat
+    # single ControlNet (the folded x + out * scale form of the HIP path)
+    lat, _ = model_fn_qwen_image(dit=dit, blockwise_controlnet=multi, visual_thinking_adapter=None, latents=noise,
+                                 timestep=torch.tensor([500.0]).to(BF), prompt_emb=pe.clone(), prompt_emb_mask=pm,
+                                 special_token_mask=None, height=h, width=w, edit_latents=None,
+                                 blockwise_controlnet_conditioning=[conds[0].clone()], blockwise_controlnet_inputs=inputs[:1],
+                                 progress_id=1, num_inference_steps=steps, is_train=False)
+    outs["latents_single"] = lat
+    outs["processed0"] = multi.preprocess(inputs[:1], [conds[0].clone()])[0]
+    # the unit's inpaint helpers (QwenImageUnit_BlockwiseControlNet, :1211-1222): host-side image / mask arithmetic
+    from PIL import Image
+    from diffsynth.pipelines.qwen_image_physical import QwenImageUnit_BlockwiseControlNet
+    unit = QwenImageUnit_BlockwiseControlNet()
+    ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")
+    ns.preprocess_image = lambda *a, **k: BasePipeline.preprocess_image(ns, *a, **k)
+    rs = np.random.RandomState(5)
+    img = (rs.rand(96, 128, 3) * 255).astype("uint8")
+    m = np.zeros((48, 64, 3), dtype="uint8")
+    m[10:30, 20:50] = 255
+    m[35:40, 5:12] = (rs.rand(5, 7, 3) * 255).astype("uint8")            # grey levels: exercises the mean / the > 0 test
+    lat_in = torch.randn((1, 16, 12, 16), generator=g).to(BF)
+    outs["unit_image"], outs["unit_mask"], outs["unit_latents_in"] = torch.from_numpy(img), torch.from_numpy(m), lat_in
+    outs["unit_latents_out"] = unit.apply_controlnet_mask_on_latents(ns, lat_in.clone(), Image.fromarray(m))
+    outs["unit_image_out"] = torch.from_numpy(np.array(unit.apply_controlnet_mask_on_image(ns, Image.fromarray(img), Image.fromarray(m))))
+    save("G13_controlnet", outs, meta={"h": h, "w": w, "T": T, "seed": 3, "layers": 2, "steps": steps, "seeds_nets": [555, 556],
+                                       "scales": [0.7, 0.5], "second_start_end": [1.0, 0.5], "timesteps": [986.96, 300.0, 500.0]})
+
+
 def G9_adapter():
     ad, adsd, (t_min, t_max) = build_adapter(4321)
     g = torch.Generator().manual_seed(9)

@@ -332,3 +332,80 @@ def test_lora_merge_alpha(alpha):
         u = ulps(eng.params[k], ref[k])          # whole matrix: elements where W and the LoRA term cancel are judged at rms scale
         # a one-ulp flip of bf16(B @ A) (fp32 summation order) is scaled by alpha before it meets W
         assert u.max().item() <= max(1.0, alpha) + 0.01 and (u > 0).float().mean().item() < 0.01, (k, u.max().item())
+
+
+def test_dual_rmsnorm_add():
+    """BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18) vs the oracle's two RMSNorms + bf16 add."""
+    from physicedit_amd import ops
+    x, y = rnd((333, 3072), 61, 2.0), rnd((333, 3072), 62, 0.7)
+    wx, wy = 1.0 + rnd((3072,), 63, 0.1), 1.0 + rnd((3072,), 64, 0.1)
+    ref = O.rmsnorm(x, wx) + O.rmsnorm(y, wy)
+    out = ops.dual_rmsnorm_add(x.cuda(), wx.cuda(), y.cuda(), wy.cuda())
+    report("dual_rmsnorm_add", out, ref, 1.01, 0.002)
+
+
+def test_model_fn_controlnet_G13(golden, eng2):
+    """Block-wise ControlNet hook (qwen_image_physical.py:1373-1396) through model_fn_qwen_image: two ControlNets (plain + inpaint
+    layout) with scales 0.7 / 0.5 and a progress gate, vs the reference's own outputs (fixture G13); then one ControlNet, the
+    form the library folds into the second Linear's epilogue."""
+    from physicedit_amd.controlnet import ControlNetInput, QwenImageBlockWiseControlNet, QwenImageBlockwiseMultiControlNet
+    from physicedit_amd.dit import model_fn_qwen_image
+    g = golden("G13_controlnet")
+    nets = [QwenImageBlockWiseControlNet(synth.make_state_dict(synth.controlnet_layout(2, add), seed), device="cuda")
+            for seed, add in ((555, 0), (556, 4))]
+    multi = QwenImageBlockwiseMultiControlNet(nets)
+    inputs = [ControlNetInput(controlnet_id=0, scale=0.7), ControlNetInput(controlnet_id=1, scale=0.5, start=1.0, end=0.5)]
+    conds = [g["conditioning0"].cuda(), g["conditioning1"].cuda()]
+    d, u = stats("controlnet img_in(patchify(cond))", multi.preprocess(inputs[:1], conds[:1])[0], g["processed0"][0])
+    assert u.max().item() <= 1.0 and (u > 0).float().mean().item() < 0.01
+    noise, edit, pe, _ = _model_fn_inputs(128, 128, 24, 0, 3)
+    for pid, tval in ((0, 986.96), (3, 300.0)):
+        lat, _ = model_fn_qwen_image(dit=eng2, blockwise_controlnet=multi, latents=noise.cuda(), timestep=torch.tensor([tval]).to(BF),
+                                     prompt_emb=pe.cuda().clone(), special_token_mask=None, height=128, width=128,
+                                     edit_latents=edit.cuda(), blockwise_controlnet_conditioning=conds,
+                                     blockwise_controlnet_inputs=inputs, progress_id=pid, num_inference_steps=4, is_train=False)
+        d, u = stats(f"model_fn + 2 controlnets, progress_id {pid}", lat, g[f"latents_progress{pid}"])
+        assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+    lat, _ = model_fn_qwen_image(dit=eng2, blockwise_controlnet=multi, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF),
+                                 prompt_emb=pe.cuda().clone(), special_token_mask=None, height=128, width=128, edit_latents=None,
+                                 blockwise_controlnet_conditioning=conds[:1], blockwise_controlnet_inputs=inputs[:1],
+                                 progress_id=1, num_inference_steps=4, is_train=False)
+    d, u = stats("model_fn + 1 controlnet", lat, g["latents_single"])
+    assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+    # the hook does change the result (a gated-out / missing hook would still pass a loose tolerance against itself)
+    plain, _ = model_fn_qwen_image(dit=eng2, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF), prompt_emb=pe.cuda().clone(),
+                                   special_token_mask=None, height=128, width=128, edit_latents=None, is_train=False)
+    assert (plain.float() - lat.float()).abs().mean().item() > 10 * d.mean().item()
+
+
+def test_loop_with_controlnet(eng2):
+    """4-step CFG loop with one block-wise ControlNet gated to the first half of the schedule (start 1.0, end 0.5) vs the
+    oracle loop: the gate, the per-step hook on both CFG branches and the once-per-image conditioning pre-processing."""
+    from physicedit_amd.controlnet import ControlNetInput, QwenImageBlockWiseControlNet, QwenImageBlockwiseMultiControlNet
+    from physicedit_amd.pipeline import DenoiseLoop
+    cs = synth.make_state_dict(synth.controlnet_layout(2), 555)
+    multi = QwenImageBlockwiseMultiControlNet([QwenImageBlockWiseControlNet(cs, device="cuda")])
+    inputs = [ControlNetInput(controlnet_id=0, scale=0.8, start=1.0, end=0.5)]
+    noise, edit, pe_p, mask_p = _model_fn_inputs(128, 128, 40, 16, 0)
+    pe_n = synth.make_prompt_emb(8, 24)
+    mask_n = synth.make_special_token_mask(24, 16)
+    g = torch.Generator().manual_seed(91)
+    cond = torch.randn((1, 16, 16, 16), generator=g).to(BF)
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    ctl = [{"sd": cs, "conditioning": cond, "scale": 0.8, "start": 1.0, "end": 0.5}]
+    ref = O.denoise_loop(sd, ad, noise, pe_p, pe_n, mask_p, mask_n, 128, 128, 4, cfg_scale=4.0, edit_latents=edit, controlnets=ctl)
+    ref32 = O.denoise_loop({k: v.float() for k, v in sd.items()}, {k: v.float() for k, v in ad.items()}, noise.float(), pe_p.float(),
+                           pe_n.float(), mask_p, mask_n, 128, 128, 4, cfg_scale=4.0, edit_latents=edit.float(), dtype=torch.float32,
+                           controlnets=[{**ctl[0], "sd": {k: v.float() for k, v in cs.items()}, "conditioning": cond.float()}])
+    loop = DenoiseLoop(eng2)
+    out = loop(noise.cuda(), pe_p.cuda().clone(), pe_n.cuda().clone(), mask_p, mask_n, 128, 128, num_inference_steps=4,
+               cfg_scale=4.0, edit_latents=[edit.cuda()], blockwise_controlnet=multi, blockwise_controlnet_inputs=inputs,
+               blockwise_controlnet_conditioning=[cond.cuda()])
+    e_hip = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
+    e_ref = (ref.float() - ref32).pow(2).mean().sqrt().item()
+    plain = O.denoise_loop(sd, ad, noise, pe_p, pe_n, mask_p, mask_n, 128, 128, 4, cfg_scale=4.0, edit_latents=edit)
+    effect = (plain.float() - ref.float()).pow(2).mean().sqrt().item()
+    print(f"[parity] loop + controlnet: rms to fp32 hip {e_hip:.4e}  reference-bf16 {e_ref:.4e}; controlnet effect {effect:.4e}")
+    assert e_hip <= 1.25 * e_ref + 1e-4
+    assert effect > 3 * e_ref          # the hook matters at this scale, so the bound above is a real check of it

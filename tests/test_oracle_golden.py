@@ -132,6 +132,51 @@ def test_G5_model_fn_inplace_quirk(golden):
     assert_same(lat, g["latents_plain"], "plain model_fn")
 
 
+def _controlnet_case():
+    """inputs of fixture G13 (tests/golden/make_golden.py::G13_controlnet): shared with the GPU test"""
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    nets = [synth.make_state_dict(synth.controlnet_layout(2, add), seed) for seed, add in ((555, 0), (556, 4))]
+    noise, edit, pe, _ = _model_fn_inputs(128, 128, 24, 0, 3)
+    return sd, nets, noise, edit, pe
+
+
+def test_G13_controlnet(golden):
+    """Block-wise ControlNet hook of model_fn (qwen_image_physical.py:1373-1396), two ControlNets with scales and a progress
+    gate, against the reference's own model_fn + QwenImageBlockwiseMultiControlNet."""
+    g = golden("G13_controlnet")
+    sd, nets, noise, edit, pe = _controlnet_case()
+    ctl = [{"sd": nets[0], "conditioning": g["conditioning0"], "scale": 0.7},
+           {"sd": nets[1], "conditioning": g["conditioning1"], "scale": 0.5, "start": 1.0, "end": 0.5}]
+    assert_same(O.controlnet_preprocess(nets[0], g["conditioning0"]), g["processed0"], "controlnet img_in(patchify(cond))")
+    for pid, tval in ((0, 986.96), (3, 300.0)):
+        lat = O.model_fn(sd, None, noise, torch.tensor([tval]).to(BF), pe.clone(), None, 128, 128, edit,
+                         controlnets=ctl, progress_id=pid, num_inference_steps=4)
+        assert_same(lat, g[f"latents_progress{pid}"], f"model_fn + 2 controlnets, progress_id {pid}")
+    assert O.controlnet_active(0, 4, 1.0, 0.5) and not O.controlnet_active(3, 4, 1.0, 0.5)
+    lat = O.model_fn(sd, None, noise, torch.tensor([500.0]).to(BF), pe.clone(), None, 128, 128, None,
+                     controlnets=ctl[:1], progress_id=1, num_inference_steps=4)
+    assert_same(lat, g["latents_single"], "model_fn + 1 controlnet")
+
+
+def test_G13_controlnet_unit_helpers(golden):
+    """QwenImageUnit_BlockwiseControlNet's inpaint helpers (:1211-1222): the oracle's restatement AND the product's host code
+    (diffsynth/pipelines/qwen_image_physical.py: pure torch / numpy / PIL, no kernels involved) against the reference unit."""
+    import numpy as np
+    from PIL import Image
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline
+    g = golden("G13_controlnet")
+    mask, image = g["unit_mask"].numpy(), g["unit_image"].numpy()
+    assert_same(O.controlnet_mask_on_latents(g["unit_latents_in"], mask), g["unit_latents_out"], "oracle mask on latents")
+    resized = np.array(Image.fromarray(mask).resize((image.shape[1], image.shape[0])))
+    assert np.array_equal(O.controlnet_mask_on_image(image, resized), g["unit_image_out"].numpy())
+    pipe = QwenImagePhysicPipeline.__new__(QwenImagePhysicPipeline)
+    pipe.device, pipe.torch_dtype = torch.device("cpu"), BF
+    assert_same(pipe.apply_controlnet_mask_on_latents(g["unit_latents_in"], Image.fromarray(mask)), g["unit_latents_out"],
+                "facade mask on latents")
+    out = pipe.apply_controlnet_mask_on_image(Image.fromarray(image), Image.fromarray(mask))
+    assert np.array_equal(np.array(out), g["unit_image_out"].numpy())
+
+
 @pytest.mark.parametrize("cfg", [1.0, 4.0])
 def test_G6_loop(golden, cfg):
     g = golden("G6_loop")
