@@ -207,7 +207,7 @@ def _heads(x: torch.Tensor, h: int = 24) -> torch.Tensor:
     return x.reshape(B, S, h, HD // h).permute(0, 2, 1, 3)
 
 
-def joint_attention(sd: SD, p: str, image, text, rope) -> Tuple[torch.Tensor, torch.Tensor]:
+def joint_attention(sd: SD, p: str, image, text, rope, attention_mask=None) -> Tuple[torch.Tensor, torch.Tensor]:
     # QwenDoubleStreamAttention.forward, qwen_image_dit.py:274-316
     a = p + "attn."
     img_q = _linear(sd, a + "to_q", image)
@@ -228,7 +228,7 @@ def joint_attention(sd: SD, p: str, image, text, rope) -> Tuple[torch.Tensor, to
     k = torch.cat([txt_k, img_k], dim=2)
     v = torch.cat([txt_v, img_v], dim=2)
     # qwen_image_flash_attention, SDPA branch (:37-38); CPU has no FA3
-    x = F.scaled_dot_product_attention(q, k, v)
+    x = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask)
     B, H, S, D = x.shape
     x = x.permute(0, 2, 1, 3).reshape(B, S, H * D).to(q.dtype)
     txt_o, img_o = x[:, :seq_txt, :], x[:, seq_txt:, :]
@@ -244,7 +244,7 @@ def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return _linear(sd, p + "net.2", x)
 
 
-def block_forward(sd: SD, i: int, image, text, temb, rope) -> Tuple[torch.Tensor, torch.Tensor]:
+def block_forward(sd: SD, i: int, image, text, temb, rope, attention_mask=None) -> Tuple[torch.Tensor, torch.Tensor]:
     # QwenImageTransformerBlock.forward, qwen_image_dit.py:359-401.  Returns (text, image).
     p = f"transformer_blocks.{i}."
     D = image.shape[-1]
@@ -256,7 +256,7 @@ def block_forward(sd: SD, i: int, image, text, temb, rope) -> Tuple[torch.Tensor
 
     img_m, img_gate = _modulate(F.layer_norm(image, (D,), eps=1e-6), img_mod_attn)
     txt_m, txt_gate = _modulate(F.layer_norm(text, (D,), eps=1e-6), txt_mod_attn)
-    img_attn, txt_attn = joint_attention(sd, p, img_m, txt_m, rope)
+    img_attn, txt_attn = joint_attention(sd, p, img_m, txt_m, rope, attention_mask)
     image = image + img_gate * img_attn
     text = text + txt_gate * txt_attn
 
@@ -296,6 +296,45 @@ def num_layers_of(sd: SD) -> int:
     while f"transformer_blocks.{n}.img_mod.1.weight" in sd:
         n += 1
     return n
+
+
+# ---- EliGen entity control (QwenImageDiT.process_entity_masks, models/qwen_image_dit.py:433-498) --------------------------------
+def process_entity_masks(sd: SD, latents, prompt_emb, entity_prompt_emb, entity_masks, height, width, image_tokens, img_shapes):
+    """-> (text [1, sum(T_i) + T, 3072] in the order entity prompts ..., global prompt; (img_freqs, txt_freqs) with the text
+    positions RESTARTING for every prompt; additive attention mask [1, 1, S, S] over the joint order [prompts ..., image]:
+    a prompt sees the image tokens of its region (any mask pixel in the token's 2 x 2 patch; the same region in every image of
+    the sequence) and itself, the global prompt sees every image token, image tokens see each other.)
+    `entity_masks` [1, N, 1, H/8, W/8] with values in {0, 1} (QwenImageUnit_EntityControl.preprocess_masks, :1157-1163);
+    every prompt_emb_mask is all ones at B = 1 (get_prompt_emb pads to the longest of ONE prompt), so lengths = shapes."""
+    all_emb = list(entity_prompt_emb) + [prompt_emb]
+    text = torch.cat([_linear(sd, "txt_in", rmsnorm(e, sd["txt_norm.weight"])) for e in all_emb], dim=1)
+    seq_lens = [e.shape[1] for e in all_emb]
+    img_f, txt_f = rope_tables(img_shapes, seq_lens[-1])
+    txt_f = torch.cat([rope_tables(img_shapes, n)[1] for n in seq_lens[:-1]] + [txt_f], dim=0)
+    masks = entity_masks.repeat(1, 1, latents.shape[1], 1, 1)
+    masks = [masks[:, i] for i in range(masks.shape[1])]
+    masks.append(torch.ones_like(masks[0]))
+    N = len(masks)
+    n_img = image_tokens.shape[1]
+    total = sum(seq_lens) + n_img
+    allowed = torch.ones((1, total, total), dtype=torch.bool)
+    image_start = sum(seq_lens)
+    cum = [0]
+    for n in seq_lens:
+        cum.append(cum[-1] + n)
+    for i in range(N):
+        im = patchify(masks[i]).sum(dim=-1) > 0                              # [1, S0]
+        im = im.unsqueeze(1).repeat(1, seq_lens[i], 1).repeat(1, 1, n_img // im.shape[-1])
+        allowed[:, cum[i]:cum[i + 1], image_start:] = im
+        allowed[:, image_start:, cum[i]:cum[i + 1]] = im.transpose(1, 2)
+    for i in range(N):
+        for j in range(N):
+            if i != j:
+                allowed[:, cum[i]:cum[i + 1], cum[j]:cum[j + 1]] = False
+    mask = allowed.float()
+    mask[mask == 0] = float("-inf")
+    mask[mask == 1] = 0
+    return text, (img_f, txt_f), mask.to(latents.dtype).unsqueeze(1)
 
 
 # ---- block-wise ControlNet (models/qwen_image_controlnet.py, pipelines/qwen_image_physical.py:157-180, :1373-1396) ----------
@@ -344,7 +383,7 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
              prompt_emb: torch.Tensor, special_token_mask: Optional[torch.Tensor],
              height: int, width: int, edit_latents=None,
              t_min: float = 20.0, t_max: float = 1000.0, controlnets=None, progress_id: int = 0,
-             num_inference_steps: int = 1) -> torch.Tensor:
+             num_inference_steps: int = 1, entity_prompt_emb=None, entity_masks=None) -> torch.Tensor:
     """One DiT forward at inference (is_train=False).  MUTATES `prompt_emb` IN PLACE on the
     special-token rows exactly as the reference does (:1336).
     `controlnets`: list of dicts {"sd": controlnet state dict, "conditioning": latents [1,16|17,h8,w8], "scale", "start", "end"}
@@ -366,13 +405,18 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
 
     image = _linear(sd, "img_in", image)
     conditioning = time_text_embed(sd, timestep, image.dtype)
-    text = _linear(sd, "txt_in", rmsnorm(prompt_emb, sd["txt_norm.weight"]))
-    vid_f, txt_f = rope_tables(img_shapes, T)
+    attention_mask = None
+    if entity_prompt_emb is not None:                      # EliGen (:1360-1364)
+        text, (vid_f, txt_f), attention_mask = process_entity_masks(sd, latents, prompt_emb, entity_prompt_emb, entity_masks,
+                                                                    height, width, image, img_shapes)
+    else:
+        text = _linear(sd, "txt_in", rmsnorm(prompt_emb, sd["txt_norm.weight"]))
+        vid_f, txt_f = rope_tables(img_shapes, T)
 
     processed = [controlnet_preprocess(c["sd"], c["conditioning"]) for c in controlnets] if controlnets else None
 
     for i in range(num_layers_of(sd)):
-        text, image = block_forward(sd, i, image, text, conditioning, (vid_f, txt_f))
+        text, image = block_forward(sd, i, image, text, conditioning, (vid_f, txt_f), attention_mask)
         if processed is not None:                          # :1389-1396
             image_slice = image[:, :image_seq_len].clone()
             res = 0

@@ -409,6 +409,56 @@ def G13_controlnet():
                                        "scales": [0.7, 0.5], "second_start_end": [1.0, 0.5], "timesteps": [986.96, 300.0, 500.0]})
 
 
+def _eligen_inputs(h, w, seed):
+    """two entity prompts (T = 12, 20) with overlapping rectangular regions + a third with an EMPTY region (its tokens only see
+    each other); masks [1, N, 1, h/8, w/8] in {0, 1} as QwenImageUnit_EntityControl.preprocess_masks produces them"""
+    ents = [synth.make_prompt_emb(seed + 20 + i, T) for i, T in enumerate((12, 20, 8))]
+    m = torch.zeros((1, 3, 1, h // 8, w // 8), dtype=BF)
+    m[0, 0, 0, 1:7, 2:9] = 1
+    m[0, 1, 0, 5:14, 6:15] = 1
+    m[0, 1, 0, 3, 3] = 1                 # a single latent pixel: its whole 2 x 2 token belongs to the region
+    return ents, m
+
+
+def G14_eligen():
+    """EliGen entity control through the reference's model_fn (qwen_image_physical.py:1360-1364 -> QwenImageDiT.process_entity_masks,
+    qwen_image_dit.py:433-498): per-prompt RoPE restart, region attention mask, with the adapter's special tokens in the global
+    prompt and an edit image of the same size (the region mask repeats over the images)."""
+    dit, sd = build_dit(2, 1234)
+    ad, adsd, _ = build_adapter(4321)
+    h = w = 128
+    T, nsp = 40, 16
+    noise, edit, pe, mask = _model_fn_inputs(h, w, T, nsp, 5)
+    ents, emask = _eligen_inputs(h, w, 5)
+    pm = torch.ones((1, T), dtype=torch.long)
+    outs = {"entity_masks": emask}
+    pe_run = pe.clone()
+    for call, tval in enumerate((986.96, 600.0)):
+        lat, _ = model_fn_qwen_image(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad, latents=noise,
+                                     timestep=torch.tensor([tval]).to(BF), prompt_emb=pe_run, prompt_emb_mask=pm,
+                                     special_token_mask=mask, height=h, width=w, edit_latents=edit,
+                                     entity_prompt_emb=[e.clone() for e in ents],
+                                     entity_prompt_emb_mask=[torch.ones((1, e.shape[1]), dtype=torch.long) for e in ents],
+                                     entity_masks=emask.clone(), is_train=False)
+        outs[f"latents_call{call}"] = lat
+        outs[f"prompt_emb_after_call{call}"] = pe_run.clone()
+    # no edit image, no adapter
+    lat, _ = model_fn_qwen_image(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=None, latents=noise,
+                                 timestep=torch.tensor([500.0]).to(BF), prompt_emb=pe.clone(), prompt_emb_mask=pm,
+                                 special_token_mask=None, height=h, width=w, edit_latents=None,
+                                 entity_prompt_emb=[e.clone() for e in ents[:2]],
+                                 entity_prompt_emb_mask=[torch.ones((1, e.shape[1]), dtype=torch.long) for e in ents[:2]],
+                                 entity_masks=emask[:, :2].clone(), is_train=False)
+    outs["latents_plain"] = lat
+    text, rot, am = dit.process_entity_masks(noise, pe, pm, [e.clone() for e in ents],
+                                             [torch.ones((1, e.shape[1]), dtype=torch.long) for e in ents], emask.clone(), h, w,
+                                             torch.zeros((1, 2 * (h // 16) * (w // 16), 64), dtype=BF), [(1, h // 16, w // 16)] * 2)
+    outs["attention_allowed"] = (am[0, 0] == 0).to(torch.uint8)
+    outs["txt_rotary_real"], outs["txt_rotary_imag"] = rot[1].real.contiguous(), rot[1].imag.contiguous()
+    save("G14_eligen", outs, meta={"h": h, "w": w, "T": T, "n_special": nsp, "seed": 5, "layers": 2, "entity_T": [12, 20, 8],
+                                   "timesteps": [986.96, 600.0, 500.0]})
+
+
 def G9_adapter():
     ad, adsd, (t_min, t_max) = build_adapter(4321)
     g = torch.Generator().manual_seed(9)

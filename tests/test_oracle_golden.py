@@ -158,6 +158,41 @@ def test_G13_controlnet(golden):
     assert_same(lat, g["latents_single"], "model_fn + 1 controlnet")
 
 
+def _eligen_inputs(h, w, seed):
+    """inputs of fixture G14 (tests/golden/make_golden.py::_eligen_inputs): shared with the GPU test"""
+    ents = [synth.make_prompt_emb(seed + 20 + i, T) for i, T in enumerate((12, 20, 8))]
+    m = torch.zeros((1, 3, 1, h // 8, w // 8), dtype=BF)
+    m[0, 0, 0, 1:7, 2:9] = 1
+    m[0, 1, 0, 5:14, 6:15] = 1
+    m[0, 1, 0, 3, 3] = 1
+    return ents, m
+
+
+def test_G14_eligen(golden):
+    """EliGen entity control (QwenImageDiT.process_entity_masks, qwen_image_dit.py:433-498) through model_fn against the
+    reference: region mask, per-prompt RoPE restart, interplay with the adapter's in-place special-token update."""
+    g = golden("G14_eligen")
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    t_min, t_max = O.adapter_t_range()
+    noise, edit, pe, mask = _model_fn_inputs(128, 128, 40, 16, 5)
+    ents, emask = _eligen_inputs(128, 128, 5)
+    assert torch.equal(emask, g["entity_masks"])
+    text, (img_f, txt_f), am = O.process_entity_masks(sd, noise, pe, ents, emask, 128, 128, torch.zeros((1, 128, 64), dtype=BF),
+                                                      [(1, 8, 8), (1, 8, 8)])
+    assert torch.equal((am[0, 0] == 0).to(torch.uint8), g["attention_allowed"])
+    assert torch.equal(txt_f.real.contiguous(), g["txt_rotary_real"]) and torch.equal(txt_f.imag.contiguous(), g["txt_rotary_imag"])
+    pe_run = pe.clone()
+    for call, tval in enumerate((986.96, 600.0)):
+        lat = O.model_fn(sd, ad, noise, torch.tensor([tval]).to(BF), pe_run, mask, 128, 128, edit, t_min, t_max,
+                         entity_prompt_emb=ents, entity_masks=emask)
+        assert_same(pe_run, g[f"prompt_emb_after_call{call}"], f"eligen prompt_emb after call {call}")
+        assert_same(lat, g[f"latents_call{call}"], f"eligen latents call {call}")
+    lat = O.model_fn(sd, None, noise, torch.tensor([500.0]).to(BF), pe.clone(), None, 128, 128, None,
+                     entity_prompt_emb=ents[:2], entity_masks=emask[:, :2])
+    assert_same(lat, g["latents_plain"], "eligen, no adapter, no edit image")
+
+
 def test_G13_controlnet_unit_helpers(golden):
     """QwenImageUnit_BlockwiseControlNet's inpaint helpers (:1211-1222): the oracle's restatement AND the product's host code
     (diffsynth/pipelines/qwen_image_physical.py: pure torch / numpy / PIL, no kernels involved) against the reference unit."""
