@@ -284,14 +284,19 @@ class PromptPrologue:
 
     # ---- PromptEmbedder (:761-835) ----------------------------------------------------------------------------
     @torch.no_grad()
-    def embed(self, prompt: str, edit_image=None, physical_txt: Optional[str] = None) -> Dict[str, Optional[torch.Tensor]]:
+    def embed_entity(self, prompt: str) -> Dict[str, Optional[torch.Tensor]]:
+        """QwenImageUnit_EntityControl.get_prompt_emb (:1136-1153): the text-only template, truncated at 1024 + 34 tokens."""
+        return self.embed(prompt, None, None, max_length=1024 + T2I_DROP)
+
+    def embed(self, prompt: str, edit_image=None, physical_txt: Optional[str] = None,
+              max_length: int = 4096 + T2I_DROP) -> Dict[str, Optional[torch.Tensor]]:
         if physical_txt is not None:
             prompt = prompt + physical_txt
         special_token_mask = None
         if edit_image is None:
             txt = [T2I_TEMPLATE.format(prompt)]
             drop = T2I_DROP
-            mi = self.tokenizer(txt, max_length=4096 + drop, padding=True, truncation=True, return_tensors="pt").to(self.device)
+            mi = self.tokenizer(txt, max_length=max_length, padding=True, truncation=True, return_tensors="pt").to(self.device)
             if mi["input_ids"].shape[1] >= 1024:
                 print(f"Warning!!! QwenImage model was trained on prompts up to 512 tokens. Current prompt requires "
                       f"{mi['input_ids'].shape[1] - drop} tokens, which may lead to unpredictable behavior.")

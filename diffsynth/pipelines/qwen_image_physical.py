@@ -291,6 +291,15 @@ class QwenImagePhysicPipeline:
         out[(m > 0).numpy()] = 0
         return Image.fromarray(out)
 
+    def preprocess_entity_masks(self, masks, height: int, width: int) -> torch.Tensor:
+        """QwenImageUnit_EntityControl.preprocess_masks + prepare_entity_inputs (:1157-1167): PIL masks -> [1, N, 1, height, width]
+        in {0, 1} at LATENT resolution (nearest resize, any channel above mid-grey)."""
+        out = []
+        for mask in masks:
+            m = self.preprocess_image(mask.resize((width, height), resample=Image.NEAREST)).mean(dim=1, keepdim=True) > 0
+            out.append(m.repeat(1, 1, 1, 1).to(device=self.device, dtype=self.torch_dtype))
+        return torch.cat(out, dim=0).unsqueeze(0)
+
     def controlnet_conditionings(self, blockwise_controlnet_inputs) -> List[torch.Tensor]:
         conditionings = []
         for ci in blockwise_controlnet_inputs:
@@ -331,9 +340,8 @@ class QwenImagePhysicPipeline:
                  stitched_image=None, state: str = None, transition: str = None, triplet: dict = None,
                  is_train: bool = True, have_text_reasoning: bool = True):
         """Same keyword surface and defaults as the reference (:545-597); returns a PIL image."""
-        for name, v in (("inpaint_mask", inpaint_mask), ("eligen_entity_prompts", eligen_entity_prompts)):
-            if v is not None:
-                raise _lib.PeError(f"{name} is outside the accelerated path (SURVEY.md section 8: out of scope)")
+        if inpaint_mask is not None:
+            raise _lib.PeError("inpaint_mask is outside the accelerated path (SURVEY.md section 8: out of scope)")
         if blockwise_controlnet_inputs is not None and self.blockwise_controlnet is None:
             raise _lib.PeError("blockwise_controlnet_inputs given but no block-wise ControlNet checkpoint was loaded")
         if enable_fp8_attention or edit_rope_interpolation:
@@ -378,6 +386,17 @@ class QwenImagePhysicPipeline:
         if use_cfg:
             pe_n = nega["prompt_emb"].to(device=self.device, dtype=self.torch_dtype).contiguous()
             m_n = nega.get("special_token_mask") if self.use_special_tokens else None
+        # EntityControl unit (:1122-1198): entity prompts through the text-only template, region masks at latent resolution
+        eligen_posi = eligen_nega = None
+        if eligen_entity_prompts and eligen_entity_masks:
+            if not hasattr(self.prompt_encoder, "embed_entity"):
+                raise _lib.PeError("eligen_entity_prompts need a prompt_encoder with embed_entity() (prompt_prologue.PromptPrologue)")
+            masks = self.preprocess_entity_masks(eligen_entity_masks, height // 8, width // 8)
+            ents = [self.prompt_encoder.embed_entity(p)["prompt_emb"].to(device=self.device, dtype=self.torch_dtype)
+                    for p in eligen_entity_prompts]
+            eligen_posi = {"entity_prompt_emb": ents, "entity_masks": masks}
+            if eligen_enable_on_negative and use_cfg:
+                eligen_nega = {"entity_prompt_emb": [pe_n] * len(ents), "entity_masks": masks}
         # BlockwiseControlNet unit (:1201-1241)
         ctl_cond = self.controlnet_conditionings(blockwise_controlnet_inputs) if blockwise_controlnet_inputs is not None else None
         # denoise loop + decode (:644-667)
@@ -386,7 +405,8 @@ class QwenImagePhysicPipeline:
         latents = loop(latents, pe_p, pe_n, m_p, m_n, height, width, num_inference_steps=num_inference_steps,
                        cfg_scale=cfg_scale, edit_latents=edit_latents or None, exponential_shift_mu=exponential_shift_mu,
                        denoising_strength=denoising_strength, blockwise_controlnet=self.blockwise_controlnet,
-                       blockwise_controlnet_inputs=blockwise_controlnet_inputs, blockwise_controlnet_conditioning=ctl_cond)
+                       blockwise_controlnet_inputs=blockwise_controlnet_inputs, blockwise_controlnet_conditioning=ctl_cond,
+                       eligen_posi=eligen_posi, eligen_nega=eligen_nega)
         self.last_latents = latents
         # vae.decode + vae_output_to_image (:664-667) in one composite: the last kernel emits HWC uint8
         u8 = self.vae.decode(latents, output_u8=True, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)

@@ -121,6 +121,12 @@ int pe_flash_attn(const void* q, const void* k, const void* vt, void* out, int H
  * whole round of the 256 CUs are split along KV and merged by a second small kernel (load balance); without
  * it (NULL) the launch is a single kernel. */
 size_t pe_flash_attn_workspace_bytes(int H, int S);
+/* pe_flash_attn under the reference's EliGen attention mask (process_entity_masks, models/qwen_image_dit.py:433-498;
+ * scaled_dot_product_attention(attn_mask=) at :37), given as one uint32 per token (see pe_dit_call.attn_words): rows
+ * [0, n_img) of the sequence are image tokens, (a, b) attend iff token_words[a] & token_words[b] != 0.  token_words: device,
+ * 16-byte aligned, S_pad entries, zero beyond S. */
+int pe_flash_attn_masked(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, float scale,
+                         void* workspace, size_t workspace_bytes, const void* token_words, int n_img, void* stream);
 
 /* LayerNorm(no affine, eps) * (1 + scale) + shift on rows of width 3072; rows [0,rows_a) use
  * (shift_a, scale_a), the remaining rows (shift_b, scale_b)  (qwen_image_dit.py:355-357,372-376). */
@@ -219,6 +225,13 @@ typedef struct pe_dit_call {
     void* noise_pred;           /* out: [16,h8,w8] bf16 */
     int n_control;              /* 0..4 active block-wise ControlNet inputs (bf16 weights only) */
     pe_control_input control[4];
+    /* EliGen entity control (QwenImageDiT.process_entity_masks, models/qwen_image_dit.py:433-498), or NULL.  The caller passes the
+     * prompts CONCATENATED in prompt_emb / rope_*_txt (entity prompts ..., global prompt; T = the total; special_idx rows offset
+     * accordingly) and one uint32 per token of the library's joint order [image rows | text rows], S_pad(64) entries, zero beyond
+     * S: image token = bit 31 | bit i for every prompt i whose region contains it (the global prompt: all of them);
+     * token of prompt i = bit i.  Attention between tokens a, b is allowed iff words[a] & words[b] != 0 -- the reference's
+     * additive 0 / -inf mask.  Default attention kernel only. */
+    const unsigned int* attn_words;
 } pe_dit_call;
 
 /* Runtime ("hot") LoRA operands of one block -- load_lora(hotload=True), qwen_image_physical.py:264-272 +

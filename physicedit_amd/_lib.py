@@ -117,6 +117,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_flash_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                               c_size_t, c_void_p]),
+    "pe_flash_attn_masked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                     c_size_t, c_void_p, c_int, c_void_p]),
     "pe_flash_attn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pe_ln_modulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_float, c_void_p]),

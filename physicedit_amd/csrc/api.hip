@@ -133,6 +133,12 @@ int pe_flash_attn(const void* q, const void* k, const void* vt, void* out, int H
     return launch_flash_attn(q, k, vt, out, H, S, S_pad, ldo, scale, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int pe_flash_attn_masked(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, float scale,
+                         void* workspace, size_t workspace_bytes, const void* token_words, int n_img, void* stream) {
+    if (token_words == nullptr) return pe::set_error(PE_ERR_INVALID_ARG, "pe_flash_attn_masked: null token_words");
+    return launch_flash_attn(q, k, vt, out, H, S, S_pad, ldo, scale, workspace, workspace_bytes, (hipStream_t)stream, token_words, n_img);
+}
+
 size_t pe_flash_attn_workspace_bytes(int H, int S) { return flash_attn_workspace_bytes(H, S); }
 
 int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,

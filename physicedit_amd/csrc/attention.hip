@@ -48,11 +48,17 @@ struct AttnPlan {
     int nqb, n_full, split;   // split == 1: no short items
 };
 
-template <int NW>
+// WORDS (EliGen entity control, QwenImageDiT.process_entity_masks, qwen_image_dit.py:433-498): the reference's additive 0 / -inf
+// mask [S,S] is block-structured -- image tokens see each other, a prompt sees the image tokens of its region and itself, prompts do
+// not see each other -- so it is carried as ONE 32-bit word per token: image token = bit 31 | the set of prompts whose region
+// contains it; token of prompt i = bit i; (q, key) is allowed iff words[q] & words[key] != 0.  Rows [0, n_img) are image tokens;
+// only tiles with a non-image key, and query blocks with a non-image row, pay for the test.  Entries [S, S_pad) must be 0.
+template <int NW, bool WORDS = false>
 __global__ void __launch_bounds__(NW * 64, 2)
 flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
                   bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
-                  float* __restrict__ part_o, float* __restrict__ part_ml) {
+                  float* __restrict__ part_o, float* __restrict__ part_ml, const uint32_t* __restrict__ words = nullptr,
+                  int n_img = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Q_BLOCK = NW * 32;
     constexpr int PIECES = 16 / NW;      // 1-KiB LDS-DMA pieces of the K tile (and of the Vt tile) moved by one wave
@@ -92,6 +98,13 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
         const bf16* qp = Qh + (size_t)qrow * 128 + h * 8;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
+    }
+
+    uint32_t wq = 0xffffffffu;
+    bool q_has_text = false;
+    if constexpr (WORDS) {
+        wq = words[min(q0 + l31, S - 1)];
+        q_has_text = q0 + 32 > n_img;              // wave-uniform: some row of this wave's 32 is not an image token
     }
 
     // staging: wave w moves K pieces {2w, 2w+1} (4 rows x 256 B each) and Vt pieces {2w, 2w+1}
@@ -161,16 +174,38 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
                     if (key >= S) sc[s2][r] = -INFINITY;
                 }
         }
+        if constexpr (WORDS) {
+            if (q_has_text || (t + 1) * KV_TILE > n_img) {      // wave-uniform
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const u32x4 wk = *(const u32x4*)(words + t * KV_TILE + s2 * 32 + 8 * a + 4 * h);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if ((wq & wk[r]) == 0) sc[s2][4 * a + r] = -INFINITY;
+                    }
+            }
+        }
         float mx = sc[0][0];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[s2][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * scale_log2);
+        float m_new = fmaxf(m_run, mx * scale_log2);
         moved = m_new != m_run;
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        if constexpr (WORDS) {
+            // a row may have seen no allowed key yet (a prompt whose region starts further down the sequence): m = -inf, and
+            // -inf - (-inf) must not reach exp2.  The row's P is 0 and its O, l stay 0 until an allowed key arrives.
+            const bool none = m_new == -INFINITY;
+            alpha = none ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            if (none) m_new = 0.0f;
+        } else {
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -980,8 +1015,11 @@ size_t flash_attn_workspace_bytes(int H, int S) {
 }
 
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
-                      int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                      int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream, const void* words,
+                      int n_img) {
     PE_REQUIRE(q && k && vt && out, "flash_attn: null pointer");
+    PE_REQUIRE(words == nullptr || (g_attn_variant == 0 && n_img >= 0 && n_img <= S && ((uintptr_t)words & 15) == 0),
+               "flash_attn: token words need the default kernel variant, 0 <= n_img <= S and a 16-byte aligned buffer");
     PE_REQUIRE(H > 0 && S > 0, "flash_attn: empty problem (H=%d S=%d)", H, S);
     PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
                S_pad, KV_TILE, S);
@@ -989,6 +1027,8 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)flash_attn_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
@@ -1014,8 +1054,11 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     const dim3 grid(plan.n_full + (plan.split > 1 ? n_short : 0));
 #define PE_ATTN_LAUNCH(NWV)                                                                                       \
     hipLaunchKernelGGL((flash_attn_kernel<NWV>), grid, dim3(NWV * 64), ATT_LDS, stream, (const bf16*)q, (const bf16*)k, \
-                       (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml)
-    if (g_attn_variant == 3 || g_attn_variant == 4)
+                       (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)nullptr, 0)
+    if (words != nullptr)
+        hipLaunchKernelGGL((flash_attn_kernel<8, true>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)words, n_img);
+    else if (g_attn_variant == 3 || g_attn_variant == 4)
         hipLaunchKernelGGL(flash_attn_w4_kernel, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                            (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, g_attn_variant == 4 ? 8.0f : 0.0f, g_attn_dbg);
     else if (g_attn_variant == 2)

@@ -455,7 +455,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         }
         if ((rc = hot_linear(h, l, 0, EPI_QKV, pp, h->hbuf, 3 * D, stream))) return rc;
         // joint attention
-        if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream))) return rc;
+        if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream,
+                                    c->attn_words, S_img)))
+            return rc;
         // output projections + gated residual (in place on x)
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {

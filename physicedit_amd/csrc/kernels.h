@@ -67,7 +67,8 @@ extern long long* g_gemm_dbg;   // device buffer for the time stamps of the prof
 // flash attention over the joint sequence (no mask), D = 128
 // ---------------------------------------------------------------------------------------------
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
-                      int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                      int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                      const void* words = nullptr, int n_img = 0);   // words: EliGen token words (attention.hip), or null
 size_t flash_attn_workspace_bytes(int H, int S);
 extern int g_attn_slots, g_attn_force_split;
 

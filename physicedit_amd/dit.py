@@ -359,11 +359,13 @@ class QwenImageDiTEngine:
     # ------------------------------------------------------------------------------------------
     def forward(self, latents: torch.Tensor, timestep: torch.Tensor, prompt_emb: torch.Tensor,
                 special_idx: Optional[torch.Tensor] = None, edit_latents=None, step: Optional[int] = None,
-                out: Optional[torch.Tensor] = None, controls=None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, controls=None, entity_prompt_emb=None, entity_masks=None) -> torch.Tensor:
         """One model_fn call.  `timestep`: [1] tensor in the pipeline dtype.  `prompt_emb` [1,T,3584] is
         MUTATED IN PLACE on `special_idx` rows.  Returns noise_pred [1,16,h8,w8].
         `controls`: active block-wise ControlNet inputs, [(QwenImageBlockWiseControlNet, processed conditioning [S0,3072], scale)]
-        (physicedit_amd.controlnet)."""
+        (physicedit_amd.controlnet).
+        `entity_prompt_emb` (list of [1,T_i,3584]) + `entity_masks` ([1,N,1,h8,w8] in {0,1}): EliGen entity control
+        (QwenImageDiT.process_entity_masks, qwen_image_dit.py:433-498)."""
         ops._chk(latents, "latents"), ops._chk(prompt_emb, "prompt_emb")
         h8, w8 = latents.shape[-2:]
         edits: List[torch.Tensor] = []
@@ -372,6 +374,11 @@ class QwenImageDiTEngine:
         img_shapes = [(1, h8 // 2, w8 // 2)] + [(1, e.shape[-2] // 2, e.shape[-1] // 2) for e in edits]
         S_img = sum(f * h * w for f, h, w in img_shapes)
         T = prompt_emb.shape[-2]
+        eligen = None
+        if entity_prompt_emb is not None:
+            eligen = self._eligen_inputs(prompt_emb, special_idx, entity_prompt_emb, entity_masks, img_shapes, h8, w8)
+            prompt_emb_all, special_idx, seg_lens, words = eligen
+            T = prompt_emb_all.shape[-2]
         if step is None:
             key = float(timestep.float().item())
             if key not in self._step_of or S_img > self._bound[0] or T > self._bound[1]:
@@ -382,7 +389,10 @@ class QwenImageDiTEngine:
         elif S_img > self._bound[0] or T > self._bound[1]:
             raise _lib.PeError(f"forward: sequence ({S_img},{T}) exceeds the bound workspace {self._bound[:2]}; "
                                "call bind() with the maximum sizes before prepare()")
-        cos_i, sin_i, cos_t, sin_t = self.rope.get(img_shapes, T)
+        if eligen is not None:
+            cos_i, sin_i, cos_t, sin_t = self.rope.get_segments(img_shapes, seg_lens)
+        else:
+            cos_i, sin_i, cos_t, sin_t = self.rope.get(img_shapes, T)
         if out is None:
             out = torch.empty((1, 16, h8, w8), dtype=BF, device=self.device)
         c = DitCall()
@@ -392,7 +402,8 @@ class QwenImageDiTEngine:
             ops._chk(e, "edit_latents")
             c.edit_latents[i] = e.data_ptr()
             c.edit_h8[i], c.edit_w8[i] = e.shape[-2], e.shape[-1]
-        c.prompt_emb, c.T = prompt_emb.data_ptr(), T
+        c.prompt_emb, c.T = (prompt_emb_all if eligen is not None else prompt_emb).data_ptr(), T
+        c.attn_words = words.data_ptr() if eligen is not None else None
         if special_idx is not None and special_idx.numel() > 0:
             if self.adapter is None:
                 raise _lib.PeError("special tokens given but no visual_thinking_adapter weights loaded")
@@ -421,7 +432,43 @@ class QwenImageDiTEngine:
                 c.control[i].scale = float(scale)
             c.n_control = len(controls)
         check(lib().pe_dit_forward(self._handle, C.byref(c), stream_ptr()), "pe_dit_forward")
+        if eligen is not None:       # the adapter updated the global prompt's special rows inside the concatenated copy (:1336)
+            prompt_emb.reshape(-1, prompt_emb.shape[-1]).copy_(prompt_emb_all.reshape(-1, prompt_emb.shape[-1])[T - prompt_emb.shape[-2]:])
         return out
+
+    def _eligen_inputs(self, prompt_emb, special_idx, entity_prompt_emb, entity_masks, img_shapes, h8, w8):
+        """Host side of process_entity_masks: the text stream becomes [entity prompts ..., global prompt] (txt_norm / txt_in are
+        row-wise, so concatenating before them is the reference's concatenation after them), and the region mask becomes one
+        word per token of the library's joint order [image | text] (include/physicedit_amd.h, pe_dit_call.attn_words)."""
+        ents = [e.to(device=self.device, dtype=BF).reshape(-1, e.shape[-1]) for e in entity_prompt_emb]
+        n_ent = len(ents)
+        if n_ent + 1 > 31:
+            raise _lib.PeError("EliGen: at most 30 entity prompts")
+        em = entity_masks.to("cpu", torch.float32)
+        if em.dim() != 5 or em.shape[0] != 1 or em.shape[1] != n_ent or tuple(em.shape[-2:]) != (h8, w8):
+            raise _lib.PeError(f"EliGen: entity_masks {tuple(entity_masks.shape)} for {n_ent} prompts and {h8}x{w8} latents")
+        S0 = (h8 // 2) * (w8 // 2)
+        S_img = sum(f * h * w for f, h, w in img_shapes)
+        if S_img % S0 != 0:
+            raise _lib.PeError("EliGen: every image of the sequence must have the size of the noise latents (the reference "
+                               "repeats the region mask over them, qwen_image_dit.py:477-478)")
+        # token (y, x) belongs to region i iff any mask pixel of its 2 x 2 latent patch (any channel) is set (:462-463, :474)
+        region = em[0].amax(dim=1).reshape(n_ent, h8 // 2, 2, w8 // 2, 2).amax(dim=(2, 4)).reshape(n_ent, S0) > 0
+        bits = torch.zeros((S0,), dtype=torch.int64)
+        for i in range(n_ent):
+            bits |= region[i].to(torch.int64) << i
+        bits |= (1 << n_ent) | (1 << 31)                      # the global prompt sees every image token; image tokens see each other
+        seg_lens = [e.shape[0] for e in ents] + [prompt_emb.shape[-2]]
+        text_bits = torch.cat([torch.full((n,), 1 << i, dtype=torch.int64) for i, n in enumerate(seg_lens)])
+        S = S_img + sum(seg_lens)
+        words = torch.zeros(((S + 63) // 64 * 64,), dtype=torch.int64)
+        words[:S_img] = bits.repeat(S_img // S0)
+        words[S_img:S] = text_bits
+        words = (words & 0xFFFFFFFF).to(torch.uint32).view(torch.int32).to(self.device)
+        prompt_emb_all = torch.cat(ents + [prompt_emb.reshape(-1, prompt_emb.shape[-1])]).unsqueeze(0).contiguous()
+        if special_idx is not None and special_idx.numel() > 0:
+            special_idx = (special_idx + sum(seg_lens[:-1])).to(torch.int32)
+        return prompt_emb_all, special_idx, seg_lens, words
 
     def debug_tensor(self, name: str, shape, dtype=BF) -> torch.Tensor:
         """Copy of an internal workspace region (tests only)."""
@@ -455,8 +502,8 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
     """Drop-in for the reference operator of the same name (qwen_image_physical.py:1302-1403),
     inference subset: returns (noise_pred, 0).  Unsupported reference features raise instead of
     silently differing."""
-    if entity_prompt_emb is not None:
-        raise _lib.PeError("model_fn_qwen_image: EliGen entity masks are outside the hot path")
+    if entity_prompt_emb is not None and entity_masks is None:
+        raise _lib.PeError("model_fn_qwen_image: entity_prompt_emb without entity_masks")
     if is_train and special_token_mask is not None:
         raise _lib.PeError("model_fn_qwen_image: is_train=True (special_token_loss) is a training feature; pass is_train=False")
     if enable_fp8_attention or edit_rope_interpolation:
@@ -481,5 +528,6 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
                      blockwise_controlnet.models[ci.controlnet_id].process_controlnet_conditioning(c)
                      for ci, c in zip(blockwise_controlnet_inputs, blockwise_controlnet_conditioning)]
         controls = blockwise_controlnet.active_controls(blockwise_controlnet_inputs, processed, progress_id, num_inference_steps)
-    pred = dit.forward(latents, timestep, prompt_emb, idx, edits or None, controls=controls)
+    pred = dit.forward(latents, timestep, prompt_emb, idx, edits or None, controls=controls,
+                       entity_prompt_emb=entity_prompt_emb, entity_masks=entity_masks)
     return pred, 0

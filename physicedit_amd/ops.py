@@ -147,8 +147,10 @@ def unpack_vt(vt: torch.Tensor, S: int) -> torch.Tensor:
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, S: int,
-               out: Optional[torch.Tensor] = None, workspace: bool = True) -> torch.Tensor:
-    """q,k [H,S_pad,128], vt [H,128,S_pad] -> [S, H*128]."""
+               out: Optional[torch.Tensor] = None, workspace: bool = True, token_words: Optional[torch.Tensor] = None,
+               n_img: int = 0) -> torch.Tensor:
+    """q,k [H,S_pad,128], vt [H,128,S_pad] -> [S, H*128].  token_words (int32 [S_pad], zero beyond S) + n_img: the EliGen mask,
+    tokens a, b attend iff token_words[a] & token_words[b] != 0 (rows [0, n_img) are image tokens)."""
     _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
     H, sp, _ = q.shape
     if out is None:
@@ -157,6 +159,13 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, S: int,
     if workspace:
         nbytes = lib().pe_flash_attn_workspace_bytes(H, S)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+    if token_words is not None:
+        _chk(token_words, "token_words", torch.int32)
+        assert token_words.numel() == sp
+        check(lib().pe_flash_attn_masked(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128,
+                                         1.0 / math.sqrt(128.0), _ptr(ws), nbytes, token_words.data_ptr(), n_img, stream_ptr()),
+              "pe_flash_attn_masked")
+        return out
     check(lib().pe_flash_attn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128,
                               1.0 / math.sqrt(128.0), _ptr(ws), nbytes, stream_ptr()), "pe_flash_attn")
     return out

@@ -41,7 +41,7 @@ class DenoiseLoop:
                  height: int, width: int, num_inference_steps: int = 30, cfg_scale: float = 4.0,
                  edit_latents=None, exponential_shift_mu: Optional[float] = None,
                  denoising_strength: float = 1.0, blockwise_controlnet=None, blockwise_controlnet_inputs=None,
-                 blockwise_controlnet_conditioning=None) -> torch.Tensor:
+                 blockwise_controlnet_conditioning=None, eligen_posi=None, eligen_nega=None) -> torch.Tensor:
         """noise [1,16,H/8,W/8]; prompt_emb_* [1,T,3584] DEVICE tensors, mutated in place on their
         special rows across the steps exactly like `inputs_posi["prompt_emb"]` in the reference."""
         dev = self.device
@@ -54,7 +54,13 @@ class DenoiseLoop:
             edits = list(edit_latents) if isinstance(edit_latents, (list, tuple)) else [edit_latents]
         use_cfg = cfg_scale != 1.0                      # (:654)
         S_img = (height // 16) * (width // 16) + sum((e.shape[-2] // 2) * (e.shape[-1] // 2) for e in edits)
-        T_max = max(prompt_emb_posi.shape[-2], prompt_emb_nega.shape[-2] if use_cfg else 0)
+        # EliGen (:1186-1198): dict(entity_prompt_emb=[...], entity_masks=[1,N,1,h8,w8]) per CFG branch; the entity prompts join the
+        # text stream, so they count for the workspace
+        ent_len = lambda e: sum(x.shape[-2] for x in e["entity_prompt_emb"]) if e else 0
+        T_max = max(prompt_emb_posi.shape[-2] + ent_len(eligen_posi),
+                    (prompt_emb_nega.shape[-2] + ent_len(eligen_nega)) if use_cfg else 0)
+        kw_p = dict(eligen_posi) if eligen_posi else {}
+        kw_n = dict(eligen_nega) if eligen_nega else {}
         dual = self.dual_stream and use_cfg
         dit_n = self.dit
         if dual:
@@ -88,15 +94,15 @@ class DenoiseLoop:
                 sp.wait_stream(main)
                 sn.wait_stream(main)
                 with torch.cuda.stream(sp):
-                    self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl)
+                    self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl, **kw_p)
                 with torch.cuda.stream(sn):
-                    dit_n.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl)
+                    dit_n.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl, **kw_n)
                 main.wait_stream(sp)
                 main.wait_stream(sn)
             else:
-                self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl)
+                self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl, **kw_p)
                 if use_cfg:
-                    self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl)
+                    self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl, **kw_n)
             ops.cfg_euler_step(pred_p, pred_n, latents, cfg_scale, sch.dsigma(i), out=nxt)
             latents, nxt = nxt, latents
         return latents

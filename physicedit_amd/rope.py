@@ -53,6 +53,16 @@ class RopeCache:
         self.device = device
         self._cache: Dict[tuple, tuple] = {}
 
+    def get_segments(self, img_shapes: Sequence[Tuple[int, int, int]], txt_lens: Sequence[int]):
+        """EliGen (QwenImageDiT.process_entity_masks, qwen_image_dit.py:439-446): several prompts in the text stream, each with
+        the text positions of a prompt that stands alone -> (cos_img, sin_img, cos_txt, sin_txt), text tables concatenated."""
+        key = (tuple(tuple(s) for s in img_shapes), tuple(int(n) for n in txt_lens))
+        if key not in self._cache:
+            parts = [self.get(img_shapes, n) for n in txt_lens]
+            self._cache[key] = (parts[0][0], parts[0][1], torch.cat([p[2] for p in parts]).contiguous(),
+                                torch.cat([p[3] for p in parts]).contiguous())
+        return self._cache[key]
+
     def get(self, img_shapes: Sequence[Tuple[int, int, int]], txt_len: int):
         """-> (cos_img, sin_img, cos_txt, sin_txt) fp32 device tensors [S_img,64] / [T,64]."""
         key = (tuple(tuple(s) for s in img_shapes), int(txt_len))

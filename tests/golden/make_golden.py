@@ -455,6 +455,21 @@ def G14_eligen():
                                              torch.zeros((1, 2 * (h // 16) * (w // 16), 64), dtype=BF), [(1, h // 16, w // 16)] * 2)
     outs["attention_allowed"] = (am[0, 0] == 0).to(torch.uint8)
     outs["txt_rotary_real"], outs["txt_rotary_imag"] = rot[1].real.contiguous(), rot[1].imag.contiguous()
+    # the unit's mask pre-processing (QwenImageUnit_EntityControl.preprocess_masks + prepare_entity_inputs, :1157-1167)
+    from PIL import Image
+    from diffsynth.pipelines.qwen_image_physical import QwenImageUnit_EntityControl
+    ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")
+    ns.preprocess_image = lambda *a, **k: BasePipeline.preprocess_image(ns, *a, **k)
+    rs = np.random.RandomState(9)
+    pil = []
+    for i in range(2):
+        m = np.zeros((96, 160, 3), dtype="uint8")
+        m[10 + 20 * i:50 + 20 * i, 30:90 + 40 * i] = 255
+        m[70:80, 5:25] = (rs.rand(10, 20, 3) * 255).astype("uint8")          # grey levels around the > 0 threshold of the mean
+        pil.append(m)
+        outs[f"unit_mask{i}"] = torch.from_numpy(m)
+    um = QwenImageUnit_EntityControl().preprocess_masks(ns, [Image.fromarray(m) for m in pil], 12, 20, 1)
+    outs["unit_entity_masks"] = torch.cat(um, dim=0).unsqueeze(0)
     save("G14_eligen", outs, meta={"h": h, "w": w, "T": T, "n_special": nsp, "seed": 5, "layers": 2, "entity_T": [12, 20, 8],
                                    "timesteps": [986.96, 600.0, 500.0]})
 

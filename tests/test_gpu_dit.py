@@ -409,3 +409,35 @@ def test_loop_with_controlnet(eng2):
     print(f"[parity] loop + controlnet: rms to fp32 hip {e_hip:.4e}  reference-bf16 {e_ref:.4e}; controlnet effect {effect:.4e}")
     assert e_hip <= 1.25 * e_ref + 1e-4
     assert effect > 3 * e_ref          # the hook matters at this scale, so the bound above is a real check of it
+
+
+def test_model_fn_eligen_G14(golden, eng2):
+    """EliGen entity control through model_fn_qwen_image (qwen_image_physical.py:1360-1364 -> process_entity_masks): region
+    attention mask, per-prompt RoPE restart, adapter special tokens inside the global prompt, an edit image of the noise size;
+    vs the reference's own outputs (fixture G14)."""
+    from physicedit_amd.dit import model_fn_qwen_image
+    from test_oracle_golden import _eligen_inputs
+    g = golden("G14_eligen")
+    noise, edit, pe, mask = _model_fn_inputs(128, 128, 40, 16, 5)
+    ents, emask = _eligen_inputs(128, 128, 5)
+    pe_run = pe.cuda().clone()
+    for call, tval in enumerate((986.96, 600.0)):
+        lat, _ = model_fn_qwen_image(dit=eng2, visual_thinking_adapter=True, latents=noise.cuda(), timestep=torch.tensor([tval]).to(BF),
+                                     prompt_emb=pe_run, special_token_mask=mask, height=128, width=128, edit_latents=edit.cuda(),
+                                     entity_prompt_emb=[e.cuda() for e in ents],
+                                     entity_prompt_emb_mask=[torch.ones((1, e.shape[1])) for e in ents], entity_masks=emask,
+                                     is_train=False)
+        m = mask[0]
+        assert torch.equal(pe_run[0, ~m.cuda()].cpu(), pe[0, ~m])
+        d, u = stats(f"eligen call{call} prompt_emb special rows", pe_run[0, m.cuda()], g[f"prompt_emb_after_call{call}"][0, m])
+        assert u.max().item() <= 4.0 and (u > 0).float().mean().item() < (0.03, 0.25)[call]
+        d, u = stats(f"eligen call{call} latents", lat, g[f"latents_call{call}"])
+        assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+    lat, _ = model_fn_qwen_image(dit=eng2, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF), prompt_emb=pe.cuda().clone(),
+                                 special_token_mask=None, height=128, width=128, edit_latents=None,
+                                 entity_prompt_emb=[e.cuda() for e in ents[:2]], entity_masks=emask[:, :2], is_train=False)
+    d, u = stats("eligen plain (no adapter, no edit)", lat, g["latents_plain"])
+    assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+    nomask, _ = model_fn_qwen_image(dit=eng2, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF), prompt_emb=pe.cuda().clone(),
+                                    special_token_mask=None, height=128, width=128, edit_latents=None, is_train=False)
+    assert (nomask.float() - lat.float()).abs().mean().item() > 10 * d.mean().item()

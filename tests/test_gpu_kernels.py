@@ -306,3 +306,49 @@ def test_cfg_euler(ops, cfg):
         ref = tab.step(pred, i, x)
         out = ops.cfg_euler_step(p.cuda(), n.cuda(), x.cuda(), cfg, sch.dsigma(i))
         assert torch.equal(out.cpu(), ref), (cfg, i)      # pure element-wise: bit exact
+
+
+@pytest.mark.parametrize("S_img,segs,force", [(128, (12, 20, 8, 40), 0), (704, (70, 130, 9, 200), 3), (1024, (64, 333), 0)])
+def test_flash_attn_token_words(ops, S_img, segs, force):
+    """pe_flash_attn_masked: the EliGen mask as one word per token vs torch SDPA with the explicit [S, S] additive mask
+    (scaled_dot_product_attention(attn_mask=), qwen_image_dit.py:37).  Regions are random; one prompt has an EMPTY region (its
+    rows see no key in any image tile: the -inf guard), and the split-KV path runs with partials that contain no allowed key."""
+    from physicedit_amd._lib import lib
+    H = 24
+    T = sum(segs)
+    S = S_img + T
+    g = torch.Generator().manual_seed(S)
+    q, k, v = (torch.randn((H, S, 128), generator=g).to(BF) for _ in range(3))
+    n = len(segs)
+    member = torch.rand((n, S_img), generator=g) < 0.3
+    member[1] = False                                   # empty region
+    member[n - 1] = True                                # the global prompt
+    words = torch.zeros((ops.s_pad_of(S),), dtype=torch.int64)
+    for i in range(n):
+        words[:S_img] |= member[i].to(torch.int64) << i
+    words[:S_img] |= 1 << 31
+    words[S_img:S] = torch.cat([torch.full((m,), 1 << i, dtype=torch.int64) for i, m in enumerate(segs)])
+    allowed = (words[:S, None] & words[None, :S]) != 0
+    bias = torch.zeros((S, S)).masked_fill(~allowed, float("-inf")).to(BF)
+    ref = F.scaled_dot_product_attention(q[None], k[None], v[None], attn_mask=bias[None, None])[0]
+    ref = ref.permute(1, 0, 2).reshape(S, H * 128)
+    ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float(), attn_mask=bias[None, None].float())[0]
+    ref32 = ref32.permute(1, 0, 2).reshape(S, H * 128)
+    sp = ops.s_pad_of(S)
+    qd = torch.zeros((H, sp, 128), dtype=BF, device="cuda"); qd[:, :S] = q.cuda()
+    kd = torch.full((H, sp, 128), float("nan"), dtype=BF, device="cuda"); kd[:, :S] = k.cuda()
+    wd = (words & 0xFFFFFFFF).to(torch.uint32).view(torch.int32).cuda()
+    try:
+        lib().pe_debug_set(b"attn_force_split", force)
+        out = ops.flash_attn(qd, kd, ops.pack_vt(v.cuda(), sp), S, token_words=wd, n_img=S_img)
+    finally:
+        lib().pe_debug_set(b"attn_force_split", 0)
+    assert torch.isfinite(out.float()).all()
+    report(f"flash_attn token words S_img={S_img} T={T}", out, ref, max_ulp=3.01, max_frac=0.50)
+    e_gpu = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
+    e_cpu = (ref.float() - ref32).pow(2).mean().sqrt().item()
+    print(f"[parity] flash_attn token words: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
+    assert e_gpu <= 1.5 * e_cpu + 1e-6
+    # the mask matters: the unmasked kernel gives something else
+    plain = ops.flash_attn(qd, kd, ops.pack_vt(v.cuda(), sp), S)
+    assert (plain.float().cpu() - ref32).pow(2).mean().sqrt().item() > 5 * e_cpu
