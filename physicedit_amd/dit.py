@@ -467,7 +467,16 @@ class QwenImageDiTEngine:
         words = (words & 0xFFFFFFFF).to(torch.uint32).view(torch.int32).to(self.device)
         prompt_emb_all = torch.cat(ents + [prompt_emb.reshape(-1, prompt_emb.shape[-1])]).unsqueeze(0).contiguous()
         if special_idx is not None and special_idx.numel() > 0:
-            special_idx = (special_idx + sum(seg_lens[:-1])).to(torch.int32)
+            # An entity entry that IS the prompt tensor (eligen_enable_on_negative hands the negative prompt_emb out N times,
+            # :1177) is updated by the adapter together with it in the reference (same storage); the adapter is row-wise, so
+            # running it on the aliased copies' special rows too gives exactly those values.
+            offs, o = [], 0
+            for e, n in zip(entity_prompt_emb, seg_lens[:-1]):
+                if e.data_ptr() == prompt_emb.data_ptr() and e.shape[-2] == prompt_emb.shape[-2]:
+                    offs.append(o)
+                o += n
+            offs.append(o)
+            special_idx = torch.cat([special_idx + a for a in offs]).to(torch.int32)
         return prompt_emb_all, special_idx, seg_lens, words
 
     def debug_tensor(self, name: str, shape, dtype=BF) -> torch.Tensor:

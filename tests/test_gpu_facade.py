@@ -206,3 +206,84 @@ def test_validate_flow_with_real_prologue(tmp_path):
     dl = (pipe.last_latents.float().cpu() - lat.float()).abs()
     print(f"[parity] validate flow with the real prologue: latents max|d| {dl.max().item():.4e} mean|d| {dl.mean().item():.4e}")
     assert dl.mean().item() <= 5e-3 and dl.max().item() <= 0.125
+
+
+def test_controlnet_and_eligen_through_the_facade(tmp_path):
+    """The two secondary features of the same __call__ the way a reference user reaches them:
+    a block-wise ControlNet checkpoint next to the DiT in from_pretrained (found by its key layout, qwen_image_physical.py:521),
+    `blockwise_controlnet_inputs=[ControlNetInput(image=, inpaint_mask=, scale=)]`, `eligen_entity_prompts` / `eligen_entity_masks`
+    -- against the oracle loop fed with the same conditioning latents / entity embeddings."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from safetensors.torch import save_file
+    from diffsynth.pipelines.qwen_image_physical import ControlNetInput, ModelConfig, QwenImagePhysicPipeline
+
+    H = W = 256
+    steps, T, nsp = 3, 48, 16
+    dit_sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    vae_sd = synth.make_state_dict(synth.vae_layout(), 77)
+    ad_sd = synth.make_state_dict(synth.adapter_layout(), 4321)
+    cn_sd = synth.make_state_dict(synth.controlnet_layout(2, 4), 556)          # the inpaint layout (17-channel conditioning)
+    base = tmp_path / "base"
+    for sub in ("dit", "vae", "controlnet"):
+        (base / "m" / sub).mkdir(parents=True)
+    save_file(dit_sd, str(base / "m/dit/model.safetensors"))
+    save_file(vae_sd, str(base / "m/vae/model.safetensors"))
+    save_file(cn_sd, str(base / "m/controlnet/model.safetensors"))
+    pipe = QwenImagePhysicPipeline.from_pretrained(
+        torch_dtype=torch.bfloat16, device="cuda",
+        model_configs=[ModelConfig(model_id="m", origin_file_pattern=f"{sub}/model.safetensors", local_model_path=str(base))
+                       for sub in ("dit", "vae", "controlnet")], dinov2_path=None)
+    assert pipe.blockwise_controlnet is not None and len(pipe.blockwise_controlnet.models) == 1
+    pipe.load_state_dict({"visual_thinking_adapter." + k: v for k, v in ad_sd.items()}, strict=False)
+
+    pe_p, mask_p = synth.make_prompt_emb(7, T), synth.make_special_token_mask(T, nsp)
+    pe_n, mask_n = synth.make_prompt_emb(8, 24), synth.make_special_token_mask(24, nsp)
+    ent_emb = {"a red ball": synth.make_prompt_emb(31, 10), "a glass table": synth.make_prompt_emb(32, 14)}
+
+    class StubPrologue:                                    # the text encoder is not what this test is about
+        def __call__(self, p, prompt, negative_prompt, edit_image, cfg, have_text_reasoning=True):
+            return ({"prompt_emb": pe_p.clone(), "special_token_mask": mask_p}, {"prompt_emb": pe_n.clone(), "special_token_mask": mask_n})
+
+        def embed_entity(self, prompt):
+            return {"prompt_emb": ent_emb[prompt].clone()}
+    pipe.prompt_encoder = StubPrologue()
+
+    rs = np.random.RandomState(3)
+    ctl_img = (rs.rand(H, W, 3) * 255).astype("uint8")
+    inpaint = np.zeros((H, W, 3), dtype="uint8"); inpaint[64:160, 80:200] = 255
+    ent_masks = []
+    for y0, y1, x0, x1 in ((16, 120, 24, 140), (100, 240, 90, 250)):
+        m = np.zeros((H, W, 3), dtype="uint8"); m[y0:y1, x0:x1] = 255
+        ent_masks.append(m)
+    cin = [ControlNetInput(controlnet_id=0, scale=0.6, start=1.0, end=0.4, image=Image.fromarray(ctl_img), inpaint_mask=Image.fromarray(inpaint))]
+    out = pipe("put the ball on the table", seed=0, num_inference_steps=steps, height=H, width=W, cfg_scale=3.0, is_train=False,
+               blockwise_controlnet_inputs=cin, eligen_entity_prompts=list(ent_emb), eligen_entity_masks=[Image.fromarray(m) for m in ent_masks],
+               eligen_enable_on_negative=True)
+    assert isinstance(out, Image.Image) and out.size == (W, H)
+
+    # ---- oracle on the same inputs
+    O.VAE_CONV_MODE = "2d"
+    try:
+        masked_img = O.controlnet_mask_on_image(ctl_img, inpaint)
+        cond = O.controlnet_mask_on_latents(O.vae_encode(vae_sd, O.preprocess_image(masked_img)), inpaint)
+    finally:
+        O.VAE_CONV_MODE = "3d"
+    emask = torch.stack([(O.preprocess_image(np.array(Image.fromarray(m).resize((W // 8, H // 8), resample=Image.NEAREST)))
+                          .mean(dim=1, keepdim=True) > 0).to(BF)[0] for m in ent_masks]).unsqueeze(0)
+    ents = list(ent_emb.values())
+    tab = O.FlowMatchTables(steps, dynamic_shift_len=(H // 16) * (W // 16))
+    t_min, t_max = O.adapter_t_range()
+    ctl = [{"sd": cn_sd, "conditioning": cond, "scale": 0.6, "start": 1.0, "end": 0.4}]
+    lat = synth.make_noise(0, H, W)
+    pp, pn = pe_p.clone(), pe_n.clone()
+    for pid, timestep in enumerate(tab.timesteps):
+        t = timestep.unsqueeze(0).to(BF)
+        kw = dict(controlnets=ctl, progress_id=pid, num_inference_steps=steps, entity_masks=emask)
+        a = O.model_fn(dit_sd, ad_sd, lat, t, pp, mask_p, H, W, None, t_min, t_max, entity_prompt_emb=ents, **kw)
+        b = O.model_fn(dit_sd, ad_sd, lat, t, pn, mask_n, H, W, None, t_min, t_max, entity_prompt_emb=[pn, pn], **kw)     # the SAME tensor, as :1177 hands it out
+        lat = tab.step(b + 3.0 * (a - b), pid, lat)
+    dl = (pipe.last_latents.float().cpu() - lat.float()).abs()
+    print(f"[parity] facade controlnet + eligen: latents max|d| {dl.max().item():.4e} mean|d| {dl.mean().item():.4e} "
+          f"(|latents| mean {lat.float().abs().mean().item():.3f})")
+    assert dl.mean().item() <= 8e-3 and dl.max().item() <= 0.25
