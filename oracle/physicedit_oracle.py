@@ -383,7 +383,7 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
              prompt_emb: torch.Tensor, special_token_mask: Optional[torch.Tensor],
              height: int, width: int, edit_latents=None,
              t_min: float = 20.0, t_max: float = 1000.0, controlnets=None, progress_id: int = 0,
-             num_inference_steps: int = 1, entity_prompt_emb=None, entity_masks=None) -> torch.Tensor:
+             num_inference_steps: int = 1, entity_prompt_emb=None, entity_masks=None, capture: Optional[dict] = None) -> torch.Tensor:
     """One DiT forward at inference (is_train=False).  MUTATES `prompt_emb` IN PLACE on the
     special-token rows exactly as the reference does (:1336).
     `controlnets`: list of dicts {"sd": controlnet state dict, "conditioning": latents [1,16|17,h8,w8], "scale", "start", "end"}
@@ -426,6 +426,8 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
                 res = res + controlnet_block(c["sd"], i, image_slice, cond) * c.get("scale", 1.0)
             image[:, :image_seq_len] = image_slice + res
 
+    if capture is not None:                                # tests: the residual streams after the last block
+        capture["image"], capture["text"] = image.clone(), text.clone()
     # AdaLayerNorm(single=True), models/utils.py:304-309
     emb = _linear(sd, "norm_out.linear", F.silu(conditioning))
     scale, shift = emb.unsqueeze(1).chunk(2, dim=2)

@@ -90,6 +90,7 @@ class DitCall(C.Structure):
         ("rope_cos_txt", c_void_p), ("rope_sin_txt", c_void_p),
         ("step", c_int), ("noise_pred", c_void_p),
         ("n_control", c_int), ("control", ControlInput * 4),
+        ("attn_words", c_void_p),
     ]
 
 

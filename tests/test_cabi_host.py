@@ -137,3 +137,37 @@ def test_lora_name_mapping_matches_oracle():
     lora = synth.make_lora(1, 1, 4)
     sd = {k: torch.zeros(s, dtype=BF) for k, s in synth.dit_layout(1)}
     assert O.lora_merge(sd, lora) == len(synth.LORA_TARGETS) == 12
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of the header's structs must have the C compiler's layout (a field missing from the ctypes side is
+    silently accepted by Python and read as garbage by the library)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    from physicedit_amd import _lib as L
+    fields = {"pe_dit_call": (L.DitCall, ["latents", "n_edit", "prompt_emb", "special_idx", "alpha", "rope_cos_img", "step",
+                                          "noise_pred", "n_control", "control", "attn_words"]),
+              "pe_control_input": (L.ControlInput, ["blocks", "conditioning", "scale"]),
+              "pe_controlnet_block": (L.ControlNetBlock, ["x_rms_w", "out_b"]),
+              "pe_dit_weights": (L.DitWeights, ["num_layers", "blocks", "weights_e4m3"]),
+              "pe_adapter_weights": (L.AdapterWeights, ["dino_w0", "vae_b2"])}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "physicedit_amd.h"', "int main(void) {"]
+    for cname, (_, names) in fields.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for n in names:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {n}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for line in out:
+        cname, size, *offs = line.split()
+        cls, names = fields[cname]
+        assert C.sizeof(cls) == int(size), (cname, C.sizeof(cls), size)
+        assert [getattr(cls, n).offset for n in names] == [int(o) for o in offs], cname
