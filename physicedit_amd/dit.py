@@ -442,6 +442,30 @@ class QwenImageDiTEngine:
         word per token of the library's joint order [image | text] (include/physicedit_amd.h, pe_dit_call.attn_words)."""
         ents = [e.to(device=self.device, dtype=BF).reshape(-1, e.shape[-1]) for e in entity_prompt_emb]
         n_ent = len(ents)
+        seg_lens = [e.shape[0] for e in ents] + [prompt_emb.shape[-2]]
+        # the token words depend on the region masks and the lengths only: built once per image (every step of both CFG branches
+        # comes through here), on the host, 4 bytes per token
+        key = (entity_masks.data_ptr(), entity_masks._version, tuple(entity_masks.shape), tuple(seg_lens), tuple(map(tuple, img_shapes)),
+               h8, w8)             # DenoiseLoop also drops the cache at the start of every image
+        cache = getattr(self, "_eligen_words", None)
+        if cache is None or cache[0] != key:
+            self._eligen_words = (key, self._eligen_token_words(entity_masks, n_ent, seg_lens, img_shapes, h8, w8))
+        words = self._eligen_words[1]
+        prompt_emb_all = torch.cat(ents + [prompt_emb.reshape(-1, prompt_emb.shape[-1])]).unsqueeze(0).contiguous()
+        if special_idx is not None and special_idx.numel() > 0:
+            # An entity entry that IS the prompt tensor (eligen_enable_on_negative hands the negative prompt_emb out N times,
+            # :1177) is updated by the adapter together with it in the reference (same storage); the adapter is row-wise, so
+            # running it on the aliased copies' special rows too gives exactly those values.
+            offs, o = [], 0
+            for e, n in zip(entity_prompt_emb, seg_lens[:-1]):
+                if e.data_ptr() == prompt_emb.data_ptr() and e.shape[-2] == prompt_emb.shape[-2]:
+                    offs.append(o)
+                o += n
+            offs.append(o)
+            special_idx = torch.cat([special_idx + a for a in offs]).to(torch.int32)
+        return prompt_emb_all, special_idx, seg_lens, words
+
+    def _eligen_token_words(self, entity_masks, n_ent, seg_lens, img_shapes, h8, w8) -> torch.Tensor:
         if n_ent + 1 > 31:
             raise _lib.PeError("EliGen: at most 30 entity prompts")
         em = entity_masks.to("cpu", torch.float32)
@@ -458,26 +482,12 @@ class QwenImageDiTEngine:
         for i in range(n_ent):
             bits |= region[i].to(torch.int64) << i
         bits |= (1 << n_ent) | (1 << 31)                      # the global prompt sees every image token; image tokens see each other
-        seg_lens = [e.shape[0] for e in ents] + [prompt_emb.shape[-2]]
         text_bits = torch.cat([torch.full((n,), 1 << i, dtype=torch.int64) for i, n in enumerate(seg_lens)])
         S = S_img + sum(seg_lens)
         words = torch.zeros(((S + 63) // 64 * 64,), dtype=torch.int64)
         words[:S_img] = bits.repeat(S_img // S0)
         words[S_img:S] = text_bits
-        words = (words & 0xFFFFFFFF).to(torch.uint32).view(torch.int32).to(self.device)
-        prompt_emb_all = torch.cat(ents + [prompt_emb.reshape(-1, prompt_emb.shape[-1])]).unsqueeze(0).contiguous()
-        if special_idx is not None and special_idx.numel() > 0:
-            # An entity entry that IS the prompt tensor (eligen_enable_on_negative hands the negative prompt_emb out N times,
-            # :1177) is updated by the adapter together with it in the reference (same storage); the adapter is row-wise, so
-            # running it on the aliased copies' special rows too gives exactly those values.
-            offs, o = [], 0
-            for e, n in zip(entity_prompt_emb, seg_lens[:-1]):
-                if e.data_ptr() == prompt_emb.data_ptr() and e.shape[-2] == prompt_emb.shape[-2]:
-                    offs.append(o)
-                o += n
-            offs.append(o)
-            special_idx = torch.cat([special_idx + a for a in offs]).to(torch.int32)
-        return prompt_emb_all, special_idx, seg_lens, words
+        return (words & 0xFFFFFFFF).to(torch.uint32).view(torch.int32).to(self.device)
 
     def debug_tensor(self, name: str, shape, dtype=BF) -> torch.Tensor:
         """Copy of an internal workspace region (tests only)."""

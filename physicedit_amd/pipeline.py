@@ -61,6 +61,7 @@ class DenoiseLoop:
                     (prompt_emb_nega.shape[-2] + ent_len(eligen_nega)) if use_cfg else 0)
         kw_p = dict(eligen_posi) if eligen_posi else {}
         kw_n = dict(eligen_nega) if eligen_nega else {}
+        self.dit._eligen_words = None                  # token words are cached per image (QwenImageDiTEngine._eligen_inputs)
         dual = self.dual_stream and use_cfg
         dit_n = self.dit
         if dual:
