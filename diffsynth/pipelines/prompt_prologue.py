@@ -19,6 +19,8 @@ from __future__ import annotations
 import json
 import math
 import os
+import collections
+import hashlib
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -246,6 +248,18 @@ class PromptPrologue:
         self.boi_token_id = tok.convert_tokens_to_ids("<begin_of_img>")
         self.eoi_token_id = tok.convert_tokens_to_ids("<end_of_img>")
         self.last_physical_txt: Optional[str] = None
+        # (prompt, negative prompt, image bytes, cfg, reasoning) -> results of __call__.  The prologue is deterministic (greedy
+        # decoding, no dropout), and its greedy decode can take as long as the whole denoising loop (profiles/r02_prologue.json),
+        # so repeated edits of one (image, instruction) pair -- other seeds, step counts, sizes -- skip it.  0 disables.
+        self.cache_size = 8
+        self._cache: "collections.OrderedDict" = collections.OrderedDict()
+
+    @staticmethod
+    def _image_key(image) -> tuple:
+        if image is None:
+            return ()
+        images = [image] if isinstance(image, Image.Image) else list(image)
+        return tuple((im.size, im.mode, hashlib.sha1(im.tobytes()).hexdigest()) for im in images)
 
     # ---- text encoder calls -------------------------------------------------------------------------------
     def _last_hidden(self, model_inputs) -> torch.Tensor:
@@ -329,6 +343,12 @@ class PromptPrologue:
     # ---- the unit runner's separate-CFG protocol (utils/__init__.py:247-283) ----------------------------------
     def __call__(self, pipe=None, prompt: str = "", negative_prompt: str = "", edit_image=None, cfg: bool = True,
                  have_text_reasoning: bool = True) -> Tuple[Dict, Dict]:
+        clone = lambda d: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}   # callers mutate prompt_emb
+        key = (prompt, negative_prompt, self._image_key(edit_image), bool(cfg), bool(have_text_reasoning))
+        if self.cache_size and key in self._cache:
+            self._cache.move_to_end(key)
+            posi, nega, self.last_physical_txt = self._cache[key]
+            return clone(posi), clone(nega)
         physical_txt = None
         if have_text_reasoning:
             if not isinstance(edit_image, Image.Image):
@@ -337,4 +357,8 @@ class PromptPrologue:
         self.last_physical_txt = physical_txt
         posi = self.embed(prompt, edit_image, physical_txt)
         nega = self.embed(negative_prompt, edit_image, None) if cfg else dict(posi)
+        if self.cache_size:
+            self._cache[key] = (clone(posi), clone(nega), physical_txt)
+            while len(self._cache) > self.cache_size:
+                self._cache.popitem(last=False)
         return posi, nega

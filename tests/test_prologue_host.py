@@ -51,6 +51,25 @@ def test_prologue_call_protocol(prologue):
         prologue(None, prompt="x", negative_prompt="", edit_image=None, cfg=True, have_text_reasoning=True)
 
 
+def test_prologue_cache_returns_private_copies(prologue, monkeypatch):
+    """A repeated (image, prompts) pair skips the text encoder, and what comes back are CLONES: the denoising loop mutates
+    prompt_emb in place (qwen_image_physical.py:1336), which must not leak into the cache."""
+    img = tiny_vl.make_image(96, 64, 5)
+    prologue._cache.clear()
+    kw = dict(prompt="melt the ice", negative_prompt="blurry", edit_image=img, cfg=True, have_text_reasoning=False)
+    p1, n1 = prologue(None, **kw)
+    calls = []
+    monkeypatch.setattr(prologue, "embed", lambda *a, **k: calls.append(a) or (_ for _ in ()).throw(AssertionError("cache miss")))
+    p1["prompt_emb"].zero_()                                       # what the loop does to its copy
+    p2, n2 = prologue(None, **kw)                                  # same image CONTENT in a new PIL object
+    p3, _ = prologue(None, **{**kw, "edit_image": tiny_vl.make_image(96, 64, 5)})
+    assert not calls and float(p2["prompt_emb"].abs().sum()) > 0
+    assert torch.equal(p2["prompt_emb"], p3["prompt_emb"]) and torch.equal(n1["prompt_emb"], n2["prompt_emb"])
+    assert p2["prompt_emb"].data_ptr() != p3["prompt_emb"].data_ptr()
+    with pytest.raises(AssertionError):                            # another image is a miss
+        prologue(None, **{**kw, "edit_image": tiny_vl.make_image(96, 64, 6)})
+
+
 def test_parse_generation_response():
     ok = PP.parse_generation_response('noise {"middle_transition_prompt": " the vase tips "} trailing')
     assert ok == {"middle_transition_prompt": "the vase tips"}
