@@ -39,6 +39,8 @@ int pe_abi_version(void);
 const char* pe_build_id(void);
 /* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant", ...).
  * Production callers never need it: the compiled defaults are the validated schedules.
+ * "gemm_variant": 15 default; 10 = the round-1 schedule (A/B reference); 14 = 4-phase ping-pong with s_memtime stamps (profiling);
+ * 16 = 15 + stream-K tail (measured slower; needs the workspace below).
  * "attn_variant": 0 default (8 waves x 32 query rows); 3 = 4 waves x 64 rows, one wave per SIMD, bit-identical to 0;
  * 4 = 3 with the running softmax max raised only when a row outgrows it by 2^8 (faster; same distance to an fp32 result,
  * fewer bf16 outputs identical to the reference SDPA's -- opt-in, see profiles/r02_attention_notes.md). */

@@ -37,7 +37,7 @@ constexpr int KDEPTH = 4;   // K-fragment ds_reads kept in flight ahead of the Q
 constexpr int ATT_STAGE = 2 * KV_TILE * 128 * 2;  // K tile 16 KiB + Vt tile 16 KiB
 constexpr int ATT_LDS = 2 * ATT_STAGE;            // 64 KiB
 long long* g_attn_dbg = nullptr;   // device buffer for the s_memtime stamps of variant 3 / 4 (10 per work-group), or null
-int g_attn_variant = 0;   // 0: 8 waves / 256 query rows per work-group (1 per CU);  1: 4 waves / 128 rows (2 per CU)
+int g_attn_variant = 0;   // 0: flash_attn_kernel, 8 waves x 32 query rows (default);  3 / 4: flash_attn_w4_kernel (textbook / lazy max update)
 
 // Work decomposition.  total = H * nqb equal (head, q-block) items never divide evenly over the 256 CUs
 // (cfg 2: 816 items = 3.19 rounds -> 4 rounds, 80 % efficiency).  So the first n_full = floor(total/slots)
@@ -350,333 +350,11 @@ flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const 
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Variant 2: "ping-pong" schedule.  Same work-group (8 waves x 32 query rows), same arithmetic and summation order
-// as flash_attn_kernel (bit-identical output), different TIME structure.  In flash_attn_kernel the one barrier per
-// KV tile keeps all waves in lockstep: the two waves of a SIMD run QK^T at the same time (sharing the matrix pipe),
-// then both run the softmax (pipe idle), then both P.V.  Here each KV tile is FOUR barrier-separated slots per wave
-//     QK  (16 MFMA)  |  SM (softmax VALU, O rescale, pack P)  |  PV (16 MFMA)  |  REST (LDS-DMA issue, next K fragments)
-// and wave group B (waves 4-7; wave w+4 shares its SIMD with wave w) runs one slot AHEAD of group A:
-//     slot      4i       4i+1     4i+2     4i+3
-//     group B   QK(i)    SM(i)    PV(i)    REST
-//     group A   REST     QK(i)    SM(i)    PV(i)
-// so every SIMD's matrix pipe always has exactly one wave feeding it and each softmax runs beside the OTHER wave's
-// MFMAs.  K/Vt tiles live in a 4-deep LDS ring (128 KiB), staged three tiles ahead in the REST slot; a wave waits for
-// its own pieces of tile i+1 at the end of SM(i) (vmcnt(8): tiles i+2, i+3 may still fly), i.e. >= 1 barrier before any
-// wave reads them, and a ring slot is rewritten >= 4 barriers after its last read.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int PP_STAGES = 4;
+// (Variant 2, a barrier-phased "ping-pong" of the two wave groups of this kernel, was bit-identical and 4.7 % slower:
+// profiles/r02_attention_notes.md.  Removed.)
+constexpr int PP_STAGES = 4;                    // variants 3 / 4: four-deep K / Vt ring
 constexpr int PP_LDS = PP_STAGES * ATT_STAGE;   // 128 KiB
 
-__global__ void __launch_bounds__(512, 2)
-flash_attn_pp_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
-                     bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
-                     float* __restrict__ part_o, float* __restrict__ part_ml) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int Q_BLOCK = 256;
-    const int lane = lane_id();
-    const int w = wave_id();
-    const int grp_a = w < 4;       // group A runs one slot behind group B
-    const int l31 = lane & 31, h = lane >> 5;
-
-    const int nqb = plan.nqb;
-    const int nt_all = (S + KV_TILE - 1) / KV_TILE;
-    int item, t_begin = 0, t_end = nt_all, part_slot = -1;
-    if ((int)blockIdx.x < plan.n_full) {
-        item = xcd_remap((int)blockIdx.x, plan.n_full);
-    } else {
-        const int j = (int)blockIdx.x - plan.n_full;
-        item = plan.n_full + j / plan.split;
-        const int part = j - (j / plan.split) * plan.split;
-        if (plan.split > 1) {
-            t_begin = (int)((long long)nt_all * part / plan.split);
-            t_end = (int)((long long)nt_all * (part + 1) / plan.split);
-            part_slot = j;
-        }
-    }
-    const int head = item / nqb;
-    const int qb = item - head * nqb;
-    const int q0 = qb * Q_BLOCK + w * 32;
-    const bf16* Qh = Q + (size_t)head * S_pad * 128;
-    const bf16* Kh = K + (size_t)head * S_pad * 128;
-    const bf16* Vh = Vt + (size_t)head * 128 * S_pad;
-
-    bf16x8 qf[8];
-    {
-        const int qrow = min(q0 + l31, S - 1);
-        const bf16* qp = Qh + (size_t)qrow * 128 + h * 8;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
-    }
-    // staging sources: wave w moves K pieces {2w, 2w+1} (4 rows x 256 B) and Vt pieces {2w, 2w+1} (8 rows x 128 B)
-    const bf16* k_src[2];
-    const bf16* v_src[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int piece = w * 2 + i;
-        const int krow = piece * 4 + (lane >> 4);
-        k_src[i] = Kh + (size_t)krow * 128 + ((lane & 15) ^ (krow & 15)) * 8;
-        const int vrow = piece * 8 + (lane >> 3);
-        v_src[i] = Vh + (size_t)vrow * S_pad + ((lane & 7) ^ ((vrow >> 1) & 7)) * 8;
-    }
-    const int n = t_end - t_begin;                 // KV tiles of this item
-    // LDS: K ring = 4 x 16 KiB at [0, 64 KiB), Vt ring = 4 x 16 KiB at [64 KiB, 128 KiB): with one lane-dependent address
-    // per fragment column every (ring slot, sub-tile) combination is a 16-bit immediate offset of the ds_read
-    constexpr int KT_BYTES = KV_TILE * 256;        // 16 KiB
-    constexpr int V_BASE = PP_STAGES * KT_BYTES;
-    auto stage = [&](int st, int i) {              // local tile i (clamped: the duplicates of the tail land in dead slots)
-        const int t = t_begin + min(i, n - 1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            glds16(k_src[j] + (size_t)t * KV_TILE * 128, smem + st * KT_BYTES + w * 2048 + j * 1024);
-            glds16(v_src[j] + t * KV_TILE, smem + V_BASE + st * KT_BYTES + w * 2048 + j * 1024);
-        }
-    };
-
-    f32x16 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    // lane-dependent fragment addresses, computed once: K row l31, 16-B chunk (2kk+h) ^ (l31 & 15); Vt row d = l31, chunk
-    // (4s2+2k2+h) ^ ((l31 >> 1) & 7)
-    int kaddr[8], vaddr[4];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) kaddr[kk] = l31 * 256 + (((kk * 2 + h) ^ (l31 & 15)) << 4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) vaddr[c] = V_BASE + l31 * 128 + (((c * 2 + h) ^ ((l31 >> 1) & 7)) << 4);
-    const bool tail = (S & (KV_TILE - 1)) != 0 && t_end == nt_all;
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    f32x16 sc[2];
-    u32x4 pk[4];
-    bf16x8 kpre[KDEPTH];     // first K fragments of the NEXT QK slot, read in the REST slot
-    auto k_frag = [&](int st, int idx) -> bf16x8 {      // idx = s2*8 + kk
-        return *(const bf16x8*)(smem + kaddr[idx & 7] + st * KT_BYTES + (idx >> 3) * 32 * 256);
-    };
-    auto v_frag = [&](int st, int idx) -> bf16x8 {      // idx = (s2*2 + k2)*4 + dt
-        return *(const bf16x8*)(smem + vaddr[idx >> 2] + st * KT_BYTES + (idx & 3) * 32 * 128);
-    };
-#define PP_BAR()                                   \
-    do {                                           \
-        __builtin_amdgcn_sched_barrier(0);         \
-        __builtin_amdgcn_s_barrier();              \
-        __builtin_amdgcn_sched_barrier(0);         \
-    } while (0)
-
-    // one KV tile in LDS ring slot ST (compile-time); `i` = local tile index
-    auto tile = [&](auto st_tag, auto mask_tag, int i) __attribute__((always_inline)) {
-        constexpr int ST = decltype(st_tag)::value;
-        constexpr bool MASK = decltype(mask_tag)::value;
-        // ---- QK slot: S^T = K . Q^T, 16 MFMAs in four groups of 4; group g+1's K fragments are read while group g's
-        // MFMAs run (the first group's are already in registers: kpre, read in the REST slot)
-        {
-            bf16x8 ka[4], kb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ka[j] = kpre[j];
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x8 (&cur)[4] = (g & 1) ? kb : ka;
-                bf16x8 (&nxt)[4] = (g & 1) ? ka : kb;
-                if (g < 3) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) nxt[j] = k_frag(ST, (g + 1) * 4 + j);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = g * 4 + j;
-                    sc[idx >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[j], qf[idx & 7], (idx & 7) == 0 ? zero : sc[idx >> 3], 0, 0, 0);
-                }
-                if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the next group's reads go out FIRST
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
-        PP_BAR();
-        // ---- SM slot: online softmax, O rescale, pack P; the first Vt fragments are read here for the PV slot
-        bf16x8 vpre[KDEPTH];
-#pragma unroll
-        for (int idx = 0; idx < KDEPTH; ++idx) vpre[idx] = v_frag(ST, idx);
-        {
-            if constexpr (MASK) {
-                const int t = t_begin + i;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                        if (key >= S) sc[s2][r] = -INFINITY;
-                    }
-            }
-            float mx = sc[0][0];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[s2][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx * scale_log2);
-            const bool moved = m_new != m_run;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            if (__any(moved)) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-            }
-            // probabilities, row sum and the packed bf16 B-operand fragments, one 8-key fragment (two accumulator quads)
-            // at a time so that the fp32 probabilities die as soon as they are packed
-            float psum = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    float pr[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pr[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][k2 * 8 + e], scale_log2, -m_new));
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) psum += pr[e];     // same order as flash_attn_kernel: r ascending
-                    asm volatile("" : "+v"(psum));                 // pin the adds here (LLVM sinks the chain to its use and spills pr)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        bf16x2 two;
-                        two[0] = (bf16)pr[2 * e];
-                        two[1] = (bf16)pr[2 * e + 1];
-                        pk[s2 * 2 + k2][e] = __builtin_bit_cast(uint32_t, two);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            l_run = __builtin_fmaf(l_run, alpha, psum);
-        }
-        asm volatile("" : "+v"(vpre[0]), "+v"(vpre[1]), "+v"(vpre[2]), "+v"(vpre[3]));   // same for the first Vt fragments
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's pieces of tile i+1 landed (i+2, i+3 may fly)
-        PP_BAR();
-        // ---- PV slot: O^T += Vt . P^T, 16 MFMAs: group g = k-step (s2, k2) = g against the four 32-row blocks of Vt
-        {
-            bf16x8 va[4], vb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) va[j] = vpre[j];
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x8 (&cur)[4] = (g & 1) ? vb : va;
-                bf16x8 (&nxt)[4] = (g & 1) ? va : vb;
-                if (g < 3) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) nxt[j] = v_frag(ST, (g + 1) * 4 + j);
-                }
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk[g]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[j], pf, o[j], 0, 0, 0);
-                if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
-        PP_BAR();
-        // ---- REST slot: stage tile i+3 into the ring slot of tile i-1, read the first K fragments of tile i+1
-        stage((ST + 3) & 3, i + 3);
-#pragma unroll
-        for (int idx = 0; idx < KDEPTH; ++idx) kpre[idx] = k_frag((ST + 1) & 3, idx);
-        // complete them HERE (the wave is about to park at the barrier anyway): otherwise the first MFMA of the next QK slot
-        // sits behind an lgkmcnt(0) that also covers that slot's fresh reads
-        asm volatile("" : "+v"(kpre[0]), "+v"(kpre[1]), "+v"(kpre[2]), "+v"(kpre[3]));
-        PP_BAR();
-    };
-
-    using T0 = std::integral_constant<int, 0>;
-    using T1 = std::integral_constant<int, 1>;
-    using T2 = std::integral_constant<int, 2>;
-    using T3 = std::integral_constant<int, 3>;
-    stage(0, 0); stage(1, 1); stage(2, 2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed
-    PP_BAR();
-#pragma unroll
-    for (int idx = 0; idx < KDEPTH; ++idx) kpre[idx] = k_frag(0, idx);
-    asm volatile("" : "+v"(kpre[0]), "+v"(kpre[1]), "+v"(kpre[2]), "+v"(kpre[3]));
-    if (grp_a) __builtin_amdgcn_s_barrier();           // group A starts one slot later
-    using NM = std::false_type;
-    using MK = std::true_type;
-    const int n_plain = tail ? n - 1 : n;              // the (only) partially filled tile is peeled out: the key mask is a template flag
-    int i = 0;
-    for (; i + 4 <= n_plain; i += 4) {
-        tile(T0{}, NM{}, i); tile(T1{}, NM{}, i + 1); tile(T2{}, NM{}, i + 2); tile(T3{}, NM{}, i + 3);
-    }
-    if (i < n_plain) tile(T0{}, NM{}, i);
-    if (i + 1 < n_plain) tile(T1{}, NM{}, i + 1);
-    if (i + 2 < n_plain) tile(T2{}, NM{}, i + 2);
-    if (tail) {
-        switch ((n - 1) & 3) {
-            case 0: tile(T0{}, MK{}, n - 1); break;
-            case 1: tile(T1{}, MK{}, n - 1); break;
-            case 2: tile(T2{}, MK{}, n - 1); break;
-            default: tile(T3{}, MK{}, n - 1); break;
-        }
-    }
-    if (!grp_a) __builtin_amdgcn_s_barrier();          // re-align
-#undef PP_BAR
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (part_slot >= 0) {
-        float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 128 + 4 * h;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = o[dt][4 * a + r];
-                *(f32x4*)(po + dt * 32 + 8 * a) = v;
-            }
-        if (h == 0) {
-            float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 2;
-            pm[0] = m_run;
-            pm[1] = l_tot;
-        }
-        return;
-    }
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + l31;
-    if (q < S) {
-        bf16* op = out + (size_t)q * ldo + head * 128 + 4 * h;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                bf16x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[dt][4 * a + r] * inv);
-                *(bf16x4*)(op + dt * 32 + 8 * a) = v;
-            }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Variant 3: four waves, ONE wave per SIMD, 64 query rows per wave (two 32-row blocks A and B) -- the structure
-// MI355X_MICROARCH.md / cdna_hip_programming.md (Appendix B) report as the fastest on this chip.  Each wave owns its SIMD's
-// whole 512-entry register file.  The split between its two halves is fixed by hand, through the register-class
-// constraints of the MFMA statements (hipcc's own assignment of a 512-register kernel shuttles accumulators between the
-// halves: ~240 v_accvgpr copies per tile and spills):
-//     accumulator half (256):  O 128  |  Q fragments 64  |  K fragments of one tile 64      -- touched by MFMAs only
-//     arch half       (256):  scores 64  |  packed P 32  |  Vt fragments 64  |  softmax temporaries, addresses
-// Every K / Vt fragment read from LDS feeds TWO MFMAs (half the LDS traffic per MFMA of the 8-wave kernels), and the softmax
-// of one block is sliced into the 16 MFMA gaps of the other block's matrix phase, in source order:
-//     phase 1   QK^T(A)   16 MFMA
-//     phase 2   QK^T(B)   16 MFMA  ||  softmax(A) slices  ||  Vt fragment reads of this tile
-//     phase 3   P.V(A)    16 MFMA  ||  softmax(B) slices
-//     -- s_waitcnt vmcnt(8) (own pieces of tile i+1) + the tile barrier --
-//     phase 4   P.V(B)    16 MFMA  ||  K fragment reads of tile i+1  ||  LDS-DMA of tile i+3 (ring slot of tile i-1)
-// Same arithmetic and summation order as flash_attn_kernel (bit-identical output).  One barrier per KV tile, 4-deep ring.
-// MFMAs are asm statements: the compiler neither pads their hazards nor counts them -- the s_nop statements below are the
-// "XDL write -> VALU read" wait states (cdna guide 5.7 item 2); LDS reads stay C++ loads (the compiler's lgkmcnt covers them).
-// ---------------------------------------------------------------------------------------------------------------
 template <int OFF> PE_DEV void lds_read_to_a(u32x4& d, int addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "i"(OFF));
 }
@@ -1024,15 +702,12 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
                S_pad, KV_TILE, S);
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
+    PE_REQUIRE(g_attn_variant == 0 || g_attn_variant == 3 || g_attn_variant == 4, "flash_attn: attn_variant %d does not exist", g_attn_variant);
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)flash_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)flash_attn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1040,9 +715,8 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     }
     const bool have_ws = workspace != nullptr && workspace_bytes >= flash_attn_workspace_bytes(H, S) &&
                          ((uintptr_t)workspace & 15) == 0;
-    const int NW = g_attn_variant == 1 ? 4 : 8;
-    const int Q_BLOCK = NW * 32;
-    const int slots = g_attn_slots * (8 / NW);
+    constexpr int Q_BLOCK = 256;                 // every variant: one work-group = 256 query rows of one head
+    const int slots = g_attn_slots;
     const AttnPlan plan = make_plan(H, S, have_ws, Q_BLOCK, slots);
     const int total = H * plan.nqb;
     const int n_short = (total - plan.n_full) * plan.split;
@@ -1052,21 +726,15 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     const float scale_log2 = scale * 1.44269504088896340736f;
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);  // QK^T + PV
     const dim3 grid(plan.n_full + (plan.split > 1 ? n_short : 0));
-#define PE_ATTN_LAUNCH(NWV)                                                                                       \
-    hipLaunchKernelGGL((flash_attn_kernel<NWV>), grid, dim3(NWV * 64), ATT_LDS, stream, (const bf16*)q, (const bf16*)k, \
-                       (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)nullptr, 0)
     if (words != nullptr)
         hipLaunchKernelGGL((flash_attn_kernel<8, true>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
                            (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)words, n_img);
     else if (g_attn_variant == 3 || g_attn_variant == 4)
         hipLaunchKernelGGL(flash_attn_w4_kernel, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                            (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, g_attn_variant == 4 ? 8.0f : 0.0f, g_attn_dbg);
-    else if (g_attn_variant == 2)
-        hipLaunchKernelGGL(flash_attn_pp_kernel, grid, dim3(512), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                           (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml);
-    else if (NW == 4) PE_ATTN_LAUNCH(4);
-    else PE_ATTN_LAUNCH(8);
-#undef PE_ATTN_LAUNCH
+    else
+        hipLaunchKernelGGL((flash_attn_kernel<8, false>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)nullptr, 0);
     int rc = check_launch("flash_attn_kernel");
     if (rc == PE_OK && plan.split > 1) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3((total - plan.n_full) * (Q_BLOCK / 8)), dim3(256), 0, stream, part_o, part_ml,

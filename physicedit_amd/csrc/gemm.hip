@@ -161,8 +161,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
 
     // per-lane fragment addressing: row = tile_row + l31, chunk = kk*2 + h, swizzle (row>>1)&7
     const int sw = (l31 >> 1) & 7;
-    const int a_row_off = (wm * 64 + l31) * 128;
-    const int w_row_off = BM * BK * 2 + (wn * 128 + l31) * 128;
 
     const int nk = K * ES / KT_BYTES;
     if constexpr (!FP8 && VAR < 12) stage(0, 0);
@@ -477,102 +475,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
             ws_cur = ws_n1;
         }
 #undef PE_CLUSTER8
-#undef PE_SGB
-    } else if constexpr (VAR == 0) {
-        // reference schedule: one barrier per K tile, whole next tile staged in a burst, loads-then-MFMAs per k-step
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // tile kt landed for every wave; everyone is done reading buffer (kt+1)&1
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-            const char* S = smem + (kt & 1) * STAGE_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int coff = ((kk * 2 + h) ^ sw) << 4;
-                bf16x8 af[2], wf[4];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(S + a_row_off + mi * 32 * 128 + coff);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const bf16x8*)(S + w_row_off + ni * 32 * 128 + coff);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-            }
-        }
-    } else if constexpr (VAR == 8) {
-        // Pipelined schedule.  Per K tile four clusters of 8 MFMAs; fragments are double buffered in
-        // registers; the tile barrier sits BEFORE the last cluster, so (a) the first fragments of tile
-        // kt+1 are read under the last cluster of tile kt, (b) the LDS-DMA of tile kt+2 starts there too.
-        // Staging is branch-free (tile index clamped) so each half of the loop body is one scheduling
-        // region, ordered with sched_group_barrier: MFMA / ds_read / LDS-DMA interleaved.
-        auto load_frags = [&](const char* S, int kk, bf16x8 (&af)[2], bf16x8 (&wf)[4]) {
-            const int coff = ((kk * 2 + h) ^ sw) << 4;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(S + a_row_off + mi * 32 * 128 + coff);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const bf16x8*)(S + w_row_off + ni * 32 * 128 + coff);
-        };
-        auto mma = [&](bf16x8 (&af)[2], bf16x8 (&wf)[4]) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-        };
-        auto stage_pairs = [&](int t, int first, int count) {   // pairs [first, first+count) of tile t
-            const int tc = min(t, nk - 1);
-            char* base = smem + (t & 1) * STAGE_BYTES + w * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i >= first && i < first + count) {
-                    glds16(a_src[i] + tc * KT_BYTES, base + i * 1024);
-                    glds16(w_src[i] + tc * KT_BYTES, base + BM * BK * 2 + i * 1024);
-                }
-            }
-        };
-#define PE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define PE_CLUSTER_SCHED(NVMEM)                                    \
-    do {                                                          \
-        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
-        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
-        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
-        for (int v_ = 0; v_ < (NVMEM); ++v_) { PE_SGB(0x008, 1); PE_SGB(0x020, 1); } \
-        PE_SGB(0x008, 5 - (NVMEM));                               \
-    } while (0)
-        bf16x8 fa0[2], fw0[4], fa1[2], fw1[4];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // tile 0 (staged above) landed
-        load_frags(smem, 0, fa0, fw0);
-        stage_pairs(1, 0, 2);
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* S = smem + (kt & 1) * STAGE_BYTES;
-            const char* Sn = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            // cluster 0
-            load_frags(S, 1, fa1, fw1);
-            stage_pairs(kt + 1, 2, 1);
-            mma(fa0, fw0);
-            PE_CLUSTER_SCHED(2);
-            // cluster 1
-            load_frags(S, 2, fa0, fw0);
-            stage_pairs(kt + 1, 3, 1);
-            mma(fa1, fw1);
-            PE_CLUSTER_SCHED(2);
-            // cluster 2
-            load_frags(S, 3, fa1, fw1);
-            mma(fa0, fw0);
-            PE_CLUSTER_SCHED(0);
-            __builtin_amdgcn_sched_barrier(0);  // keep all 8 MFMAs above the wait: they cover the kk=3 reads
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();      // tile kt+1 landed everywhere; nobody reads tile kt's LDS any more
-            __builtin_amdgcn_sched_barrier(0);
-            // cluster 3
-            load_frags(Sn, 0, fa0, fw0);
-            stage_pairs(kt + 2, 0, 2);
-            mma(fa1, fw1);
-            PE_CLUSTER_SCHED(4);
-        }
-#undef PE_CLUSTER_SCHED
 #undef PE_SGB
     } else if constexpr (VAR == 10) {
         // v8 + a THREE-deep W ring: the weight matrix is the cold operand of every block GEMM (each of
@@ -1009,17 +911,12 @@ static int launch_v(const GemmArgs& args, int ntiles, hipStream_t stream) {
 
 template <int EPI>
 static int launch_t(const GemmArgs& args, int ntiles, bool fp8, hipStream_t stream) {
-    if (fp8) return g_gemm_variant == 12 ? launch_v<EPI, 12, true>(args, ntiles, stream)
-                  : g_gemm_variant == 13 ? launch_v<EPI, 13, true>(args, ntiles, stream)
-                  : g_gemm_variant == 10 ? launch_v<EPI, 10, true>(args, ntiles, stream)
-                                         : launch_v<EPI, 15, true>(args, ntiles, stream);
-    if (g_gemm_variant == 12) return launch_v<EPI, 12>(args, ntiles, stream);
-    if (g_gemm_variant == 13) return launch_v<EPI, 13>(args, ntiles, stream);
+    // instantiated schedules: 15 (default), 10 (the round-1 schedule, kept as the A/B reference), 14 (the 4-phase ping-pong with
+    // s_memtime stamps, profiling only), 16 (15 + stream-K tail, a measured negative result kept as a knob).  The other round-1 / 2
+    // experiments (0, 8, 12, 13) are described in profiles/r01_gemm_ablation.md and profiles/r02_gemm_notes.md and were removed.
+    if (fp8) return g_gemm_variant == 10 ? launch_v<EPI, 10, true>(args, ntiles, stream) : launch_v<EPI, 15, true>(args, ntiles, stream);
     if (g_gemm_variant == 14) return launch_v<EPI, 14>(args, ntiles, stream);
-    if (g_gemm_variant == 15) return launch_v<EPI, 15>(args, ntiles, stream);
     if (g_gemm_variant == 16) return launch_v<EPI, 16>(args, ntiles, stream);
-    if (g_gemm_variant == 0) return launch_v<EPI, 0>(args, ntiles, stream);   // A/B reference schedules
-    if (g_gemm_variant == 8) return launch_v<EPI, 8>(args, ntiles, stream);
     if (g_gemm_variant == 10) return launch_v<EPI, 10>(args, ntiles, stream);
     return launch_v<EPI, GEMM_DEFAULT_VARIANT>(args, ntiles, stream);
 }
