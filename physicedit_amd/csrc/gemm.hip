@@ -67,13 +67,12 @@ PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 
 // VAR selects the main-loop schedule (A/B-tested in one process through pe_debug_set("gemm_variant"); the full study
 // incl. the ablation variants that no longer live here is profiles/r01_gemm_ablation.md):
-//   0   reference: one barrier per K tile, staging burst, loads then MFMAs per 16-deep k-step (compiler-scheduled)
-//   8   pipelined clusters: fragments double buffered in registers, tile barrier before the LAST cluster, staging
-//       spread over the clusters, MFMA / ds_read / LDS-DMA interleave pinned with sched_group_barrier
-//   10  8 + three-deep W ring and counted vmcnt (round-1 default)
-//   12  "ping-pong": the two wave groups run the same stream one barrier apart, 4 phases x 8 MFMAs per K tile
-//   13  12 with A[mi 0] of the next tile pre-read (balanced ds_read counts per phase)
-//   14  12 + s_memtime stamps (profiling only)
+//   10  (round-1 default, kept as the A/B reference) pipelined clusters: fragments double buffered in registers, tile barrier
+//       before the LAST cluster, staging spread over the clusters, MFMA / ds_read / LDS-DMA interleave pinned with
+//       sched_group_barrier, three-deep W ring and counted vmcnt
+//   14  "ping-pong": the two wave groups run the same stream one barrier apart, 4 phases x 8 MFMAs per K tile; with s_memtime
+//       stamps (profiling only).  (The code paths guarded by VAR >= 12 / VAR == 13 belong to this family; 0, 8, 12 and 13
+//       themselves are no longer instantiated.)
 //   15  (default) ping-pong with 2 phases x 16 MFMAs per K tile, A half tiles staged by the group that reads them
 //   16  15 + stream-K tail (the tiles of a partially filled last round are cut along K into 256 equal ranges, fp32
 //       partials exchanged through a workspace).  Correct and deterministic, but SLOWER on MI355X (profiles/
