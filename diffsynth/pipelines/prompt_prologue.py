@@ -232,12 +232,36 @@ def build_text_encoder(state_dict: Dict[str, torch.Tensor], device, torch_dtype=
     return model.eval()
 
 
+def accelerate_decode(model) -> int:
+    """Autoregressive decoding applies every nn.Linear of the language model to ONE row: 15 GB of weights per generated token, an
+    HBM-bound GEMV.  On the GPU those calls are routed to the library's pe_gemv_bf16 (fp32 accumulation, one rounding, like
+    nn.Linear); everything with more than one row (prefill, the vision tower) stays on torch.nn.functional.linear.  The
+    summation order differs from the BLAS GEMV's, as it does between BLAS versions: greedy decoding may break a near-tie the
+    other way.  Returns the number of wrapped modules."""
+    import torch.nn.functional as F
+    from physicedit_amd import ops
+    n = 0
+    for m in model.modules():
+        if (isinstance(m, torch.nn.Linear) and m.weight.is_cuda and m.weight.dtype == torch.bfloat16 and m.weight.is_contiguous()
+                and m.in_features % 8 == 0 and m.in_features <= 32768):
+            def forward(x, _m=m):
+                if x.numel() == _m.in_features and x.dtype == torch.bfloat16 and x.is_contiguous():
+                    return ops.gemv(x, _m.weight, _m.bias).view(*x.shape[:-1], _m.out_features)
+                return F.linear(x, _m.weight, _m.bias)
+            m.forward = forward
+            n += 1
+    return n
+
+
 class PromptPrologue:
     """callable installed as `pipe.prompt_encoder`:
     (pipe, prompt=, negative_prompt=, edit_image=, cfg=, have_text_reasoning=) -> (posi, nega) dicts."""
 
-    def __init__(self, text_encoder, processor, tokenizer=None, device="cuda", torch_dtype=torch.bfloat16):
+    def __init__(self, text_encoder, processor, tokenizer=None, device="cuda", torch_dtype=torch.bfloat16, decode_gemv: bool = True):
         self.text_encoder = text_encoder
+        self.decode_gemv = 0
+        if decode_gemv and text_encoder is not None and torch.device(device).type == "cuda":
+            self.decode_gemv = accelerate_decode(text_encoder)
         self.processor = processor
         self.tokenizer = tokenizer if tokenizer is not None else processor.tokenizer
         self.device = torch.device(device)

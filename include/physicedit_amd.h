@@ -137,6 +137,10 @@ int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, cons
 
 /* RMSNorm with weight over rows of width 3584 (txt_norm; models/utils.py:250-257). */
 int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, void* stream);
+/* nn.Linear applied to ONE row: y[N] = bf16(W[N,K] . x[K] + bias[N]) (fp32 accumulation, one rounding), bias nullable, K % 8 == 0.
+ * The HBM-bound shape of autoregressive decoding: used by the prompt prologue (Qwen2.5-VL `generate`,
+ * pipelines/qwen_image_physical.py:859-873) in place of the BLAS GEMV behind torch.nn.functional.linear. */
+int pe_gemv_bf16(const void* x, const void* W, const void* bias, void* y, int N, int K, void* stream);
 /* BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18): out = bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of
  * dim = 3072, each RMSNorm with the roundings of models/utils.py:250-257. */
 int pe_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,

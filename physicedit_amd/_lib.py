@@ -95,7 +95,7 @@ class DitCall(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/physicedit_amd.h declares
-ABI_VERSION = 4   # include/physicedit_amd.h: bumped on any signature / struct change
+ABI_VERSION = 5   # include/physicedit_amd.h: bumped on any signature / struct change
 
 SIGNATURES = {
     "pe_last_error": (C.c_char_p, []),
@@ -124,6 +124,7 @@ SIGNATURES = {
     "pe_ln_modulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_float, c_void_p]),
     "pe_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "pe_gemv_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_dual_rmsnorm_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "pe_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pe_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -32,7 +32,7 @@ using namespace pe;
 extern "C" {
 
 const char* pe_last_error(void) { return g_err; }
-int pe_abi_version(void) { return 4; }
+int pe_abi_version(void) { return 5; }
 #ifndef PE_SRC_HASH
 #define PE_SRC_HASH "unknown"
 #endif
@@ -153,6 +153,10 @@ int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float
 int pe_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,
                         void* stream) {
     return launch_dual_rmsnorm_add(x, wx, y, wy, out, rows, dim, eps, (hipStream_t)stream);
+}
+
+int pe_gemv_bf16(const void* x, const void* W, const void* bias, void* y, int N, int K, void* stream) {
+    return launch_gemv(x, W, bias, y, N, K, (hipStream_t)stream);
 }
 
 int pe_patchify(const void* latents, void* tokens, int C, int H2, int W2, void* stream) {

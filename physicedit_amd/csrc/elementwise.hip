@@ -243,6 +243,55 @@ int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// GEMV: y[n] = bf16(sum_k W[n,k] x[k] + bias[n]) -- nn.Linear on ONE row (the autoregressive decode of the prompt prologue's text
+// encoder: 15 GB of weights read once per generated token, i.e. HBM bound).  One wave per output row at a time, 2 rows in flight
+// per wave, 16-B loads, x staged once per work-group in LDS, fp32 accumulation in k order per lane + a wave reduction.
+// ------------------------------------------------------------------------------------------------
+constexpr int GEMV_ROWS = 16;     // rows per work-group (4 waves x 2 rows x 2 rounds)
+__global__ void __launch_bounds__(256) gemv_bf16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+                                                        const bf16* __restrict__ bias, bf16* __restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
+    bf16* xs = (bf16*)gemv_smem;
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
+    __syncthreads();
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    const int row0 = (int)blockIdx.x * GEMV_ROWS + w * 2;
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const int ra = row0 + rnd * 8, rb = ra + 1;
+        if (ra >= N) break;
+        const bf16* wa = W + (size_t)ra * K;
+        const bf16* wb = W + (size_t)min(rb, N - 1) * K;
+        float sa = 0.f, sb = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            const bf16x8 xv = *(const bf16x8*)(xs + k);
+            const bf16x8 va = *(const bf16x8*)(wa + k);
+            const bf16x8 vb = *(const bf16x8*)(wb + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sa = __builtin_fmaf((float)va[j], (float)xv[j], sa);
+                sb = __builtin_fmaf((float)vb[j], (float)xv[j], sb);
+            }
+        }
+        sa = wave_sum(sa);
+        sb = wave_sum(sb);
+        if (lane == 0) {
+            y[ra] = (bf16)(sa + (bias ? (float)bias[ra] : 0.f));
+            if (rb < N) y[rb] = (bf16)(sb + (bias ? (float)bias[rb] : 0.f));
+        }
+    }
+}
+
+int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream) {
+    PE_REQUIRE(x && W && y, "gemv: null pointer");
+    PE_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && K <= 32768, "gemv: N=%d K=%d (K must be a multiple of 8, at most 32768)", N, K);
+    hipLaunchKernelGGL(gemv_bf16_kernel, dim3((N + GEMV_ROWS - 1) / GEMV_ROWS), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
+                       (const bf16*)W, (const bf16*)bias, (bf16*)y, N, K);
+    return check_launch("gemv_bf16_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // SiLU (torch.nn.SiLU on bf16: fp32 inside, one rounding)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, size_t n8) {

@@ -206,6 +206,16 @@ def rmsnorm(x, w, eps: float = 1e-6) -> torch.Tensor:
     return out
 
 
+def gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear on one row: x [K] (any shape with K elements), w [N,K] -> [N]."""
+    _chk(x, "x"), _chk(w, "w")
+    N, K = w.shape
+    assert x.numel() == K
+    out = torch.empty((N,), dtype=BF, device=x.device)
+    check(lib().pe_gemv_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), N, K, stream_ptr()), "pe_gemv_bf16")
+    return out
+
+
 def dual_rmsnorm_add(x, wx, y, wy, eps: float = 1e-6) -> torch.Tensor:
     """BlockWiseControlBlock input: bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of 3072."""
     _chk(x, "x"), _chk(y, "y"), _chk(wx, "wx"), _chk(wy, "wy")

@@ -381,3 +381,13 @@ def test_flash_attn_token_words_full_size(ops):
     # text rows (the ones the mask constrains most) separately
     ut = u[S_img:]
     assert ut.max().item() <= 4.0 and (ut > 0).float().mean().item() < 0.6
+
+
+@pytest.mark.parametrize("N,K,with_bias", [(3584, 3584, True), (512, 3584, True), (18944, 3584, False), (3584, 18944, False), (1001, 64, True)])
+def test_gemv(ops, N, K, with_bias):
+    """pe_gemv_bf16 = nn.Linear on one row (the decode step of the prompt prologue's text encoder): vs an fp32-accumulated product."""
+    x, w = rnd((K,), 71), rnd((N, K), 72, K ** -0.5)
+    b = rnd((N,), 73) if with_bias else None
+    ref = (w.float() @ x.float() + (b.float() if with_bias else 0)).to(BF)
+    out = ops.gemv(x.cuda(), w.cuda(), b.cuda() if with_bias else None)
+    report(f"gemv {N}x{K}", out, ref, 1.01, 0.02)

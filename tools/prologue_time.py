@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--decode-tokens", type=int, default=128)
     ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--no-gemv", action="store_true", help="leave the single-row Linears of the decode on torch's BLAS GEMV")
     args = ap.parse_args()
     import torch
     import tiny_vl
@@ -72,7 +73,7 @@ def main():
     build_s = time.perf_counter() - t0
     n_params = sum(p.numel() for p in model.parameters())
 
-    prologue = pp.PromptPrologue(model, processor, device=dev)
+    prologue = pp.PromptPrologue(model, processor, device=dev, decode_gemv=not args.no_gemv)
     image = tiny_vl.make_image(1024, 1024, 0)
     prompt = "push the red ball off the table " * 3                       # ~100 byte-level tokens
     physical = "\nReasoning: " + "the ball rolls to the edge, tips over and falls under gravity. " * 4    # ~270 tokens
@@ -109,6 +110,7 @@ def main():
     res = {
         "what": "prompt prologue at real size (Qwen2.5-VL-7B architecture, random weights), stock transformers on PyTorch-ROCm",
         "parameters_billion": round(n_params / 1e9, 3), "layers": args.layers, "build_seconds": round(build_s, 2),
+        "single_row_linears_on_pe_gemv_bf16": prologue.decode_gemv,
         "embed_positive": {"tokens_after_drop": int(posi["prompt_emb"].shape[1]), "seconds": round(t_posi, 4)},
         "embed_negative": {"tokens_after_drop": int(nega["prompt_emb"].shape[1]), "seconds": round(t_nega, 4)},
         "generate": {"prompt_tokens": int(mi["input_ids"].shape[1]), "prefill_plus_1_token_seconds": round(t_gen1, 4),
