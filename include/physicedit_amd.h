@@ -141,6 +141,9 @@ int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float
  * The HBM-bound shape of autoregressive decoding: used by the prompt prologue (Qwen2.5-VL `generate`,
  * pipelines/qwen_image_physical.py:859-873) in place of the BLAS GEMV behind torch.nn.functional.linear. */
 int pe_gemv_bf16(const void* x, const void* W, const void* bias, void* y, int N, int K, void* stream);
+/* The gated MLP's first half on one row (transformers Qwen2MLP.forward): y[n] = bf16(silu(bf16(Wg[n,:].x)) * bf16(Wu[n,:].x)),
+ * SiLU evaluated in fp32 and rounded once, as torch.nn.SiLU does on a bf16 tensor. */
+int pe_gemv_swiglu_bf16(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, void* stream);
 /* BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18): out = bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of
  * dim = 3072, each RMSNorm with the roundings of models/utils.py:250-257. */
 int pe_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,

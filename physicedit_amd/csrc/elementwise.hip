@@ -283,6 +283,50 @@ __global__ void __launch_bounds__(256) gemv_bf16_kernel(const bf16* __restrict__
     }
 }
 
+// y[n] = bf16(silu(g) * u) with g = bf16(Wg[n,:] . x), u = bf16(Wu[n,:] . x): the gated MLP's first half on one row
+// (Qwen2MLP.forward: act_fn(gate_proj(x)) * up_proj(x); SiLU in fp32 with one rounding, then the bf16 product)
+__global__ void __launch_bounds__(256) gemv_swiglu_kernel(const bf16* __restrict__ x, const bf16* __restrict__ Wg,
+                                                          const bf16* __restrict__ Wu, bf16* __restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
+    bf16* xs = (bf16*)gemv_smem;
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
+    __syncthreads();
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const int n = (int)blockIdx.x * 8 + rnd * 4 + w;
+        if (n >= N) break;
+        const bf16* wa = Wg + (size_t)n * K;
+        const bf16* wb = Wu + (size_t)n * K;
+        float sa = 0.f, sb = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            const bf16x8 xv = *(const bf16x8*)(xs + k);
+            const bf16x8 va = *(const bf16x8*)(wa + k);
+            const bf16x8 vb = *(const bf16x8*)(wb + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sa = __builtin_fmaf((float)va[j], (float)xv[j], sa);
+                sb = __builtin_fmaf((float)vb[j], (float)xv[j], sb);
+            }
+        }
+        sa = wave_sum(sa);
+        sb = wave_sum(sb);
+        if (lane == 0) {
+            const float g = bf16r(sa), u = bf16r(sb);
+            y[n] = (bf16)(bf16r(g / (1.0f + __expf(-g))) * u);
+        }
+    }
+}
+
+int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, hipStream_t stream) {
+    PE_REQUIRE(x && Wg && Wu && y, "gemv_swiglu: null pointer");
+    PE_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && K <= 32768, "gemv_swiglu: N=%d K=%d (K must be a multiple of 8, at most 32768)", N, K);
+    hipLaunchKernelGGL(gemv_swiglu_kernel, dim3((N + 7) / 8), dim3(256), (size_t)K * 2, stream, (const bf16*)x, (const bf16*)Wg,
+                       (const bf16*)Wu, (bf16*)y, N, K);
+    return check_launch("gemv_swiglu_kernel");
+}
+
 int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream) {
     PE_REQUIRE(x && W && y, "gemv: null pointer");
     PE_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && K <= 32768, "gemv: N=%d K=%d (K must be a multiple of 8, at most 32768)", N, K);

@@ -91,6 +91,7 @@ int launch_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const 
                             hipStream_t stream);
 int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream);
 int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream);
+int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, hipStream_t stream);
 int launch_patchify(const void* latents, void* tokens, int C, int H2, int W2, hipStream_t stream);
 int launch_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, hipStream_t stream);
 int launch_gather_rows(const void* src, const int* idx, void* dst, int nrows, int dim, hipStream_t stream);

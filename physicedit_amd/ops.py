@@ -216,6 +216,17 @@ def gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) 
     return out
 
 
+def gemv_swiglu(x: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor) -> torch.Tensor:
+    """silu(w_gate @ x) * (w_up @ x) on one row, with nn.Linear / nn.SiLU roundings: x [K], w_* [N,K] -> [N]."""
+    _chk(x, "x"), _chk(w_gate, "w_gate"), _chk(w_up, "w_up")
+    N, K = w_gate.shape
+    assert x.numel() == K and tuple(w_up.shape) == (N, K)
+    out = torch.empty((N,), dtype=BF, device=x.device)
+    check(lib().pe_gemv_swiglu_bf16(x.data_ptr(), w_gate.data_ptr(), w_up.data_ptr(), out.data_ptr(), N, K, stream_ptr()),
+          "pe_gemv_swiglu_bf16")
+    return out
+
+
 def dual_rmsnorm_add(x, wx, y, wy, eps: float = 1e-6) -> torch.Tensor:
     """BlockWiseControlBlock input: bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of 3072."""
     _chk(x, "x"), _chk(y, "y"), _chk(wx, "wx"), _chk(wy, "wy")

@@ -391,3 +391,14 @@ def test_gemv(ops, N, K, with_bias):
     ref = (w.float() @ x.float() + (b.float() if with_bias else 0)).to(BF)
     out = ops.gemv(x.cuda(), w.cuda(), b.cuda() if with_bias else None)
     report(f"gemv {N}x{K}", out, ref, 1.01, 0.02)
+
+
+def test_gemv_swiglu(ops):
+    """pe_gemv_swiglu_bf16 vs act_fn(gate_proj(x)) * up_proj(x) with torch's bf16 roundings (fp32-accumulated products)."""
+    N, K = 18944, 3584
+    x, wg, wu = rnd((K,), 81), rnd((N, K), 82, K ** -0.5), rnd((N, K), 83, K ** -0.5)
+    g = (wg.float() @ x.float()).to(BF)
+    u = (wu.float() @ x.float()).to(BF)
+    ref = F.silu(g) * u
+    out = ops.gemv_swiglu(x.cuda(), wg.cuda(), wu.cuda())
+    report("gemv_swiglu", out, ref, 2.01, 0.03)
