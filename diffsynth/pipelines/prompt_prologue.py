@@ -272,7 +272,50 @@ def accelerate_decode(model) -> int:
                 return _orig(x)
             m.forward = mlp_forward
             n += 1
+        elif (type(m).__name__ == "Qwen2_5_VLAttention" and getattr(m, "head_dim", 0) == 128 and m.q_proj.weight.is_cuda
+              and m.q_proj.weight.dtype == torch.bfloat16 and m.q_proj.in_features % 8 == 0):
+            n += _patch_decode_attention(m, ops)
     return n
+
+
+def _patch_decode_attention(m, ops) -> int:
+    """q_len = 1 path of Qwen2_5_VLAttention.forward (transformers): q / k / v projections + multimodal rotary embedding in two
+    launches (pe_decode_qkv_rope) instead of ~25 element-wise ones, the cache update left to transformers' Cache object, then one
+    GQA-aware single-query attention launch (pe_decode_attention) instead of repeat_kv copies + SDPA + transposes, then o_proj
+    (already a pe_gemv_bf16).  Anything else (prefill, batches, attention weights requested) takes the original forward."""
+    orig = m.forward
+    try:
+        section = list(m.config.rope_parameters["mrope_section"])
+    except Exception:
+        section = list(getattr(m, "rope_scaling", {}).get("mrope_section", []))
+    if sum(section) * 2 != 128:
+        return 0
+    sel = torch.tensor([i % 3 for i, n_ in enumerate(section * 2) for _ in range(n_)], device=m.q_proj.weight.device)
+    ar = torch.arange(128, device=sel.device)
+    last = {"id": None, "cs": None, "sn": None}
+    hq, hkv = m.q_proj.out_features // 128, m.k_proj.out_features // 128
+
+    def forward(hidden_states, attention_mask=None, position_ids=None, past_key_values=None, output_attentions=False,
+                use_cache=False, position_embeddings=None, **kwargs):
+        if (hidden_states.shape[0] != 1 or hidden_states.shape[1] != 1 or past_key_values is None or output_attentions
+                or position_embeddings is None or hidden_states.dtype != torch.bfloat16 or not hidden_states.is_contiguous()):
+            return orig(hidden_states, attention_mask=attention_mask, position_ids=position_ids, past_key_values=past_key_values,
+                        output_attentions=output_attentions, use_cache=use_cache, position_embeddings=position_embeddings, **kwargs)
+        cos, sin = position_embeddings
+        if last["id"] != id(cos):                  # the same (cos, sin) pair reaches every layer of one step
+            last["id"] = id(cos)
+            last["cs"] = cos[:, 0, 0, :][sel, ar].to(torch.bfloat16).contiguous()
+            last["sn"] = sin[:, 0, 0, :][sel, ar].to(torch.bfloat16).contiguous()
+        q, k, v = ops.decode_qkv_rope(hidden_states, m.q_proj.weight, m.q_proj.bias, m.k_proj.weight, m.k_proj.bias,
+                                      m.v_proj.weight, m.v_proj.bias, last["cs"], last["sn"])
+        kc, vc = past_key_values.update(k.view(1, hkv, 1, 128), v.view(1, hkv, 1, 128), m.layer_idx)
+        if not (kc.is_contiguous() and vc.is_contiguous()):
+            kc, vc = kc.contiguous(), vc.contiguous()
+        out = ops.decode_attention(q, kc[0], vc[0], float(m.scaling))
+        return m.o_proj(out.view(1, 1, hq * 128)), None
+
+    m.forward = forward
+    return 1
 
 
 class PromptPrologue:

@@ -144,6 +144,17 @@ int pe_gemv_bf16(const void* x, const void* W, const void* bias, void* y, int N,
 /* The gated MLP's first half on one row (transformers Qwen2MLP.forward): y[n] = bf16(silu(bf16(Wg[n,:].x)) * bf16(Wu[n,:].x)),
  * SiLU evaluated in fp32 and rounded once, as torch.nn.SiLU does on a bf16 tensor. */
 int pe_gemv_swiglu_bf16(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, void* stream);
+/* Decode step of a GQA attention layer with 128-wide heads (transformers Qwen2_5_VLAttention.forward at q_len = 1):
+ * pe_decode_qkv_rope: q / k / v = Linear(x) (three weight / bias sets, one launch), then rotary embedding of the q and k heads with
+ *   the section-selected tables cos_sel / sin_sel [128] bf16: y = bf16(bf16(t * cos) + bf16(rotate_half(t) * sin)).
+ *   q [n_q_heads*128], k, v [n_kv_heads*128] bf16.
+ * pe_decode_attention: softmax(q K^T * scale) V of that one query against the cache k_cache, v_cache [n_kv_heads][L][128]
+ *   (query head h reads kv head h / (n_q_heads / n_kv_heads)); fp32 scores and sums, P rounded to bf16 before P.V.  L <= 15360. */
+int pe_decode_qkv_rope(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv, const void* bv,
+                       const void* cos_sel, const void* sin_sel, void* q, void* k, void* v, int n_q_heads, int n_kv_heads, int K,
+                       void* stream);
+int pe_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads, int L,
+                        float scale, void* stream);
 /* BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18): out = bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of
  * dim = 3072, each RMSNorm with the roundings of models/utils.py:250-257. */
 int pe_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,

@@ -163,6 +163,17 @@ int pe_gemv_swiglu_bf16(const void* x, const void* Wg, const void* Wu, void* y, 
     return launch_gemv_swiglu(x, Wg, Wu, y, N, K, (hipStream_t)stream);
 }
 
+int pe_decode_qkv_rope(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv, const void* bv,
+                       const void* cos_sel, const void* sin_sel, void* q, void* k, void* v, int n_q_heads, int n_kv_heads, int K,
+                       void* stream) {
+    return launch_decode_qkv(x, Wq, bq, Wk, bk, Wv, bv, cos_sel, sin_sel, q, k, v, n_q_heads, n_kv_heads, K, (hipStream_t)stream);
+}
+
+int pe_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads, int L,
+                        float scale, void* stream) {
+    return launch_attn_decode(q, k_cache, v_cache, out, n_q_heads, n_kv_heads, L, scale, (hipStream_t)stream);
+}
+
 int pe_patchify(const void* latents, void* tokens, int C, int H2, int W2, void* stream) {
     return launch_patchify(latents, tokens, C, H2, W2, (hipStream_t)stream);
 }

@@ -327,6 +327,137 @@ int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, i
     return check_launch("gemv_swiglu_kernel");
 }
 
+// Decode-step attention input of a GQA transformer layer (transformers Qwen2_5_VLAttention.forward, q_len = 1): q / k / v
+// projections of ONE row in one launch over the concatenated row space (three weight / bias sets), then rotary embedding of the
+// q and k heads:  y = bf16(bf16(x * cos) + bf16(rotate_half(x) * sin))  with rotate_half(x) = cat(-x[64:], x[:64]) per 128-wide
+// head (apply_multimodal_rotary_pos_emb after the mrope section selection, which the caller does once per step).
+__global__ void __launch_bounds__(256) gemv3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W0, const bf16* __restrict__ b0,
+                                                    int N0, const bf16* __restrict__ W1, const bf16* __restrict__ b1, int N1,
+                                                    const bf16* __restrict__ W2, const bf16* __restrict__ b2, int N2,
+                                                    bf16* __restrict__ y0, bf16* __restrict__ y1, bf16* __restrict__ y2, int K) {
+    extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
+    bf16* xs = (bf16*)gemv_smem;
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
+    __syncthreads();
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    const int N = N0 + N1 + N2;
+#pragma unroll
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        const int n = (int)blockIdx.x * GEMV_ROWS + rnd * 4 + w;
+        if (n >= N) break;
+        const bf16* wr;
+        const bf16* br;
+        bf16* yr;
+        int r = n;
+        if (r < N0) { wr = W0; br = b0; yr = y0; }
+        else if ((r -= N0) < N1) { wr = W1; br = b1; yr = y1; }
+        else { r -= N1; wr = W2; br = b2; yr = y2; }
+        const bf16* row = wr + (size_t)r * K;
+        float acc = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            const bf16x8 xv = *(const bf16x8*)(xs + k);
+            const bf16x8 wv = *(const bf16x8*)(row + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_fmaf((float)wv[j], (float)xv[j], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) yr[r] = (bf16)(acc + (br ? (float)br[r] : 0.f));
+    }
+}
+
+__global__ void __launch_bounds__(128) rope_heads_kernel(bf16* __restrict__ q, int n_q, bf16* __restrict__ k, int n_k,
+                                                         const bf16* __restrict__ cs, const bf16* __restrict__ sn) {
+    const int head = (int)blockIdx.x, i = (int)threadIdx.x;
+    bf16* v = head < n_q ? q + (size_t)head * 128 : k + (size_t)(head - n_q) * 128;
+    const float a = (float)v[i];
+    const float r = i < 64 ? -(float)v[i + 64] : (float)v[i - 64];
+    __syncthreads();                               // every lane has read its two inputs before anyone overwrites
+    v[i] = (bf16)(bf16r(a * (float)cs[i]) + bf16r(r * (float)sn[i]));
+}
+
+int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv,
+                      const void* bv, const void* cos_sel, const void* sin_sel, void* q, void* k, void* v, int n_q_heads,
+                      int n_kv_heads, int K, hipStream_t stream) {
+    PE_REQUIRE(x && Wq && Wk && Wv && cos_sel && sin_sel && q && k && v, "decode_qkv: null pointer");
+    PE_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && K > 0 && K % 8 == 0 && K <= 32768, "decode_qkv: bad shape");
+    const int N0 = n_q_heads * 128, N1 = n_kv_heads * 128;
+    hipLaunchKernelGGL(gemv3_kernel, dim3((N0 + 2 * N1 + GEMV_ROWS - 1) / GEMV_ROWS), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
+                       (const bf16*)Wq, (const bf16*)bq, N0, (const bf16*)Wk, (const bf16*)bk, N1, (const bf16*)Wv, (const bf16*)bv, N1,
+                       (bf16*)q, (bf16*)k, (bf16*)v, K);
+    int rc = check_launch("gemv3_kernel");
+    if (rc != PE_OK) return rc;
+    hipLaunchKernelGGL(rope_heads_kernel, dim3(n_q_heads + n_kv_heads), dim3(128), 0, stream, (bf16*)q, n_q_heads, (bf16*)k, n_kv_heads,
+                       (const bf16*)cos_sel, (const bf16*)sin_sel);
+    return check_launch("rope_heads_kernel");
+}
+
+// One query token against a KV cache [n_kv][L][128] (GQA: query head h reads kv head h / (n_q / n_kv)), no mask:
+// softmax(q K^T * scale) V with fp32 scores and sums, P rounded to bf16 before P.V (as the fused SDPA kernels do).
+__global__ void __launch_bounds__(256) attn_decode_kernel(const bf16* __restrict__ q, const bf16* __restrict__ Kc,
+                                                          const bf16* __restrict__ Vc, bf16* __restrict__ out, int n_q, int n_kv,
+                                                          int L, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+    float* sc = (float*)dec_smem;                  // [L] scores, then probabilities
+    __shared__ float red[8];
+    __shared__ float part[128];
+    const int h = (int)blockIdx.x, t = (int)threadIdx.x;
+    const int kvh = h / (n_q / n_kv);
+    const bf16* kb = Kc + (size_t)kvh * L * 128;
+    const bf16* vb = Vc + (size_t)kvh * L * 128;
+    float qf[128];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const bf16x8 t8 = *(const bf16x8*)(q + (size_t)h * 128 + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[c * 8 + j] = (float)t8[j];
+    }
+    float mx = -INFINITY;
+    for (int j = t; j < L; j += 256) {
+        const bf16* kr = kb + (size_t)j * 128;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const bf16x8 k8 = *(const bf16x8*)(kr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qf[c * 8 + e], (float)k8[e], acc);
+        }
+        acc *= scale;
+        sc[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = t; j < L; j += 256) {
+        const float p = __expf(sc[j] - mx);
+        sum += p;
+        sc[j] = bf16r(p);
+    }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) red[4 + (t >> 6)] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    // P.V: thread t accumulates output channel t & 127 over half of the keys
+    const int d = t & 127, half = t >> 7;
+    float acc = 0.f;
+    for (int j = half; j < L; j += 2) acc = __builtin_fmaf(sc[j], (float)vb[(size_t)j * 128 + d], acc);
+    if (half == 1) part[d] = acc;
+    __syncthreads();
+    if (half == 0) out[(size_t)h * 128 + d] = (bf16)((acc + part[d]) / sum);
+}
+
+int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int L, float scale,
+                       hipStream_t stream) {
+    PE_REQUIRE(q && Kc && Vc && out, "attn_decode: null pointer");
+    PE_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && L > 0 && L <= 15360, "attn_decode: bad shape (L=%d)", L);
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(n_q_heads), dim3(256), (size_t)L * 4, stream, (const bf16*)q, (const bf16*)Kc,
+                       (const bf16*)Vc, (bf16*)out, n_q_heads, n_kv_heads, L, scale);
+    return check_launch("attn_decode_kernel");
+}
+
 int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream) {
     PE_REQUIRE(x && W && y, "gemv: null pointer");
     PE_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && K <= 32768, "gemv: N=%d K=%d (K must be a multiple of 8, at most 32768)", N, K);

@@ -91,6 +91,11 @@ int launch_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const 
                             hipStream_t stream);
 int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream);
 int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream);
+int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv,
+                      const void* bv, const void* cos_sel, const void* sin_sel, void* q, void* k, void* v, int n_q_heads,
+                      int n_kv_heads, int K, hipStream_t stream);
+int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int L, float scale,
+                       hipStream_t stream);
 int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, hipStream_t stream);
 int launch_patchify(const void* latents, void* tokens, int C, int H2, int W2, hipStream_t stream);
 int launch_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, hipStream_t stream);

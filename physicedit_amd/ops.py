@@ -227,6 +227,32 @@ def gemv_swiglu(x: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor) -> to
     return out
 
 
+def decode_qkv_rope(x, wq, bq, wk, bk, wv, bv, cos_sel, sin_sel):
+    """q / k / v projections of one row + rotary embedding of the q and k heads (128-wide): -> q [Hq,128], k, v [Hkv,128]."""
+    for t, n in ((x, "x"), (wq, "wq"), (wk, "wk"), (wv, "wv"), (cos_sel, "cos"), (sin_sel, "sin")):
+        _chk(t, n)
+    K = wq.shape[1]
+    hq, hkv = wq.shape[0] // 128, wk.shape[0] // 128
+    assert x.numel() == K and cos_sel.numel() == 128 and sin_sel.numel() == 128 and wv.shape == wk.shape
+    q = torch.empty((hq, 128), dtype=BF, device=x.device)
+    k = torch.empty((hkv, 128), dtype=BF, device=x.device)
+    v = torch.empty((hkv, 128), dtype=BF, device=x.device)
+    check(lib().pe_decode_qkv_rope(x.data_ptr(), wq.data_ptr(), _ptr(bq), wk.data_ptr(), _ptr(bk), wv.data_ptr(), _ptr(bv),
+                                   cos_sel.data_ptr(), sin_sel.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), hq, hkv, K,
+                                   stream_ptr()), "pe_decode_qkv_rope")
+    return q, k, v
+
+
+def decode_attention(q, k_cache, v_cache, scale: float) -> torch.Tensor:
+    """one query [Hq,128] against a cache [Hkv,L,128] (GQA) -> [Hq*128]."""
+    _chk(q, "q"), _chk(k_cache, "k_cache"), _chk(v_cache, "v_cache")
+    hq, (hkv, L, _) = q.shape[0], k_cache.shape
+    out = torch.empty((hq * 128,), dtype=BF, device=q.device)
+    check(lib().pe_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(), hq, hkv, L, scale,
+                                    stream_ptr()), "pe_decode_attention")
+    return out
+
+
 def dual_rmsnorm_add(x, wx, y, wy, eps: float = 1e-6) -> torch.Tensor:
     """BlockWiseControlBlock input: bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of 3072."""
     _chk(x, "x"), _chk(y, "y"), _chk(wx, "wx"), _chk(wy, "wy")

@@ -402,3 +402,41 @@ def test_gemv_swiglu(ops):
     ref = F.silu(g) * u
     out = ops.gemv_swiglu(x.cuda(), wg.cuda(), wu.cuda())
     report("gemv_swiglu", out, ref, 2.01, 0.03)
+
+
+def test_decode_qkv_rope(ops):
+    """pe_decode_qkv_rope vs the same steps in torch (transformers Qwen2_5_VLAttention.forward at q_len = 1: three Linears, then
+    q * cos + rotate_half(q) * sin in bf16)."""
+    K, hq, hkv = 3584, 28, 4
+    x = rnd((K,), 91)
+    wq, wk, wv = rnd((hq * 128, K), 92, K ** -0.5), rnd((hkv * 128, K), 93, K ** -0.5), rnd((hkv * 128, K), 94, K ** -0.5)
+    bq, bk, bv = rnd((hq * 128,), 95), rnd((hkv * 128,), 96), rnd((hkv * 128,), 97)
+    ang = torch.rand((128,), generator=torch.Generator().manual_seed(98)) * 6.28
+    cs, sn = ang.cos().to(BF), ang.sin().to(BF)
+
+    def lin(w, b):
+        return (w.float() @ x.float() + b.float()).to(BF)
+
+    def rope(t):
+        t = t.view(-1, 128)
+        rot = torch.cat([-t[:, 64:], t[:, :64]], dim=-1)
+        return (t * cs) + (rot * sn)
+    q, k, v = ops.decode_qkv_rope(x.cuda(), wq.cuda(), bq.cuda(), wk.cuda(), bk.cuda(), wv.cuda(), bv.cuda(), cs.cuda(), sn.cuda())
+    report("decode v", v.reshape(-1), lin(wv, bv), 1.01, 0.02)
+    report("decode q + rope", q, rope(lin(wq, bq)), 2.01, 0.03)
+    report("decode k + rope", k, rope(lin(wk, bk)), 2.01, 0.03)
+
+
+@pytest.mark.parametrize("L", [1, 77, 1348, 2400])
+def test_decode_attention(ops, L):
+    """pe_decode_attention: one query per head against a GQA cache vs torch SDPA on the repeated cache."""
+    hq, hkv = 28, 4
+    q, kc, vc = rnd((hq, 128), 101), rnd((hkv, L, 128), 102), rnd((hkv, L, 128), 103)
+    kr, vr = kc.repeat_interleave(hq // hkv, dim=0), vc.repeat_interleave(hq // hkv, dim=0)
+    ref32 = F.scaled_dot_product_attention(q[:, None].float(), kr.float(), vr.float()).reshape(-1)
+    ref = F.scaled_dot_product_attention(q[:, None], kr, vr).reshape(-1)
+    out = ops.decode_attention(q.cuda(), kc.cuda(), vc.cuda(), 128 ** -0.5)
+    e_gpu = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
+    e_cpu = (ref.float() - ref32).pow(2).mean().sqrt().item()
+    print(f"[parity] decode attention L={L}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
+    assert torch.isfinite(out.float()).all() and e_gpu <= 1.5 * e_cpu + 1e-4
