@@ -400,32 +400,40 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const bf16* __restrict
     extern __shared__ __attribute__((aligned(16))) char dec_smem[];
     float* sc = (float*)dec_smem;                  // [L] scores, then probabilities
     __shared__ float red[8];
-    __shared__ float part[128];
+    __shared__ float part[16][128];
     const int h = (int)blockIdx.x, t = (int)threadIdx.x;
     const int kvh = h / (n_q / n_kv);
     const bf16* kb = Kc + (size_t)kvh * L * 128;
     const bf16* vb = Vc + (size_t)kvh * L * 128;
-    float qf[128];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const bf16x8 t8 = *(const bf16x8*)(q + (size_t)h * 128 + c * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[c * 8 + j] = (float)t8[j];
-    }
+    // scores: 4 lanes share one key row (64 contiguous bytes each), 64 keys per work-group iteration, two shuffles per key
     float mx = -INFINITY;
-    for (int j = t; j < L; j += 256) {
-        const bf16* kr = kb + (size_t)j * 128;
-        float acc = 0.f;
+    {
+        const int s4 = t & 3, g4 = t >> 2;         // g4 0..63
+        float qf[32];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const bf16x8 k8 = *(const bf16x8*)(kr + c * 8);
+        for (int c = 0; c < 4; ++c) {
+            const bf16x8 t8 = *(const bf16x8*)(q + (size_t)h * 128 + s4 * 32 + c * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qf[c * 8 + e], (float)k8[e], acc);
+            for (int j = 0; j < 8; ++j) qf[c * 8 + j] = (float)t8[j];
         }
-        acc *= scale;
-        sc[j] = acc;
-        mx = fmaxf(mx, acc);
+#pragma unroll 2
+        for (int j = g4; j < L; j += 64) {
+            const bf16* kr = kb + (size_t)j * 128 + s4 * 32;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bf16x8 k8 = *(const bf16x8*)(kr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qf[c * 8 + e], (float)k8[e], acc);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc *= scale;
+            if (s4 == 0) sc[j] = acc;
+            mx = fmaxf(mx, acc);
+        }
     }
+    const int sub = t & 15, grp = t >> 4;          // P.V below: grp 0..15
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if ((t & 63) == 0) red[t >> 6] = mx;
     __syncthreads();
@@ -440,13 +448,24 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const bf16* __restrict
     if ((t & 63) == 0) red[4 + (t >> 6)] = sum;
     __syncthreads();
     sum = red[4] + red[5] + red[6] + red[7];
-    // P.V: thread t accumulates output channel t & 127 over half of the keys
-    const int d = t & 127, half = t >> 7;
-    float acc = 0.f;
-    for (int j = half; j < L; j += 2) acc = __builtin_fmaf(sc[j], (float)vb[(size_t)j * 128 + d], acc);
-    if (half == 1) part[d] = acc;
+    // P.V: lane `sub` owns output channels 8 sub .. 8 sub + 7, group `grp` every 16th key; the 16 groups meet in LDS
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int j = grp; j < L; j += 16) {
+        const bf16x8 v8 = *(const bf16x8*)(vb + (size_t)j * 128 + sub * 8);
+        const float p = sc[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)v8[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[grp][sub * 8 + e] = acc[e];
     __syncthreads();
-    if (half == 0) out[(size_t)h * 128 + d] = (bf16)((acc + part[d]) / sum);
+    if (t < 128) {
+        float o = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) o += part[g2][t];
+        out[(size_t)h * 128 + t] = (bf16)(o / sum);
+    }
 }
 
 int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int L, float scale,
