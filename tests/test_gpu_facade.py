@@ -287,3 +287,57 @@ def test_controlnet_and_eligen_through_the_facade(tmp_path):
     print(f"[parity] facade controlnet + eligen: latents max|d| {dl.max().item():.4e} mean|d| {dl.mean().item():.4e} "
           f"(|latents| mean {lat.float().abs().mean().item():.3f})")
     assert dl.mean().item() <= 8e-3 and dl.max().item() <= 0.25
+
+
+def test_accelerated_decode_matches_transformers():
+    """accelerate_decode (prompt_prologue.py) swaps the decode step's single-row Linears, gated MLP, RMSNorms, q/k/v + rotary
+    embedding and single-query attention for library kernels.  Two copies of a 4-layer model at the REAL widths (hidden 3584, 28 / 4
+    heads of 128, MLP 18944), same seeded weights: the next-token logits after a prefill + 6 decode steps must agree to bf16 noise,
+    far below the spread of the logits."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import copy
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    from diffsynth.pipelines import prompt_prologue as PP
+    cfg = copy.deepcopy(PP.TEXT_ENCODER_CONFIG)
+    cfg["text_config"].update(num_hidden_layers=4, vocab_size=4096, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    cfg["vision_config"].update(depth=1, fullatt_block_indexes=[0])
+    cfg.update(image_token_id=10, video_token_id=11, vision_start_token_id=12, vision_end_token_id=13, bos_token_id=1, eos_token_id=2)
+
+    def build():
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.bfloat16)
+        try:
+            with torch.device("cuda"):
+                m = Qwen2_5_VLForConditionalGeneration(Qwen2_5_VLConfig(**cfg))
+        finally:
+            torch.set_default_dtype(old)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if p.dim() >= 2:
+                    p.normal_(0.0, 0.05, generator=g)
+                elif "norm" in name:
+                    p.fill_(1.0)
+                else:
+                    p.normal_(0.0, 0.02, generator=g)
+        return m.eval()
+    stock, fast = build(), build()
+    assert PP.accelerate_decode(fast) >= 4 * (7 + 2 + 1 + 1)        # per layer: 7 Linears, 2 norms, the MLP, the attention
+    ids = torch.randint(20, 4000, (1, 37), generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run(m):
+        with torch.no_grad():
+            out = m(input_ids=ids, use_cache=True)
+            cache, logits = out.past_key_values, out.logits[:, -1]
+            tok = ids[:, -1:]
+            for step in range(6):                                   # teacher-forced: both models see the same tokens
+                tok = (tok * 7 + 13 + step) % 3900 + 20
+                out = m(input_ids=tok, past_key_values=cache, use_cache=True)
+                cache, logits = out.past_key_values, out.logits[:, -1]
+        return logits.float()
+    a, b = run(stock), run(fast)
+    spread = a.std().item()
+    err = (a - b).abs().max().item()
+    print(f"[parity] accelerated decode: max |dlogit| {err:.4e}, logit std {spread:.4e}, top-1 equal {bool(a.argmax() == b.argmax())}")
+    assert torch.isfinite(b).all() and err <= 0.05 * spread

@@ -73,8 +73,18 @@ def main():
     build_s = time.perf_counter() - t0
     n_params = sum(p.numel() for p in model.parameters())
 
-    prologue = pp.PromptPrologue(model, processor, device=dev, decode_gemv=not args.no_gemv)
     image = tiny_vl.make_image(1024, 1024, 0)
+    # greedy tokens of the UNPATCHED model first (the patch below replaces forwards in place): a sanity check of the decode kernels
+    check_text = processor.apply_chat_template([{"role": "user", "content": [{"type": "input_text", "text": "what happens next?"},
+                                                                             {"type": "image"}]}], tokenize=False,
+                                               add_generation_prompt=True, add_vision_id=True)
+    check_in = processor(text=[check_text], images=pp.resize_for_vl(image), padding=True, return_tensors="pt").to(dev)
+    with torch.no_grad():
+        stock_tokens = model.generate(**check_in, max_new_tokens=48, min_new_tokens=48)[0, check_in["input_ids"].shape[1]:].tolist()
+    prologue = pp.PromptPrologue(model, processor, device=dev, decode_gemv=not args.no_gemv)
+    with torch.no_grad():
+        fast_tokens = model.generate(**check_in, max_new_tokens=48, min_new_tokens=48)[0, check_in["input_ids"].shape[1]:].tolist()
+    same_prefix = next((i for i, (a, b) in enumerate(zip(stock_tokens, fast_tokens)) if a != b), len(stock_tokens))
     prompt = "push the red ball off the table " * 3                       # ~100 byte-level tokens
     physical = "\nReasoning: " + "the ball rolls to the edge, tips over and falls under gravity. " * 4    # ~270 tokens
 
@@ -111,6 +121,8 @@ def main():
         "what": "prompt prologue at real size (Qwen2.5-VL-7B architecture, random weights), stock transformers on PyTorch-ROCm",
         "parameters_billion": round(n_params / 1e9, 3), "layers": args.layers, "build_seconds": round(build_s, 2),
         "single_row_linears_on_pe_gemv_bf16": prologue.decode_gemv,
+        "greedy_tokens_identical_to_unpatched_model": f"{same_prefix} of {len(stock_tokens)} (random weights: near-uniform logits, the "
+                                                      "hardest case for a tie-break)",
         "embed_positive": {"tokens_after_drop": int(posi["prompt_emb"].shape[1]), "seconds": round(t_posi, 4)},
         "embed_negative": {"tokens_after_drop": int(nega["prompt_emb"].shape[1]), "seconds": round(t_nega, 4)},
         "generate": {"prompt_tokens": int(mi["input_ids"].shape[1]), "prefill_plus_1_token_seconds": round(t_gen1, 4),
