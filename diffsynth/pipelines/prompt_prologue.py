@@ -275,6 +275,8 @@ def accelerate_decode(model) -> int:
         elif (type(m).__name__ == "Qwen2_5_VLAttention" and getattr(m, "head_dim", 0) == 128 and m.q_proj.weight.is_cuda
               and m.q_proj.weight.dtype == torch.bfloat16 and m.q_proj.in_features % 8 == 0):
             n += _patch_decode_attention(m, ops)
+        elif type(m).__name__ == "Qwen2_5_VLDecoderLayer":
+            n += _patch_decode_layer(m, ops)
     return n
 
 
@@ -302,6 +304,10 @@ def _patch_decode_attention(m, ops) -> int:
             return orig(hidden_states, attention_mask=attention_mask, position_ids=position_ids, past_key_values=past_key_values,
                         output_attentions=output_attentions, use_cache=use_cache, position_embeddings=position_embeddings, **kwargs)
         cos, sin = position_embeddings
+        return m.o_proj(core(hidden_states, past_key_values, cos, sin).view(1, 1, hq * 128)), None
+
+    def core(hidden_states, past_key_values, cos, sin):
+        """attention output of the one new token BEFORE o_proj, [Hq * 128]"""
         if last["id"] != id(cos):                  # the same (cos, sin) pair reaches every layer of one step
             last["id"] = id(cos)
             last["cs"] = cos[:, 0, 0, :][sel, ar].to(torch.bfloat16).contiguous()
@@ -311,10 +317,39 @@ def _patch_decode_attention(m, ops) -> int:
         kc, vc = past_key_values.update(k.view(1, hkv, 1, 128), v.view(1, hkv, 1, 128), m.layer_idx)
         if not (kc.is_contiguous() and vc.is_contiguous()):
             kc, vc = kc.contiguous(), vc.contiguous()
-        out = ops.decode_attention(q, kc[0], vc[0], float(m.scaling))
-        return m.o_proj(out.view(1, 1, hq * 128)), None
+        return ops.decode_attention(q, kc[0], vc[0], float(m.scaling))
 
     m.forward = forward
+    m._pe_decode_core = core
+    return 1
+
+
+def _patch_decode_layer(layer, ops) -> int:
+    """q_len = 1 path of Qwen2_5_VLDecoderLayer.forward: the two `residual + sublayer(x)` additions ride in the epilogue of the
+    o_proj / down_proj GEMVs (pe_gemv_res_bf16: the Linear's output and the sum are rounded separately, as in eager PyTorch), so a
+    layer is 8 launches: norm, q/k/v + rotary, 2 x cache append (transformers), attention, o_proj + residual, norm, gate/up + SiLU,
+    down_proj + residual."""
+    orig = layer.forward
+    attn, mlp = layer.self_attn, layer.mlp
+    if not (type(mlp).__name__ == "Qwen2MLP" and mlp.down_proj.bias is None and mlp.gate_proj.bias is None and mlp.up_proj.bias is None
+            and getattr(attn, "head_dim", 0) == 128 and attn.o_proj.weight.is_cuda and attn.o_proj.weight.dtype == torch.bfloat16):
+        return 0
+
+    def forward(hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                position_embeddings=None, **kwargs):
+        core = getattr(attn, "_pe_decode_core", None)
+        if (core is None or hidden_states.shape[0] != 1 or hidden_states.shape[1] != 1 or past_key_values is None
+                or position_embeddings is None or hidden_states.dtype != torch.bfloat16 or not hidden_states.is_contiguous()
+                or kwargs.get("output_attentions")):
+            return orig(hidden_states, attention_mask=attention_mask, position_ids=position_ids, past_key_values=past_key_values,
+                        use_cache=use_cache, position_embeddings=position_embeddings, **kwargs)
+        cos, sin = position_embeddings
+        a = core(layer.input_layernorm(hidden_states), past_key_values, cos, sin)
+        h1 = ops.gemv(a, attn.o_proj.weight, attn.o_proj.bias, res=hidden_states.view(-1)).view(1, 1, -1)
+        hid = ops.gemv_swiglu(layer.post_attention_layernorm(h1), mlp.gate_proj.weight, mlp.up_proj.weight)
+        return ops.gemv(hid, mlp.down_proj.weight, None, res=h1.view(-1)).view(1, 1, -1)
+
+    layer.forward = forward
     return 1
 
 

@@ -141,12 +141,15 @@ int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float
  * The HBM-bound shape of autoregressive decoding: used by the prompt prologue (Qwen2.5-VL `generate`,
  * pipelines/qwen_image_physical.py:859-873) in place of the BLAS GEMV behind torch.nn.functional.linear. */
 int pe_gemv_bf16(const void* x, const void* W, const void* bias, void* y, int N, int K, void* stream);
+/* the same followed by a decoder layer's residual: y[n] = bf16(res[n] + bf16(W[n,:] . x + bias[n])); y may alias res */
+int pe_gemv_res_bf16(const void* x, const void* W, const void* bias, const void* res, void* y, int N, int K, void* stream);
 /* The gated MLP's first half on one row (transformers Qwen2MLP.forward): y[n] = bf16(silu(bf16(Wg[n,:].x)) * bf16(Wu[n,:].x)),
  * SiLU evaluated in fp32 and rounded once, as torch.nn.SiLU does on a bf16 tensor. */
 int pe_gemv_swiglu_bf16(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, void* stream);
 /* Decode step of a GQA attention layer with 128-wide heads (transformers Qwen2_5_VLAttention.forward at q_len = 1):
  * pe_decode_qkv_rope: q / k / v = Linear(x) (three weight / bias sets, one launch), then rotary embedding of the q and k heads with
- *   the section-selected tables cos_sel / sin_sel [128] bf16: y = bf16(bf16(t * cos) + bf16(rotate_half(t) * sin)).
+ *   the section-selected tables cos_sel / sin_sel [128] bf16: y = bf16(bf16(t * cos) + bf16(rotate_half(t) * sin)), fused into
+ *   the projection kernel (a wave computes rows i and i + 64 of a head together).
  *   q [n_q_heads*128], k, v [n_kv_heads*128] bf16.
  * pe_decode_attention: softmax(q K^T * scale) V of that one query against the cache k_cache, v_cache [n_kv_heads][L][128]
  *   (query head h reads kv head h / (n_q_heads / n_kv_heads)); fp32 scores and sums, P rounded to bf16 before P.V.  L <= 15360. */

@@ -159,6 +159,10 @@ int pe_gemv_bf16(const void* x, const void* W, const void* bias, void* y, int N,
     return launch_gemv(x, W, bias, y, N, K, (hipStream_t)stream);
 }
 
+int pe_gemv_res_bf16(const void* x, const void* W, const void* bias, const void* res, void* y, int N, int K, void* stream) {
+    return launch_gemv(x, W, bias, y, N, K, (hipStream_t)stream, res);
+}
+
 int pe_gemv_swiglu_bf16(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, void* stream) {
     return launch_gemv_swiglu(x, Wg, Wu, y, N, K, (hipStream_t)stream);
 }

@@ -249,7 +249,8 @@ int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 constexpr int GEMV_ROWS = 16;     // rows per work-group (4 waves x 2 rows x 2 rounds)
 __global__ void __launch_bounds__(256) gemv_bf16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
-                                                        const bf16* __restrict__ bias, bf16* __restrict__ y, int N, int K) {
+                                                        const bf16* __restrict__ bias, const bf16* __restrict__ res,
+                                                        bf16* __restrict__ y, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
     bf16* xs = (bf16*)gemv_smem;
     for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
@@ -276,9 +277,13 @@ __global__ void __launch_bounds__(256) gemv_bf16_kernel(const bf16* __restrict__
         }
         sa = wave_sum(sa);
         sb = wave_sum(sb);
-        if (lane == 0) {
-            y[ra] = (bf16)(sa + (bias ? (float)bias[ra] : 0.f));
-            if (rb < N) y[rb] = (bf16)(sb + (bias ? (float)bias[rb] : 0.f));
+        if (lane == 0) {                           // res: the decoder layer's `residual + linear(x)`, the sum rounded separately
+            const float ya = bf16r(sa + (bias ? (float)bias[ra] : 0.f));
+            y[ra] = res ? (bf16)((float)res[ra] + ya) : (bf16)ya;
+            if (rb < N) {
+                const float yb = bf16r(sb + (bias ? (float)bias[rb] : 0.f));
+                y[rb] = res ? (bf16)((float)res[rb] + yb) : (bf16)yb;
+            }
         }
     }
 }
@@ -334,46 +339,60 @@ int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, i
 __global__ void __launch_bounds__(256) gemv3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W0, const bf16* __restrict__ b0,
                                                     int N0, const bf16* __restrict__ W1, const bf16* __restrict__ b1, int N1,
                                                     const bf16* __restrict__ W2, const bf16* __restrict__ b2, int N2,
-                                                    bf16* __restrict__ y0, bf16* __restrict__ y1, bf16* __restrict__ y2, int K) {
+                                                    bf16* __restrict__ y0, bf16* __restrict__ y1, bf16* __restrict__ y2, int K,
+                                                    const bf16* __restrict__ cs, const bf16* __restrict__ sn) {
     extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
     bf16* xs = (bf16*)gemv_smem;
     for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
     __syncthreads();
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
-    const int N = N0 + N1 + N2;
+    // work item p = a PAIR of rows: for q / k the rows (i, i + 64) of one 128-wide head, which the rotary embedding mixes; for v two
+    // neighbouring rows.  8 pairs per work-group.
+    const int npairs = (N0 + N1 + N2) / 2;
 #pragma unroll
-    for (int rnd = 0; rnd < 4; ++rnd) {
-        const int n = (int)blockIdx.x * GEMV_ROWS + rnd * 4 + w;
-        if (n >= N) break;
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const int p = (int)blockIdx.x * 8 + rnd * 4 + w;
+        if (p >= npairs) break;
         const bf16* wr;
         const bf16* br;
         bf16* yr;
-        int r = n;
-        if (r < N0) { wr = W0; br = b0; yr = y0; }
-        else if ((r -= N0) < N1) { wr = W1; br = b1; yr = y1; }
-        else { r -= N1; wr = W2; br = b2; yr = y2; }
-        const bf16* row = wr + (size_t)r * K;
-        float acc = 0.f;
+        int ra, rb;
+        bool rope = true;
+        int q2 = p;
+        if (q2 < N0 / 2) { wr = W0; br = b0; yr = y0; }
+        else if ((q2 -= N0 / 2) < N1 / 2) { wr = W1; br = b1; yr = y1; }
+        else { q2 -= N1 / 2; wr = W2; br = b2; yr = y2; rope = false; }
+        if (rope) { ra = (q2 >> 6) * 128 + (q2 & 63); rb = ra + 64; }
+        else { ra = q2 * 2; rb = ra + 1; }
+        const bf16* rowa = wr + (size_t)ra * K;
+        const bf16* rowb = wr + (size_t)rb * K;
+        float sa = 0.f, sb = 0.f;
         for (int k = lane * 8; k < K; k += 64 * 8) {
             const bf16x8 xv = *(const bf16x8*)(xs + k);
-            const bf16x8 wv = *(const bf16x8*)(row + k);
+            const bf16x8 va = *(const bf16x8*)(rowa + k);
+            const bf16x8 vb = *(const bf16x8*)(rowb + k);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = __builtin_fmaf((float)wv[j], (float)xv[j], acc);
+            for (int j = 0; j < 8; ++j) {
+                sa = __builtin_fmaf((float)va[j], (float)xv[j], sa);
+                sb = __builtin_fmaf((float)vb[j], (float)xv[j], sb);
+            }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) yr[r] = (bf16)(acc + (br ? (float)br[r] : 0.f));
+        sa = wave_sum(sa);
+        sb = wave_sum(sb);
+        if (lane == 0) {
+            const float a = bf16r(sa + (br ? (float)br[ra] : 0.f));
+            const float b = bf16r(sb + (br ? (float)br[rb] : 0.f));
+            if (rope) {     // q * cos + rotate_half(q) * sin, rotate_half(q) = cat(-q[64:], q[:64]); every product and the sum rounded
+                const int i = ra & 127;
+                yr[ra] = (bf16)(bf16r(a * (float)cs[i]) + bf16r(-b * (float)sn[i]));
+                yr[rb] = (bf16)(bf16r(b * (float)cs[i + 64]) + bf16r(a * (float)sn[i + 64]));
+            } else {
+                yr[ra] = (bf16)a;
+                yr[rb] = (bf16)b;
+            }
+        }
     }
-}
-
-__global__ void __launch_bounds__(128) rope_heads_kernel(bf16* __restrict__ q, int n_q, bf16* __restrict__ k, int n_k,
-                                                         const bf16* __restrict__ cs, const bf16* __restrict__ sn) {
-    const int head = (int)blockIdx.x, i = (int)threadIdx.x;
-    bf16* v = head < n_q ? q + (size_t)head * 128 : k + (size_t)(head - n_q) * 128;
-    const float a = (float)v[i];
-    const float r = i < 64 ? -(float)v[i + 64] : (float)v[i - 64];
-    __syncthreads();                               // every lane has read its two inputs before anyone overwrites
-    v[i] = (bf16)(bf16r(a * (float)cs[i]) + bf16r(r * (float)sn[i]));
 }
 
 int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv,
@@ -382,14 +401,10 @@ int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void*
     PE_REQUIRE(x && Wq && Wk && Wv && cos_sel && sin_sel && q && k && v, "decode_qkv: null pointer");
     PE_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && K > 0 && K % 8 == 0 && K <= 32768, "decode_qkv: bad shape");
     const int N0 = n_q_heads * 128, N1 = n_kv_heads * 128;
-    hipLaunchKernelGGL(gemv3_kernel, dim3((N0 + 2 * N1 + GEMV_ROWS - 1) / GEMV_ROWS), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
+    hipLaunchKernelGGL(gemv3_kernel, dim3(((N0 + 2 * N1) / 2 + 7) / 8), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
                        (const bf16*)Wq, (const bf16*)bq, N0, (const bf16*)Wk, (const bf16*)bk, N1, (const bf16*)Wv, (const bf16*)bv, N1,
-                       (bf16*)q, (bf16*)k, (bf16*)v, K);
-    int rc = check_launch("gemv3_kernel");
-    if (rc != PE_OK) return rc;
-    hipLaunchKernelGGL(rope_heads_kernel, dim3(n_q_heads + n_kv_heads), dim3(128), 0, stream, (bf16*)q, n_q_heads, (bf16*)k, n_kv_heads,
-                       (const bf16*)cos_sel, (const bf16*)sin_sel);
-    return check_launch("rope_heads_kernel");
+                       (bf16*)q, (bf16*)k, (bf16*)v, K, (const bf16*)cos_sel, (const bf16*)sin_sel);
+    return check_launch("gemv3_kernel");
 }
 
 // One query token against a KV cache [n_kv][L][128] (GQA: query head h reads kv head h / (n_q / n_kv)), no mask:
@@ -477,11 +492,11 @@ int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out,
     return check_launch("attn_decode_kernel");
 }
 
-int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream) {
+int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream, const void* res) {
     PE_REQUIRE(x && W && y, "gemv: null pointer");
     PE_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && K <= 32768, "gemv: N=%d K=%d (K must be a multiple of 8, at most 32768)", N, K);
     hipLaunchKernelGGL(gemv_bf16_kernel, dim3((N + GEMV_ROWS - 1) / GEMV_ROWS), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
-                       (const bf16*)W, (const bf16*)bias, (bf16*)y, N, K);
+                       (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)y, N, K);
     return check_launch("gemv_bf16_kernel");
 }
 

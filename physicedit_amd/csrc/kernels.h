@@ -90,7 +90,7 @@ int launch_silu(const void* x, void* out, size_t n, hipStream_t stream);
 int launch_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,
                             hipStream_t stream);
 int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream);
-int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream);
+int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream, const void* res = nullptr);
 int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv,
                       const void* bv, const void* cos_sel, const void* sin_sel, void* q, void* k, void* v, int n_q_heads,
                       int n_kv_heads, int K, hipStream_t stream);

@@ -206,12 +206,18 @@ def rmsnorm(x, w, eps: float = 1e-6) -> torch.Tensor:
     return out
 
 
-def gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.Linear on one row: x [K] (any shape with K elements), w [N,K] -> [N]."""
+def gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear on one row: x [K] (any shape with K elements), w [N,K] -> [N]; with `res` [N]: res + linear(x), both rounded."""
     _chk(x, "x"), _chk(w, "w")
     N, K = w.shape
     assert x.numel() == K
     out = torch.empty((N,), dtype=BF, device=x.device)
+    if res is not None:
+        _chk(res, "res")
+        assert res.numel() == N
+        check(lib().pe_gemv_res_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), res.data_ptr(), out.data_ptr(), N, K, stream_ptr()),
+              "pe_gemv_res_bf16")
+        return out
     check(lib().pe_gemv_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), N, K, stream_ptr()), "pe_gemv_bf16")
     return out
 

@@ -393,6 +393,15 @@ def test_gemv(ops, N, K, with_bias):
     report(f"gemv {N}x{K}", out, ref, 1.01, 0.02)
 
 
+def test_gemv_residual(ops):
+    """pe_gemv_res_bf16 = residual + nn.Linear(x) with the Linear's output rounded to bf16 before the add, as eager PyTorch does."""
+    N, K = 3584, 18944
+    x, w, r = rnd((K,), 74), rnd((N, K), 75, K ** -0.5), rnd((N,), 76)
+    ref = r + (w.float() @ x.float()).to(BF)
+    out = ops.gemv(x.cuda(), w.cuda(), None, res=r.cuda())
+    report("gemv + residual", out, ref, 1.01, 0.02)
+
+
 def test_gemv_swiglu(ops):
     """pe_gemv_swiglu_bf16 vs act_fn(gate_proj(x)) * up_proj(x) with torch's bf16 roundings (fp32-accumulated products)."""
     N, K = 18944, 3584
