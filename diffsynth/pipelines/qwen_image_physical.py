@@ -277,6 +277,28 @@ class QwenImagePhysicPipeline:
             return self.vae.encode(self.preprocess_image(image))       # exotic modes: the stand-alone map
         return self.vae.encode(torch.from_numpy(np.ascontiguousarray(u8)).to(self.device))
 
+    # ---- QwenImageUnit_Inpaint (:714-729): one [1,1,H/8,W/8] plane of host arithmetic per image
+    def preprocess_inpaint_mask(self, inpaint_mask, height: int, width: int, blur_size=None, blur_sigma=None):
+        """mask.convert("RGB").resize((W/8, H/8)) -> [0, 1] in the pipeline dtype -> mean over RGB -> optional Gaussian blur
+        (torchvision.transforms.GaussianBlur(kernel_size = 2 * blur_size + 1, sigma) in the reference; restated here from its
+        published algorithm -- reflect padding, separable normalised kernel in the tensor's dtype -- because torchvision is not
+        part of this image: parity of the BLUR is unpinned, the rest is pinned by tests/golden G15)."""
+        if inpaint_mask is None:
+            return None
+        u8 = np.array(inpaint_mask.convert("RGB").resize((width // 8, height // 8)), dtype=np.float32)
+        m = torch.from_numpy(u8).to(self.torch_dtype) * (1 / 255) + 0            # preprocess_image(min_value=0, max_value=1)
+        m = m.permute(2, 0, 1)[None].mean(dim=1, keepdim=True)
+        if blur_size is not None and blur_sigma is not None:
+            k = int(blur_size) * 2 + 1
+            half = (k - 1) * 0.5
+            x = torch.linspace(-half, half, steps=k)
+            pdf = torch.exp(-0.5 * (x / float(blur_sigma)).pow(2))
+            k1 = (pdf / pdf.sum()).to(m.dtype)
+            k2 = torch.mm(k1[:, None], k1[None, :])[None, None]
+            pad = k // 2
+            m = torch.nn.functional.conv2d(torch.nn.functional.pad(m, [pad] * 4, mode="reflect"), k2)
+        return m.to(device=self.device, dtype=self.torch_dtype).contiguous()
+
     # ---- QwenImageUnit_BlockwiseControlNet (:1201-1241): host-side image / mask arithmetic around one VAE encode per input
     def apply_controlnet_mask_on_latents(self, latents: torch.Tensor, mask: Image.Image) -> torch.Tensor:
         m = (self.preprocess_image(mask) + 1) / 2
@@ -340,8 +362,8 @@ class QwenImagePhysicPipeline:
                  stitched_image=None, state: str = None, transition: str = None, triplet: dict = None,
                  is_train: bool = True, have_text_reasoning: bool = True):
         """Same keyword surface and defaults as the reference (:545-597); returns a PIL image."""
-        if inpaint_mask is not None:
-            raise _lib.PeError("inpaint_mask is outside the accelerated path (SURVEY.md section 8: out of scope)")
+        if inpaint_mask is not None and input_image is None:
+            raise _lib.PeError("inpaint_mask needs input_image (the reference's step() blends towards the INPUT latents)")
         if blockwise_controlnet_inputs is not None and self.blockwise_controlnet is None:
             raise _lib.PeError("blockwise_controlnet_inputs given but no block-wise ControlNet checkpoint was loaded")
         if enable_fp8_attention or edit_rope_interpolation:
@@ -362,10 +384,11 @@ class QwenImagePhysicPipeline:
         self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength,
                                      dynamic_shift_len=(height // 16) * (width // 16),
                                      exponential_shift_mu=exponential_shift_mu)
-        latents = noise
+        latents, x0 = noise, None
         if input_image is not None:     # InputImageEmbedder (:693-711)
             x0 = self._encode_image(input_image)
-            latents = self.scheduler.add_noise(x0, noise, timestep=self.scheduler.timesteps[0]).to(self.torch_dtype)
+            latents = self.scheduler.add_noise(x0, noise.to(x0.device), timestep=self.scheduler.timesteps[0]).to(self.torch_dtype)
+        mask8 = self.preprocess_inpaint_mask(inpaint_mask, height, width, inpaint_blur_size, inpaint_blur_sigma)
         # EditImageEmbedder (:1244-1283) / ContextImageEmbedder (:1286-1299)
         edit_latents: List[torch.Tensor] = []
         resized_edit = edit_image
@@ -406,7 +429,8 @@ class QwenImagePhysicPipeline:
                        cfg_scale=cfg_scale, edit_latents=edit_latents or None, exponential_shift_mu=exponential_shift_mu,
                        denoising_strength=denoising_strength, blockwise_controlnet=self.blockwise_controlnet,
                        blockwise_controlnet_inputs=blockwise_controlnet_inputs, blockwise_controlnet_conditioning=ctl_cond,
-                       eligen_posi=eligen_posi, eligen_nega=eligen_nega)
+                       eligen_posi=eligen_posi, eligen_nega=eligen_nega, input_latents=x0 if mask8 is not None else None,
+                       inpaint_mask=mask8)
         self.last_latents = latents
         # vae.decode + vae_output_to_image (:664-667) in one composite: the last kernel emits HWC uint8
         u8 = self.vae.decode(latents, output_u8=True, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)

@@ -171,6 +171,13 @@ int pe_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, void
  * schedulers/flow_match.py:81); use_cfg = 0 => noise_pred = posi (cfg_scale == 1.0 branch, :654). */
 int pe_cfg_euler_step(const void* posi, const void* nega, const void* latents, void* latents_out, size_t n,
                       float cfg_scale, int use_cfg, float dsigma, void* stream);
+/* The same step of an inpainting run (BasePipeline.step with inpaint_mask, utils/__init__.py:146-156): between the CFG combination
+ * and the Euler update, noise_pred = expected * (1 - mask) + noise_pred * mask with expected = (latents - input_latents) / sigma
+ * (schedulers/flow_match.py:85-91, sigma = sigmas[progress_id] > 0), every operation rounded to bf16 as the reference's tensor
+ * ops are.  inpaint_mask: [plane] bf16 (one H/8 x W/8 plane, broadcast over the n / plane channels). */
+int pe_cfg_inpaint_euler_step(const void* posi, const void* nega, const void* latents, const void* input_latents,
+                              const void* inpaint_mask, void* latents_out, size_t n, size_t plane, float cfg_scale, int use_cfg,
+                              float sigma, float dsigma, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DiT composite

@@ -81,6 +81,15 @@ class FlowMatchTables:
         self.sigmas = sigmas
         self.timesteps = sigmas * 1000
 
+    def add_noise(self, original_samples, noise, progress_id=0):
+        # flow_match.py:94-100
+        sigma = self.sigmas[progress_id]
+        return (1 - sigma) * original_samples + sigma * noise
+
+    def return_to_timestep(self, progress_id, sample, sample_stablized):
+        # flow_match.py:85-91
+        return (sample - sample_stablized) / self.sigmas[progress_id]
+
     def step(self, model_output, progress_id, sample):
         # utils/__init__.py:150-156 -> flow_match.py:72-82 (argmin over |timesteps - t| == progress_id)
         sigma = self.sigmas[progress_id]
@@ -440,11 +449,14 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
 def denoise_loop(sd: SD, ad: Optional[SD], noise: torch.Tensor, prompt_emb_posi: torch.Tensor,
                  prompt_emb_nega: Optional[torch.Tensor], mask_posi, mask_nega,
                  height: int, width: int, num_inference_steps: int, cfg_scale: float = 4.0,
-                 edit_latents=None, dtype=torch.bfloat16, controlnets=None) -> torch.Tensor:
+                 edit_latents=None, dtype=torch.bfloat16, controlnets=None, denoising_strength: float = 1.0,
+                 input_latents=None, inpaint_mask=None) -> torch.Tensor:
     """QwenImagePhysicPipeline.__call__ lines 600 + 644-661 (loop only; prologue outputs are the
     arguments).  prompt_emb_* are cloned once here and then mutated across steps like the
-    reference's `inputs_posi` / `inputs_nega` dict entries."""
-    tab = FlowMatchTables(num_inference_steps, dynamic_shift_len=(height // 16) * (width // 16))
+    reference's `inputs_posi` / `inputs_nega` dict entries.  `noise` is the loop's first `latents` (for an image-to-image run the
+    caller has applied `add_noise`); input_latents + inpaint_mask: the blend of BasePipeline.step (utils/__init__.py:146-156)."""
+    tab = FlowMatchTables(num_inference_steps, dynamic_shift_len=(height // 16) * (width // 16),
+                          denoising_strength=denoising_strength)
     t_min, t_max = adapter_t_range()
     latents = noise.clone()
     pe_p = prompt_emb_posi.clone()
@@ -456,6 +468,9 @@ def denoise_loop(sd: SD, ad: Optional[SD], noise: torch.Tensor, prompt_emb_posi:
         if cfg_scale != 1.0:
             pred_n = model_fn(sd, ad, latents, t, pe_n, mask_nega, height, width, edit_latents, t_min, t_max, **kw)
             pred = pred_n + cfg_scale * (pred - pred_n)
+        if inpaint_mask is not None:
+            expected = tab.return_to_timestep(progress_id, latents, input_latents)
+            pred = expected * (1 - inpaint_mask) + pred * inpaint_mask      # blend_with_mask(base, addition, mask)
         latents = tab.step(pred, progress_id, latents)
     return latents
 
@@ -699,12 +714,18 @@ def vae_decode(vs: SD, x: torch.Tensor) -> torch.Tensor:
 # ======================================================================================
 # image <-> tensor   (utils/__init__.py:60-83)
 # ======================================================================================
-def preprocess_image(img_u8_hwc, dtype=torch.bfloat16) -> torch.Tensor:
+def preprocess_image(img_u8_hwc, dtype=torch.bfloat16, min_value=-1, max_value=1) -> torch.Tensor:
     import numpy as np
     image = torch.Tensor(np.array(img_u8_hwc, dtype=np.float32))
     image = image.to(dtype=dtype)
-    image = image * ((1 - (-1)) / 255) + (-1)
+    image = image * ((max_value - min_value) / 255) + min_value
     return image.permute(2, 0, 1).unsqueeze(0)
+
+
+def inpaint_mask_plane(mask_rgb_u8_hwc, dtype=torch.bfloat16) -> torch.Tensor:
+    """QwenImageUnit_Inpaint.process (:720-729) without the optional torchvision blur, for a mask already converted to RGB and
+    resized to (W/8, H/8): [0, 1] values, mean over the three channels -> [1, 1, H/8, W/8]."""
+    return preprocess_image(mask_rgb_u8_hwc, dtype, min_value=0, max_value=1).mean(dim=1, keepdim=True)
 
 
 def vae_output_to_u8(vae_output: torch.Tensor) -> torch.Tensor:

@@ -133,6 +133,8 @@ SIGNATURES = {
     "pe_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pe_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pe_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_void_p]),
+    "pe_cfg_inpaint_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float,
+                                          c_int, c_float, c_float, c_void_p]),
     "pe_dit_create": (c_int, [C.POINTER(DitWeights), C.POINTER(AdapterWeights), C.POINTER(c_void_p)]),
     "pe_dit_destroy": (None, [c_void_p]),
     "pe_dit_set_hot_lora": (c_int, [c_void_p, C.POINTER(DitBlockLora), c_int]),

@@ -191,6 +191,14 @@ int pe_cfg_euler_step(const void* posi, const void* nega, const void* latents, v
     return launch_cfg_euler(posi, nega, latents, latents_out, n, cfg_scale, use_cfg, dsigma, (hipStream_t)stream);
 }
 
+int pe_cfg_inpaint_euler_step(const void* posi, const void* nega, const void* latents, const void* input_latents,
+                              const void* inpaint_mask, void* latents_out, size_t n, size_t plane, float cfg_scale, int use_cfg,
+                              float sigma, float dsigma, void* stream) {
+    PE_REQUIRE(input_latents && inpaint_mask, "pe_cfg_inpaint_euler_step: null input latents / mask");
+    return launch_cfg_euler(posi, nega, latents, latents_out, n, cfg_scale, use_cfg, dsigma, (hipStream_t)stream, input_latents,
+                            inpaint_mask, plane, sigma);
+}
+
 int pe_conv2d_nhwc(const void* in, const void* w, const void* bias, const void* res, void* out, const void* zero_page,
                    int Hin, int Win, int Cin_p, int Cout_p, int ksize, int stride, int upsample2x, void* stream) {
     return launch_conv_nhwc(in, w, bias, res, out, zero_page, Hin, Win, Cin_p, Cout_p, ksize, stride, upsample2x,

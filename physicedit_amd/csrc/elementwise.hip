@@ -690,26 +690,40 @@ int launch_adapter_mix_scatter(const void* dino, const void* vae, float alpha, f
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cfg_euler_kernel(const bf16* __restrict__ posi, const bf16* __restrict__ nega,
                                                         const bf16* __restrict__ lat, bf16* __restrict__ out,
-                                                        size_t n, float cfg, int use_cfg, float dsigma) {
+                                                        size_t n, float cfg, int use_cfg, float dsigma,
+                                                        const bf16* __restrict__ x0, const bf16* __restrict__ mask, size_t plane,
+                                                        float sigma) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float np = (float)posi[i];
+        const float l = (float)lat[i];
         if (use_cfg) {
             const float ng = (float)nega[i];
             const float d = bf16r(np - ng);
             const float e = bf16r(cfg * d);
             np = bf16r(ng + e);
         }
-        out[i] = (bf16)((float)lat[i] + bf16r(np * dsigma));
+        if (mask) {
+            // BasePipeline.step with an inpaint mask (utils/__init__.py:146-154): outside the mask the model's prediction is
+            // replaced by the one that leads back to the input latents; every torch op rounds to bf16
+            const float m = (float)mask[i % plane];
+            const float expect = bf16r(bf16r(l - (float)x0[i]) / sigma);             // scheduler.return_to_timestep
+            np = bf16r(bf16r(expect * bf16r(1.0f - m)) + bf16r(np * m));             // blend_with_mask
+        }
+        out[i] = (bf16)(l + bf16r(np * dsigma));
     }
 }
 
 int launch_cfg_euler(const void* posi, const void* nega, const void* latents, void* out, size_t n,
-                     float cfg_scale, int use_cfg, float dsigma, hipStream_t stream) {
+                     float cfg_scale, int use_cfg, float dsigma, hipStream_t stream,
+                     const void* input_latents, const void* mask, size_t plane, float sigma) {
     PE_REQUIRE(posi && latents && out && (!use_cfg || nega), "cfg_euler: null pointer");
     PE_REQUIRE(n > 0, "cfg_euler: empty");
+    PE_REQUIRE(!mask || (input_latents && plane > 0 && n % plane == 0 && sigma > 0.f),
+               "cfg_euler: inpaint needs input latents, a mask plane that divides n (%zu / %zu) and sigma > 0", n, plane);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)posi, (const bf16*)nega,
-                       (const bf16*)latents, (bf16*)out, n, cfg_scale, use_cfg, dsigma);
+                       (const bf16*)latents, (bf16*)out, n, cfg_scale, use_cfg, dsigma, (const bf16*)input_latents,
+                       (const bf16*)mask, mask ? plane : (size_t)1, sigma);
     return check_launch("cfg_euler_kernel");
 }
 

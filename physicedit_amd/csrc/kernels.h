@@ -103,7 +103,8 @@ int launch_gather_rows(const void* src, const int* idx, void* dst, int nrows, in
 int launch_adapter_mix_scatter(const void* dino, const void* vae, float alpha, float one_minus_alpha,
                                const int* idx, void* prompt_emb, int nrows, int dim, hipStream_t stream);
 int launch_cfg_euler(const void* posi, const void* nega, const void* latents, void* out, size_t n,
-                     float cfg_scale, int use_cfg, float dsigma, hipStream_t stream);
+                     float cfg_scale, int use_cfg, float dsigma, hipStream_t stream,
+                     const void* input_latents = nullptr, const void* mask = nullptr, size_t plane = 0, float sigma = 0.f);
 
 // ---------------------------------------------------------------------------------------------
 // VAE (vae.hip): NHWC bf16 activations, channels padded to a multiple of 32

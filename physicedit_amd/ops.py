@@ -283,11 +283,25 @@ def unpatchify(tokens: torch.Tensor, C_: int, H2: int, W2: int) -> torch.Tensor:
     return out
 
 
-def cfg_euler_step(posi, nega, latents, cfg_scale: float, dsigma: float, out=None) -> torch.Tensor:
+def cfg_euler_step(posi, nega, latents, cfg_scale: float, dsigma: float, out=None, input_latents=None, inpaint_mask=None,
+                   sigma: float = 0.0) -> torch.Tensor:
+    """CFG combination + Euler update; with `inpaint_mask` ([1,1,H,W] or [H,W] bf16) and `input_latents` also the inpainting blend
+    of BasePipeline.step (utils/__init__.py:146-156), `sigma` = sigmas[progress_id]."""
     _chk(posi, "posi"), _chk(latents, "latents")
     if out is None:
         out = torch.empty_like(latents)
     use_cfg = 1 if (nega is not None and cfg_scale != 1.0) else 0
+    if inpaint_mask is not None:
+        _chk(inpaint_mask, "inpaint_mask"), _chk(input_latents, "input_latents")
+        plane = inpaint_mask.numel()
+        if input_latents.shape != latents.shape or plane != latents.shape[-1] * latents.shape[-2]:
+            raise _lib.PeError(f"inpaint: input_latents {tuple(input_latents.shape)} / mask {tuple(inpaint_mask.shape)} do not match "
+                          f"latents {tuple(latents.shape)}")
+        check(lib().pe_cfg_inpaint_euler_step(posi.data_ptr(), _ptr(nega) if use_cfg else None, latents.data_ptr(),
+                                              input_latents.data_ptr(), inpaint_mask.data_ptr(), out.data_ptr(), latents.numel(),
+                                              plane, float(cfg_scale), use_cfg, float(sigma), float(dsigma), stream_ptr()),
+              "pe_cfg_inpaint_euler_step")
+        return out
     check(lib().pe_cfg_euler_step(posi.data_ptr(), _ptr(nega) if use_cfg else None, latents.data_ptr(), out.data_ptr(),
                                   latents.numel(), float(cfg_scale), use_cfg, float(dsigma), stream_ptr()),
           "pe_cfg_euler_step")

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .dit import QwenImageDiTEngine, special_indices
 from .scheduler import qwen_image_scheduler
 
@@ -41,9 +41,12 @@ class DenoiseLoop:
                  height: int, width: int, num_inference_steps: int = 30, cfg_scale: float = 4.0,
                  edit_latents=None, exponential_shift_mu: Optional[float] = None,
                  denoising_strength: float = 1.0, blockwise_controlnet=None, blockwise_controlnet_inputs=None,
-                 blockwise_controlnet_conditioning=None, eligen_posi=None, eligen_nega=None) -> torch.Tensor:
-        """noise [1,16,H/8,W/8]; prompt_emb_* [1,T,3584] DEVICE tensors, mutated in place on their
-        special rows across the steps exactly like `inputs_posi["prompt_emb"]` in the reference."""
+                 blockwise_controlnet_conditioning=None, eligen_posi=None, eligen_nega=None,
+                 input_latents: Optional[torch.Tensor] = None, inpaint_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """noise [1,16,H/8,W/8] (for an image-to-image run: already `scheduler.add_noise(input_latents, noise, timesteps[0])`);
+        prompt_emb_* [1,T,3584] DEVICE tensors, mutated in place on their special rows across the steps exactly like
+        `inputs_posi["prompt_emb"]` in the reference.  `inpaint_mask` [1,1,H/8,W/8] + `input_latents`: the blend of
+        BasePipeline.step (utils/__init__.py:150-156) rides in the CFG / Euler kernel."""
         dev = self.device
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps, denoising_strength=denoising_strength,
@@ -81,6 +84,12 @@ class DenoiseLoop:
         pred_p = torch.empty_like(latents)
         pred_n = torch.empty_like(latents) if use_cfg else None
         main = torch.cuda.current_stream(dev)
+        x0 = mask = None
+        if inpaint_mask is not None:
+            if input_latents is None:
+                raise _lib.PeError("inpaint_mask needs input_latents (the reference's step() would fail on None - None)")
+            x0 = input_latents.to(device=dev, dtype=self.torch_dtype).contiguous()
+            mask = inpaint_mask.to(device=dev, dtype=self.torch_dtype).contiguous()
         # block-wise ControlNet (:1373-1396): img_in of each conditioning once (the reference redoes it every call with the same
         # result), then per step the inputs whose progress window contains the step
         processed = None
@@ -104,6 +113,10 @@ class DenoiseLoop:
                 self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl, **kw_p)
                 if use_cfg:
                     self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl, **kw_n)
-            ops.cfg_euler_step(pred_p, pred_n, latents, cfg_scale, sch.dsigma(i), out=nxt)
+            if inpaint_mask is not None:
+                ops.cfg_euler_step(pred_p, pred_n, latents, cfg_scale, sch.dsigma(i), out=nxt, input_latents=x0, inpaint_mask=mask,
+                                   sigma=float(sch.sigmas[i]))
+            else:
+                ops.cfg_euler_step(pred_p, pred_n, latents, cfg_scale, sch.dsigma(i), out=nxt)
             latents, nxt = nxt, latents
         return latents

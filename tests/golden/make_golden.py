@@ -488,6 +488,52 @@ def G9_adapter():
     save("G9_adapter", outs)
 
 
+def G15_inpaint():
+    """image-to-image + inpainting on the G6 model: QwenImageUnit_Inpaint.process (:714-729, no blur: torchvision is a stub here),
+    InputImageEmbedder's add_noise (:708), and BasePipeline.step with the mask (utils/__init__.py:146-156), 4 steps, CFG 4."""
+    from PIL import Image
+    from diffsynth.pipelines.qwen_image_physical import QwenImageUnit_Inpaint
+    dit, sd = build_dit(2, 1234)
+    ad, adsd, _ = build_adapter(4321)
+    h = w = 128
+    steps, strength, cfg = 4, 0.7, 4.0
+    noise, edit, pe_p, mask_p = _model_fn_inputs(h, w, 40, 16, 0)
+    pe_n = synth.make_prompt_emb(8, 24)
+    mask_n = synth.make_special_token_mask(24, 16)
+    g = torch.Generator().manual_seed(150)
+    x0 = (torch.randn((1, 16, h // 8, w // 8), generator=g) * 0.7).to(BF)
+    yy, xx = np.mgrid[0:h, 0:w]
+    m_u8 = (np.clip(1.4 - np.hypot(yy - 70, xx - 50) / 30.0, 0, 1) * 255).astype("uint8")     # soft disc: fractional mask values
+    mask_img = Image.fromarray(m_u8, mode="L")
+    ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")
+    ns.preprocess_image = lambda *a, **k: BasePipeline.preprocess_image(ns, *a, **k)
+    mask = QwenImageUnit_Inpaint().process(ns, mask_img, h, w, None, None)["inpaint_mask"]
+    sch = ref_scheduler()
+    sch.set_timesteps(steps, denoising_strength=strength, dynamic_shift_len=(h // 16) * (w // 16))
+    latents = sch.add_noise(x0, noise, timestep=sch.timesteps[0])
+    outs = {"mask": mask.clone(), "mask_rgb_u8": torch.from_numpy(np.array(mask_img.convert("RGB").resize((w // 8, h // 8)))),
+            "latents_start": latents.clone()}
+    pp, pn = pe_p.clone(), pe_n.clone()
+    step_ns = types.SimpleNamespace()
+    step_ns.blend_with_mask = lambda *a: BasePipeline.blend_with_mask(step_ns, *a)
+    for progress_id, timestep in enumerate(sch.timesteps):
+        timestep = timestep.unsqueeze(0).to(dtype=BF)
+        kw = dict(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad, latents=latents, height=h, width=w,
+                  edit_latents=edit, is_train=False, timestep=timestep, progress_id=progress_id)
+        posi, _ = model_fn_qwen_image(prompt_emb=pp, prompt_emb_mask=torch.ones((1, 40), dtype=torch.long),
+                                      special_token_mask=mask_p, **kw)
+        nega, _ = model_fn_qwen_image(prompt_emb=pn, prompt_emb_mask=torch.ones((1, 24), dtype=torch.long),
+                                      special_token_mask=mask_n, **kw)
+        pred = nega + cfg * (posi - nega)
+        outs[f"pred_step{progress_id}"] = pred.clone()
+        outs[f"latents_in_step{progress_id}"] = latents.clone()
+        latents = BasePipeline.step(step_ns, sch, latents=latents, progress_id=progress_id, noise_pred=pred, input_latents=x0,
+                                    inpaint_mask=mask)
+        outs[f"latents_step{progress_id}"] = latents.clone()
+    save("G15_inpaint", outs, meta={"h": h, "w": w, "steps": steps, "T_pos": 40, "T_neg": 24, "n_special": 16,
+                                    "denoising_strength": strength, "cfg": cfg, "x0_seed": 150})
+
+
 def G10_image():
     ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
     ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")

@@ -162,6 +162,54 @@ def test_loop_G6(golden, eng2, cfg):
     assert d.mean().item() <= 6e-3
 
 
+def test_inpaint_step_kernel_G15(golden):
+    """pe_cfg_inpaint_euler_step on the reference's own per-step inputs (CFG-combined prediction, latents, input latents, mask):
+    element-wise bf16 arithmetic, so the bar is bit-identical."""
+    from physicedit_amd import ops
+    from physicedit_amd.scheduler import qwen_image_scheduler
+    g, meta = golden("G15_inpaint", with_meta=True)
+    h = w = meta["h"]
+    x0 = (torch.randn((1, 16, h // 8, w // 8), generator=torch.Generator().manual_seed(meta["x0_seed"])) * 0.7).to(BF)
+    sch = qwen_image_scheduler()
+    sch.set_timesteps(meta["steps"], denoising_strength=meta["denoising_strength"], dynamic_shift_len=(h // 16) * (w // 16))
+    for i in range(meta["steps"]):
+        out = ops.cfg_euler_step(g[f"pred_step{i}"].cuda(), None, g[f"latents_in_step{i}"].cuda(), 1.0, sch.dsigma(i),
+                                 input_latents=x0.cuda(), inpaint_mask=g["mask"].cuda(), sigma=float(sch.sigmas[i]))
+        assert torch.equal(out.cpu(), g[f"latents_step{i}"]), f"inpaint step {i}"
+
+
+def test_loop_inpaint_G15(golden, eng2):
+    """image-to-image + inpainting through DenoiseLoop: final latents vs the reference's, next to an fp32 run of the same loop."""
+    from physicedit_amd.pipeline import DenoiseLoop
+    g, meta = golden("G15_inpaint", with_meta=True)
+    h = w = meta["h"]
+    steps, cfg, strength = meta["steps"], meta["cfg"], meta["denoising_strength"]
+    noise, edit, pe_p, mask_p = _model_fn_inputs(h, w, 40, 16, 0)
+    pe_n = synth.make_prompt_emb(8, 24)
+    mask_n = synth.make_special_token_mask(24, 16)
+    x0 = (torch.randn((1, 16, h // 8, w // 8), generator=torch.Generator().manual_seed(meta["x0_seed"])) * 0.7).to(BF)
+    loop = DenoiseLoop(eng2)
+    lat = loop(g["latents_start"], pe_p.cuda().clone(), pe_n.cuda().clone(), mask_p, mask_n, h, w, num_inference_steps=steps,
+               cfg_scale=cfg, edit_latents=edit.cuda(), denoising_strength=strength, input_latents=x0, inpaint_mask=g["mask"])
+    ref = g[f"latents_step{steps - 1}"]
+    d, u = stats("inpaint loop final latents", lat, ref)
+    sd32 = {k: v.float() for k, v in synth.make_state_dict(synth.dit_layout(2), 1234).items()}
+    ad32 = {k: v.float() for k, v in synth.make_state_dict(synth.adapter_layout(), 4321).items()}
+    lat32 = O.denoise_loop(sd32, ad32, g["latents_start"].float(), pe_p.float(), pe_n.float(), mask_p, mask_n, h, w, steps,
+                           cfg_scale=cfg, edit_latents=edit.float(), dtype=torch.float32, denoising_strength=strength,
+                           input_latents=x0.float(), inpaint_mask=g["mask"].float())
+    e_hip = (lat.float().cpu() - lat32).abs().max().item()
+    e_ref = (ref.float() - lat32).abs().max().item()
+    print(f"[parity] inpaint loop: max distance to fp32 loop: hip {e_hip:.4e}  reference-bf16 {e_ref:.4e}")
+    assert e_hip <= 2.0 * e_ref + 1e-3 and d.mean().item() <= 6e-3
+    # outside the mask (mask == 0) the loop must lead back towards the input latents exactly as the reference's does
+    keep = (g["mask"][0, 0] == 0)
+    assert keep.any()
+    dk = (lat.float().cpu()[0][:, keep] - ref.float()[0][:, keep]).abs().max().item()
+    print(f"[parity] inpaint loop, kept region: max |d| {dk:.3e}")
+    assert dk <= 2e-2
+
+
 def test_lora_merge_G8(golden):
     from physicedit_amd.dit import QwenImageDiTEngine
     g, meta = golden("G8_lora", with_meta=True)

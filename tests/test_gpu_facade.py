@@ -289,6 +289,60 @@ def test_controlnet_and_eligen_through_the_facade(tmp_path):
     assert dl.mean().item() <= 8e-3 and dl.max().item() <= 0.25
 
 
+def test_inpaint_through_the_facade(tmp_path):
+    """`input_image` + `denoising_strength` + `inpaint_mask` of the same __call__ (InputImageEmbedder :693-711, QwenImageUnit_Inpaint
+    :714-729, BasePipeline.step utils/__init__.py:150-156) against the oracle loop on the same image, mask and prompt embeddings."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from safetensors.torch import save_file
+    from diffsynth.pipelines.qwen_image_physical import ModelConfig, QwenImagePhysicPipeline
+
+    H = W = 256
+    steps, T, nsp, strength = 3, 48, 16, 0.6
+    dit_sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    vae_sd = synth.make_state_dict(synth.vae_layout(), 77)
+    ad_sd = synth.make_state_dict(synth.adapter_layout(), 4321)
+    base = tmp_path / "base"
+    for sub in ("dit", "vae"):
+        (base / "m" / sub).mkdir(parents=True)
+    save_file(dit_sd, str(base / "m/dit/model.safetensors"))
+    save_file(vae_sd, str(base / "m/vae/model.safetensors"))
+    pipe = QwenImagePhysicPipeline.from_pretrained(
+        torch_dtype=torch.bfloat16, device="cuda",
+        model_configs=[ModelConfig(model_id="m", origin_file_pattern=f"{sub}/model.safetensors", local_model_path=str(base))
+                       for sub in ("dit", "vae")], dinov2_path=None)
+    pipe.load_state_dict({"visual_thinking_adapter." + k: v for k, v in ad_sd.items()}, strict=False)
+    pe_p, mask_p = synth.make_prompt_emb(7, T), synth.make_special_token_mask(T, nsp)
+    pe_n, mask_n = synth.make_prompt_emb(8, 24), synth.make_special_token_mask(24, nsp)
+
+    class StubPrologue:
+        def __call__(self, p, prompt, negative_prompt, edit_image, cfg, have_text_reasoning=True):
+            return ({"prompt_emb": pe_p.clone(), "special_token_mask": mask_p}, {"prompt_emb": pe_n.clone(), "special_token_mask": mask_n})
+    pipe.prompt_encoder = StubPrologue()
+
+    img = synth.make_edit_image_u8(H, W, seed=21)
+    yy, xx = np.mgrid[0:H, 0:W]
+    m_u8 = (np.clip(1.5 - np.hypot(yy - 120, xx - 140) / 50.0, 0, 1) * 255).astype("uint8")
+    out = pipe("fill the hole", seed=0, num_inference_steps=steps, height=H, width=W, cfg_scale=3.0, is_train=False,
+               input_image=Image.fromarray(img), denoising_strength=strength, inpaint_mask=Image.fromarray(m_u8, mode="L"))
+    assert isinstance(out, Image.Image) and out.size == (W, H)
+
+    O.VAE_CONV_MODE = "2d"
+    try:
+        x0 = O.vae_encode(vae_sd, O.preprocess_image(img))
+    finally:
+        O.VAE_CONV_MODE = "3d"
+    mask = O.inpaint_mask_plane(np.array(Image.fromarray(m_u8, mode="L").convert("RGB").resize((W // 8, H // 8))))
+    tab = O.FlowMatchTables(steps, dynamic_shift_len=(H // 16) * (W // 16), denoising_strength=strength)
+    start = tab.add_noise(x0, synth.make_noise(0, H, W), 0).to(BF)
+    lat = O.denoise_loop(dit_sd, ad_sd, start, pe_p, pe_n, mask_p, mask_n, H, W, steps, cfg_scale=3.0, denoising_strength=strength,
+                         input_latents=x0, inpaint_mask=mask)
+    dl = (pipe.last_latents.float().cpu() - lat.float()).abs()
+    print(f"[parity] facade inpaint: latents max|d| {dl.max().item():.4e} mean|d| {dl.mean().item():.4e} "
+          f"(|latents| mean {lat.float().abs().mean().item():.3f})")
+    assert dl.mean().item() <= 8e-3 and dl.max().item() <= 0.25
+
+
 def test_accelerated_decode_matches_transformers():
     """accelerate_decode (prompt_prologue.py) swaps the decode step's single-row Linears, gated MLP, RMSNorms, q/k/v + rotary
     embedding and single-query attention for library kernels.  Two copies of a 4-layer model at the REAL widths (hidden 3584, 28 / 4

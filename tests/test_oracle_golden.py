@@ -224,6 +224,37 @@ def test_G6_loop(golden, cfg):
     assert_same(lat, g[f"latents_cfg{cfg}_step3"], f"loop cfg {cfg}")
 
 
+def test_G15_inpaint(golden):
+    """image-to-image + inpainting: the mask unit (:714-729), add_noise (:708) and BasePipeline.step's blend (utils/__init__.py:
+    146-156) -- the oracle's restatement and the facade's host-side mask preparation, bit for bit against the reference."""
+    from PIL import Image
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline
+    g, meta = golden("G15_inpaint", with_meta=True)
+    h = w = meta["h"]
+    mask = O.inpaint_mask_plane(g["mask_rgb_u8"].numpy())
+    assert_same(mask, g["mask"], "oracle inpaint mask")
+    assert 0.05 < ((mask > 0) & (mask < 1)).float().mean().item()          # the fixture has fractional mask values
+    pipe = QwenImagePhysicPipeline.__new__(QwenImagePhysicPipeline)
+    pipe.device, pipe.torch_dtype = torch.device("cpu"), BF
+    yy, xx = np.mgrid[0:h, 0:w]
+    m_u8 = (np.clip(1.4 - np.hypot(yy - 70, xx - 50) / 30.0, 0, 1) * 255).astype("uint8")      # the generator's mask image
+    assert_same(pipe.preprocess_inpaint_mask(Image.fromarray(m_u8, mode="L"), h, w), g["mask"], "facade inpaint mask")
+    blurred = pipe.preprocess_inpaint_mask(Image.fromarray(m_u8, mode="L"), h, w, 2, 1.5)
+    assert blurred.shape == mask.shape and abs(blurred.float().mean().item() - mask.float().mean().item()) < 0.02
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    noise, edit, pe_p, mask_p = _model_fn_inputs(h, w, 40, 16, 0)
+    pe_n = synth.make_prompt_emb(8, 24)
+    mask_n = synth.make_special_token_mask(24, 16)
+    x0 = (torch.randn((1, 16, h // 8, w // 8), generator=torch.Generator().manual_seed(meta["x0_seed"])) * 0.7).to(BF)
+    tab = O.FlowMatchTables(meta["steps"], dynamic_shift_len=(h // 16) * (w // 16), denoising_strength=meta["denoising_strength"])
+    start = tab.add_noise(x0, noise, 0)
+    assert_same(start, g["latents_start"], "add_noise")
+    lat = O.denoise_loop(sd, ad, start, pe_p, pe_n, mask_p, mask_n, h, w, meta["steps"], cfg_scale=meta["cfg"], edit_latents=edit,
+                         denoising_strength=meta["denoising_strength"], input_latents=x0, inpaint_mask=mask)
+    assert_same(lat, g[f"latents_step{meta['steps'] - 1}"], "inpaint loop")
+
+
 def test_G7_vae(golden):
     g = golden("G7_vae")
     vs = synth.make_state_dict(synth.vae_layout(), 77)
