@@ -268,12 +268,47 @@ def main():
                 "vae_conv": {"achieved_tflops": (prof["conv"]["work"] / (prof["conv"]["ms"] * 1e-3) / 1e12) if prof["conv"]["ms"] > 0 else None},
             },
         }
+        if not args.fp8:
+            ceil = mfma_power_ceiling(dev)
+            out["roofline"]["power_limited_ceiling"] = ceil
+            if ceil["random_normal_operands"] > 0:
+                out["roofline"]["frac_of_power_limited_ceiling"] = achieved / ceil["random_normal_operands"]
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def mfma_power_ceiling(dev):
+    """The library's matrix-pipe probe (pe_mfma_probe: bf16 MFMAs only, no LDS / memory traffic), timed here after the timed region
+    on N(0,1) bf16 fragments (~0.3 s sustained) and on zeros: `peak` in `roofline` is the nominal 2.4 GHz figure, which this chip
+    only holds on zero operands; on random operands its power limit caps the matrix pipe itself at the rate reported here."""
+    import ctypes
+    import torch
+    from physicedit_amd._lib import check, lib, stream_ptr
+    BF = torch.bfloat16
+    res = {}
+    out = torch.empty(512 * 512, dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    for name in ("random_normal", "zeros"):
+        frags = (torch.randn(8 << 20, generator=g, device=dev).to(BF) if name == "random_normal"
+                 else torch.zeros(8 << 20, dtype=BF, device=dev))
+        fl = ctypes.c_double(0.0)
+        best = 0.0
+        for iters in (2000, 120000, 120000):          # warm-up, then two sustained launches
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().pe_mfma_probe(frags.data_ptr(), out.data_ptr(), 512, iters, ctypes.byref(fl), stream_ptr()), "pe_mfma_probe")
+            e1.record()
+            torch.cuda.synchronize()
+            if iters > 2000:
+                best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        res[name] = best
+    return {"what": "pe_mfma_probe: v_mfma_f32_32x32x16_bf16 only, 8 waves/CU, operands in registers, measured in this process "
+                    "after the timed region", "unit": "TFLOP/s", "random_normal_operands": res["random_normal"],
+            "zero_operands": res["zeros"]}
 
 
 def pmc_traffic(args):

@@ -397,6 +397,11 @@ size_t pe_adapter_workspace_bytes(int n);
 int pe_adapter_forward(const pe_adapter_weights* adapter, const void* x, int n, float alpha, float one_minus_alpha, void* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement aid: a loop of bf16 MFMAs only (no LDS, no memory traffic) over the fragments at `frags` (16 MiB of bf16, caller
+ * filled: zeros -> the nominal dense peak; random values -> the rate the chip's POWER LIMIT allows on such operands, the ceiling of
+ * every bf16 MFMA kernel on that data).  out: blocks * 512 floats.  *flops receives the FLOPs of the launch; time it with events. */
+int pe_mfma_probe(const void* frags, void* out, int blocks, int iters, double* flops, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Measurement: HIP-event timing of sampled launches, recorded on the launch stream.
  * kind: 0 = MFMA GEMM (work = algorithmic FLOPs 2MNK), 1 = flash attention (4*S*S*128*H FLOPs),

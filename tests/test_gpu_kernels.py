@@ -449,3 +449,15 @@ def test_decode_attention(ops, L):
     e_cpu = (ref.float() - ref32).pow(2).mean().sqrt().item()
     print(f"[parity] decode attention L={L}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
     assert torch.isfinite(out.float()).all() and e_gpu <= 1.5 * e_cpu + 1e-4
+
+
+def test_mfma_probe(ops):
+    """pe_mfma_probe (measurement aid of bench.py's roofline block): launches, reports its FLOP count, zero fragments give zeros."""
+    import ctypes
+    from physicedit_amd._lib import check, lib, stream_ptr
+    frags = torch.zeros(8 << 20, dtype=BF, device="cuda")
+    out = torch.full((4 * 512,), 7.0, dtype=torch.float32, device="cuda")
+    fl = ctypes.c_double(0.0)
+    check(lib().pe_mfma_probe(frags.data_ptr(), out.data_ptr(), 4, 10, ctypes.byref(fl), stream_ptr()), "pe_mfma_probe")
+    torch.cuda.synchronize()
+    assert fl.value == 4 * 8 * 10 * 32 * 2.0 * 32 * 32 * 16 and (out == 0).all()
