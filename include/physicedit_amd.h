@@ -14,7 +14,11 @@
  *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream) passed as void*;
  *   - every entry point returns 0 on success, <0 on failure (pe_last_error() has the message);
  *     nothing throws across the boundary; no entry point synchronises the device;
- *   - scratch memory is a caller-provided workspace (size from pe_dit_workspace_bytes).
+ *   - scratch memory is a caller-provided workspace (size from pe_dit_workspace_bytes);
+ *   - threads: operators and composites may be called concurrently from several host threads as long as each pe_dit / pe_vae
+ *     handle (and its workspace) is used by one thread at a time -- a handle is the unit of re-entrancy, a second pe_dit_create() on the
+ *     same weight table gives another one (weights are borrowed, not copied); pe_last_error() is per thread.  The experiment knobs (pe_debug_set*) and the event profiler
+ *     (pe_profile_*) are process-global measurement tools: set them while no other thread is launching.
  */
 #ifndef PHYSICEDIT_AMD_H
 #define PHYSICEDIT_AMD_H

@@ -24,6 +24,7 @@
 //          No permlane / LDS round trip for P.
 // LDS tiles are XOR-swizzled at 16-B granularity (applied on the LDS-DMA source address and on the
 // read) so every ds_read_b128 lane group is bank-conflict free.
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -703,15 +704,15 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
                S_pad, KV_TILE, S);
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
     PE_REQUIRE(g_attn_variant == 0 || g_attn_variant == 3 || g_attn_variant == 4, "flash_attn: attn_variant %d does not exist", g_attn_variant);
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
+    if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const bool have_ws = workspace != nullptr && workspace_bytes >= flash_attn_workspace_bytes(H, S) &&
                          ((uintptr_t)workspace & 15) == 0;

@@ -896,13 +896,13 @@ int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 
 template <int EPI, int VAR, bool FP8 = false>
 static int launch_v(const GemmArgs& args, int ntiles, hipStream_t stream) {
-    static bool configured = false;
+    static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
     constexpr int lds = (FP8 || VAR >= 10) ? GEMM_LDS_V10 : GEMM_LDS;
-    if (!configured) {
+    if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, VAR, FP8>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR, FP8>), dim3(ntiles), dim3(GEMM_THREADS), lds, stream, args);
     return check_launch(FP8 ? "gemm_fp8_kernel" : "gemm_bf16_kernel");

@@ -13,6 +13,7 @@
 //     reads (2y+dy, 2x+dx)), so no im2col buffer and no upsampled tensor ever exist in HBM;
 //   * epilogue: bias -> bf16 (the conv's own rounding) -> optional residual add -> bf16, transposed
 //     through LDS so stores are 16 B per lane along channels.
+#include <atomic>
 #include "common.h"
 #include "kernels.h"
 
@@ -189,11 +190,11 @@ int launch_conv_nhwc(const void* in, const void* w, const void* bias, const void
         a.pad = ksize == 3 ? 1 : 0;
         a.Hout = upsample ? Hin * 2 : Hin; a.Wout = upsample ? Win * 2 : Win;
     }
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
+    if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_nhwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const int npix = a.Hout * a.Wout;
     const int grid = ((npix + CV_BM - 1) / CV_BM) * ((Cout_p + CV_BN - 1) / CV_BN);
@@ -494,11 +495,11 @@ int launch_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, hi
         int rc = check_launch("vae_vt_kernel");
         if (rc) return rc;
     }
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
+    if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)vae_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VA_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "vae_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const float scale_log2 = (float)(1.0 / sqrt((double)VA_D)) * 1.44269504088896340736f;
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)N * N * VA_D, stream);
