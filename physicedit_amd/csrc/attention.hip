@@ -697,8 +697,8 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
                       int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream, const void* words,
                       int n_img) {
     PE_REQUIRE(q && k && vt && out, "flash_attn: null pointer");
-    PE_REQUIRE(words == nullptr || (g_attn_variant == 0 && n_img >= 0 && n_img <= S && ((uintptr_t)words & 15) == 0),
-               "flash_attn: token words need the default kernel variant, 0 <= n_img <= S and a 16-byte aligned buffer");
+    PE_REQUIRE(words == nullptr || (n_img >= 0 && n_img <= S && ((uintptr_t)words & 15) == 0),
+               "flash_attn: token words need 0 <= n_img <= S and a 16-byte aligned buffer");      // always the 8-wave masked kernel
     PE_REQUIRE(H > 0 && S > 0, "flash_attn: empty problem (H=%d S=%d)", H, S);
     PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
                S_pad, KV_TILE, S);
