@@ -242,6 +242,7 @@ def accelerate_decode(model) -> int:
     import torch.nn.functional as F
     from physicedit_amd import ops
     n = 0
+    rope_cache = {"cos": None, "cs": None, "sn": None}      # the section-selected rotary row of the current step, shared by all layers
     for m in model.modules():
         if (isinstance(m, torch.nn.Linear) and m.weight.is_cuda and m.weight.dtype == torch.bfloat16 and m.weight.is_contiguous()
                 and m.in_features % 8 == 0 and m.in_features <= 32768):
@@ -274,13 +275,139 @@ def accelerate_decode(model) -> int:
             n += 1
         elif (type(m).__name__ == "Qwen2_5_VLAttention" and getattr(m, "head_dim", 0) == 128 and m.q_proj.weight.is_cuda
               and m.q_proj.weight.dtype == torch.bfloat16 and m.q_proj.in_features % 8 == 0):
-            n += _patch_decode_attention(m, ops)
+            n += _patch_decode_attention(m, ops, rope_cache)
         elif type(m).__name__ == "Qwen2_5_VLDecoderLayer":
             n += _patch_decode_layer(m, ops)
     return n
 
 
-def _patch_decode_attention(m, ops) -> int:
+class GraphDecoder:
+    """Greedy `generate` of the text encoder (qwen_image_physical.py:859-873: `text_encoder.generate(**model_inputs,
+    max_new_tokens=1000)`, greedy by the model's generation config) with the whole decode step -- embedding row, 28 decoder layers
+    of 6 launches (q/k/v + rotary + cache append with the input norm fused, attention, o_proj + residual, gate/up + SiLU with the
+    post-attention norm fused, down_proj + residual), lm_head with the final norm fused, arg-max -- captured ONCE per call in a hipGraph and replayed per token: no Python, no
+    launch latency, no Cache object in the loop.  The prefill stays on transformers; its DynamicCache is copied into static planes
+    [layer][kv_head][prompt + max_new_tokens][128] that the q/k/v launch appends to (pe_decode_step_*: everything that changes per
+    token is read from device memory).  Same kernels, same order, same roundings as `accelerate_decode`, so the tokens are the ones
+    the patched `generate()` produces.  EOS is tested on the host every `chunk` tokens; the overshoot is discarded."""
+
+    def __init__(self, model, chunk: int = 16):
+        from physicedit_amd import ops
+        self.ops, self.model, self.chunk = ops, model, chunk
+        lm = model.model.language_model
+        self.lm = lm
+        self.layers = list(lm.layers)
+        at = self.layers[0].self_attn
+        w = at.q_proj.weight
+        if not (w.is_cuda and w.dtype == torch.bfloat16 and getattr(at, "head_dim", 0) == 128 and lm.embed_tokens.weight.dtype == w.dtype):
+            raise ValueError("GraphDecoder needs a bf16 CUDA language model with 128-wide heads")
+        try:
+            section = list(at.config.rope_parameters["mrope_section"])
+        except Exception:
+            section = list(getattr(at, "rope_scaling", {}).get("mrope_section", []))
+        if sum(section) * 2 != 128:
+            raise ValueError("GraphDecoder: unexpected mrope sections")
+        self.sel = torch.tensor([i % 3 for i, n_ in enumerate(section * 2) for _ in range(n_)], device=w.device)
+        self.hkv = at.k_proj.out_features // 128
+        for ly in self.layers:
+            if ly.self_attn.o_proj.bias is not None or ly.mlp.down_proj.bias is not None or ly.mlp.gate_proj.bias is not None:
+                raise ValueError("GraphDecoder: unexpected biases in o_proj / the MLP")
+
+    def _step(self, st):
+        """one decode step on the current stream (captured); st: dict of static device tensors"""
+        ops = self.ops
+        x = ops.decode_embed(self.lm.embed_tokens.weight, st["token"])
+        for l, ly in enumerate(self.layers):
+            at, mlp = ly.self_attn, ly.mlp
+            # the two RMSNorms ride in the staging of the launches they feed (bit-identical to pe_rmsnorm): 6 launches per layer
+            q = ops.decode_step_qkv(x, at.q_proj.weight, at.q_proj.bias, at.k_proj.weight, at.k_proj.bias, at.v_proj.weight,
+                                    at.v_proj.bias, st["cos"], st["sin"], st["kc"][l], st["vc"][l], st["step"], st["base"],
+                                    norm_w=ly.input_layernorm.weight, eps=float(ly.input_layernorm.variance_epsilon))
+            a = ops.decode_step_attention(q, st["kc"][l], st["vc"][l], st["step"], st["base"], float(at.scaling))
+            h1 = ops.gemv(a, at.o_proj.weight, None, res=x)
+            hid = ops.gemv_swiglu_norm(h1, ly.post_attention_layernorm.weight, float(ly.post_attention_layernorm.variance_epsilon),
+                                       mlp.gate_proj.weight, mlp.up_proj.weight)
+            x = ops.gemv(hid, mlp.down_proj.weight, None, res=h1)
+        logits = ops.gemv_norm(x, self.lm.norm.weight, float(self.lm.norm.variance_epsilon), self.model.lm_head.weight,
+                               self.model.lm_head.bias)
+        ops.decode_argmax(logits, st["token"], st["out_ids"], st["step"])
+
+    @torch.no_grad()
+    def generate(self, max_new_tokens: int = 1000, **model_inputs) -> torch.Tensor:
+        """-> [1, prompt + generated] token ids, like GenerationMixin.generate for a batch of one (EOS included when it came)."""
+        model, dev = self.model, self.lm.embed_tokens.weight.device
+        ids = model_inputs["input_ids"]
+        if ids.shape[0] != 1:
+            raise ValueError("GraphDecoder.generate: batch of one")
+        Lp = ids.shape[1]
+        gen = model.generation_config
+        eos = gen.eos_token_id
+        eos = set() if eos is None else set(eos if isinstance(eos, (list, tuple)) else [eos])
+        min_new = int(getattr(gen, "min_new_tokens", 0) or 0)
+        cap = Lp + max_new_tokens
+        if cap > 15360:
+            raise ValueError("GraphDecoder.generate: prompt + max_new_tokens exceeds the decode attention's 15360-row cache")
+        # ---- prefill on transformers (one pass over the prompt; image tokens, mrope positions, rope_deltas are its business)
+        try:
+            out = model(**model_inputs, use_cache=True, logits_to_keep=1)
+        except TypeError:
+            out = model(**model_inputs, use_cache=True)
+        first = int(out.logits[0, -1].float().argmax())
+        past = out.past_key_values
+        L = len(self.layers)
+        kc = torch.zeros((L, self.hkv, cap, 128), dtype=torch.bfloat16, device=dev)
+        vc = torch.zeros_like(kc)
+        for l in range(L):
+            if hasattr(past, "layers"):                    # transformers >= 4.54: DynamicCache.layers[l].keys / .values
+                k, v = past.layers[l].keys, past.layers[l].values
+            elif hasattr(past, "key_cache"):
+                k, v = past.key_cache[l], past.value_cache[l]
+            else:
+                k, v = past[l][0], past[l][1]
+            kc[l, :, :Lp].copy_(k[0])
+            vc[l, :, :Lp].copy_(v[0])
+        del out, past
+        # ---- rotary tables of the decode positions: position of generated token t = prompt length + t + rope_delta on all 3 axes
+        delta = getattr(model.model, "rope_deltas", None)
+        delta = int(delta.reshape(-1)[0]) if delta is not None else 0
+        pos = (torch.arange(Lp, Lp + max_new_tokens, device=dev) + delta).view(1, 1, -1).expand(3, 1, -1)
+        cos, sin = self.lm.rotary_emb(kc.new_zeros(1), pos)               # [3, 1, T, 128]
+        ar = torch.arange(128, device=dev)
+        st = {"kc": kc, "vc": vc, "base": Lp,
+              "cos": cos[:, 0].permute(1, 0, 2)[:, self.sel, ar].to(torch.bfloat16).contiguous(),
+              "sin": sin[:, 0].permute(1, 0, 2)[:, self.sel, ar].to(torch.bfloat16).contiguous(),
+              "token": torch.tensor([first], dtype=torch.int32, device=dev), "step": torch.zeros(1, dtype=torch.int32, device=dev),
+              "out_ids": torch.zeros(max(max_new_tokens - 1, 1), dtype=torch.int32, device=dev)}
+        tokens = [first]
+        n_steps = max_new_tokens - 1                       # the prefill produced the first new token
+        if n_steps > 0 and not (first in eos and min_new <= 1):
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._step(st)                             # warm-up outside the capture (lazy module loads, allocator)
+                side.synchronize()
+                st["step"].zero_()
+                st["token"].fill_(first)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    self._step(st)
+                done = 0
+                while done < n_steps:
+                    n = min(self.chunk, n_steps - done)
+                    for _ in range(n):
+                        graph.replay()
+                    new = st["out_ids"][done:done + n].tolist()            # synchronises
+                    done += n
+                    stop = next((i for i, t in enumerate(new) if t in eos and len(tokens) + i + 1 >= max(min_new, 1)), None)
+                    if stop is not None:
+                        tokens += new[:stop + 1]
+                        break
+                    tokens += new
+            torch.cuda.current_stream(dev).wait_stream(side)
+        return torch.cat([ids, torch.tensor([tokens], dtype=ids.dtype, device=ids.device)], dim=1)
+
+
+def _patch_decode_attention(m, ops, shared=None) -> int:
     """q_len = 1 path of Qwen2_5_VLAttention.forward (transformers): q / k / v projections + multimodal rotary embedding in two
     launches (pe_decode_qkv_rope) instead of ~25 element-wise ones, the cache update left to transformers' Cache object, then one
     GQA-aware single-query attention launch (pe_decode_attention) instead of repeat_kv copies + SDPA + transposes, then o_proj
@@ -294,7 +421,7 @@ def _patch_decode_attention(m, ops) -> int:
         return 0
     sel = torch.tensor([i % 3 for i, n_ in enumerate(section * 2) for _ in range(n_)], device=m.q_proj.weight.device)
     ar = torch.arange(128, device=sel.device)
-    last = {"id": None, "cs": None, "sn": None}
+    last = shared if shared is not None else {"cos": None, "cs": None, "sn": None}
     hq, hkv = m.q_proj.out_features // 128, m.k_proj.out_features // 128
 
     def forward(hidden_states, attention_mask=None, position_ids=None, past_key_values=None, output_attentions=False,
@@ -308,8 +435,8 @@ def _patch_decode_attention(m, ops) -> int:
 
     def core(hidden_states, past_key_values, cos, sin):
         """attention output of the one new token BEFORE o_proj, [Hq * 128]"""
-        if last["id"] != id(cos):                  # the same (cos, sin) pair reaches every layer of one step
-            last["id"] = id(cos)
+        if last["cos"] is not cos:                 # the same (cos, sin) pair reaches every layer of one step.  The tensor itself is
+            last["cos"] = cos                      # kept (not its id()): a freed tensor's id is reused by the next step's
             last["cs"] = cos[:, 0, 0, :][sel, ar].to(torch.bfloat16).contiguous()
             last["sn"] = sin[:, 0, 0, :][sel, ar].to(torch.bfloat16).contiguous()
         q, k, v = ops.decode_qkv_rope(hidden_states, m.q_proj.weight, m.q_proj.bias, m.k_proj.weight, m.k_proj.bias,
@@ -357,11 +484,18 @@ class PromptPrologue:
     """callable installed as `pipe.prompt_encoder`:
     (pipe, prompt=, negative_prompt=, edit_image=, cfg=, have_text_reasoning=) -> (posi, nega) dicts."""
 
-    def __init__(self, text_encoder, processor, tokenizer=None, device="cuda", torch_dtype=torch.bfloat16, decode_gemv: bool = True):
+    def __init__(self, text_encoder, processor, tokenizer=None, device="cuda", torch_dtype=torch.bfloat16, decode_gemv: bool = True,
+                 decode_graph: bool = True):
         self.text_encoder = text_encoder
         self.decode_gemv = 0
+        self.graph_decoder = None
         if decode_gemv and text_encoder is not None and torch.device(device).type == "cuda":
             self.decode_gemv = accelerate_decode(text_encoder)
+            if decode_graph:
+                try:
+                    self.graph_decoder = GraphDecoder(text_encoder)
+                except (ValueError, AttributeError) as e:            # another architecture / dtype: transformers' generate()
+                    print(f"[prompt_prologue] captured decode step not available ({e}); using generate()")
         self.processor = processor
         self.tokenizer = tokenizer if tokenizer is not None else processor.tokenizer
         self.device = torch.device(device)
@@ -403,6 +537,13 @@ class PromptPrologue:
 
     # ---- PhysicalVerbalEmbedder at inference (:943-967, :859-873) -------------------------------------------
     @torch.no_grad()
+    def generate_ids(self, model_inputs, max_new_tokens: int):
+        """`text_encoder.generate(**model_inputs, max_new_tokens=...)`: through the captured decode step when the encoder qualifies
+        (bf16 on the GPU, greedy), through transformers otherwise."""
+        if self.graph_decoder is not None and not getattr(self.text_encoder.generation_config, "do_sample", False):
+            return self.graph_decoder.generate(max_new_tokens=max_new_tokens, **model_inputs)
+        return self.text_encoder.generate(**model_inputs, max_new_tokens=max_new_tokens)
+
     def physical_text(self, prompt: str, edit_image: Image.Image) -> str:
         messages = [
             {"role": "system", "content": SYSTEM_PROMPT_SAMPLE},
@@ -411,7 +552,7 @@ class PromptPrologue:
         ]
         text = self.processor.apply_chat_template(messages, tokenize=False, add_generation_prompt=True, add_vision_id=True)
         model_inputs = self.processor(text=[text], images=resize_for_vl(edit_image), padding=True, return_tensors="pt").to(self.device)
-        decoded_ids = self.text_encoder.generate(**model_inputs, max_new_tokens=1000)
+        decoded_ids = self.generate_ids(model_inputs, max_new_tokens=1000)
         trimmed = [out_ids[len(in_ids):] for in_ids, out_ids in zip(model_inputs["input_ids"], decoded_ids)]
         decoded = self.tokenizer.batch_decode(trimmed, skip_special_tokens=True, clean_up_tokenization_spaces=False)[0]
         try:

@@ -162,6 +162,27 @@ int pe_decode_qkv_rope(const void* x, const void* Wq, const void* bq, const void
                        void* stream);
 int pe_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads, int L,
                         float scale, void* stream);
+/* The same decode step in a form a captured graph (hipGraph) can replay: everything that changes from token to token is read from
+ * DEVICE memory.  `step` counts the tokens generated so far; the q / k / v launch takes its rotary tables from row *step of
+ * cos_table / sin_table [n_steps][128] and writes the new k / v rows straight into the caches [n_kv_heads][cache_len][128] at row
+ * base_len + *step (base_len = prompt length); the attention reads base_len + *step + 1 valid rows; pe_decode_embed copies row
+ * *token of the embedding table; pe_decode_argmax writes the arg-max of the logits (first index among equal maxima) to *token and
+ * out_ids[*step], then increments *step.  A step past the cache capacity writes nothing.  cache_len <= 15360.
+ * Used by diffsynth/pipelines/prompt_prologue.py::GraphDecoder for the greedy `generate` of qwen_image_physical.py:859-873. */
+int pe_decode_step_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv, const void* bv,
+                       const void* cos_table, const void* sin_table, void* q, void* k_cache, void* v_cache, int n_q_heads,
+                       int n_kv_heads, int K, const int* step, int base_len, int cache_len, const void* norm_w /* nullable */, float eps,
+                       void* stream);
+/* Single-row Linears whose input is RMSNorm(x) * norm_w (text width K = 3584; also the `norm_w` of pe_decode_step_qkv): the
+ * normalisation happens while x is staged in LDS, bit-identical to pe_rmsnorm followed by the plain form. */
+int pe_gemv_norm_bf16(const void* x, const void* norm_w, float eps, const void* W, const void* bias, void* y, int N, int K,
+                      void* stream);
+int pe_gemv_swiglu_norm_bf16(const void* x, const void* norm_w, float eps, const void* Wg, const void* Wu, void* y, int N, int K,
+                             void* stream);
+int pe_decode_step_attention(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads,
+                             const int* step, int base_len, int cache_len, float scale, void* stream);
+int pe_decode_embed(const void* table, const int* token, void* x, int dim, int vocab, void* stream);
+int pe_decode_argmax(const void* logits, int vocab, int* token, int* out_ids, int* step, int max_steps, void* stream);
 /* BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18): out = bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of
  * dim = 3072, each RMSNorm with the roundings of models/utils.py:250-257. */
 int pe_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,

@@ -127,6 +127,12 @@ SIGNATURES = {
     "pe_gemv_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_decode_qkv_rope": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_void_p]),
     "pe_decode_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "pe_decode_step_qkv": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p]),
+    "pe_gemv_norm_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pe_gemv_swiglu_norm_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pe_decode_step_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "pe_decode_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pe_decode_argmax": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pe_gemv_res_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_gemv_swiglu_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_dual_rmsnorm_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -178,6 +178,41 @@ int pe_decode_attention(const void* q, const void* k_cache, const void* v_cache,
     return launch_attn_decode(q, k_cache, v_cache, out, n_q_heads, n_kv_heads, L, scale, (hipStream_t)stream);
 }
 
+int pe_decode_step_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv, const void* bv,
+                       const void* cos_table, const void* sin_table, void* q, void* k_cache, void* v_cache, int n_q_heads,
+                       int n_kv_heads, int K, const int* step, int base_len, int cache_len, const void* norm_w, float eps,
+                       void* stream) {
+    PE_REQUIRE(step, "pe_decode_step_qkv: null step counter");
+    return launch_decode_qkv(x, Wq, bq, Wk, bk, Wv, bv, cos_table, sin_table, q, k_cache, v_cache, n_q_heads, n_kv_heads, K,
+                             (hipStream_t)stream, step, base_len, cache_len, norm_w, eps);
+}
+
+int pe_gemv_norm_bf16(const void* x, const void* norm_w, float eps, const void* W, const void* bias, void* y, int N, int K,
+                      void* stream) {
+    PE_REQUIRE(norm_w, "pe_gemv_norm_bf16: null norm weight");
+    return launch_gemv(x, W, bias, y, N, K, (hipStream_t)stream, nullptr, norm_w, eps);
+}
+
+int pe_gemv_swiglu_norm_bf16(const void* x, const void* norm_w, float eps, const void* Wg, const void* Wu, void* y, int N, int K,
+                             void* stream) {
+    PE_REQUIRE(norm_w, "pe_gemv_swiglu_norm_bf16: null norm weight");
+    return launch_gemv_swiglu(x, Wg, Wu, y, N, K, (hipStream_t)stream, norm_w, eps);
+}
+
+int pe_decode_step_attention(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads,
+                             const int* step, int base_len, int cache_len, float scale, void* stream) {
+    PE_REQUIRE(step, "pe_decode_step_attention: null step counter");
+    return launch_attn_decode(q, k_cache, v_cache, out, n_q_heads, n_kv_heads, cache_len, scale, (hipStream_t)stream, step, base_len);
+}
+
+int pe_decode_embed(const void* table, const int* token, void* x, int dim, int vocab, void* stream) {
+    return launch_embed_row(table, token, x, dim, vocab, (hipStream_t)stream);
+}
+
+int pe_decode_argmax(const void* logits, int vocab, int* token, int* out_ids, int* step, int max_steps, void* stream) {
+    return launch_argmax_step(logits, vocab, token, out_ids, step, max_steps, (hipStream_t)stream);
+}
+
 int pe_patchify(const void* latents, void* tokens, int C, int H2, int W2, void* stream) {
     return launch_patchify(latents, tokens, C, H2, W2, (hipStream_t)stream);
 }

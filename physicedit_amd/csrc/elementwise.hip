@@ -1,6 +1,7 @@
 // HBM-bound row / element-wise kernels of the DiT forward and the sampler (gfx950).
 // Every arithmetic step rounds to bf16 exactly where the reference's bf16 torch graph does
 // (SURVEY.md Appendix A); loads and stores are 16 B per lane.
+#include <atomic>
 #include "common.h"
 #include "kernels.h"
 
@@ -248,13 +249,41 @@ int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream) {
 // per wave, 16-B loads, x staged once per work-group in LDS, fp32 accumulation in k order per lane + a wave reduction.
 // ------------------------------------------------------------------------------------------------
 constexpr int GEMV_ROWS = 16;     // rows per work-group (4 waves x 2 rows x 2 rounds)
+
+// x -> LDS for the single-row kernels of a 256-thread work-group.  With norm_w (K == 3584 only): the input is RMSNorm(x) * norm_w,
+// every wave recomputes the row statistic with rmsnorm_kernel<7>'s lane -> element mapping and summation order, so the staged
+// values are bit-identical to a separate pe_rmsnorm launch (which the captured decode step saves: 2 of 8 launches per layer).
+PE_DEV void stage_row(bf16* __restrict__ xs, const bf16* __restrict__ x, int K, const bf16* __restrict__ norm_w, float eps) {
+    if (!norm_w) {
+        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
+    } else {
+        const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const bf16x8 t = *(const bf16x8*)(x + (i * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sq += (float)t[j] * (float)t[j];
+        }
+        const float rs = rsqrtf(wave_sum(sq) / 3584.0f + eps);
+        for (int i = w; i < 7; i += 4) {
+            const int c = (i * 64 + lane) * 8;
+            const bf16x8 t = *(const bf16x8*)(x + c);
+            const bf16x8 wv = *(const bf16x8*)(norm_w + c);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)(bf16r((float)t[j] * rs) * (float)wv[j]);
+            *(bf16x8*)(xs + c) = o;
+        }
+    }
+    __syncthreads();
+}
 __global__ void __launch_bounds__(256) gemv_bf16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
                                                         const bf16* __restrict__ bias, const bf16* __restrict__ res,
-                                                        bf16* __restrict__ y, int N, int K) {
+                                                        bf16* __restrict__ y, int N, int K, const bf16* __restrict__ norm_w, float eps) {
     extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
     bf16* xs = (bf16*)gemv_smem;
-    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
-    __syncthreads();
+    stage_row(xs, x, K, norm_w, eps);
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
     const int row0 = (int)blockIdx.x * GEMV_ROWS + w * 2;
@@ -291,11 +320,11 @@ __global__ void __launch_bounds__(256) gemv_bf16_kernel(const bf16* __restrict__
 // y[n] = bf16(silu(g) * u) with g = bf16(Wg[n,:] . x), u = bf16(Wu[n,:] . x): the gated MLP's first half on one row
 // (Qwen2MLP.forward: act_fn(gate_proj(x)) * up_proj(x); SiLU in fp32 with one rounding, then the bf16 product)
 __global__ void __launch_bounds__(256) gemv_swiglu_kernel(const bf16* __restrict__ x, const bf16* __restrict__ Wg,
-                                                          const bf16* __restrict__ Wu, bf16* __restrict__ y, int N, int K) {
+                                                          const bf16* __restrict__ Wu, bf16* __restrict__ y, int N, int K,
+                                                          const bf16* __restrict__ norm_w, float eps) {
     extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
     bf16* xs = (bf16*)gemv_smem;
-    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
-    __syncthreads();
+    stage_row(xs, x, K, norm_w, eps);
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
 #pragma unroll
@@ -324,11 +353,13 @@ __global__ void __launch_bounds__(256) gemv_swiglu_kernel(const bf16* __restrict
     }
 }
 
-int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, hipStream_t stream) {
+int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, hipStream_t stream, const void* norm_w,
+                       float eps) {
     PE_REQUIRE(x && Wg && Wu && y, "gemv_swiglu: null pointer");
+    PE_REQUIRE(!norm_w || K == 3584, "gemv_swiglu: the fused RMSNorm is for the text width 3584 (K=%d)", K);
     PE_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && K <= 32768, "gemv_swiglu: N=%d K=%d (K must be a multiple of 8, at most 32768)", N, K);
     hipLaunchKernelGGL(gemv_swiglu_kernel, dim3((N + 7) / 8), dim3(256), (size_t)K * 2, stream, (const bf16*)x, (const bf16*)Wg,
-                       (const bf16*)Wu, (bf16*)y, N, K);
+                       (const bf16*)Wu, (bf16*)y, N, K, (const bf16*)norm_w, eps);
     return check_launch("gemv_swiglu_kernel");
 }
 
@@ -340,11 +371,22 @@ __global__ void __launch_bounds__(256) gemv3_kernel(const bf16* __restrict__ x, 
                                                     int N0, const bf16* __restrict__ W1, const bf16* __restrict__ b1, int N1,
                                                     const bf16* __restrict__ W2, const bf16* __restrict__ b2, int N2,
                                                     bf16* __restrict__ y0, bf16* __restrict__ y1, bf16* __restrict__ y2, int K,
-                                                    const bf16* __restrict__ cs, const bf16* __restrict__ sn) {
+                                                    const bf16* __restrict__ cs, const bf16* __restrict__ sn,
+                                                    const int* __restrict__ step, int base, int ld,
+                                                    const bf16* __restrict__ norm_w, float eps) {
     extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
     bf16* xs = (bf16*)gemv_smem;
-    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(bf16x8*)(xs + i) = *(const bf16x8*)(x + i);
-    __syncthreads();
+    // captured-graph form (step != nullptr): the rotary tables are [n_steps][128] and indexed by the device-side step counter, and
+    // the k / v rows go straight into the caches [n_kv][ld][128] at row base + *step
+    int pos = -1;
+    if (step) {
+        const int st = *step;
+        cs += (size_t)st * 128;
+        sn += (size_t)st * 128;
+        pos = base + st;
+        if (pos >= ld) return;                     // cache full: the host never replays that far; never write past it
+    }
+    stage_row(xs, x, K, norm_w, eps);
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
     // work item p = a PAIR of rows: for q / k the rows (i, i + 64) of one 128-wide head, which the rotary embedding mixes; for v two
@@ -360,9 +402,10 @@ __global__ void __launch_bounds__(256) gemv3_kernel(const bf16* __restrict__ x, 
         int ra, rb;
         bool rope = true;
         int q2 = p;
+        bool cached = false;
         if (q2 < N0 / 2) { wr = W0; br = b0; yr = y0; }
-        else if ((q2 -= N0 / 2) < N1 / 2) { wr = W1; br = b1; yr = y1; }
-        else { q2 -= N1 / 2; wr = W2; br = b2; yr = y2; rope = false; }
+        else if ((q2 -= N0 / 2) < N1 / 2) { wr = W1; br = b1; yr = y1; cached = pos >= 0; }
+        else { q2 -= N1 / 2; wr = W2; br = b2; yr = y2; rope = false; cached = pos >= 0; }
         if (rope) { ra = (q2 >> 6) * 128 + (q2 & 63); rb = ra + 64; }
         else { ra = q2 * 2; rb = ra + 1; }
         const bf16* rowa = wr + (size_t)ra * K;
@@ -383,13 +426,16 @@ __global__ void __launch_bounds__(256) gemv3_kernel(const bf16* __restrict__ x, 
         if (lane == 0) {
             const float a = bf16r(sa + (br ? (float)br[ra] : 0.f));
             const float b = bf16r(sb + (br ? (float)br[rb] : 0.f));
+            // output row r of head r >> 7: plain vector, or row `pos` of that head's cache plane
+            const size_t oa = cached ? ((size_t)(ra >> 7) * ld + pos) * 128 + (ra & 127) : (size_t)ra;
+            const size_t ob = cached ? ((size_t)(rb >> 7) * ld + pos) * 128 + (rb & 127) : (size_t)rb;
             if (rope) {     // q * cos + rotate_half(q) * sin, rotate_half(q) = cat(-q[64:], q[:64]); every product and the sum rounded
                 const int i = ra & 127;
-                yr[ra] = (bf16)(bf16r(a * (float)cs[i]) + bf16r(-b * (float)sn[i]));
-                yr[rb] = (bf16)(bf16r(b * (float)cs[i + 64]) + bf16r(a * (float)sn[i + 64]));
+                yr[oa] = (bf16)(bf16r(a * (float)cs[i]) + bf16r(-b * (float)sn[i]));
+                yr[ob] = (bf16)(bf16r(b * (float)cs[i + 64]) + bf16r(a * (float)sn[i + 64]));
             } else {
-                yr[ra] = (bf16)a;
-                yr[rb] = (bf16)b;
+                yr[oa] = (bf16)a;
+                yr[ob] = (bf16)b;
             }
         }
     }
@@ -397,33 +443,41 @@ __global__ void __launch_bounds__(256) gemv3_kernel(const bf16* __restrict__ x, 
 
 int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv,
                       const void* bv, const void* cos_sel, const void* sin_sel, void* q, void* k, void* v, int n_q_heads,
-                      int n_kv_heads, int K, hipStream_t stream) {
+                      int n_kv_heads, int K, hipStream_t stream, const int* step, int base, int ld, const void* norm_w, float eps) {
     PE_REQUIRE(x && Wq && Wk && Wv && cos_sel && sin_sel && q && k && v, "decode_qkv: null pointer");
+    PE_REQUIRE(!norm_w || K == 3584, "decode_qkv: the fused RMSNorm is for the text width 3584 (K=%d)", K);
     PE_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && K > 0 && K % 8 == 0 && K <= 32768, "decode_qkv: bad shape");
+    PE_REQUIRE(!step || (base >= 0 && ld > base), "decode_qkv: cache of %d rows cannot take row %d", ld, base);
     const int N0 = n_q_heads * 128, N1 = n_kv_heads * 128;
     hipLaunchKernelGGL(gemv3_kernel, dim3(((N0 + 2 * N1) / 2 + 7) / 8), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
                        (const bf16*)Wq, (const bf16*)bq, N0, (const bf16*)Wk, (const bf16*)bk, N1, (const bf16*)Wv, (const bf16*)bv, N1,
-                       (bf16*)q, (bf16*)k, (bf16*)v, K, (const bf16*)cos_sel, (const bf16*)sin_sel);
+                       (bf16*)q, (bf16*)k, (bf16*)v, K, (const bf16*)cos_sel, (const bf16*)sin_sel, step, base, ld,
+                       (const bf16*)norm_w, eps);
     return check_launch("gemv3_kernel");
 }
 
-// One query token against a KV cache [n_kv][L][128] (GQA: query head h reads kv head h / (n_q / n_kv)), no mask:
+// One query token against a KV cache [n_kv][ld][128] (GQA: query head h reads kv head h / (n_q / n_kv)), no mask:
 // softmax(q K^T * scale) V with fp32 scores and sums, P rounded to bf16 before P.V (as the fused SDPA kernels do).
-__global__ void __launch_bounds__(256) attn_decode_kernel(const bf16* __restrict__ q, const bf16* __restrict__ Kc,
-                                                          const bf16* __restrict__ Vc, bf16* __restrict__ out, int n_q, int n_kv,
-                                                          int L, float scale) {
+// One work-group of 16 waves per query head: the launch is latency bound (28 heads, ~0.7 MB of cache each), so what counts is the
+// number of loads in flight per CU.
+constexpr int DEC_NT = 1024;
+__global__ void __launch_bounds__(DEC_NT) attn_decode_kernel(const bf16* __restrict__ q, const bf16* __restrict__ Kc,
+                                                             const bf16* __restrict__ Vc, bf16* __restrict__ out, int n_q, int n_kv,
+                                                             int L, float scale, const int* __restrict__ step, int base, int ld) {
     extern __shared__ __attribute__((aligned(16))) char dec_smem[];
     float* sc = (float*)dec_smem;                  // [L] scores, then probabilities
-    __shared__ float red[8];
-    __shared__ float part[16][128];
+    constexpr int NW = DEC_NT / 64;
+    __shared__ float red[2 * NW];
+    __shared__ float part[NW][128];
     const int h = (int)blockIdx.x, t = (int)threadIdx.x;
     const int kvh = h / (n_q / n_kv);
-    const bf16* kb = Kc + (size_t)kvh * L * 128;
-    const bf16* vb = Vc + (size_t)kvh * L * 128;
-    // scores: 4 lanes share one key row (64 contiguous bytes each), 64 keys per work-group iteration, two shuffles per key
+    if (step) L = min(base + *step + 1, ld);       // captured-graph form: the cache planes hold ld rows, base + *step + 1 are valid
+    const bf16* kb = Kc + (size_t)kvh * ld * 128;
+    const bf16* vb = Vc + (size_t)kvh * ld * 128;
+    // scores: 4 lanes share one key row (64 contiguous bytes each), DEC_NT / 4 keys per work-group iteration, two shuffles per key
     float mx = -INFINITY;
     {
-        const int s4 = t & 3, g4 = t >> 2;         // g4 0..63
+        const int s4 = t & 3, g4 = t >> 2;
         float qf[32];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -432,7 +486,7 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const bf16* __restrict
             for (int j = 0; j < 8; ++j) qf[c * 8 + j] = (float)t8[j];
         }
 #pragma unroll 2
-        for (int j = g4; j < L; j += 64) {
+        for (int j = g4; j < L; j += DEC_NT / 4) {
             const bf16* kr = kb + (size_t)j * 128 + s4 * 32;
             float acc = 0.f;
 #pragma unroll
@@ -448,55 +502,126 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const bf16* __restrict
             mx = fmaxf(mx, acc);
         }
     }
-    const int sub = t & 15, grp = t >> 4;          // P.V below: grp 0..15
+    const int sub = t & 15, grp = t >> 4;          // P.V below: DEC_NT / 16 groups, 4 per wave
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if ((t & 63) == 0) red[t >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
     float sum = 0.f;
-    for (int j = t; j < L; j += 256) {
+    for (int j = t; j < L; j += DEC_NT) {
         const float p = __expf(sc[j] - mx);
         sum += p;
         sc[j] = bf16r(p);
     }
     sum = wave_sum(sum);
-    if ((t & 63) == 0) red[4 + (t >> 6)] = sum;
+    if ((t & 63) == 0) red[NW + (t >> 6)] = sum;
     __syncthreads();
-    sum = red[4] + red[5] + red[6] + red[7];
-    // P.V: lane `sub` owns output channels 8 sub .. 8 sub + 7, group `grp` every 16th key; the 16 groups meet in LDS
+    sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += red[NW + w];
+    // P.V: lane `sub` owns output channels 8 sub .. 8 sub + 7, group `grp` every (DEC_NT / 16)-th key; the four groups of a wave meet
+    // by shuffles, the waves in LDS
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int j = grp; j < L; j += 16) {
+    for (int j = grp; j < L; j += DEC_NT / 16) {
         const bf16x8 v8 = *(const bf16x8*)(vb + (size_t)j * 128 + sub * 8);
         const float p = sc[j];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)v8[e], acc[e]);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[grp][sub * 8 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if ((t & 63) < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[t >> 6][sub * 8 + e] = acc[e];
+    }
     __syncthreads();
     if (t < 128) {
         float o = 0.f;
 #pragma unroll
-        for (int g2 = 0; g2 < 16; ++g2) o += part[g2][t];
+        for (int w = 0; w < NW; ++w) o += part[w][t];
         out[(size_t)h * 128 + t] = (bf16)(o / sum);
     }
 }
 
 int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int L, float scale,
-                       hipStream_t stream) {
+                       hipStream_t stream, const int* step, int base) {
     PE_REQUIRE(q && Kc && Vc && out, "attn_decode: null pointer");
     PE_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && L > 0 && L <= 15360, "attn_decode: bad shape (L=%d)", L);
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(n_q_heads), dim3(256), (size_t)L * 4, stream, (const bf16*)q, (const bf16*)Kc,
-                       (const bf16*)Vc, (bf16*)out, n_q_heads, n_kv_heads, L, scale);
+    PE_REQUIRE(!step || (base >= 0 && base < L), "attn_decode: base=%d outside the cache of %d rows", base, L);
+    static std::atomic<bool> configured{false};    // the score buffer of a 15360-row cache + the static partials exceed the 64 KiB default
+    if (!configured.load(std::memory_order_acquire)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 15360 * 4);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "attn_decode: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured.store(true, std::memory_order_release);
+    }
+    // with a step counter, L is the CAPACITY of the cache planes (and of the score buffer in LDS); the kernel reads the valid length
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(n_q_heads), dim3(DEC_NT), (size_t)L * 4, stream, (const bf16*)q, (const bf16*)Kc,
+                       (const bf16*)Vc, (bf16*)out, n_q_heads, n_kv_heads, L, scale, step, base, L);
     return check_launch("attn_decode_kernel");
 }
 
-int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream, const void* res) {
+// Greedy sampling glue of a captured decode step: token embedding lookup by a device-side token id, and arg-max of the logits
+// (first index among equal maxima, like torch.argmax) that also appends the token to the output list and advances the step counter.
+__global__ void __launch_bounds__(256) embed_row_kernel(const bf16* __restrict__ table, const int* __restrict__ token, bf16* __restrict__ x,
+                                                        int dim, int vocab) {
+    const int tk = min(max(*token, 0), vocab - 1);
+    for (int i = (int)(blockIdx.x * 256 + threadIdx.x) * 8; i < dim; i += (int)gridDim.x * 256 * 8)
+        *(bf16x8*)(x + i) = *(const bf16x8*)(table + (size_t)tk * dim + i);
+}
+
+__global__ void __launch_bounds__(1024) argmax_step_kernel(const bf16* __restrict__ logits, int V, int* __restrict__ token,
+                                                           int* __restrict__ out_ids, int* __restrict__ step, int max_steps) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = (int)threadIdx.x; i < V; i += 1024) {
+        const float v = (float)logits[i];
+        if (v > best) { best = v; idx = i; }       // ascending i per thread: the first maximum stays
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (idx == 0x7fffffff) idx = 0;            // all NaN / -inf
+        const int st = *step;
+        *token = idx;
+        if (st < max_steps) out_ids[st] = idx;
+        *step = st + 1;
+    }
+}
+
+int launch_embed_row(const void* table, const int* token, void* x, int dim, int vocab, hipStream_t stream) {
+    PE_REQUIRE(table && token && x && dim > 0 && dim % 8 == 0 && vocab > 0, "embed_row: bad arguments");
+    hipLaunchKernelGGL(embed_row_kernel, dim3((dim / 8 + 255) / 256), dim3(256), 0, stream, (const bf16*)table, token, (bf16*)x, dim, vocab);
+    return check_launch("embed_row_kernel");
+}
+
+int launch_argmax_step(const void* logits, int V, int* token, int* out_ids, int* step, int max_steps, hipStream_t stream) {
+    PE_REQUIRE(logits && token && out_ids && step && V > 0 && max_steps > 0, "argmax_step: bad arguments");
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(1), dim3(1024), 0, stream, (const bf16*)logits, V, token, out_ids, step, max_steps);
+    return check_launch("argmax_step_kernel");
+}
+
+int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream, const void* res,
+                const void* norm_w, float eps) {
     PE_REQUIRE(x && W && y, "gemv: null pointer");
+    PE_REQUIRE(!norm_w || K == 3584, "gemv: the fused RMSNorm is for the text width 3584 (K=%d)", K);
     PE_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && K <= 32768, "gemv: N=%d K=%d (K must be a multiple of 8, at most 32768)", N, K);
     hipLaunchKernelGGL(gemv_bf16_kernel, dim3((N + GEMV_ROWS - 1) / GEMV_ROWS), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
-                       (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)y, N, K);
+                       (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)y, N, K, (const bf16*)norm_w, eps);
     return check_launch("gemv_bf16_kernel");
 }
 

@@ -90,13 +90,18 @@ int launch_silu(const void* x, void* out, size_t n, hipStream_t stream);
 int launch_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,
                             hipStream_t stream);
 int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream);
-int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream, const void* res = nullptr);
+int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream, const void* res = nullptr,
+                const void* norm_w = nullptr, float eps = 0.f);
 int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv,
                       const void* bv, const void* cos_sel, const void* sin_sel, void* q, void* k, void* v, int n_q_heads,
-                      int n_kv_heads, int K, hipStream_t stream);
+                      int n_kv_heads, int K, hipStream_t stream, const int* step = nullptr, int base = 0, int ld = 0,
+                      const void* norm_w = nullptr, float eps = 0.f);
 int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int L, float scale,
-                       hipStream_t stream);
-int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, hipStream_t stream);
+                       hipStream_t stream, const int* step = nullptr, int base = 0);
+int launch_embed_row(const void* table, const int* token, void* x, int dim, int vocab, hipStream_t stream);
+int launch_argmax_step(const void* logits, int V, int* token, int* out_ids, int* step, int max_steps, hipStream_t stream);
+int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, hipStream_t stream,
+                       const void* norm_w = nullptr, float eps = 0.f);
 int launch_patchify(const void* latents, void* tokens, int C, int H2, int W2, hipStream_t stream);
 int launch_unpatchify(const void* tokens, void* latents, int C, int H2, int W2, hipStream_t stream);
 int launch_gather_rows(const void* src, const int* idx, void* dst, int nrows, int dim, hipStream_t stream);

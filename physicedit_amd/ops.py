@@ -306,3 +306,73 @@ def cfg_euler_step(posi, nega, latents, cfg_scale: float, dsigma: float, out=Non
                                   latents.numel(), float(cfg_scale), use_cfg, float(dsigma), stream_ptr()),
           "pe_cfg_euler_step")
     return out
+
+
+# ---- the decode step in graph-capturable form (device-side step counter; include/physicedit_amd.h "pe_decode_step_*") -----------
+def _chk_i32(t, name):
+    if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+        raise _lib.PeError(f"{name}: need a contiguous int32 device tensor")
+
+
+def decode_step_qkv(x, wq, bq, wk, bk, wv, bv, cos_table, sin_table, k_cache, v_cache, step, base_len: int, norm_w=None,
+                    eps: float = 1e-6) -> torch.Tensor:
+    """q / k / v projections + rotary embedding of the token at sequence position base_len + *step; k, v go into row base_len + *step
+    of k_cache / v_cache [n_kv, cache_len, 128]; returns q [n_q * 128].  norm_w: the input is RMSNorm(x) * norm_w (fused)."""
+    for t, n in ((x, "x"), (wq, "wq"), (wk, "wk"), (wv, "wv"), (cos_table, "cos_table"), (sin_table, "sin_table"),
+                 (k_cache, "k_cache"), (v_cache, "v_cache")):
+        _chk(t, n)
+    _chk_i32(step, "step")
+    K = x.numel()
+    hq, hkv, cache_len = wq.shape[0] // 128, k_cache.shape[0], k_cache.shape[1]
+    assert wk.shape[0] == hkv * 128 and k_cache.shape == v_cache.shape and k_cache.shape[2] == 128 and cos_table.shape[-1] == 128
+    q = torch.empty((hq * 128,), dtype=BF, device=x.device)
+    check(lib().pe_decode_step_qkv(x.data_ptr(), wq.data_ptr(), _ptr(bq), wk.data_ptr(), _ptr(bk), wv.data_ptr(), _ptr(bv),
+                                   cos_table.data_ptr(), sin_table.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                   hq, hkv, K, step.data_ptr(), int(base_len), cache_len, _ptr(norm_w), float(eps), stream_ptr()),
+          "pe_decode_step_qkv")
+    return q
+
+
+def decode_step_attention(q, k_cache, v_cache, step, base_len: int, scale: float) -> torch.Tensor:
+    _chk(q, "q"), _chk(k_cache, "k_cache"), _chk(v_cache, "v_cache"), _chk_i32(step, "step")
+    hq, hkv, cache_len = q.numel() // 128, k_cache.shape[0], k_cache.shape[1]
+    out = torch.empty((hq * 128,), dtype=BF, device=q.device)
+    check(lib().pe_decode_step_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(), hq, hkv,
+                                         step.data_ptr(), int(base_len), cache_len, float(scale), stream_ptr()),
+          "pe_decode_step_attention")
+    return out
+
+
+def decode_embed(table, token) -> torch.Tensor:
+    _chk(table, "table"), _chk_i32(token, "token")
+    x = torch.empty((table.shape[1],), dtype=BF, device=table.device)
+    check(lib().pe_decode_embed(table.data_ptr(), token.data_ptr(), x.data_ptr(), table.shape[1], table.shape[0], stream_ptr()),
+          "pe_decode_embed")
+    return x
+
+
+def decode_argmax(logits, token, out_ids, step) -> None:
+    _chk(logits, "logits"), _chk_i32(token, "token"), _chk_i32(out_ids, "out_ids"), _chk_i32(step, "step")
+    check(lib().pe_decode_argmax(logits.data_ptr(), logits.numel(), token.data_ptr(), out_ids.data_ptr(), step.data_ptr(),
+                                 out_ids.numel(), stream_ptr()), "pe_decode_argmax")
+
+
+def gemv_norm(x, norm_w, eps: float, w, bias=None) -> torch.Tensor:
+    """linear(RMSNorm(x) * norm_w) on one row of width 3584, the norm fused into the staging of x."""
+    _chk(x, "x"), _chk(w, "w"), _chk(norm_w, "norm_w")
+    N, K = w.shape
+    assert x.numel() == K == norm_w.numel()
+    out = torch.empty((N,), dtype=BF, device=x.device)
+    check(lib().pe_gemv_norm_bf16(x.data_ptr(), norm_w.data_ptr(), float(eps), w.data_ptr(), _ptr(bias), out.data_ptr(), N, K,
+                                  stream_ptr()), "pe_gemv_norm_bf16")
+    return out
+
+
+def gemv_swiglu_norm(x, norm_w, eps: float, wg, wu) -> torch.Tensor:
+    _chk(x, "x"), _chk(wg, "wg"), _chk(wu, "wu"), _chk(norm_w, "norm_w")
+    N, K = wg.shape
+    assert x.numel() == K == norm_w.numel() and wu.shape == wg.shape
+    out = torch.empty((N,), dtype=BF, device=x.device)
+    check(lib().pe_gemv_swiglu_norm_bf16(x.data_ptr(), norm_w.data_ptr(), float(eps), wg.data_ptr(), wu.data_ptr(), out.data_ptr(),
+                                         N, K, stream_ptr()), "pe_gemv_swiglu_norm_bf16")
+    return out

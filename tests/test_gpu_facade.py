@@ -395,3 +395,63 @@ def test_accelerated_decode_matches_transformers():
     err = (a - b).abs().max().item()
     print(f"[parity] accelerated decode: max |dlogit| {err:.4e}, logit std {spread:.4e}, top-1 equal {bool(a.argmax() == b.argmax())}")
     assert torch.isfinite(b).all() and err <= 0.05 * spread
+
+
+def test_graph_decoder_matches_generate():
+    """GraphDecoder (the decode step captured in a hipGraph, KV cache in static planes, device-side step counter) against
+    transformers' generate() on the same accelerated model: same kernels in the same order, so the greedy tokens must be IDENTICAL,
+    with and without an EOS in the middle; text-only prompt (rope_delta 0) at the real widths, 4 layers."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import copy
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    from diffsynth.pipelines import prompt_prologue as PP
+    cfg = copy.deepcopy(PP.TEXT_ENCODER_CONFIG)
+    cfg["text_config"].update(num_hidden_layers=4, vocab_size=4096, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    cfg["vision_config"].update(depth=1, fullatt_block_indexes=[0])
+    cfg.update(image_token_id=10, video_token_id=11, vision_start_token_id=12, vision_end_token_id=13, bos_token_id=1, eos_token_id=2)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device("cuda"):
+            m = Qwen2_5_VLForConditionalGeneration(Qwen2_5_VLConfig(**cfg))
+    finally:
+        torch.set_default_dtype(old)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.05, generator=g)
+            elif "norm" in name:
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+    m.eval()
+    m.generation_config.do_sample = False
+    m.generation_config.pad_token_id = 0
+    m.generation_config.eos_token_id = None
+    assert PP.accelerate_decode(m) > 0
+    dec = PP.GraphDecoder(m, chunk=8)
+    ids = torch.randint(20, 4000, (1, 37), generator=torch.Generator().manual_seed(3)).cuda()
+    inputs = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    with torch.no_grad():
+        ref = m.generate(**inputs, max_new_tokens=40, min_new_tokens=40)
+    got = dec.generate(max_new_tokens=40, **inputs)
+    n_same = int((ref[0, 37:] == got[0, 37:]).sum()) if ref.shape == got.shape else -1
+    print(f"[parity] graph decoder: {n_same} of 40 greedy tokens identical to generate(); shapes {tuple(ref.shape)} {tuple(got.shape)}")
+    assert ref.shape == got.shape and torch.equal(ref, got)
+    # an EOS in the middle: both must stop right after it (the chunked host-side test discards the overshoot)
+    eos = int(ref[0, 37 + 13])
+    first = (ref[0, 37:] == eos).nonzero()[0, 0].item()
+    m.generation_config.eos_token_id = eos
+    with torch.no_grad():
+        ref2 = m.generate(**inputs, max_new_tokens=40)
+    got2 = dec.generate(max_new_tokens=40, **inputs)
+    assert ref2.shape[1] == 37 + first + 1 and torch.equal(ref2, got2)
+    # a second call re-captures with another prompt length
+    ids3 = ids[:, :29].contiguous()
+    m.generation_config.eos_token_id = None
+    with torch.no_grad():
+        ref3 = m.generate(input_ids=ids3, attention_mask=torch.ones_like(ids3), max_new_tokens=12, min_new_tokens=12)
+    got3 = dec.generate(max_new_tokens=12, input_ids=ids3, attention_mask=torch.ones_like(ids3))
+    assert torch.equal(ref3, got3)

@@ -461,3 +461,66 @@ def test_mfma_probe(ops):
     check(lib().pe_mfma_probe(frags.data_ptr(), out.data_ptr(), 4, 10, ctypes.byref(fl), stream_ptr()), "pe_mfma_probe")
     torch.cuda.synchronize()
     assert fl.value == 4 * 8 * 10 * 32 * 2.0 * 32 * 32 * 16 and (out == 0).all()
+
+
+def test_decode_step_kernels(ops):
+    """the graph-capturable decode-step launches (device-side step counter) against their host-parameter forms: q/k/v + rotary with
+    step-indexed tables and in-cache k / v rows, attention over base + step + 1 rows of a larger cache, embedding row, arg-max."""
+    K, hq, hkv, cap, base = 3584, 28, 4, 96, 40
+    x = rnd((K,), 111).cuda()
+    wq, wk, wv = (rnd((n, K), s, K ** -0.5).cuda() for n, s in ((hq * 128, 112), (hkv * 128, 113), (hkv * 128, 114)))
+    bq, bk, bv = (rnd((n,), s).cuda() for n, s in ((hq * 128, 115), (hkv * 128, 116), (hkv * 128, 117)))
+    ang = torch.rand((8, 128), generator=torch.Generator().manual_seed(118)) * 6.28
+    cs, sn = ang.cos().to(BF).cuda(), ang.sin().to(BF).cuda()
+    kc, vc = rnd((hkv, cap, 128), 119).cuda(), rnd((hkv, cap, 128), 120).cuda()
+    kc0, vc0 = kc.clone(), vc.clone()
+    step = torch.tensor([5], dtype=torch.int32, device="cuda")
+    q = ops.decode_step_qkv(x, wq, bq, wk, bk, wv, bv, cs, sn, kc, vc, step, base)
+    q_ref, k_ref, v_ref = ops.decode_qkv_rope(x, wq, bq, wk, bk, wv, bv, cs[5].contiguous(), sn[5].contiguous())
+    assert torch.equal(q, q_ref.reshape(-1))
+    assert torch.equal(kc[:, base + 5], k_ref.view(hkv, 128)) and torch.equal(vc[:, base + 5], v_ref.view(hkv, 128))
+    keep = torch.ones(cap, dtype=torch.bool); keep[base + 5] = False
+    assert torch.equal(kc[:, keep], kc0[:, keep]) and torch.equal(vc[:, keep], vc0[:, keep])
+    out = ops.decode_step_attention(q, kc, vc, step, base, 128 ** -0.5)
+    L = base + 6
+    ref = ops.decode_attention(q.view(hq, 128), kc[:, :L].contiguous(), vc[:, :L].contiguous(), 128 ** -0.5)
+    assert torch.equal(out, ref.reshape(-1))
+    # a step past the capacity writes nothing
+    kc1, vc1 = kc.clone(), vc.clone()
+    ops.decode_step_qkv(x, wq, bq, wk, bk, wv, bv, cs, sn, kc, vc, torch.tensor([7], dtype=torch.int32, device="cuda"), cap - 7)
+    assert torch.equal(kc, kc1) and torch.equal(vc, vc1)
+    table = rnd((50, 256), 121).cuda()
+    tok = torch.tensor([17], dtype=torch.int32, device="cuda")
+    assert torch.equal(ops.decode_embed(table, tok), table[17])
+    logits = rnd((5000,), 122).cuda()
+    logits[4321] = logits.max() + 1
+    logits[77] = logits[4321]                                      # a tie: the first index wins, as torch.argmax
+    out_ids = torch.zeros(8, dtype=torch.int32, device="cuda")
+    st = torch.tensor([3], dtype=torch.int32, device="cuda")
+    ops.decode_argmax(logits, tok, out_ids, st)
+    torch.cuda.synchronize()
+    assert tok.item() == 77 == int(logits.float().argmax()) and out_ids[3].item() == 77 and st.item() == 4
+
+
+def test_fused_rmsnorm_single_row_forms(ops):
+    """pe_gemv_norm_bf16 / pe_gemv_swiglu_norm_bf16 / pe_decode_step_qkv(norm_w=): the RMSNorm fused into the staging of x must be
+    BIT-identical to pe_rmsnorm followed by the plain launch (the captured decode step relies on it to reproduce generate())."""
+    K = 3584
+    x = rnd((K,), 131).cuda()
+    nw = (1.0 + 0.1 * rnd((K,), 132).float()).to(BF).cuda()
+    xn = ops.rmsnorm(x.view(1, K), nw, 1e-6).view(-1)
+    w = rnd((1024, K), 133, K ** -0.5).cuda()
+    b = rnd((1024,), 134).cuda()
+    assert torch.equal(ops.gemv_norm(x, nw, 1e-6, w, b), ops.gemv(xn, w, b))
+    wg, wu = rnd((2048, K), 135, K ** -0.5).cuda(), rnd((2048, K), 136, K ** -0.5).cuda()
+    assert torch.equal(ops.gemv_swiglu_norm(x, nw, 1e-6, wg, wu), ops.gemv_swiglu(xn, wg, wu))
+    hq, hkv, cap = 28, 4, 16
+    wq, wk, wv = (rnd((n, K), s, K ** -0.5).cuda() for n, s in ((hq * 128, 137), (hkv * 128, 138), (hkv * 128, 139)))
+    ang = torch.rand((4, 128), generator=torch.Generator().manual_seed(140)) * 6.28
+    cs, sn = ang.cos().to(BF).cuda(), ang.sin().to(BF).cuda()
+    step = torch.tensor([2], dtype=torch.int32, device="cuda")
+    kc1, vc1 = torch.zeros((hkv, cap, 128), dtype=BF, device="cuda"), torch.zeros((hkv, cap, 128), dtype=BF, device="cuda")
+    kc2, vc2 = torch.zeros_like(kc1), torch.zeros_like(vc1)
+    q1 = ops.decode_step_qkv(x, wq, None, wk, None, wv, None, cs, sn, kc1, vc1, step, 3, norm_w=nw, eps=1e-6)
+    q2 = ops.decode_step_qkv(xn, wq, None, wk, None, wv, None, cs, sn, kc2, vc2, step, 3)
+    assert torch.equal(q1, q2) and torch.equal(kc1, kc2) and torch.equal(vc1, vc2) and kc1[:, 5].abs().sum() > 0
