@@ -366,8 +366,8 @@ class QwenImagePhysicPipeline:
             raise _lib.PeError("inpaint_mask needs input_image (the reference's step() blends towards the INPUT latents)")
         if blockwise_controlnet_inputs is not None and self.blockwise_controlnet is None:
             raise _lib.PeError("blockwise_controlnet_inputs given but no block-wise ControlNet checkpoint was loaded")
-        if enable_fp8_attention or edit_rope_interpolation:
-            raise _lib.PeError("enable_fp8_attention / edit_rope_interpolation are not implemented")
+        if enable_fp8_attention:
+            raise _lib.PeError("enable_fp8_attention (FlashAttention-3 fp8 on Hopper in the reference) is not implemented")
         if is_train and self.use_special_tokens:
             raise _lib.PeError("is_train=True runs the DINOv2/resampler training path; inference scripts pass is_train=False")
         if self.dit is None or self.vae is None:
@@ -430,7 +430,7 @@ class QwenImagePhysicPipeline:
                        denoising_strength=denoising_strength, blockwise_controlnet=self.blockwise_controlnet,
                        blockwise_controlnet_inputs=blockwise_controlnet_inputs, blockwise_controlnet_conditioning=ctl_cond,
                        eligen_posi=eligen_posi, eligen_nega=eligen_nega, input_latents=x0 if mask8 is not None else None,
-                       inpaint_mask=mask8)
+                       inpaint_mask=mask8, edit_rope_interpolation=edit_rope_interpolation)
         self.last_latents = latents
         # vae.decode + vae_output_to_image (:664-667) in one composite: the last kernel emits HWC uint8
         u8 = self.vae.decode(latents, output_u8=True, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)

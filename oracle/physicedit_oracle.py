@@ -157,12 +157,25 @@ def _rope_params(index: torch.Tensor, dim: int) -> torch.Tensor:
     return torch.polar(torch.ones_like(freqs), freqs)
 
 
-def rope_tables(img_shapes: Sequence[Tuple[int, int, int]], txt_len: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """QwenEmbedRope.forward (qwen_image_dit.py:123-165) with scale_rope=True, axes (16,56,56).
+def rope_tables(img_shapes: Sequence[Tuple[int, int, int]], txt_len: int, sampling: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """QwenEmbedRope.forward (qwen_image_dit.py:123-165) with scale_rope=True, axes (16,56,56); sampling=True: forward_sampling
+    (:168-226) on a FRESH module (its per-"{idx}_{h}_{w}" cache makes later calls history dependent): an image idx > 0 whose
+    grid differs from image 0's is sampled from image 0's table at linspace(0, n0 - 1, n).long(), frame entries its own.
     Returns complex64 (vid_freqs [S_img,64], txt_freqs [T,64])."""
     vid = []
     max_vid_index = 0
     for idx, (frame, height, width) in enumerate(img_shapes):
+        if sampling and idx > 0 and (height, width) != tuple(img_shapes[0][1:]):
+            frame_0, height_0, width_0 = img_shapes[0]
+            spatial_0 = vid[0].reshape(frame_0, height_0, width_0, -1)
+            h_grid, w_grid = torch.meshgrid(torch.linspace(0, height_0 - 1, height).long(),
+                                            torch.linspace(0, width_0 - 1, width).long(), indexing="ij")
+            sampled = spatial_0[:, h_grid, w_grid, :]
+            fr = _rope_params(torch.arange(idx, idx + frame), _AXES_DIM[0])
+            sampled[:, :, :, :fr.shape[-1]] = fr.view(frame, 1, 1, -1).expand(frame, height, width, -1)
+            vid.append(sampled.reshape(frame * height * width, -1).clone())
+            max_vid_index = max(height // 2, width // 2, max_vid_index)
+            continue
         fr = _rope_params(torch.arange(idx, idx + frame), _AXES_DIM[0])  # pos_freqs[0][idx:idx+frame]
         h_idx = torch.cat([torch.arange(-(height - height // 2), 0), torch.arange(0, height // 2)])
         w_idx = torch.cat([torch.arange(-(width - width // 2), 0), torch.arange(0, width // 2)])
@@ -392,7 +405,8 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
              prompt_emb: torch.Tensor, special_token_mask: Optional[torch.Tensor],
              height: int, width: int, edit_latents=None,
              t_min: float = 20.0, t_max: float = 1000.0, controlnets=None, progress_id: int = 0,
-             num_inference_steps: int = 1, entity_prompt_emb=None, entity_masks=None, capture: Optional[dict] = None) -> torch.Tensor:
+             num_inference_steps: int = 1, entity_prompt_emb=None, entity_masks=None, capture: Optional[dict] = None,
+             edit_rope_interpolation: bool = False) -> torch.Tensor:
     """One DiT forward at inference (is_train=False).  MUTATES `prompt_emb` IN PLACE on the
     special-token rows exactly as the reference does (:1336).
     `controlnets`: list of dicts {"sd": controlnet state dict, "conditioning": latents [1,16|17,h8,w8], "scale", "start", "end"}
@@ -420,7 +434,7 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
                                                                     height, width, image, img_shapes)
     else:
         text = _linear(sd, "txt_in", rmsnorm(prompt_emb, sd["txt_norm.weight"]))
-        vid_f, txt_f = rope_tables(img_shapes, T)
+        vid_f, txt_f = rope_tables(img_shapes, T, sampling=edit_rope_interpolation)      # :1367-1370
 
     processed = [controlnet_preprocess(c["sd"], c["conditioning"]) for c in controlnets] if controlnets else None
 

@@ -359,13 +359,15 @@ class QwenImageDiTEngine:
     # ------------------------------------------------------------------------------------------
     def forward(self, latents: torch.Tensor, timestep: torch.Tensor, prompt_emb: torch.Tensor,
                 special_idx: Optional[torch.Tensor] = None, edit_latents=None, step: Optional[int] = None,
-                out: Optional[torch.Tensor] = None, controls=None, entity_prompt_emb=None, entity_masks=None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, controls=None, entity_prompt_emb=None, entity_masks=None,
+                edit_rope_interpolation: bool = False) -> torch.Tensor:
         """One model_fn call.  `timestep`: [1] tensor in the pipeline dtype.  `prompt_emb` [1,T,3584] is
         MUTATED IN PLACE on `special_idx` rows.  Returns noise_pred [1,16,h8,w8].
         `controls`: active block-wise ControlNet inputs, [(QwenImageBlockWiseControlNet, processed conditioning [S0,3072], scale)]
         (physicedit_amd.controlnet).
         `entity_prompt_emb` (list of [1,T_i,3584]) + `entity_masks` ([1,N,1,h8,w8] in {0,1}): EliGen entity control
-        (QwenImageDiT.process_entity_masks, qwen_image_dit.py:433-498)."""
+        (QwenImageDiT.process_entity_masks, qwen_image_dit.py:433-498).
+        `edit_rope_interpolation`: RoPE tables of QwenEmbedRope.forward_sampling (:1367-1368); ignored with EliGen, as in the reference."""
         ops._chk(latents, "latents"), ops._chk(prompt_emb, "prompt_emb")
         h8, w8 = latents.shape[-2:]
         edits: List[torch.Tensor] = []
@@ -392,7 +394,7 @@ class QwenImageDiTEngine:
         if eligen is not None:
             cos_i, sin_i, cos_t, sin_t = self.rope.get_segments(img_shapes, seg_lens)
         else:
-            cos_i, sin_i, cos_t, sin_t = self.rope.get(img_shapes, T)
+            cos_i, sin_i, cos_t, sin_t = self.rope.get(img_shapes, T, sampling=bool(edit_rope_interpolation))
         if out is None:
             out = torch.empty((1, 16, h8, w8), dtype=BF, device=self.device)
         c = DitCall()
@@ -525,8 +527,8 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
         raise _lib.PeError("model_fn_qwen_image: entity_prompt_emb without entity_masks")
     if is_train and special_token_mask is not None:
         raise _lib.PeError("model_fn_qwen_image: is_train=True (special_token_loss) is a training feature; pass is_train=False")
-    if enable_fp8_attention or edit_rope_interpolation:
-        raise _lib.PeError("model_fn_qwen_image: fp8 attention / rope interpolation not implemented")
+    if enable_fp8_attention:
+        raise _lib.PeError("model_fn_qwen_image: fp8 attention (FlashAttention-3 on Hopper in the reference) is not implemented")
     edits = []
     if context_latents is not None:
         edits.append(context_latents)      # context tokens come right after the noise tokens (:1348-1351)
@@ -548,5 +550,5 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
                      for ci, c in zip(blockwise_controlnet_inputs, blockwise_controlnet_conditioning)]
         controls = blockwise_controlnet.active_controls(blockwise_controlnet_inputs, processed, progress_id, num_inference_steps)
     pred = dit.forward(latents, timestep, prompt_emb, idx, edits or None, controls=controls,
-                       entity_prompt_emb=entity_prompt_emb, entity_masks=entity_masks)
+                       entity_prompt_emb=entity_prompt_emb, entity_masks=entity_masks, edit_rope_interpolation=edit_rope_interpolation)
     return pred, 0

@@ -534,6 +534,31 @@ def G15_inpaint():
                                     "denoising_strength": strength, "cfg": cfg, "x0_seed": 150})
 
 
+def G16_rope_sampling():
+    """`edit_rope_interpolation=True` (:1367-1368 -> QwenEmbedRope.forward_sampling, qwen_image_dit.py:168-226): the tables of a fresh
+    module for three grids, and model_fn on a 256x256 target with a 192x320 edit image (12x20 tokens sampled from the 16x16 grid)."""
+    rope = QwenEmbedRope(theta=10000, axes_dim=[16, 56, 56], scale_rope=True)
+    vid, txt = rope.forward_sampling([(1, 8, 8), (1, 6, 10), (1, 8, 8), (1, 11, 5)], [37], device=torch.device("cpu"))
+    dit, sd = build_dit(2, 1234)
+    ad, adsd, _ = build_adapter(4321)
+    h = w = 256
+    T, nsp = 48, 16
+    noise, _, pe, mask = _model_fn_inputs(h, w, T, nsp, 0)
+    g = torch.Generator().manual_seed(160)
+    edit = torch.randn((1, 16, 192 // 8, 320 // 8), generator=g).to(BF)
+    lat, _ = model_fn_qwen_image(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad, latents=noise,
+                                 timestep=torch.tensor([812.5]).to(BF), prompt_emb=pe.clone(), prompt_emb_mask=torch.ones((1, T), dtype=torch.long),
+                                 special_token_mask=mask, height=h, width=w, edit_latents=edit, is_train=False,
+                                 edit_rope_interpolation=True)
+    lat_plain, _ = model_fn_qwen_image(dit=build_dit(2, 1234)[0], blockwise_controlnet=None, visual_thinking_adapter=ad, latents=noise,
+                                       timestep=torch.tensor([812.5]).to(BF), prompt_emb=pe.clone(),
+                                       prompt_emb_mask=torch.ones((1, T), dtype=torch.long), special_token_mask=mask, height=h, width=w,
+                                       edit_latents=edit, is_train=False, edit_rope_interpolation=False)
+    save("G16_rope_sampling", {"vid_re": vid.real.contiguous(), "vid_im": vid.imag.contiguous(), "txt_re": txt.real.contiguous(),
+                               "txt_im": txt.imag.contiguous(), "latents": lat, "latents_plain": lat_plain},
+         meta={"h": h, "w": w, "T": T, "n_special": nsp, "edit_h": 192, "edit_w": 320, "edit_seed": 160, "timestep": 812.5})
+
+
 def G10_image():
     ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
     ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")

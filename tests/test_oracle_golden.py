@@ -255,6 +255,32 @@ def test_G15_inpaint(golden):
     assert_same(lat, g[f"latents_step{meta['steps'] - 1}"], "inpaint loop")
 
 
+def test_G16_rope_sampling(golden):
+    """`edit_rope_interpolation=True` (QwenEmbedRope.forward_sampling): oracle tables and the product's host-side tables (rope.py)
+    bit-exact against a fresh reference module; oracle model_fn bit-exact with the flag, and the flag changes the result."""
+    from physicedit_amd import rope as R
+    g, meta = golden("G16_rope_sampling", with_meta=True)
+    shapes = [(1, 8, 8), (1, 6, 10), (1, 8, 8), (1, 11, 5)]
+    vid, txt = O.rope_tables(shapes, 37, sampling=True)
+    assert torch.equal(vid.real, g["vid_re"]) and torch.equal(vid.imag, g["vid_im"])
+    assert torch.equal(txt.real, g["txt_re"]) and torch.equal(txt.imag, g["txt_im"])
+    ci, si, ct, st = R.rope_cos_sin(shapes, 37, sampling=True)
+    assert torch.equal(ci, g["vid_re"]) and torch.equal(si, g["vid_im"]) and torch.equal(ct, g["txt_re"]) and torch.equal(st, g["txt_im"])
+    plain = R.rope_cos_sin(shapes, 37)[0]
+    assert torch.equal(plain[:64], ci[:64]) and not torch.equal(plain[64:124], ci[64:124]) and torch.equal(plain[124:188], ci[124:188])
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    noise, _, pe, mask = _model_fn_inputs(meta["h"], meta["w"], meta["T"], meta["n_special"], 0)
+    edit = torch.randn((1, 16, meta["edit_h"] // 8, meta["edit_w"] // 8), generator=torch.Generator().manual_seed(meta["edit_seed"])).to(BF)
+    t = torch.tensor([meta["timestep"]]).to(BF)
+    t_min, t_max = O.adapter_t_range()
+    lat = O.model_fn(sd, ad, noise, t, pe.clone(), mask, meta["h"], meta["w"], edit, t_min, t_max, edit_rope_interpolation=True)
+    assert_same(lat, g["latents"], "model_fn with sampled rope")
+    lat0 = O.model_fn(sd, ad, noise, t, pe.clone(), mask, meta["h"], meta["w"], edit, t_min, t_max)
+    assert_same(lat0, g["latents_plain"], "model_fn, same inputs, regular rope")
+    assert not torch.equal(g["latents"], g["latents_plain"])
+
+
 def test_G7_vae(golden):
     g = golden("G7_vae")
     vs = synth.make_state_dict(synth.vae_layout(), 77)
