@@ -330,6 +330,12 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* call, void* stream);
 
 /* Debug/test taps: device pointers into the bound workspace (valid after pe_dit_forward). */
 const void* pe_dit_debug_ptr(pe_dit_handle h, const char* name);
+/* Training-loss head (model_fn's `is_train=True` branch, qwen_image_physical.py:1337-1338 -> VisualThinkingDualAdapter.get_loss,
+ * pipelines/helpers.py:166-183): the two per-head mean squared errors between the adapter predictions of the LAST pe_dit_forward on
+ * this handle (its n_special rows x 3584) and the targets gt_dino / gt_vae [n_special, 3584] bf16, with the reference's roundings
+ * ((pred - gt) -> bf16, square -> bf16, fp32 mean).  out2: two floats on the device.  The time-dependent weighting of the two
+ * (scalar arithmetic) is host code: physicedit_amd/dit.py::special_token_loss. */
+int pe_dit_special_token_mse(pe_dit_handle h, const void* gt_dino, const void* gt_vae, int n_special, float* out2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * VAE operators (QwenImageVAE.encode/decode, models/qwen_image_vae.py:706-729).  Activations are

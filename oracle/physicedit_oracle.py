@@ -310,6 +310,20 @@ def adapter_forward(ad: SD, x: torch.Tensor, timestep: torch.Tensor, t_min: floa
     return mixed, pred_dino, pred_vae
 
 
+def adapter_get_loss(pred_dino, pred_vae, gt_dino, gt_vae, timestep, t_min: float, t_max: float, epsilon: float = 0.1):
+    # VisualThinkingDualAdapter.get_loss, helpers.py:166-183
+    alpha = adapter_alpha(timestep, t_min, t_max).type_as(pred_dino)
+    loss_dino = F.mse_loss(pred_dino, gt_dino, reduction="none").mean(dim=[1, 2])
+    loss_vae = F.mse_loss(pred_vae, gt_vae, reduction="none").mean(dim=[1, 2])
+    w = alpha.squeeze()
+    weight_dino = w + epsilon
+    weight_vae = (1 - w) + epsilon
+    total_weight = weight_dino + weight_vae
+    weight_dino = weight_dino / total_weight
+    weight_vae = weight_vae / total_weight
+    return (weight_dino * loss_dino + weight_vae * loss_vae).mean()
+
+
 # ======================================================================================
 # model_fn   (pipelines/qwen_image_physical.py:1302-1403)
 # ======================================================================================
@@ -406,15 +420,18 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
              height: int, width: int, edit_latents=None,
              t_min: float = 20.0, t_max: float = 1000.0, controlnets=None, progress_id: int = 0,
              num_inference_steps: int = 1, entity_prompt_emb=None, entity_masks=None, capture: Optional[dict] = None,
-             edit_rope_interpolation: bool = False) -> torch.Tensor:
+             edit_rope_interpolation: bool = False, pseudo_special_emb=None) -> torch.Tensor:
     """One DiT forward at inference (is_train=False).  MUTATES `prompt_emb` IN PLACE on the
     special-token rows exactly as the reference does (:1336).
     `controlnets`: list of dicts {"sd": controlnet state dict, "conditioning": latents [1,16|17,h8,w8], "scale", "start", "end"}
     (one per ControlNetInput; the unit that VAE-encodes the control image is outside this function)."""
     if special_token_mask is not None:
         special = prompt_emb[special_token_mask].view(prompt_emb.shape[0], -1, prompt_emb.size(-1))
-        special, _, _ = adapter_forward(ad, special, timestep, t_min, t_max)
+        special, dino_pred, vae_pred = adapter_forward(ad, special, timestep, t_min, t_max)
         prompt_emb[special_token_mask] = special.reshape(-1, prompt_emb.size(-1))
+        if pseudo_special_emb is not None and capture is not None:      # is_train=True (:1337-1338); (gt_dino, gt_vae)
+            capture["special_token_loss"] = adapter_get_loss(dino_pred, vae_pred, pseudo_special_emb[0], pseudo_special_emb[1],
+                                                             timestep, t_min, t_max)
 
     img_shapes = [(latents.shape[0], latents.shape[2] // 2, latents.shape[3] // 2)]
     T = prompt_emb.shape[1]

@@ -150,6 +150,7 @@ SIGNATURES = {
     "pe_dit_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "pe_dit_prepare": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "pe_dit_forward": (c_int, [c_void_p, C.POINTER(DitCall), c_void_p]),
+    "pe_dit_special_token_mse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "pe_dit_debug_ptr": (c_void_p, [c_void_p, C.c_char_p]),
     "pe_conv2d_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),

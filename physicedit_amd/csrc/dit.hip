@@ -542,6 +542,12 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
     return PE_OK;
 }
 
+int pe_dit_special_token_mse(pe_dit_handle h, const void* gt_dino, const void* gt_vae, int n_special, float* out2, void* stream) {
+    PE_REQUIRE(h && h->ws && h->has_adapter, "pe_dit_special_token_mse: handle without workspace / adapter");
+    PE_REQUIRE(n_special > 0 && n_special <= MAX_SPECIAL, "pe_dit_special_token_mse: n_special=%d", n_special);
+    return launch_adapter_mse(h->sp_dino, gt_dino, h->sp_vae, gt_vae, (size_t)n_special * TXT, out2, (hipStream_t)stream);
+}
+
 const void* pe_dit_debug_ptr(pe_dit_handle h, const char* name) {
     if (!h || !h->ws || !name) return nullptr;
     const std::string n(name);
@@ -556,6 +562,8 @@ const void* pe_dit_debug_ptr(pe_dit_handle h, const char* name) {
     if (n == "mod_tab") return h->mod_tab;
     if (n == "final_tab") return h->final_tab;
     if (n == "proj") return h->proj;
+    if (n == "sp_dino") return h->sp_dino;
+    if (n == "sp_vae") return h->sp_vae;
     return nullptr;
 }
 

@@ -566,6 +566,43 @@ int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out,
     return check_launch("attn_decode_kernel");
 }
 
+// Training-loss head of the visual-thinking adapter (VisualThinkingDualAdapter.get_loss, pipelines/helpers.py:166-183), the part that
+// touches tensors: F.mse_loss(pred, gt, reduction='none').mean(dim=[1, 2]) for the two heads -- (pred - gt) rounded to bf16, its
+// square rounded to bf16, fp32 mean.  One work-group per head; out[head] = fp32 mean (the caller rounds it to bf16 as .mean() does).
+__global__ void __launch_bounds__(1024) adapter_mse_kernel(const bf16* __restrict__ pd, const bf16* __restrict__ gd,
+                                                           const bf16* __restrict__ pv, const bf16* __restrict__ gv,
+                                                           size_t n, float* __restrict__ out) {
+    __shared__ float red[16];
+    const bf16* p = blockIdx.x == 0 ? pd : pv;
+    const bf16* g = blockIdx.x == 0 ? gd : gv;
+    float acc = 0.f;
+    for (size_t i = (size_t)threadIdx.x * 8; i < n; i += 1024 * 8) {
+        const bf16x8 a = *(const bf16x8*)(p + i);
+        const bf16x8 b = *(const bf16x8*)(g + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = bf16r((float)a[j] - (float)b[j]);
+            acc += bf16r(d * d);
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s2 = 0.f;
+        for (int w = 0; w < 16; ++w) s2 += red[w];
+        out[blockIdx.x] = s2 / (float)n;
+    }
+}
+
+int launch_adapter_mse(const void* pred_dino, const void* gt_dino, const void* pred_vae, const void* gt_vae, size_t n, float* out,
+                       hipStream_t stream) {
+    PE_REQUIRE(pred_dino && gt_dino && pred_vae && gt_vae && out && n > 0 && n % 8 == 0, "adapter_mse: bad arguments");
+    hipLaunchKernelGGL(adapter_mse_kernel, dim3(2), dim3(1024), 0, stream, (const bf16*)pred_dino, (const bf16*)gt_dino,
+                       (const bf16*)pred_vae, (const bf16*)gt_vae, n, out);
+    return check_launch("adapter_mse_kernel");
+}
+
 // Greedy sampling glue of a captured decode step: token embedding lookup by a device-side token id, and arg-max of the logits
 // (first index among equal maxima, like torch.argmax) that also appends the token to the output list and advances the step counter.
 __global__ void __launch_bounds__(256) embed_row_kernel(const bf16* __restrict__ table, const int* __restrict__ token, bf16* __restrict__ x,

@@ -98,6 +98,8 @@ int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void*
                       const void* norm_w = nullptr, float eps = 0.f);
 int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int L, float scale,
                        hipStream_t stream, const int* step = nullptr, int base = 0);
+int launch_adapter_mse(const void* pred_dino, const void* gt_dino, const void* pred_vae, const void* gt_vae, size_t n, float* out,
+                       hipStream_t stream);
 int launch_embed_row(const void* table, const int* token, void* x, int dim, int vocab, hipStream_t stream);
 int launch_argmax_step(const void* logits, int V, int* token, int* out_ids, int* step, int max_steps, hipStream_t stream);
 int launch_gemv_swiglu(const void* x, const void* Wg, const void* Wu, void* y, int N, int K, hipStream_t stream,

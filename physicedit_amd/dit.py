@@ -491,6 +491,29 @@ class QwenImageDiTEngine:
         words[S_img:S] = text_bits
         return (words & 0xFFFFFFFF).to(torch.uint32).view(torch.int32).to(self.device)
 
+    def special_token_loss(self, timestep: torch.Tensor, n_special: int, gt_dino: torch.Tensor, gt_vae: torch.Tensor,
+                           epsilon: float = 0.1) -> torch.Tensor:
+        """VisualThinkingDualAdapter.get_loss (pipelines/helpers.py:166-183) for the adapter predictions of the LAST forward on this
+        engine: the two mean squared errors come from the device (pe_dit_special_token_mse, the reference's roundings), the
+        time-dependent weighting is the reference's scalar arithmetic on one-element bf16 tensors, done here on the host.
+        Synchronises (training only).  Returns a 0-dim bf16 tensor like the reference."""
+        gd = gt_dino.to(device=self.device, dtype=BF).contiguous()
+        gv = gt_vae.to(device=self.device, dtype=BF).contiguous()
+        if gd.numel() != n_special * 3584 or gv.numel() != n_special * 3584:
+            raise _lib.PeError(f"special_token_loss: targets {tuple(gd.shape)} / {tuple(gv.shape)} for {n_special} special tokens")
+        out2 = torch.empty(2, dtype=torch.float32, device=self.device)
+        check(lib().pe_dit_special_token_mse(self._handle, gd.data_ptr(), gv.data_ptr(), int(n_special), out2.data_ptr(), stream_ptr()),
+              "pe_dit_special_token_mse")
+        loss_dino, loss_vae = out2.cpu().to(BF).unbind(0)                       # .mean(dim=[1, 2]) of a bf16 tensor -> bf16
+        t = timestep.detach().cpu()
+        alpha = ((t - self.t_min) / (self.t_max - self.t_min + 1e-6)).clamp(0.0, 1.0).view(-1, 1, 1).to(BF)     # _get_alpha + type_as
+        w = alpha.squeeze()
+        weight_dino = w + epsilon
+        weight_vae = (1 - w) + epsilon
+        total = weight_dino + weight_vae
+        weight_dino, weight_vae = weight_dino / total, weight_vae / total
+        return (weight_dino * loss_dino + weight_vae * loss_vae).mean()
+
     def debug_tensor(self, name: str, shape, dtype=BF) -> torch.Tensor:
         """Copy of an internal workspace region (tests only)."""
         ptr = lib().pe_dit_debug_ptr(self._handle, name.encode())
@@ -525,8 +548,10 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
     silently differing."""
     if entity_prompt_emb is not None and entity_masks is None:
         raise _lib.PeError("model_fn_qwen_image: entity_prompt_emb without entity_masks")
-    if is_train and special_token_mask is not None:
-        raise _lib.PeError("model_fn_qwen_image: is_train=True (special_token_loss) is a training feature; pass is_train=False")
+    want_loss = bool(is_train) and special_token_mask is not None
+    if want_loss and (pseudo_special_emb_dino is None or pseudo_special_emb_vae is None):
+        raise _lib.PeError("model_fn_qwen_image: is_train=True needs pseudo_special_emb_dino / pseudo_special_emb_vae (the targets of "
+                           "get_loss, produced by the training-time PhysicalVisualEmbedder); inference passes is_train=False")
     if enable_fp8_attention:
         raise _lib.PeError("model_fn_qwen_image: fp8 attention (FlashAttention-3 on Hopper in the reference) is not implemented")
     edits = []
@@ -551,4 +576,6 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
         controls = blockwise_controlnet.active_controls(blockwise_controlnet_inputs, processed, progress_id, num_inference_steps)
     pred = dit.forward(latents, timestep, prompt_emb, idx, edits or None, controls=controls,
                        entity_prompt_emb=entity_prompt_emb, entity_masks=entity_masks, edit_rope_interpolation=edit_rope_interpolation)
+    if want_loss:        # :1337-1338: the loss value of the training path (forward only: this library has no backward)
+        return pred, dit.special_token_loss(timestep, idx.numel(), pseudo_special_emb_dino, pseudo_special_emb_vae)
     return pred, 0

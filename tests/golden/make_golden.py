@@ -559,6 +559,29 @@ def G16_rope_sampling():
          meta={"h": h, "w": w, "T": T, "n_special": nsp, "edit_h": 192, "edit_w": 320, "edit_seed": 160, "timestep": 812.5})
 
 
+def G17_special_token_loss():
+    """model_fn with is_train=True (:1337-1338): the reference's own get_loss on synthetic targets, three timesteps (alpha 1, in
+    between, 0 -- the adapter's t range is [20, 1000] by construction in build_adapter)."""
+    dit, sd = build_dit(2, 1234)
+    ad, adsd, _ = build_adapter(4321)
+    h = w = 128
+    T, nsp = 40, 16
+    noise, edit, pe, mask = _model_fn_inputs(h, w, T, nsp, 0)
+    g = torch.Generator().manual_seed(170)
+    gt_d = (torch.randn((1, nsp, 3584), generator=g) * 0.5).to(BF)
+    gt_v = (torch.randn((1, nsp, 3584), generator=g) * 0.5).to(BF)
+    outs = {}
+    tvals = (986.96, 431.5, 12.0)
+    for i, tval in enumerate(tvals):
+        lat, loss = model_fn_qwen_image(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad, latents=noise,
+                                        timestep=torch.tensor([tval]).to(BF), prompt_emb=pe.clone(),
+                                        prompt_emb_mask=torch.ones((1, T), dtype=torch.long), special_token_mask=mask, height=h, width=w,
+                                        edit_latents=edit, is_train=True, pseudo_special_emb_dino=gt_d, pseudo_special_emb_vae=gt_v)
+        outs[f"loss_{i}"] = loss.reshape(1).clone()
+        outs[f"latents_{i}"] = lat
+    save("G17_special_token_loss", outs, meta={"h": h, "w": w, "T": T, "n_special": nsp, "gt_seed": 170, "timesteps": list(tvals)})
+
+
 def G10_image():
     ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
     ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")

@@ -232,6 +232,31 @@ def test_model_fn_rope_sampling_G16(golden, eng2):
     assert cross > 2 * own          # measured 3.8x: two random layers barely feel the positions of the edit tokens
 
 
+def test_special_token_loss_G17(golden, eng2):
+    """model_fn_qwen_image(is_train=True, pseudo_special_emb_*): the loss head of the training path (forward value only) against the
+    reference's get_loss; the adapter predictions it is computed from come out of the DiT composite's workspace."""
+    from physicedit_amd.dit import model_fn_qwen_image
+    g, meta = golden("G17_special_token_loss", with_meta=True)
+    noise, edit, pe, mask = _model_fn_inputs(meta["h"], meta["w"], meta["T"], meta["n_special"], 0)
+    gen = torch.Generator().manual_seed(meta["gt_seed"])
+    gt_d = (torch.randn((1, meta["n_special"], 3584), generator=gen) * 0.5).to(BF)
+    gt_v = (torch.randn((1, meta["n_special"], 3584), generator=gen) * 0.5).to(BF)
+    for i, tval in enumerate(meta["timesteps"]):
+        lat, loss = model_fn_qwen_image(dit=eng2, visual_thinking_adapter=True, latents=noise.cuda(), timestep=torch.tensor([tval]).to(BF),
+                                        prompt_emb=pe.cuda().clone(), prompt_emb_mask=torch.ones((1, meta["T"])), special_token_mask=mask,
+                                        height=meta["h"], width=meta["w"], edit_latents=edit.cuda(), is_train=True,
+                                        pseudo_special_emb_dino=gt_d, pseudo_special_emb_vae=gt_v)
+        ref = g[f"loss_{i}"][0]
+        rel = abs(float(loss) - float(ref)) / abs(float(ref))
+        print(f"[parity] special_token_loss t={tval}: hip {float(loss):.6f}  reference {float(ref):.6f}  rel {rel:.2e}")
+        assert loss.dtype == BF and rel <= 2 ** -7                        # one bf16 ulp of a scalar that sums 57k squared bf16 differences
+        d, u = stats(f"model_fn is_train latents t={tval}", lat, g[f"latents_{i}"])
+        assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+    with pytest.raises(Exception):
+        model_fn_qwen_image(dit=eng2, visual_thinking_adapter=True, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF),
+                            prompt_emb=pe.cuda().clone(), special_token_mask=mask, height=meta["h"], width=meta["w"], is_train=True)
+
+
 def test_lora_merge_G8(golden):
     from physicedit_amd.dit import QwenImageDiTEngine
     g, meta = golden("G8_lora", with_meta=True)

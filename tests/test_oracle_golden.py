@@ -281,6 +281,25 @@ def test_G16_rope_sampling(golden):
     assert not torch.equal(g["latents"], g["latents_plain"])
 
 
+def test_G17_special_token_loss(golden):
+    """model_fn's is_train=True branch (:1337-1338 -> VisualThinkingDualAdapter.get_loss): the oracle's loss value, bit for bit."""
+    g, meta = golden("G17_special_token_loss", with_meta=True)
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    noise, edit, pe, mask = _model_fn_inputs(meta["h"], meta["w"], meta["T"], meta["n_special"], 0)
+    gen = torch.Generator().manual_seed(meta["gt_seed"])
+    gt_d = (torch.randn((1, meta["n_special"], 3584), generator=gen) * 0.5).to(BF)
+    gt_v = (torch.randn((1, meta["n_special"], 3584), generator=gen) * 0.5).to(BF)
+    t_min, t_max = O.adapter_t_range()
+    for i, tval in enumerate(meta["timesteps"]):
+        cap = {}
+        lat = O.model_fn(sd, ad, noise, torch.tensor([tval]).to(BF), pe.clone(), mask, meta["h"], meta["w"], edit, t_min, t_max,
+                         pseudo_special_emb=(gt_d, gt_v), capture=cap)
+        assert_same(lat, g[f"latents_{i}"], f"latents t={tval}")
+        assert torch.equal(cap["special_token_loss"].reshape(1), g[f"loss_{i}"]), (tval, cap["special_token_loss"], g[f"loss_{i}"])
+    assert len({float(g[f"loss_{i}"]) for i in range(3)}) == 3         # the weighting moves with the timestep
+
+
 def test_G7_vae(golden):
     g = golden("G7_vae")
     vs = synth.make_state_dict(synth.vae_layout(), 77)
