@@ -419,8 +419,8 @@ class QwenImageDiTEngine:
         c.noise_pred = out.data_ptr()
         c.n_control = 0
         if controls:
-            if self.fp8:
-                raise _lib.PeError("block-wise ControlNet with the e4m3 DiT is not implemented (its Linears would be fp8_linear too)")
+            # with the e4m3 DiT the ControlNet stays bf16, as in the reference: enable_vram_management wraps its Linears with
+            # computation_dtype = the pipeline dtype (qwen_image_physical.py:478-493), only the DiT gets the fp8 dtype
             if len(controls) > 4:
                 raise _lib.PeError("at most 4 active ControlNet inputs per call")
             S0 = (h8 // 2) * (w8 // 2)

@@ -182,6 +182,36 @@ def test_model_fn_e4m3(hot_lora):
     assert d.max().item() <= mode.max().item()
 
 
+def test_model_fn_e4m3_with_bf16_controlnet():
+    """"FP8 computation" + block-wise ControlNet: the reference gives the fp8 computation dtype to the DiT only, the ControlNet's
+    Linears keep the pipeline dtype (qwen_image_physical.py:478-493) -- e4m3 block Linears, bf16 hook -- vs the oracle on the e4m3 DiT
+    state dict with the bf16 ControlNet."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd import synth
+    from physicedit_amd.controlnet import QwenImageBlockWiseControlNet
+    from physicedit_amd.dit import QwenImageDiTEngine, special_indices
+    sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+    cn_sd = synth.make_state_dict(synth.controlnet_layout(2, 0), 555)
+    t_min, t_max = O.adapter_t_range()
+    noise, edit, pe, mask = _inputs(128, 128, 40, 8, 3)
+    cond = torch.randn((1, 16, 16, 16), generator=torch.Generator().manual_seed(9)).to(BF)
+    t = torch.tensor([700.0]).to(BF)
+    ctl = [{"sd": cn_sd, "conditioning": cond, "scale": 0.8, "start": 1.0, "end": 0.0}]
+    ref_plain = O.model_fn(O.to_fp8_state_dict(sd), ad, noise, t, pe.clone(), mask, 128, 128, edit, t_min, t_max)
+    ref = O.model_fn(O.to_fp8_state_dict(sd), ad, noise, t, pe.clone(), mask, 128, 128, edit, t_min, t_max, controlnets=ctl)
+    eng = QwenImageDiTEngine(sd, ad, device="cuda")
+    eng.enable_fp8_computation()
+    net = QwenImageBlockWiseControlNet(cn_sd, device="cuda")
+    got = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, "cuda"), edit.cuda(),
+                      controls=[(net, net.process_controlnet_conditioning(cond), 0.8)])
+    effect = _dist("e4m3 + controlnet: effect of the ControlNet (oracle with vs without)", ref, ref_plain)
+    d = _dist("e4m3 + controlnet: model_fn vs oracle", got, ref)
+    assert torch.isfinite(got.float()).all()
+    assert d.mean().item() <= 0.25 * effect.mean().item() and d.max().item() <= effect.max().item()
+
+
 def test_loop_e4m3_dual_stream_bit_identical():
     """e4m3 mode through the sampler loop (fork()ed second context shares the e4m3 weights): finite output, and
     dual-stream == single-stream bit for bit."""
