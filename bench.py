@@ -317,7 +317,7 @@ def pmc_traffic(args):
     passes of tools/pmc_collect.sh (profiles/r02_pmc.json, which records its own command line).  They are per-launch properties
     of (kernel, shape), so they are reported ONLY when this run launches the same kernels on the same shapes -- same layer count,
     geometry, prompt lengths, operand dtype and stream count as the recorded command -- and are null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r02_pmc.json")
     if not os.path.exists(path):
         return None, None, None
     rec = json.load(open(path))
@@ -326,7 +326,7 @@ def pmc_traffic(args):
             c.get("t_pos") == args.t_pos and c.get("t_neg") == args.t_neg and bool(c.get("fp8")) == bool(args.fp8) and
             bool(c.get("dual_stream")) == bool(args.dual_stream))
     if not same:
-        return None, None, f"profiles/r02_pmc.json was collected for another configuration ({rec.get('command')}): not reported"
+        return None, None, f"profiles/{os.path.basename(path)} was collected for another configuration ({rec.get('command')}): not reported"
     # the block GEMMs only (QKV 1224, MLP-up 1632, out-proj / MLP-down 408 work-groups at this geometry): the hoisted modulation
     # GEMMs of pe_dit_prepare (M = steps) share the kernel name but are not what `roofline` is about
     rows = [r for r in rec["kernels"] if "gemm_bf16_kernel" in r["kernel"] and r.get("algorithmic_gflop_per_launch")]
@@ -336,7 +336,7 @@ def pmc_traffic(args):
     traffic = sum(r["traffic_bytes_per_launch"] * r["launches"] for r in rows) / n
     busy = [r for r in rows if r.get("mfma_busy") is not None]
     mfma = sum(r["mfma_busy"] * r["launches"] for r in busy) / sum(r["launches"] for r in busy) if busy else None
-    return traffic, mfma, f"profiles/r02_pmc.json ({rec.get('command')})"
+    return traffic, mfma, f"profiles/{os.path.basename(path)} ({rec.get('command')})"
 
 
 def cpu_baseline(args):
