@@ -607,18 +607,24 @@ class PromptPrologue:
 
     # ---- the unit runner's separate-CFG protocol (utils/__init__.py:247-283) ----------------------------------
     def __call__(self, pipe=None, prompt: str = "", negative_prompt: str = "", edit_image=None, cfg: bool = True,
-                 have_text_reasoning: bool = True) -> Tuple[Dict, Dict]:
+                 have_text_reasoning: bool = True, physical_txt: Optional[str] = None) -> Tuple[Dict, Dict]:
+        """`physical_txt`: reasoning text supplied by the caller instead of generated (PhysicalVerbalEmbedder.process, :976-983:
+        the annotated-triplet branch, taken when the rules / key frames / input image of a dataset sample are all given)."""
         clone = lambda d: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}   # callers mutate prompt_emb
-        key = (prompt, negative_prompt, self._image_key(edit_image), bool(cfg), bool(have_text_reasoning))
+        key = (prompt, negative_prompt, self._image_key(edit_image), bool(cfg), bool(have_text_reasoning), physical_txt)
+        given = physical_txt
         if self.cache_size and key in self._cache:
             self._cache.move_to_end(key)
             posi, nega, self.last_physical_txt = self._cache[key]
             return clone(posi), clone(nega)
         physical_txt = None
         if have_text_reasoning:
-            if not isinstance(edit_image, Image.Image):
-                raise ValueError("have_text_reasoning=True needs one edit image (encode_physical_prompt_sample, :943-967)")
-            physical_txt = self.physical_text(prompt, edit_image)
+            if given is not None:
+                physical_txt = given
+            else:
+                if not isinstance(edit_image, Image.Image):
+                    raise ValueError("have_text_reasoning=True needs one edit image (encode_physical_prompt_sample, :943-967)")
+                physical_txt = self.physical_text(prompt, edit_image)
         self.last_physical_txt = physical_txt
         posi = self.embed(prompt, edit_image, physical_txt)
         nega = self.embed(negative_prompt, edit_image, None) if cfg else dict(posi)

@@ -401,8 +401,14 @@ class QwenImagePhysicPipeline:
             edit_latents += [self._encode_image(im) for im in images]
         # prompt prologue (PhysicalVerbalEmbedder + PromptEmbedder in the reference, :732-990): host code
         use_cfg = cfg_scale != 1.0
+        extra = {}
+        if (have_text_reasoning and supported_rules is not None and contradicted_rules is not None and middle_key_frames is not None
+                and input_image is not None):
+            # PhysicalVerbalEmbedder.process (:976-983): a fully annotated sample brings its reasoning text along
+            extra["physical_txt"] = (f"Middle Transition Prompt: {(triplet or {}).get('middle_transition_prompt', '')}\n"
+                                     f"Final State Prompt: {(triplet or {}).get('final_state_prompt', '')}")
         posi, nega = self.prompt_encoder(self, prompt=prompt, negative_prompt=negative_prompt, edit_image=resized_edit,
-                                         cfg=use_cfg, have_text_reasoning=have_text_reasoning)
+                                         cfg=use_cfg, have_text_reasoning=have_text_reasoning, **extra)
         pe_p = posi["prompt_emb"].to(device=self.device, dtype=self.torch_dtype).contiguous()
         m_p = posi.get("special_token_mask") if self.use_special_tokens else None
         pe_n = m_n = None

@@ -70,6 +70,20 @@ def test_prologue_cache_returns_private_copies(prologue, monkeypatch):
         prologue(None, **{**kw, "edit_image": tiny_vl.make_image(96, 64, 6)})
 
 
+def test_prologue_takes_a_supplied_physical_text(prologue, monkeypatch):
+    """PhysicalVerbalEmbedder.process (:976-983): a fully annotated sample brings its reasoning text; nothing is generated, and the
+    text extends the positive prompt exactly like a generated one."""
+    img = tiny_vl.make_image(96, 96, 7)
+    prologue._cache.clear()
+    monkeypatch.setattr(prologue, "physical_text", lambda *a, **k: (_ for _ in ()).throw(AssertionError("generate() called")))
+    txt = "Middle Transition Prompt: the ice softens\nFinal State Prompt: a puddle"
+    posi, nega = prologue(None, prompt="melt the ice", negative_prompt="", edit_image=img, cfg=True, have_text_reasoning=True,
+                          physical_txt=txt)
+    assert prologue.last_physical_txt == txt
+    ref = prologue.embed("melt the ice", img, txt)
+    assert torch.equal(posi["prompt_emb"], ref["prompt_emb"]) and nega["prompt_emb"].shape[1] < posi["prompt_emb"].shape[1]
+
+
 def test_parse_generation_response():
     ok = PP.parse_generation_response('noise {"middle_transition_prompt": " the vase tips "} trailing')
     assert ok == {"middle_transition_prompt": "the vase tips"}
