@@ -540,7 +540,12 @@ class PromptPrologue:
     def generate_ids(self, model_inputs, max_new_tokens: int):
         """`text_encoder.generate(**model_inputs, max_new_tokens=...)`: through the captured decode step when the encoder qualifies
         (bf16 on the GPU, greedy), through transformers otherwise."""
-        if self.graph_decoder is not None and not getattr(self.text_encoder.generation_config, "do_sample", False):
+        gen = self.text_encoder.generation_config
+        plain_greedy = (not getattr(gen, "do_sample", False) and (getattr(gen, "num_beams", 1) or 1) == 1
+                        and (getattr(gen, "repetition_penalty", None) or 1.0) == 1.0
+                        and not getattr(gen, "no_repeat_ngram_size", 0) and not getattr(gen, "bad_words_ids", None)
+                        and not getattr(gen, "suppress_tokens", None) and not getattr(gen, "forced_eos_token_id", None))
+        if self.graph_decoder is not None and plain_greedy and model_inputs["input_ids"].shape[0] == 1:
             return self.graph_decoder.generate(max_new_tokens=max_new_tokens, **model_inputs)
         return self.text_encoder.generate(**model_inputs, max_new_tokens=max_new_tokens)
 
