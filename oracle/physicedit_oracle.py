@@ -310,6 +310,57 @@ def adapter_forward(ad: SD, x: torch.Tensor, timestep: torch.Tensor, t_min: floa
     return mixed, pred_dino, pred_vae
 
 
+# ---- training-time prior (QwenImageUnit_PhysicalVisualEmbedder.process, :1060-1118, after DINOv2 / the VAE have run) ------------------
+def perceiver_resampler(sd: SD, p: str, x: torch.Tensor, heads: int = 8) -> torch.Tensor:
+    """PerceiverResampler.forward (pipelines/helpers.py:92-109) with PerceiverAttention (:21-64) and FeedForward (:8-19); x [1, n, dim]."""
+    dim = x.shape[-1]
+    n = x.shape[1]
+    latents = sd[p + "latents"].unsqueeze(0)
+    x = x + sd[p + "pos_emb.weight"][torch.arange(n)]
+    i = 0
+    while f"{p}layers.{i}.0.to_q.weight" in sd:
+        a, f = f"{p}layers.{i}.0.", f"{p}layers.{i}.1.net."
+        xm = F.layer_norm(x, (dim,), sd[a + "norm_media.weight"], sd[a + "norm_media.bias"])
+        lt = F.layer_norm(latents, (dim,), sd[a + "norm_latents.weight"], sd[a + "norm_latents.bias"])
+        q = F.linear(lt, sd[a + "to_q.weight"])
+        k, v = F.linear(torch.cat((xm, lt), dim=1), sd[a + "to_kv.weight"]).chunk(2, dim=-1)
+        split = lambda t: t.view(1, t.shape[1], heads, -1).permute(0, 2, 1, 3)
+        q, k, v = split(q), split(k), split(v)
+        dots = torch.einsum("b h i d, b h j d -> b h i j", q, k) * (q.shape[-1] ** -0.5)
+        dots = dots - dots.amax(dim=-1, keepdim=True).detach()
+        attn = dots.softmax(dim=-1)
+        out = torch.einsum("b h i j, b h j d -> b h i d", attn, v)
+        out = out.permute(0, 2, 1, 3).reshape(1, out.shape[2], -1)
+        latents = latents + F.linear(out, sd[a + "to_out.weight"])
+        h = F.layer_norm(latents, (dim,), sd[f + "0.weight"], sd[f + "0.bias"])
+        h = F.gelu(F.linear(h, sd[f + "1.weight"], sd[f + "1.bias"]))
+        latents = latents + F.linear(h, sd[f + "3.weight"], sd[f + "3.bias"])
+        i += 1
+    return F.layer_norm(latents, (dim,), sd[p + "norm.weight"], sd[p + "norm.bias"])
+
+
+def resampler_adapter(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    # VisualThinkingAdapter.forward, helpers.py:111-120
+    return F.linear(F.gelu(F.linear(x, sd[p + "net.0.weight"], sd[p + "net.0.bias"])), sd[p + "net.2.weight"], sd[p + "net.2.bias"])
+
+
+def visual_prior(sd: SD, dino_middle: torch.Tensor, dino_source: torch.Tensor, lat_middle: torch.Tensor, lat_source: torch.Tensor):
+    """QwenImageUnit_PhysicalVisualEmbedder.process (:1071-1118) from the DINOv2 patch features of the key frames [B, L, 768] / of the
+    source image [1, L, 768] and their VAE latents [B, 16, h, w] / [1, 16, h, w] on: frame-index embedding, frames concatenated
+    along the sequence, resampler + adapter, middle - source.  -> (pseudo_special_emb_dino, pseudo_special_emb_vae) [1, 64, 3584]."""
+    B = dino_middle.shape[0]
+    dm = dino_middle + sd["dino_time_embed.weight"][torch.arange(B)].unsqueeze(1)
+    dm = dm.reshape(1, -1, dm.shape[-1])
+    d_mid = resampler_adapter(sd, "dino_resampler_adapter.", perceiver_resampler(sd, "dino_resampler.", dm))
+    d_src = resampler_adapter(sd, "dino_resampler_adapter.", perceiver_resampler(sd, "dino_resampler.", dino_source.reshape(1, -1, 768)))
+    pat = lambda z: z.reshape(z.shape[0], 16, z.shape[2] // 2, 2, z.shape[3] // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(z.shape[0], -1, 64)
+    vm = pat(lat_middle) + sd["vae_time_embed.weight"][torch.arange(B)].unsqueeze(1)
+    vm = vm.reshape(1, -1, 64)
+    v_mid = resampler_adapter(sd, "vae_resampler_adapter.", perceiver_resampler(sd, "vae_resampler.", vm))
+    v_src = resampler_adapter(sd, "vae_resampler_adapter.", perceiver_resampler(sd, "vae_resampler.", pat(lat_source).reshape(1, -1, 64)))
+    return d_mid - d_src, v_mid - v_src
+
+
 def adapter_get_loss(pred_dino, pred_vae, gt_dino, gt_vae, timestep, t_min: float, t_max: float, epsilon: float = 0.1):
     # VisualThinkingDualAdapter.get_loss, helpers.py:166-183
     alpha = adapter_alpha(timestep, t_min, t_max).type_as(pred_dino)

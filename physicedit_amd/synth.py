@@ -112,6 +112,33 @@ def adapter_layout() -> List[Tuple[str, Shape]]:
     return out
 
 
+def _resampler_layout(prefix: str, dim: int, max_media: int, depth: int = 2, heads: int = 8, dim_head: int = 64,
+                      num_latents: int = 64) -> List[Tuple[str, Shape]]:
+    inner = heads * dim_head
+    out: List[Tuple[str, Shape]] = [(prefix + "latents", (num_latents, dim)), (prefix + "pos_emb.weight", (max_media, dim))]
+    for i in range(depth):
+        a, f = f"{prefix}layers.{i}.0.", f"{prefix}layers.{i}.1.net."
+        out += [(a + "norm_media.weight", (dim,)), (a + "norm_media.bias", (dim,)), (a + "norm_latents.weight", (dim,)),
+                (a + "norm_latents.bias", (dim,)), (a + "to_q.weight", (inner, dim)), (a + "to_kv.weight", (2 * inner, dim)),
+                (a + "to_out.weight", (dim, inner)),
+                (f + "0.weight", (dim,)), (f + "0.bias", (dim,)), (f + "1.weight", (4 * dim, dim)), (f + "1.bias", (4 * dim,)),
+                (f + "3.weight", (dim, 4 * dim)), (f + "3.bias", (dim,))]
+    out += [(prefix + "norm.weight", (dim,)), (prefix + "norm.bias", (dim,))]
+    return out
+
+
+def prior_layout() -> List[Tuple[str, Shape]]:
+    """The training-time prior modules of QwenImagePhysicPipeline (pipelines/qwen_image_physical.py:205-219): two
+    PerceiverResamplers (pipelines/helpers.py:66-109; dim 768 over DINOv2 patch tokens, dim 64 over patchified VAE latents; 64 latents,
+    depth 2, 8 heads of 64), their frame-index embeddings and the two VisualThinkingAdapters (helpers.py:111-120) into the text width."""
+    out = _resampler_layout("dino_resampler.", 768, 4096) + [("dino_time_embed.weight", (6, 768))]
+    out += _resampler_layout("vae_resampler.", 64, 10240) + [("vae_time_embed.weight", (6, 64))]
+    for name, dim in (("dino_resampler_adapter", 768), ("vae_resampler_adapter", 64)):
+        out += [(f"{name}.net.0.weight", (3 * TXT_DIM, dim)), (f"{name}.net.0.bias", (3 * TXT_DIM,)),
+                (f"{name}.net.2.weight", (TXT_DIM, 3 * TXT_DIM)), (f"{name}.net.2.bias", (TXT_DIM,))]
+    return out
+
+
 def _vae_res(prefix: str, cin: int, cout: int) -> List[Tuple[str, Shape]]:
     out: List[Tuple[str, Shape]] = [
         (prefix + "norm1.gamma", (cin, 1, 1, 1)),

@@ -582,6 +582,49 @@ def G17_special_token_loss():
     save("G17_special_token_loss", outs, meta={"h": h, "w": w, "T": T, "n_special": nsp, "gt_seed": 170, "timesteps": list(tvals)})
 
 
+def G18_visual_prior():
+    """The training-time prior after DINOv2 / the VAE (QwenImageUnit_PhysicalVisualEmbedder.process, :1071-1118) on the reference's own
+    PerceiverResampler / VisualThinkingAdapter / nn.Embedding modules with synthetic weights: 3 key frames, DINOv2-shaped features
+    [3, 256, 768] and 96 x 160 px frames (latents [3, 16, 12, 20])."""
+    from einops import rearrange
+    from diffsynth.pipelines.helpers import PerceiverResampler, VisualThinkingAdapter
+    sd = synth.make_state_dict(synth.prior_layout(), 1818)
+    mods = {}
+    with torch.device("meta"):
+        mods["dino_resampler"] = PerceiverResampler(dim=768, num_latents=64, depth=2)
+        mods["vae_resampler"] = PerceiverResampler(dim=64, num_latents=64, depth=2, max_num_media_tokens=10240)
+        mods["dino_resampler_adapter"] = VisualThinkingAdapter(in_dim=768, out_dim=3584)
+        mods["vae_resampler_adapter"] = VisualThinkingAdapter(in_dim=64, out_dim=3584)
+        mods["dino_time_embed"] = torch.nn.Embedding(6, 768)
+        mods["vae_time_embed"] = torch.nn.Embedding(6, 64)
+    for name, m in mods.items():
+        m.load_state_dict({k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + ".")}, assign=True, strict=True)
+        m.eval()
+    g = torch.Generator().manual_seed(181)
+    B = 3
+    dino_mid = torch.randn((B, 256, 768), generator=g).to(BF)
+    dino_src = torch.randn((1, 256, 768), generator=g).to(BF)
+    lat_mid = torch.randn((B, 16, 12, 20), generator=g).to(BF)
+    lat_src = torch.randn((1, 16, 12, 20), generator=g).to(BF)
+    # :1071-1088
+    st = dino_mid + mods["dino_time_embed"](torch.arange(B)).unsqueeze(1)
+    st = rearrange(st, "B L H -> 1 (B L) H")
+    res_mid = mods["dino_resampler"](st)
+    d_mid = mods["dino_resampler_adapter"](res_mid)
+    d_src = mods["dino_resampler_adapter"](mods["dino_resampler"](rearrange(dino_src, "B L H -> 1 (B L) H")))
+    pseudo_dino = d_mid - d_src
+    # :1094-1116
+    mp = rearrange(lat_mid, "B C (H P) (W Q) -> B (H W) (C P Q)", H=lat_mid.shape[2] // 2, W=lat_mid.shape[3] // 2, P=2, Q=2)
+    mp = mp + mods["vae_time_embed"](torch.arange(B)).unsqueeze(1)
+    mp = rearrange(mp, "B L H -> 1 (B L) H")
+    v_mid = mods["vae_resampler_adapter"](mods["vae_resampler"](mp))
+    sp = rearrange(lat_src, "B C (H P) (W Q) -> B (H W) (C P Q)", H=lat_src.shape[2] // 2, W=lat_src.shape[3] // 2, P=2, Q=2)
+    v_src = mods["vae_resampler_adapter"](mods["vae_resampler"](rearrange(sp, "B L H -> 1 (B L) H")))
+    pseudo_vae = v_mid - v_src
+    save("G18_visual_prior", {"dino_resampled_middle": res_mid, "pseudo_dino": pseudo_dino, "pseudo_vae": pseudo_vae},
+         meta={"weights_seed": 1818, "inputs_seed": 181, "frames": B, "lat_h": 12, "lat_w": 20})
+
+
 def G10_image():
     ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
     ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")

@@ -300,6 +300,28 @@ def test_G17_special_token_loss(golden):
     assert len({float(g[f"loss_{i}"]) for i in range(3)}) == 3         # the weighting moves with the timestep
 
 
+def _prior_inputs(meta):
+    g = torch.Generator().manual_seed(meta["inputs_seed"])
+    B = meta["frames"]
+    return (torch.randn((B, 256, 768), generator=g).to(BF), torch.randn((1, 256, 768), generator=g).to(BF),
+            torch.randn((B, 16, meta["lat_h"], meta["lat_w"]), generator=g).to(BF),
+            torch.randn((1, 16, meta["lat_h"], meta["lat_w"]), generator=g).to(BF))
+
+
+def test_G18_visual_prior(golden):
+    """The training-time prior after DINOv2 / the VAE (PhysicalVisualEmbedder.process :1071-1118: frame embeddings, two Perceiver
+    resamplers, two adapters, middle - source) against the reference's own modules, bit for bit."""
+    g, meta = golden("G18_visual_prior", with_meta=True)
+    sd = synth.make_state_dict(synth.prior_layout(), meta["weights_seed"])
+    dino_mid, dino_src, lat_mid, lat_src = _prior_inputs(meta)
+    B = meta["frames"]
+    dm = (dino_mid + sd["dino_time_embed.weight"][torch.arange(B)].unsqueeze(1)).reshape(1, -1, 768)
+    assert_same(O.perceiver_resampler(sd, "dino_resampler.", dm), g["dino_resampled_middle"], "dino resampler")
+    pd, pv = O.visual_prior(sd, dino_mid, dino_src, lat_mid, lat_src)
+    assert_same(pd, g["pseudo_dino"], "pseudo_special_emb_dino")
+    assert_same(pv, g["pseudo_vae"], "pseudo_special_emb_vae")
+
+
 def test_G7_vae(golden):
     g = golden("G7_vae")
     vs = synth.make_state_dict(synth.vae_layout(), 77)
