@@ -141,6 +141,17 @@ int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, cons
 
 /* RMSNorm with weight over rows of width 3584 (txt_norm; models/utils.py:250-257). */
 int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float eps, void* stream);
+/* Small operators of the training-time prior (QwenImageUnit_PhysicalVisualEmbedder, pipelines/
+ * qwen_image_physical.py:1071-1118 -> PerceiverResampler, pipelines/helpers.py:8-109); its Linears are pe_gemm_bf16 launches.
+ * pe_add_bf16: x = bf16(x + sign * y), sign = +1 / -1 (positional / frame embeddings, residuals, `middle - source`), n % 8 == 0.
+ * pe_layernorm_affine: nn.LayerNorm(dim) with weight and bias, fp32 statistics, one rounding; dim % 8 == 0.
+ * pe_perceiver_attention: PerceiverAttention's core for heads of 64 (helpers.py:52-62): q [n_queries, heads*64], kv [n_keys,
+ *   2*heads*64] (keys | values), out [n_queries, heads*64]; dots, scaled dots, dots - max, softmax and the result are each rounded
+ *   to bf16 as the reference's tensor ops round them.  n_keys <= 15360. */
+int pe_add_bf16(void* x, const void* y, size_t n, float sign, void* stream);
+int pe_layernorm_affine(const void* x, const void* weight, const void* bias, void* out, int rows, int dim, float eps, void* stream);
+int pe_perceiver_attention(const void* q, const void* kv, void* out, int n_queries, int n_keys, int heads, float scale, void* stream);
+
 /* nn.Linear applied to ONE row: y[N] = bf16(W[N,K] . x[K] + bias[N]) (fp32 accumulation, one rounding), bias nullable, K % 8 == 0.
  * The HBM-bound shape of autoregressive decoding: used by the prompt prologue (Qwen2.5-VL `generate`,
  * pipelines/qwen_image_physical.py:859-873) in place of the BLAS GEMV behind torch.nn.functional.linear. */

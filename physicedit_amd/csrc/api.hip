@@ -155,6 +155,19 @@ int pe_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void
     return launch_dual_rmsnorm_add(x, wx, y, wy, out, rows, dim, eps, (hipStream_t)stream);
 }
 
+int pe_add_bf16(void* x, const void* y, size_t n, float sign, void* stream) {
+    PE_REQUIRE(sign == 1.0f || sign == -1.0f, "pe_add_bf16: sign must be +1 or -1");
+    return launch_add_inplace(x, y, n, (hipStream_t)stream, sign);
+}
+
+int pe_layernorm_affine(const void* x, const void* weight, const void* bias, void* out, int rows, int dim, float eps, void* stream) {
+    return launch_layernorm_affine(x, weight, bias, out, rows, dim, eps, (hipStream_t)stream);
+}
+
+int pe_perceiver_attention(const void* q, const void* kv, void* out, int n_queries, int n_keys, int heads, float scale, void* stream) {
+    return launch_perceiver_attn(q, kv, out, n_queries, n_keys, heads, scale, (hipStream_t)stream);
+}
+
 int pe_gemv_bf16(const void* x, const void* W, const void* bias, void* y, int N, int K, void* stream) {
     return launch_gemv(x, W, bias, y, N, K, (hipStream_t)stream);
 }

@@ -224,23 +224,128 @@ int launch_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const 
     return check_launch("dual_rmsnorm_add_kernel");
 }
 
-// x[i] = bf16(x[i] + y[i]) over n elements (n % 8 == 0)
-__global__ void __launch_bounds__(256) add_inplace_kernel(bf16* __restrict__ x, const bf16* __restrict__ y, size_t n8) {
+// x[i] = bf16(x[i] + sign * y[i]) over n elements (n % 8 == 0)
+__global__ void __launch_bounds__(256) add_inplace_kernel(bf16* __restrict__ x, const bf16* __restrict__ y, size_t n8, float sign) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
         bf16x8 a = *(const bf16x8*)(x + i * 8);
         const bf16x8 b = *(const bf16x8*)(y + i * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = (bf16)((float)a[j] + (float)b[j]);
+        for (int j = 0; j < 8; ++j) a[j] = (bf16)((float)a[j] + sign * (float)b[j]);
         *(bf16x8*)(x + i * 8) = a;
     }
 }
 
-int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream) {
+int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream, float sign) {
     PE_REQUIRE(x && y && n % 8 == 0, "add_inplace: null pointer or n %% 8 != 0");
     const size_t n8 = n / 8;
     const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, (bf16*)x, (const bf16*)y, n8);
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, (bf16*)x, (const bf16*)y, n8, sign);
     return check_launch("add_inplace_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// The two small kernels of the training-time prior's Perceiver resamplers (pipelines/helpers.py:8-109; row f2 of SURVEY.md section 8).
+// nn.LayerNorm with affine parameters: fp32 statistics (two passes over the row), (x - mean) * rstd * w + b, ONE rounding.  One wave
+// per row, any dim % 8 == 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) layernorm_affine_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                               const bf16* __restrict__ b, bf16* __restrict__ out, int rows, int dim,
+                                                               float eps) {
+    const int lane = lane_id();
+    const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16* xr = x + (size_t)row * dim;
+    float s = 0.f;
+    for (int c = lane * 8; c < dim; c += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)t[j];
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float v = 0.f;
+    for (int c = lane * 8; c < dim; c += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = (float)t[j] - mean;
+            v += d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)dim + eps);
+    for (int c = lane * 8; c < dim; c += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + c);
+        const bf16x8 wv = *(const bf16x8*)(w + c);
+        const bf16x8 bv = *(const bf16x8*)(b + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(((float)t[j] - mean) * rstd * (float)wv[j] + (float)bv[j]);
+        *(bf16x8*)(out + (size_t)row * dim + c) = o;
+    }
+}
+
+int launch_layernorm_affine(const void* x, const void* w, const void* b, void* out, int rows, int dim, float eps, hipStream_t stream) {
+    PE_REQUIRE(x && w && b && out && rows > 0 && dim > 0 && dim % 8 == 0, "layernorm_affine: bad arguments (rows=%d dim=%d)", rows, dim);
+    hipLaunchKernelGGL(layernorm_affine_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (const bf16*)w,
+                       (const bf16*)b, (bf16*)out, rows, dim, eps);
+    return check_launch("layernorm_affine_kernel");
+}
+
+// PerceiverAttention core (helpers.py:52-62) for heads of 64: q [nq, H*64], kv [nk, 2*H*64] (keys in the first H*64 columns, values
+// in the last), out [nq, H*64].  The reference materialises every intermediate in bf16, and so does this: dots = bf16(q . k) (fp32
+// accumulation), * scale -> bf16, - row max -> bf16, softmax in fp32 -> bf16, attn . v -> bf16.  One work-group per (head, query): the
+// whole problem is 64 queries x <= 10 k keys.
+__global__ void __launch_bounds__(256) perceiver_attn_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kv,
+                                                             bf16* __restrict__ out, int nk, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char pa_smem[];
+    float* sc = (float*)pa_smem;                   // [nk]
+    __shared__ float qs[64];
+    __shared__ float red[8];
+    __shared__ float part[4][64];
+    const int h = (int)blockIdx.x, qi = (int)blockIdx.y, t = (int)threadIdx.x;
+    const int ldq = H * 64, ldkv = 2 * H * 64;
+    if (t < 64) qs[t] = (float)q[(size_t)qi * ldq + h * 64 + t];
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = t; j < nk; j += 256) {
+        const bf16* kr = kv + (size_t)j * ldkv + h * 64;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bf16x8 k8 = *(const bf16x8*)(kr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qs[c * 8 + e], (float)k8[e], acc);
+        }
+        const float s = bf16r(bf16r(acc) * scale);
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = t; j < nk; j += 256) {
+        const float p = __expf(bf16r(sc[j] - mx));
+        sc[j] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) red[4 + (t >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    const int d = t & 63, grp = t >> 6;
+    float o = 0.f;
+    for (int j = grp; j < nk; j += 4) o = __builtin_fmaf(bf16r(sc[j] * inv), (float)kv[(size_t)j * ldkv + H * 64 + h * 64 + d], o);
+    part[grp][d] = o;
+    __syncthreads();
+    if (t < 64) out[(size_t)qi * ldq + h * 64 + t] = (bf16)(part[0][t] + part[1][t] + part[2][t] + part[3][t]);
+}
+
+int launch_perceiver_attn(const void* q, const void* kv, void* out, int nq, int nk, int heads, float scale, hipStream_t stream) {
+    PE_REQUIRE(q && kv && out && nq > 0 && nk > 0 && nk <= 15360 && heads > 0, "perceiver_attn: bad arguments (nq=%d nk=%d)", nq, nk);
+    hipLaunchKernelGGL(perceiver_attn_kernel, dim3(heads, nq), dim3(256), (size_t)nk * 4, stream, (const bf16*)q, (const bf16*)kv,
+                       (bf16*)out, nk, heads, scale);
+    return check_launch("perceiver_attn_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -376,3 +376,32 @@ def gemv_swiglu_norm(x, norm_w, eps: float, wg, wu) -> torch.Tensor:
     check(lib().pe_gemv_swiglu_norm_bf16(x.data_ptr(), norm_w.data_ptr(), float(eps), wg.data_ptr(), wu.data_ptr(), out.data_ptr(),
                                          N, K, stream_ptr()), "pe_gemv_swiglu_norm_bf16")
     return out
+
+
+# ---- small operators of the training-time prior (row f2) ------------------------------------------------------------------------
+def add_(x: torch.Tensor, y: torch.Tensor, sign: float = 1.0) -> torch.Tensor:
+    """x = bf16(x + sign * y) in place (same shape, numel % 8 == 0)."""
+    _chk(x, "x"), _chk(y, "y")
+    assert x.shape == y.shape
+    check(lib().pe_add_bf16(x.data_ptr(), y.data_ptr(), x.numel(), float(sign), stream_ptr()), "pe_add_bf16")
+    return x
+
+
+def layernorm_affine(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _chk(x, "x"), _chk(w, "w"), _chk(b, "b")
+    rows, dim = x.shape
+    out = torch.empty_like(x)
+    check(lib().pe_layernorm_affine(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), rows, dim, float(eps), stream_ptr()),
+          "pe_layernorm_affine")
+    return out
+
+
+def perceiver_attention(q: torch.Tensor, kv: torch.Tensor, heads: int = 8) -> torch.Tensor:
+    """q [nq, heads*64], kv [nk, 2*heads*64] -> [nq, heads*64] (PerceiverAttention core, helpers.py:52-62)."""
+    _chk(q, "q"), _chk(kv, "kv")
+    nq, nk = q.shape[0], kv.shape[0]
+    assert q.shape[1] == heads * 64 and kv.shape[1] == 2 * heads * 64
+    out = torch.empty_like(q)
+    check(lib().pe_perceiver_attention(q.data_ptr(), kv.data_ptr(), out.data_ptr(), nq, nk, heads, 64 ** -0.5, stream_ptr()),
+          "pe_perceiver_attention")
+    return out

@@ -257,6 +257,38 @@ def test_special_token_loss_G17(golden, eng2):
                             prompt_emb=pe.cuda().clone(), special_token_mask=mask, height=meta["h"], width=meta["w"], is_train=True)
 
 
+def test_visual_prior_G18(golden):
+    """Training-time prior after the encoders (row f2): frame embeddings, two Perceiver resamplers, two adapters, middle - source on
+    the library's kernels vs the reference's own modules (fixture G18).  Four LayerNorms, two bf16-materialised softmaxes and eight
+    Linears deep; the yardstick is an fp32 evaluation of the same graph."""
+    from physicedit_amd.prior import PhysicalVisualPrior
+    from test_oracle_golden import _prior_inputs
+    g, meta = golden("G18_visual_prior", with_meta=True)
+    sd = synth.make_state_dict(synth.prior_layout(), meta["weights_seed"])
+    dino_mid, dino_src, lat_mid, lat_src = _prior_inputs(meta)
+    prior = PhysicalVisualPrior(sd, device="cuda")
+    B = meta["frames"]
+    res = prior.dino_resampler.forward(prior._frames(dino_mid, prior.dino_time))
+    d, u = stats("dino resampler (middle frames)", res, g["dino_resampled_middle"][0])
+    sd32 = {k: v.float() for k, v in sd.items()}
+    dm32 = (dino_mid.float() + sd32["dino_time_embed.weight"][torch.arange(B)].unsqueeze(1)).reshape(1, -1, 768)
+    res32 = O.perceiver_resampler(sd32, "dino_resampler.", dm32)[0]
+    r_hip = (res.float().cpu() - res32).pow(2).mean().sqrt().item()
+    r_ref = (g["dino_resampled_middle"][0].float() - res32).pow(2).mean().sqrt().item()
+    print(f"[parity] dino resampler: rms distance to fp32: hip {r_hip:.4e}  reference-bf16 {r_ref:.4e}")
+    assert u.max().item() <= 16.0 and r_hip <= 1.25 * r_ref + 1e-5
+    pd, pv = prior(dino_mid, dino_src, lat_mid, lat_src)
+    pd32, pv32 = O.visual_prior(sd32, dino_mid.float(), dino_src.float(), lat_mid.float(), lat_src.float())
+    for name, got, ref, ref32 in (("pseudo_special_emb_dino", pd, g["pseudo_dino"], pd32), ("pseudo_special_emb_vae", pv, g["pseudo_vae"], pv32)):
+        e_hip = (got.float().cpu() - ref32).pow(2).mean().sqrt().item()
+        e_ref = (ref.float() - ref32).pow(2).mean().sqrt().item()
+        dd = (got.float().cpu() - ref.float()).abs()
+        print(f"[parity] {name}: rms distance to fp32: hip {e_hip:.4e}  reference-bf16 {e_ref:.4e}; vs reference max|d| {dd.max().item():.3e} "
+              f"mean|d| {dd.mean().item():.3e} (|ref| mean {ref.float().abs().mean().item():.3e})")
+        assert got.shape == ref.shape and torch.isfinite(got.float()).all()
+        assert e_hip <= 1.25 * e_ref + 1e-5
+
+
 def test_lora_merge_G8(golden):
     from physicedit_amd.dit import QwenImageDiTEngine
     g, meta = golden("G8_lora", with_meta=True)

@@ -524,3 +524,38 @@ def test_fused_rmsnorm_single_row_forms(ops):
     q1 = ops.decode_step_qkv(x, wq, None, wk, None, wv, None, cs, sn, kc1, vc1, step, 3, norm_w=nw, eps=1e-6)
     q2 = ops.decode_step_qkv(xn, wq, None, wk, None, wv, None, cs, sn, kc2, vc2, step, 3)
     assert torch.equal(q1, q2) and torch.equal(kc1, kc2) and torch.equal(vc1, vc2) and kc1[:, 5].abs().sum() > 0
+
+
+@pytest.mark.parametrize("rows,dim", [(64, 768), (832, 768), (304, 64), (7, 3072)])
+def test_layernorm_affine(ops, rows, dim):
+    """pe_layernorm_affine vs torch.nn.functional.layer_norm on bf16 tensors (fp32 statistics, one rounding)."""
+    x, w, b = rnd((rows, dim), 141) * 1.7 + 0.3, (1.0 + 0.1 * rnd((dim,), 142).float()).to(BF), (0.1 * rnd((dim,), 143).float()).to(BF)
+    ref = F.layer_norm(x, (dim,), w, b)
+    out = ops.layernorm_affine(x.cuda(), w.cuda(), b.cuda())
+    report(f"layernorm_affine {rows}x{dim}", out, ref, 1.01, 0.02)
+
+
+@pytest.mark.parametrize("nk", [64 + 64, 768 + 64, 5000])
+def test_perceiver_attention(ops, nk):
+    """pe_perceiver_attention vs PerceiverAttention's core with the reference's bf16-materialised intermediates (helpers.py:52-62)."""
+    H, nq = 8, 64
+    q, kv = rnd((nq, H * 64), 151), rnd((nk, 2 * H * 64), 152)
+    k, v = kv[:, :H * 64], kv[:, H * 64:]
+    split = lambda t: t.view(1, t.shape[0], H, 64).permute(0, 2, 1, 3)
+    def run(dt):
+        qq, kk, vv = split(q.to(dt)), split(k.to(dt)), split(v.to(dt))
+        dots = torch.einsum("b h i d, b h j d -> b h i j", qq, kk) * (64 ** -0.5)
+        dots = dots - dots.amax(dim=-1, keepdim=True)
+        o = torch.einsum("b h i j, b h j d -> b h i d", dots.softmax(dim=-1), vv)
+        return o.permute(0, 2, 1, 3).reshape(nq, H * 64)
+    ref, ref32 = run(BF), run(torch.float32)
+    out = ops.perceiver_attention(q.cuda(), kv.cuda(), H)
+    e_hip = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
+    e_ref = (ref.float() - ref32).pow(2).mean().sqrt().item()
+    print(f"[parity] perceiver attention nk={nk}: rms distance to fp32: hip {e_hip:.3e}  torch-bf16 {e_ref:.3e}")
+    assert torch.isfinite(out.float()).all() and e_hip <= 1.25 * e_ref + 1e-5
+
+
+def test_add_signed(ops):
+    x, y = rnd((3, 40), 161), rnd((3, 40), 162)
+    assert torch.equal(ops.add_(x.cuda().clone(), y.cuda(), -1.0).cpu(), x - y) and torch.equal(ops.add_(x.cuda().clone(), y.cuda()).cpu(), x + y)
