@@ -92,7 +92,11 @@ class QwenImagePhysicPipeline:
         self.torch_dtype = torch_dtype
         self.height_division_factor = 16
         self.width_division_factor = 16
-        self.dinov2_path = dinov2_path          # DINOv2 is only executed when is_train=True (training): unused here
+        self.dinov2_path = dinov2_path          # DINOv2 is only executed when is_train=True (the training-time prior)
+        self.dinov2 = None                      # transformers Dinov2WithRegistersModel (or any module: frames [B,3,224,224] -> [B,L,768])
+        self.dino_input_size = 224              # (:213)
+        self._prior = None                      # physicedit_amd.prior.PhysicalVisualPrior, built from extra_state on first use
+        self.last_pseudo_special_emb = None
         self.scheduler = qwen_image_scheduler()  # (:192)
         self.dit: Optional[QwenImageDiTEngine] = None
         self.vae: Optional[QwenImageVAE] = None
@@ -277,6 +281,63 @@ class QwenImagePhysicPipeline:
             return self.vae.encode(self.preprocess_image(image))       # exotic modes: the stand-alone map
         return self.vae.encode(torch.from_numpy(np.ascontiguousarray(u8)).to(self.device))
 
+    # ---- QwenImageUnit_PhysicalVisualEmbedder (:992-1120): the training-time prior.  DINOv2 is `transformers` code on PyTorch-ROCm
+    # (third party, like the text encoder); what follows it runs on the library (physicedit_amd/prior.py).
+    def _load_dinov2(self):
+        if self.dinov2 is None:
+            if self.dinov2_path is None:
+                raise _lib.PeError("is_train=True needs DINOv2: pass dinov2_path= to from_pretrained() or set pipe.dinov2")
+            from transformers import Dinov2WithRegistersModel
+            enc = Dinov2WithRegistersModel.from_pretrained(self.dinov2_path, local_files_only=True)
+            enc.layernorm.elementwise_affine = False          # Dinov2withNorm (pipelines/dinov2.py:21-24)
+            enc.layernorm.weight = None
+            enc.layernorm.bias = None
+            self.dinov2 = enc.to(device=self.device, dtype=self.torch_dtype).eval().requires_grad_(False)
+        return self.dinov2
+
+    def dino_input_preprocess(self, frames, dino_input_size: int = None) -> torch.Tensor:
+        """dino_input_preprocess (:1043-1057): torchvision Resize(1.5 * size, BICUBIC) on the shorter edge, RandomCrop(size), ToTensor,
+        ImageNet mean / std.  torchvision is not in this image: restated with PIL (what torchvision's Resize calls for PIL inputs)
+        and torch.randint for the crop offsets (RandomCrop.get_params) -- parity unpinned, and random by construction."""
+        size = dino_input_size or self.dino_input_size
+        first = int(size * 1.5)
+        out = []
+        for im in frames:
+            w, h = im.size
+            nw, nh = (first, int(first * h / w)) if w <= h else (int(first * w / h), first)
+            im = im.convert("RGB").resize((nw, nh), Image.BICUBIC)
+            i = int(torch.randint(0, nh - size + 1, size=(1,)).item())
+            j = int(torch.randint(0, nw - size + 1, size=(1,)).item())
+            t = torch.from_numpy(np.array(im.crop((j, i, j + size, i + size)), dtype=np.uint8)).permute(2, 0, 1).to(torch.float32).div(255)
+            out.append(t)
+        x = torch.stack(out).to(self.device)
+        mean = torch.tensor([0.485, 0.456, 0.406], device=self.device).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=self.device).view(1, 3, 1, 1)
+        return (x - mean) / std
+
+    def _dino_features(self, pixels: torch.Tensor) -> torch.Tensor:
+        enc = self._load_dinov2()
+        out = enc(pixels.to(next(enc.parameters()).dtype))
+        hs = out.last_hidden_state if hasattr(out, "last_hidden_state") else out
+        return hs[:, 5:] if hasattr(out, "last_hidden_state") else hs       # 1 CLS + 4 register tokens dropped (dinov2.py:30-31)
+
+    def physical_visual_embedder(self, middle_key_frames, edit_image):
+        """-> (pseudo_special_emb_dino, pseudo_special_emb_vae), the targets of model_fn's special-token loss (:1060-1118)."""
+        if self._prior is None:
+            from physicedit_amd import synth
+            from physicedit_amd.prior import PhysicalVisualPrior
+            need = [k for k, _ in synth.prior_layout()]
+            missing = [k for k in need if k not in self.extra_state]
+            if missing:
+                raise _lib.PeError(f"is_train=True: the checkpoint has no training-time prior weights (missing e.g. {missing[:3]})")
+            self._prior = PhysicalVisualPrior({k: self.extra_state[k] for k in need}, device=self.device)
+        frames = list(middle_key_frames)
+        dino_mid = self._dino_features(self.dino_input_preprocess(frames))
+        dino_src = self._dino_features(self.dino_input_preprocess([edit_image]))
+        lat_mid = torch.cat([self._encode_image(f) for f in frames])
+        lat_src = self._encode_image(edit_image)
+        return self._prior(dino_mid, dino_src, lat_mid, lat_src)
+
     # ---- QwenImageUnit_Inpaint (:714-729): one [1,1,H/8,W/8] plane of host arithmetic per image
     def preprocess_inpaint_mask(self, inpaint_mask, height: int, width: int, blur_size=None, blur_sigma=None):
         """mask.convert("RGB").resize((W/8, H/8)) -> [0, 1] in the pipeline dtype -> mean over RGB -> optional Gaussian blur
@@ -368,8 +429,9 @@ class QwenImagePhysicPipeline:
             raise _lib.PeError("blockwise_controlnet_inputs given but no block-wise ControlNet checkpoint was loaded")
         if enable_fp8_attention:
             raise _lib.PeError("enable_fp8_attention (FlashAttention-3 fp8 on Hopper in the reference) is not implemented")
-        if is_train and self.use_special_tokens:
-            raise _lib.PeError("is_train=True runs the DINOv2/resampler training path; inference scripts pass is_train=False")
+        if is_train and self.use_special_tokens and (middle_key_frames is None or not isinstance(edit_image, Image.Image)):
+            raise _lib.PeError("is_train=True runs the training-time prior (PhysicalVisualEmbedder, :992-1120) and needs "
+                               "middle_key_frames and one edit_image; inference scripts pass is_train=False")
         if self.dit is None or self.vae is None:
             raise _lib.PeError("pipeline has no DiT/VAE weights: use from_pretrained() or set_dit()/set_vae()")
         if self.prompt_encoder is None:
@@ -399,6 +461,11 @@ class QwenImagePhysicPipeline:
             images = [self._auto_resize(im) if edit_image_auto_resize else im for im in images]
             resized_edit = images[0] if isinstance(edit_image, Image.Image) else images
             edit_latents += [self._encode_image(im) for im in images]
+        if is_train and self.use_special_tokens:
+            # the unit the reference only runs with is_train=True (:632-633).  Its outputs feed model_fn's special_token_loss, which
+            # __call__ discards (:653: `noise_pred_posi, _ = ...`): the image is the one is_train=False gives; the targets are kept
+            # for the caller (training code evaluates model_fn_qwen_image(is_train=True, pseudo_special_emb_*=...) itself).
+            self.last_pseudo_special_emb = self.physical_visual_embedder(middle_key_frames, resized_edit)
         # prompt prologue (PhysicalVerbalEmbedder + PromptEmbedder in the reference, :732-990): host code
         use_cfg = cfg_scale != 1.0
         extra = {}

@@ -455,3 +455,73 @@ def test_graph_decoder_matches_generate():
         ref3 = m.generate(input_ids=ids3, attention_mask=torch.ones_like(ids3), max_new_tokens=12, min_new_tokens=12)
     got3 = dec.generate(max_new_tokens=12, input_ids=ids3, attention_mask=torch.ones_like(ids3))
     assert torch.equal(ref3, got3)
+
+
+def test_is_train_runs_the_visual_prior_through_the_facade(tmp_path):
+    """`pipe(..., is_train=True, middle_key_frames=[...])` (the reference's default flag): the training-time unit
+    QwenImageUnit_PhysicalVisualEmbedder (:992-1120) runs -- DINOv2 through transformers (a 2-layer random one of the real width here),
+    everything after it on the library -- its targets match the oracle fed with the same encoder features, and the image is the
+    one is_train=False produces (the reference discards the loss in __call__, :653)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from safetensors.torch import save_file
+    from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+    from diffsynth.pipelines.qwen_image_physical import ModelConfig, QwenImagePhysicPipeline
+
+    H = W = 128
+    steps, T, nsp = 2, 40, 16
+    dit_sd = synth.make_state_dict(synth.dit_layout(2), 1234)
+    vae_sd = synth.make_state_dict(synth.vae_layout(), 77)
+    ad_sd = synth.make_state_dict(synth.adapter_layout(), 4321)
+    prior_sd = synth.make_state_dict(synth.prior_layout(), 1818)
+    base = tmp_path / "base"
+    for sub in ("dit", "vae"):
+        (base / "m" / sub).mkdir(parents=True)
+    save_file(dit_sd, str(base / "m/dit/model.safetensors"))
+    save_file(vae_sd, str(base / "m/vae/model.safetensors"))
+    pipe = QwenImagePhysicPipeline.from_pretrained(
+        torch_dtype=torch.bfloat16, device="cuda",
+        model_configs=[ModelConfig(model_id="m", origin_file_pattern=f"{sub}/model.safetensors", local_model_path=str(base))
+                       for sub in ("dit", "vae")], dinov2_path=None)
+    pipe.load_state_dict({**{"visual_thinking_adapter." + k: v for k, v in ad_sd.items()}, **prior_sd}, strict=False)
+    torch.manual_seed(3)
+    enc = Dinov2WithRegistersModel(Dinov2WithRegistersConfig(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, image_size=224,
+                                                             patch_size=14, num_register_tokens=4))
+    enc.layernorm.elementwise_affine, enc.layernorm.weight, enc.layernorm.bias = False, None, None
+    pipe.dinov2 = enc.to(device="cuda", dtype=torch.bfloat16).eval().requires_grad_(False)
+    pe_p, mask_p = synth.make_prompt_emb(7, T), synth.make_special_token_mask(T, nsp)
+    pe_n, mask_n = synth.make_prompt_emb(8, 24), synth.make_special_token_mask(24, nsp)
+
+    class StubPrologue:
+        def __call__(self, p, prompt, negative_prompt, edit_image, cfg, have_text_reasoning=True, **kw):
+            return ({"prompt_emb": pe_p.clone(), "special_token_mask": mask_p}, {"prompt_emb": pe_n.clone(), "special_token_mask": mask_n})
+    pipe.prompt_encoder = StubPrologue()
+    edit = Image.fromarray(synth.make_edit_image_u8(H, W, seed=31))
+    frames = [Image.fromarray(synth.make_edit_image_u8(96, 160, seed=40 + i)) for i in range(3)]
+    kw = dict(seed=0, num_inference_steps=steps, height=H, width=W, cfg_scale=3.0, edit_image=edit, edit_image_auto_resize=False,
+              have_text_reasoning=False)
+    with pytest.raises(Exception):
+        pipe("tilt the glass", is_train=True, **kw)                      # no key frames
+    torch.manual_seed(5)
+    pipe("tilt the glass", is_train=True, middle_key_frames=frames, **kw)
+    lat_train = pipe.last_latents.clone()
+    pd, pv = pipe.last_pseudo_special_emb
+    pipe("tilt the glass", is_train=False, **kw)
+    assert torch.equal(lat_train, pipe.last_latents)
+    # ---- oracle on the same encoder features (same crops: the same global RNG draws)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        dino_mid = pipe._dino_features(pipe.dino_input_preprocess(frames)).cpu()
+        dino_src = pipe._dino_features(pipe.dino_input_preprocess([edit])).cpu()
+    assert dino_mid.shape == (3, 256, 768)
+    O.VAE_CONV_MODE = "2d"
+    try:
+        lat_mid = torch.cat([O.vae_encode(vae_sd, O.preprocess_image(np.array(f))) for f in frames])
+        lat_src = O.vae_encode(vae_sd, O.preprocess_image(np.array(edit)))
+    finally:
+        O.VAE_CONV_MODE = "3d"
+    rd, rv = O.visual_prior(prior_sd, dino_mid, dino_src, lat_mid, lat_src)
+    for name, got, ref in (("pseudo_special_emb_dino", pd, rd), ("pseudo_special_emb_vae", pv, rv)):
+        dd = (got.float().cpu() - ref.float()).abs()
+        print(f"[parity] facade {name}: max|d| {dd.max().item():.3e} mean|d| {dd.mean().item():.3e} (|ref| mean {ref.float().abs().mean().item():.3e})")
+        assert got.shape == (1, 64, 3584) and dd.mean().item() <= 0.06 * ref.float().abs().mean().item()   # a difference of two close vectors: 2.8 % measured
