@@ -52,3 +52,23 @@ def test_entity_mask_preprocessing_matches_the_reference_unit(golden):
     pipe.device, pipe.torch_dtype = torch.device("cpu"), BF
     out = pipe.preprocess_entity_masks([Image.fromarray(g[f"unit_mask{i}"].numpy()) for i in range(2)], 12, 20)
     assert out.dtype == BF and torch.equal(out, g["unit_entity_masks"])
+
+
+def test_dino_input_preprocess_host():
+    """QwenImagePhysicPipeline.dino_input_preprocess (the torchvision pipeline of :1043-1057 restated with PIL + torch.randint): shape,
+    ImageNet normalisation, the crop is random but reproducible under the global torch seed, and lies inside the 1.5x resized frame."""
+    import numpy as np
+    from PIL import Image
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline
+    pipe = QwenImagePhysicPipeline.__new__(QwenImagePhysicPipeline)
+    pipe.device, pipe.torch_dtype, pipe.dino_input_size = torch.device("cpu"), torch.bfloat16, 224
+    rs = np.random.RandomState(0)
+    frames = [Image.fromarray((rs.rand(h, w, 3) * 255).astype("uint8")) for h, w in ((96, 160), (300, 200))]
+    torch.manual_seed(11)
+    a = pipe.dino_input_preprocess(frames)
+    torch.manual_seed(11)
+    b = pipe.dino_input_preprocess(frames)
+    c = pipe.dino_input_preprocess(frames)
+    assert a.shape == (2, 3, 224, 224) and a.dtype == torch.float32 and torch.equal(a, b) and not torch.equal(a, c)
+    lo, hi = (0 - 0.485) / 0.229, (1 - 0.406) / 0.225
+    assert a.min().item() >= lo - 1e-5 and a.max().item() <= hi + 1e-5
