@@ -64,17 +64,24 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[2]: DiT stored in e4m3 + enable_dit_fp8_computation (every DiT Linear runs "
                          "fp8_linear); NOT the headline configuration, reported with dtype fp8")
-    ap.add_argument("--attn-variant", type=int, default=0, choices=[0, 3, 4],
-                    help="flash-attention kernel: 0 = default (8 waves x 32 rows; the textbook online-softmax update, P rounded at "
-                         "the same scale as the reference's SDPA); 3 = 4 waves x 64 rows, one wave per SIMD, bit-identical to 0; "
-                         "4 = 3 with the running max raised only when a row outgrows it by 2^8 (faster; same distance to fp32, "
-                         "fewer bf16 outputs identical to the reference's: profiles/r02_attention_notes.md).  Non-zero values are "
-                         "reported in config.attn_variant and are not the headline configuration")
+    ap.add_argument("--attn-variant", type=int, default=4, choices=[0, 3, 4],
+                    help="flash-attention kernel: 4 = library default since round 3 (4 waves x 64 rows, one wave per SIMD, running max "
+                         "raised only when a row outgrows it by 2^8: the same rms distance to an fp32 evaluation as the reference's bf16 "
+                         "SDPA, measured at 60 layers x S = 2208, profiles/r03_attention_notes.md); 3 = the same kernel with the textbook "
+                         "max update, bit-identical to 0; 0 = 8 waves x 32 rows, textbook update (the round-1/2 default).  Values other "
+                         "than 4 are A/B knobs, reported in config.attn_variant")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (backend nccl = RCCL) and run the batch-closing all-gather, the barriers and "
+                         "the max-over-ranks all-reduce even at --gpus 1, so that the only thing a 1-GPU box leaves unexecuted of "
+                         "the N > 1 path is the rank count (tests/test_gpu_parallel.py)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (after the headline timed region, N = 1 headline runs also time 2 images each of "
+                         "the 1328x1328 / 50-step geometry of configs[4] on this one GPU and of configs[2], the e4m3 Linears)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_only:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_only:
         # `python bench.py --gpus N` without a launcher: become the launcher.  One process per GPU under
         # torch.distributed.run on 127.0.0.1 (the same command line the driver uses); rank 0 prints the JSON line.
         import socket
@@ -103,10 +110,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+    if world > 1:
+        # the ranks share the host: the CPU-side parts of the model build (LoRA / adapter / VAE tensors are generated with torch CPU
+        # ops) must not oversubscribe it N-fold
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
 
     from physicedit_amd import synth, ops
     from physicedit_amd._lib import lib
@@ -137,7 +148,7 @@ def main():
         torch.cuda.empty_cache()
     vae = QwenImageVAE(synth.make_state_dict(synth.vae_layout(), 77), device=dev)
     loop = DenoiseLoop(eng, dual_stream=args.dual_stream)
-    if args.attn_variant:
+    if args.attn_variant != 4:
         from physicedit_amd._lib import lib
         assert lib().pe_debug_set(b"attn_variant", args.attn_variant) == 0
     torch.cuda.synchronize()
@@ -184,15 +195,18 @@ def main():
     if dist is not None:
         # close the batch INSIDE the timed region: ONE RCCL all-gather of the final latents over xGMI
         # (512 KiB per image)
-        gathered = parallel.gather_units([r[0] for r in results], args.steps * world)
+        gathered = parallel.gather_units([r[0] for r in results], args.steps * world, always_collective=True)
         assert len(gathered) == args.steps * world
     torch.cuda.synchronize()
     barrier()
     t_end = time.perf_counter()
     elapsed = t_end - t_start
+    per_rank = [elapsed]
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, elapsed)
         elapsed = float(tmax.item())
     ok = all(torch.isfinite(r[1].float()).all().item() for r in results)
 
@@ -242,6 +256,7 @@ def main():
                        "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
                        "attn_variant": args.attn_variant,
                        "batch_closing_collective": ("one RCCL all_gather of the final latents, inside the timed region" if dist is not None else None),
+                       "per_rank_elapsed_s": [round(float(t), 4) for t in per_rank],
                        "finite_outputs": ok},
             "whole_path": {"algorithmic_pflop_per_image": fl / 1e15,
                            "achieved_tflops_per_gpu": fl * value / world / 1e12,
@@ -273,12 +288,62 @@ def main():
             out["roofline"]["power_limited_ceiling"] = ceil
             if ceil["random_normal_operands"] > 0:
                 out["roofline"]["frac_of_power_limited_ceiling"] = achieved / ceil["random_normal_operands"]
+        if world == 1 and headline and not args.fp8 and not args.no_secondary:
+            out["secondary"] = secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_n, read_prof)
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_n, read_prof, n_images=2):
+    """The other single-GPU configurations of BASELINE.json, timed in the SAME process after the headline region (so the
+    driver's run carries them): (a) configs[4]'s geometry -- 1328 x 1328 target (83 x 83 noise tokens), 50 steps, same 1024 x 1024
+    edit image, S = 11497 -- on this one GPU; (b) configs[2] -- every DiT Linear as fp8_linear on e4m3 weights.  Each: one
+    2-step warm-up image (workspace, RoPE tables), then `n_images` full images between synchronisations; GEMM rate from HIP
+    events of the launches inside that region.  (b) converts the weights in place, so it runs last."""
+    import torch
+    from physicedit_amd import synth
+    from physicedit_amd._lib import lib
+    from physicedit_amd.pipeline import DenoiseLoop
+    res = {}
+
+    def run(label, H, W, steps, peak, dtype):
+        loop = DenoiseLoop(eng, dual_stream=args.dual_stream)
+        noises = [synth.make_noise(5000 + i, H, W).to(dev) for i in range(n_images + 1)]
+
+        def image(i, n_steps):
+            lat = loop(noises[i], pe_p0.clone(), pe_n0.clone(), mask_p, mask_n, H, W, num_inference_steps=n_steps,
+                       cfg_scale=args.cfg, edit_latents=vae.encode(edit_img))
+            return vae.decode(lat)
+        image(0, 2)
+        torch.cuda.synchronize()
+        lib().pe_profile_enable(8192, 32)
+        t0 = time.perf_counter()
+        imgs = [image(1 + i, steps) for i in range(n_images)]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_images
+        prof = read_prof()
+        g = prof["gemm"]
+        fl = flops_image(H, W, steps, args.t_pos, args.t_neg, args.cfg, args.layers)
+        gemm_tf = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else None
+        res[label] = {"ms_per_image": dt * 1e3, "images_per_s": 1.0 / dt, "images_timed": n_images, "dtype": dtype,
+                      "geometry": f"{H}x{W}, {steps} steps, CFG {args.cfg}, T_pos={args.t_pos} T_neg={args.t_neg}",
+                      "algorithmic_pflop_per_image": fl / 1e15, "achieved_tflops": fl / dt / 1e12,
+                      "frac_of_bf16_mfma_peak": fl / dt / 1e12 / PEAK_BF16_TFLOPS,
+                      "roofline": {"kernel": "gemm (all epilogues)", "bound": "mfma", "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s",
+                                   "frac": (gemm_tf / peak) if gemm_tf else None, "launches_sampled": g["sampled"]},
+                      "flash_attn_tflops": (prof["attn"]["work"] / (prof["attn"]["ms"] * 1e-3) / 1e12) if prof["attn"]["ms"] > 0 else None,
+                      "finite_outputs": all(torch.isfinite(x.float()).all().item() for x in imgs)}
+
+    run("configs[4] geometry on one GPU (1328x1328, 50 steps, bf16)", 1328, 1328, 50, PEAK_BF16_TFLOPS, "bf16")
+    eng.enable_fp8_computation()
+    torch.cuda.empty_cache()
+    run("configs[2] (DiT Linears in e4m3: fp8_linear; attention, norms, adapter, VAE bf16)", args.height, args.width,
+        args.inference_steps, PEAK_FP8_TFLOPS, "fp8_e4m3")
+    return res
 
 
 def mfma_power_ceiling(dev):

@@ -81,26 +81,29 @@ def resize_for_vl(image: Image.Image, target_area: int = 384 * 384) -> Image.Ima
 
 
 def parse_generation_response(response: str) -> Dict[str, str]:
-    """_parse_generation_response (:876-907): the outermost {...} as JSON with exactly one of the accepted key sets."""
-    start, end = response.find("{"), response.rfind("}")
-    if start == -1 or end == -1 or end <= start:
-        raise ValueError(f"Cannot find JSON in response: {response}")
-    payload = response[start:end + 1]
+    """What `_parse_generation_response` accepts (:875-907): the text between the first "{" and the last "}" must be a JSON object
+    whose known fields (the union of ACCEPTED_FIELD_SETS; null counts as absent, anything else must be a string) are EXACTLY one
+    of the accepted sets.  Returns the stripped strings in the declared order of that set -- the reference walks a Python `set`,
+    so for the three-field form its order changes with the interpreter's hash seed; a fixed order is one of its outcomes.
+    ValueError for everything else (the caller then keeps the raw text, :868-871)."""
+    lo, hi = response.find("{"), response.rfind("}")
+    if not 0 <= lo < hi:
+        raise ValueError("the generated text holds no JSON object")
     try:
-        data = json.loads(payload)
-    except json.JSONDecodeError as exc:
-        raise ValueError(f"Cannot parse JSON: {payload}") from exc
-    allowed = tuple({f for fields in ACCEPTED_FIELD_SETS for f in fields})
-    result: Dict[str, str] = {}
-    for key in allowed:
-        value = data.get(key)
-        if value is not None:
-            if not isinstance(value, str):
-                raise ValueError(f"Field {key} must be string, got {type(value)}: {data}")
-            result[key] = value.strip()
-    if not any(set(result) == set(fields) for fields in ACCEPTED_FIELD_SETS):
-        raise ValueError(f"Unsupported response format. Expected one of {ACCEPTED_FIELD_SETS}, got keys {sorted(result)}: {data}")
-    return result
+        obj = json.loads(response[lo:hi + 1])
+    except json.JSONDecodeError as err:
+        raise ValueError("the braces of the generated text do not enclose valid JSON") from err
+    if not isinstance(obj, dict):
+        raise ValueError("the generated JSON is not an object")
+    known = {name for names in ACCEPTED_FIELD_SETS for name in names}
+    present = {name: obj[name] for name in obj if name in known and obj[name] is not None}
+    wrong = [name for name, value in present.items() if not isinstance(value, str)]
+    if wrong:
+        raise ValueError(f"non-string value for {wrong[0]!r} ({type(present[wrong[0]]).__name__})")
+    for names in ACCEPTED_FIELD_SETS:
+        if set(names) == set(present):
+            return {name: present[name].strip() for name in names}
+    raise ValueError(f"fields {sorted(present)} are none of the accepted sets {ACCEPTED_FIELD_SETS}")
 
 
 class MiniQwen2VLProcessor:

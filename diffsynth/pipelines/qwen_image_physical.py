@@ -82,6 +82,16 @@ class _AdapterView:
         return dict(self.state)
 
 
+def _accepts_kwarg(fn, name: str) -> bool:
+    """Does the callable take keyword `name` (explicitly or through **kwargs)?"""
+    import inspect
+    try:
+        params = inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return True
+    return name in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
 class QwenImagePhysicPipeline:
     use_special_tokens = True
 
@@ -471,9 +481,17 @@ class QwenImagePhysicPipeline:
         extra = {}
         if (have_text_reasoning and supported_rules is not None and contradicted_rules is not None and middle_key_frames is not None
                 and input_image is not None):
-            # PhysicalVerbalEmbedder.process (:976-983): a fully annotated sample brings its reasoning text along
-            extra["physical_txt"] = (f"Middle Transition Prompt: {(triplet or {}).get('middle_transition_prompt', '')}\n"
-                                     f"Final State Prompt: {(triplet or {}).get('final_state_prompt', '')}")
+            # PhysicalVerbalEmbedder.process (:976-983): a fully annotated sample brings its reasoning text along.  As in the
+            # reference (`triplet.get(...)` on the argument), a missing triplet is an error and a missing key an empty string.
+            if not isinstance(triplet, dict):
+                raise _lib.PeError("annotated sample (supported_rules, contradicted_rules, middle_key_frames, input_image) needs "
+                                   "the `triplet` dict (middle_transition_prompt / final_state_prompt, :980-982)")
+            extra["physical_txt"] = (f"Middle Transition Prompt: {triplet.get('middle_transition_prompt', '')}\n"
+                                     f"Final State Prompt: {triplet.get('final_state_prompt', '')}")
+        if extra and not _accepts_kwarg(self.prompt_encoder, "physical_txt"):
+            # a plug-in written to the contract without the `physical_txt` keyword: the reasoning text is appended to the positive
+            # prompt, which is what the prompt embedder does with it anyway (`prompt + physical_txt`, prompt_prologue.embed)
+            prompt = prompt + extra.pop("physical_txt")
         posi, nega = self.prompt_encoder(self, prompt=prompt, negative_prompt=negative_prompt, edit_image=resized_edit,
                                          cfg=use_cfg, have_text_reasoning=have_text_reasoning, **extra)
         pe_p = posi["prompt_emb"].to(device=self.device, dtype=self.torch_dtype).contiguous()
@@ -496,7 +514,7 @@ class QwenImagePhysicPipeline:
         # BlockwiseControlNet unit (:1201-1241)
         ctl_cond = self.controlnet_conditionings(blockwise_controlnet_inputs) if blockwise_controlnet_inputs is not None else None
         # denoise loop + decode (:644-667)
-        loop = DenoiseLoop(self.dit)
+        loop = DenoiseLoop(self.dit, cfg_pair=getattr(self, "cfg_pair", None))     # cfg_pair: set by physicedit_amd.parallel.edit_batch
         loop.scheduler = self.scheduler
         latents = loop(latents, pe_p, pe_n, m_p, m_n, height, width, num_inference_steps=num_inference_steps,
                        cfg_scale=cfg_scale, edit_latents=edit_latents or None, exponential_shift_mu=exponential_shift_mu,

@@ -43,20 +43,19 @@ int pe_abi_version(void);
 const char* pe_build_id(void);
 /* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant", ...).
  * Production callers never need it: the compiled defaults are the validated schedules.
- * "gemm_variant": 15 default; 10 = the round-1 schedule (A/B reference); 14 = 4-phase ping-pong with s_memtime stamps (profiling);
- * 16 = 15 + stream-K tail (measured slower; needs the workspace below).
- * "attn_variant": 0 default (8 waves x 32 query rows); 3 = 4 waves x 64 rows, one wave per SIMD, bit-identical to 0;
- * 4 = 3 with the running softmax max raised only when a row outgrows it by 2^8 (faster; same distance to an fp32 result,
- * fewer bf16 outputs identical to the reference SDPA's -- opt-in, see profiles/r02_attention_notes.md). */
+ * "gemm_variant": 17 default (persistent work-groups with cross-tile prefetch; launches of at most one round of tiles run 15);
+ * 15 = one tile per work-group (the round-2 default; writes s_memtime stamps when "gemm_stamps" is attached); 10 = the round-1
+ * schedule (A/B reference).  "gemm_band": M tiles per band of the XCD-aware tile order (default 8).  "gemm_persist_wgs":
+ * work-groups of schedule 17's grid (0 = one per CU).
+ * "attn_variant": 4 default (4 waves x 64 query rows, one wave per SIMD, running softmax max raised only when a row outgrows
+ * it by 2^8: same distance to an fp32 result as the reference's own bf16 SDPA, profiles/r03_attention_notes.md); 3 = the same
+ * kernel with the textbook max update, bit-identical to 0; 0 = 8 waves x 32 query rows, textbook update (the round-1/2 default,
+ * and always the kernel of the masked form). */
 int pe_debug_set(const char* key, int value);
 /* Device buffer for a profiling variant's output ("gemm_stamps": long long [work-groups][8] s_memtime stamps of
- * gemm variant 14; "attn_stamps": long long [work-groups][10] of attention variants 3 / 4 built with -DPE_W4_STAMPS=1);
+ * gemm variant 15; "attn_stamps": long long [work-groups][10] of attention variants 3 / 4 built with -DPE_W4_STAMPS=1);
  * NULL detaches it. */
 int pe_debug_set_ptr(const char* key, void* device_ptr);
-/* Bytes of the optional stream-K workspace of the GEMM (fp32 partial tiles + flags; zero-fill it once).  The DiT composite
- * carves its own from the bound workspace; the granular operators use the one registered with
- * pe_debug_set_ptr("gemm_streamk_ws", p), or none (every tile computed whole). */
-size_t pe_gemm_streamk_workspace_bytes(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Granular operators (each is one kernel launch; used by the parity tests and by the composites)

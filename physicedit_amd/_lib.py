@@ -95,7 +95,7 @@ class DitCall(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/physicedit_amd.h declares
-ABI_VERSION = 5   # include/physicedit_amd.h: bumped on any signature / struct change
+ABI_VERSION = 6   # include/physicedit_amd.h: bumped on any signature / struct change
 
 SIGNATURES = {
     "pe_last_error": (C.c_char_p, []),
@@ -103,7 +103,6 @@ SIGNATURES = {
     "pe_build_id": (C.c_char_p, []),
     "pe_debug_set": (c_int, [C.c_char_p, c_int]),
     "pe_debug_set_ptr": (c_int, [C.c_char_p, c_void_p]),
-    "pe_gemm_streamk_workspace_bytes": (c_size_t, []),
     "pe_gemm_bf16": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_int, c_void_p]),
     "pe_gemm_bf16_pre": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,

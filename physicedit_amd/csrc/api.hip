@@ -32,7 +32,7 @@ using namespace pe;
 extern "C" {
 
 const char* pe_last_error(void) { return g_err; }
-int pe_abi_version(void) { return 5; }
+int pe_abi_version(void) { return 6; }
 #ifndef PE_SRC_HASH
 #define PE_SRC_HASH "unknown"
 #endif
@@ -42,7 +42,8 @@ int pe_debug_set(const char* key, int value) {
     PE_REQUIRE(key != nullptr, "pe_debug_set: null key");
     if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return PE_OK; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
-    if (!strcmp(key, "gemm_streamk")) { g_gemm_streamk = value; return PE_OK; }
+    if (!strcmp(key, "gemm_band")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_band out of range"); g_gemm_band = value; return PE_OK; }
+    if (!strcmp(key, "gemm_persist_wgs")) { PE_REQUIRE(value >= 0 && value <= 1024, "gemm_persist_wgs out of range"); g_gemm_persist_wgs = value; return PE_OK; }
     if (!strcmp(key, "attn_slots")) { PE_REQUIRE(value > 0 && value <= 256, "attn_slots out of range"); g_attn_slots = value; return PE_OK; }
     if (!strcmp(key, "attn_force_split")) { g_attn_force_split = value; return PE_OK; }
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set: unknown key %s", key);
@@ -52,11 +53,8 @@ int pe_debug_set_ptr(const char* key, void* p) {
     PE_REQUIRE(key != nullptr, "pe_debug_set_ptr: null key");
     if (!strcmp(key, "gemm_stamps")) { g_gemm_dbg = (long long*)p; return PE_OK; }
     if (!strcmp(key, "attn_stamps")) { g_attn_dbg = (long long*)p; return PE_OK; }
-    if (!strcmp(key, "gemm_streamk_ws")) { g_gemm_sk_ws = p; return PE_OK; }   // pe_gemm_streamk_workspace_bytes() bytes, zero-filled once
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set_ptr: unknown key %s", key);
 }
-
-size_t pe_gemm_streamk_workspace_bytes(void) { return gemm_streamk_ws_bytes(); }
 
 int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
                  int M, int N, int K, const void* gate, const void* res, int ldr, void* stream) {

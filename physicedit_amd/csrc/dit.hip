@@ -41,7 +41,6 @@ struct pe_dit {
     char *sp_in, *sp_hid, *sp_dino, *sp_vae;
     char* attn_ws;
     size_t attn_ws_bytes = 0;
-    char* sk_ws;                        // stream-K workspace of the GEMMs (fp32 partial tiles + flags), see gemm.hip
     char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
     char* aq;                           // e4m3 mode: quantised activation rows of the Linear being run [S, FF] bytes
     float* asc;                         // e4m3 mode: their per-row scales
@@ -95,7 +94,6 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->sp_vae, (size_t)MAX_SPECIAL * TXT * 2);
     h->attn_ws_bytes = flash_attn_workspace_bytes(HEADS, (int)S);
     take(&h->attn_ws, h->attn_ws_bytes);
-    take(&h->sk_ws, gemm_streamk_ws_bytes());
     const size_t rows = S > (size_t)n_steps ? S : (size_t)n_steps;
     take(&h->lora_t, rows * 3 * 128 * 2);
     if (h->w.weights_e4m3) {
@@ -113,7 +111,7 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
 // activation rows (per-row scale), then the e4m3 GEMM.  K is padded to the GEMM's 128 granule (only img_in, K = 64:
 // its weight arrives zero-padded to [3072,128]).
 static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t stream) {
-    if (!h->w.weights_e4m3) return launch_gemm(epi, pp, n, stream, h->sk_ws);
+    if (!h->w.weights_e4m3) return launch_gemm(epi, pp, n, stream);
     int rc;
     const bool joint = n == 2 && pp[0].K == pp[1].K && pp[0].lda == pp[1].lda &&
                        (const char*)pp[1].A == (const char*)pp[0].A + (size_t)pp[0].M * pp[0].lda * 2;
@@ -133,7 +131,7 @@ static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t st
         off += (size_t)Ms * Kp;
         row += Ms;
     }
-    return launch_gemm(epi, pp, n, stream, h->sk_ws);
+    return launch_gemm(epi, pp, n, stream);
 }
 
 // does any hot LoRA set carry group g (0 qkv, 1 out, 2 down, 3 mod) of block l (both streams)?
@@ -191,8 +189,8 @@ static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], ch
             tb[s].pre = ybuf + row0[s] * ldy * 2; tb[s].ldp = ldy;
             if (!last) { tb[s].out = ybuf + row0[s] * ldy * 2; tb[s].ldo = ldy; }   // in place: a lane reads pre before the tile is stored
         }
-        if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
-        if ((rc = launch_gemm(last ? epi : EPI_BIAS, tb, 2, stream, h->sk_ws))) return rc;
+        if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+        if ((rc = launch_gemm(last ? epi : EPI_BIAS, tb, 2, stream))) return rc;
     }
     return PE_OK;
 }
@@ -273,9 +271,6 @@ int pe_dit_bind_workspace(pe_dit_handle h, void* workspace, size_t bytes, int S_
     // Q/K pad rows only feed masked scores.  Zero all three once.
     hipError_t e = hipMemsetAsync(h->q, 0, (size_t)(h->attn - h->q), (hipStream_t)stream);
     if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
-    // stream-K flags start at "no epoch seen" (the partial slots themselves need no initialisation)
-    e = hipMemsetAsync(h->sk_ws + gemm_streamk_ws_bytes() - 4096, 0, 4096, (hipStream_t)stream);
-    if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
     return PE_OK;
 }
 
@@ -329,8 +324,8 @@ int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void
                 tb[s].M = n_steps; tb[s].N = MOD; tb[s].K = r;
             }
             if (!have) continue;
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, h->sk_ws))) return rc;
-            if ((rc = launch_gemm(EPI_BIAS, tb, 2, stream, h->sk_ws))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, tb, 2, stream))) return rc;
         }
     }
     memset(&p, 0, sizeof(p));
@@ -383,11 +378,11 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             memset(&p, 0, sizeof(p));
             p.A = h->sp_in; p.lda = TXT; p.W = w0; p.bias = b0; p.out = h->sp_hid; p.ldo = AD_HID;
             p.M = ns; p.N = AD_HID; p.K = TXT;
-            if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream, h->sk_ws))) return rc;
+            if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream))) return rc;
             memset(&p, 0, sizeof(p));
             p.A = h->sp_hid; p.lda = AD_HID; p.W = w2; p.bias = b2; p.out = head == 0 ? h->sp_dino : h->sp_vae;
             p.ldo = TXT; p.M = ns; p.N = TXT; p.K = AD_HID;
-            if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream, h->sk_ws))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
         }
         if ((rc = launch_adapter_mix_scatter(h->sp_dino, h->sp_vae, c->alpha, c->one_minus_alpha, c->special_idx,
                                              c->prompt_emb, ns, TXT, stream)))
@@ -516,11 +511,11 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                     return rc;
                 memset(&p, 0, sizeof(p));
                 p.A = h->xmod; p.lda = D; p.W = cb.in_w; p.bias = cb.in_b; p.out = h->attn; p.ldo = D; p.M = S0; p.N = D; p.K = D;
-                if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream, h->sk_ws))) return rc;
+                if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream))) return rc;
                 memset(&p, 0, sizeof(p));
                 p.A = h->attn; p.lda = D; p.W = cb.out_w; p.bias = cb.out_b; p.out = acc; p.ldo = D; p.res = acc; p.ldr = D;
                 p.has_gate_scalar = 1; p.gate_scalar = c->control[ci].scale; p.M = S0; p.N = D; p.K = D;
-                if ((rc = launch_gemm(EPI_GATE_RES, &p, 1, stream, h->sk_ws))) return rc;
+                if ((rc = launch_gemm(EPI_GATE_RES, &p, 1, stream))) return rc;
             }
             if (!single && (rc = launch_add_inplace(x_img, acc, (size_t)S0 * D, stream))) return rc;
         }

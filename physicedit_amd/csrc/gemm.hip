@@ -10,17 +10,21 @@
 // Structure (MI355X-first, not a CUDA tiling):
 //   * 256x256x64 block tile, 512 threads = 8 waves as 4(M) x 2(N); each wave owns 64x128 of C as
 //     2x4 v_mfma_f32_32x32x16_bf16 tiles (128 fp32 accumulators / lane).
-//   * A and W tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip),
-//     double buffered (2 x 64 KiB of the CU's 160 KiB), one barrier per K tile.
+//   * A and W tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip): A double
+//     buffered, W in a three-deep ring (2 x 32 KiB + 3 x 32 KiB = all of the CU's 160 KiB).
 //   * LDS image is [row][64 k] bf16 = 128 B rows; the 16-B chunk index is XORed with (row>>1)&7 so
 //     every ds_read_b128 lane group covers all 64 banks.  LDS-DMA writes lane-linear, so the
 //     permutation is applied to the per-lane SOURCE address and again on the read.
 //   * operands are fed "swapped" (MFMA A-operand = W fragment, B-operand = activation fragment):
 //     each lane then holds 4 consecutive N columns of one M row per accumulator quad.
-//   * epilogue: y = bf16(acc + bias) is transposed through the (now free) LDS so every lane owns
-//     8 consecutive columns of a row: 16-B bias/gate/residual loads and 16-B stores, 256-B segments.
-//   * work-group ids are remapped XCD-aware (8 private L2s) and walk 8-tile-tall bands.
+//   * epilogue: y = bf16(acc + bias) is transposed through LDS so every lane owns 8 consecutive
+//     columns of a row: 16-B bias/gate/residual loads and 16-B stores, 256-B segments.
+//   * work-group ids are remapped XCD-aware (8 private L2s) and walk `band`-tile-tall bands.
 //   * "grouped" launch: up to 2 problems (image stream + text stream) share one grid.
+//   * schedule 17 (round 3): PERSISTENT work-groups (one per CU) that walk their tiles b, b + G, ...; the
+//     main loop's tail prefetches -- which a one-tile work-group spends on clamped dummy loads -- fetch
+//     the NEXT tile's first K tiles instead, the epilogue runs in the two LDS regions the stream does
+//     not need, and its stores drain under the next tile's main loop.
 #include <stdlib.h>
 
 #include <atomic>
@@ -33,51 +37,37 @@ namespace pe {
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 64 KiB
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;        // 128 KiB
-constexpr int GEMM_LDS_V10 = 5 * (STAGE_BYTES / 2);  // A x2 + W x3 = 160 KiB (all of a CU's LDS)
-constexpr int BAND = 8;
-constexpr int GEMM_DEFAULT_VARIANT = 15;  // validated schedule: two staggered wave groups, 2 x 16 MFMAs per K tile (see VAR list)
+constexpr int GEMM_LDS = 5 * 32768;   // A x2 + W x3 = 160 KiB (all of a CU's LDS)
+constexpr int GEMM_DEFAULT_BAND = 8;
+constexpr int GEMM_DEFAULT_VARIANT = 17;  // see the VAR list below
 
 struct GemmArgs {
     GemmProblem p[2];
-    int tiles0;
-    long long* dbg;   // VAR 14 only: per work-group s_memtime stamps [grid][8] (pe_debug_set_ptr("gemm_stamps", p))
-    // stream-K tail (VAR 15): blocks [0, n_full) compute whole tiles; the last sk_tiles tiles (tile ids n_full ..) are
-    // cut along K into SK_WGS equal ranges of K tiles, one per block of the tail phase (blocks n_full .. n_full+SK_WGS-1)
-    int n_full, sk_tiles;
-    float* sk_ws;          // [SK_WGS][256*256] fp32 partial accumulators (one slot per tail block)
-    unsigned* sk_flags;    // [SK_WGS] epoch of the last launch whose partial in that slot is complete
-    unsigned* sk_status;   // [1] set to 1 if an owner gave up waiting (never in a correct run)
-    unsigned sk_epoch;
+    int tiles0;       // tiles of problem 0 (tile ids >= tiles0 belong to problem 1)
+    int ntiles;       // all tiles of the launch (schedule 17: the grid is smaller)
+    int band;         // M tiles per band of the tile order
+    long long* dbg;   // per work-group s_memtime stamps [grid][8] of schedule 15 (pe_debug_set_ptr("gemm_stamps", p)), or null
 };
-constexpr int SK_WGS = 256;               // one tail block per CU
-constexpr int SK_SLOT_FLOATS = BM * BN;   // 256 KiB per partial
 long long* g_gemm_dbg = nullptr;
 
-// VAR 14 = VAR 12 + time stamps of wave 0 (profiling build of the default schedule; never the production variant)
 #define PE_STAMP(k)                                                                                     \
     do {                                                                                                \
-        if constexpr (VAR == 14 || VAR == 15 || VAR == 16) {                                            \
+        if constexpr (VAR == 15) {                                                                      \
             if (args.dbg != nullptr && threadIdx.x == 0) args.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); \
         }                                                                                               \
     } while (0)
 
 PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 
-// VAR selects the main-loop schedule (A/B-tested in one process through pe_debug_set("gemm_variant"); the full study
-// incl. the ablation variants that no longer live here is profiles/r01_gemm_ablation.md):
+// VAR selects the main-loop schedule (A/B-tested in one process through pe_debug_set("gemm_variant"); the studies,
+// incl. the variants that no longer live here, are profiles/r01_gemm_ablation.md, r02_gemm_notes.md, r03_gemm_notes.md):
 //   10  (round-1 default, kept as the A/B reference) pipelined clusters: fragments double buffered in registers, tile barrier
 //       before the LAST cluster, staging spread over the clusters, MFMA / ds_read / LDS-DMA interleave pinned with
 //       sched_group_barrier, three-deep W ring and counted vmcnt
-//   14  "ping-pong": the two wave groups run the same stream one barrier apart, 4 phases x 8 MFMAs per K tile; with s_memtime
-//       stamps (profiling only).  (The code paths guarded by VAR >= 12 / VAR == 13 belong to this family; 0, 8, 12 and 13
-//       themselves are no longer instantiated.)
-//   15  (default) ping-pong with 2 phases x 16 MFMAs per K tile, A half tiles staged by the group that reads them
-//   16  15 + stream-K tail (the tiles of a partially filled last round are cut along K into 256 equal ranges, fp32
-//       partials exchanged through a workspace).  Correct and deterministic, but SLOWER on MI355X (profiles/
-//       r02_gemm_notes.md): the ranges of different tiles sit at different K offsets, so the L2 sharing of A/W panels
-//       between the tiles of a band is lost, and 64 MB of partials move twice.  Kept as an experiment knob.
+//   15  (round-2 default) "ping-pong": the two wave groups run the same stream one barrier apart, 2 phases x 16 MFMAs per
+//       K tile, A half tiles staged by the group that reads them; one tile per work-group
+//   17  (default) 15's main loop in persistent work-groups with cross-tile prefetch (gemm_persistent below); launches of
+//       at most one round of tiles run 15
 //
 // FP8 = true: operands are OCP e4m3 bytes (activation rows quantised by quantize_rows_e4m3, weights stored in e4m3),
 // the K tile is 128 elements (the SAME 128-B LDS rows, staging and swizzle), the MFMA is the CDNA4 block-scaled
@@ -86,39 +76,289 @@ PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
-// One output tile (or, in the stream-K tail, the K range [k_lo, k_hi) of one): `bid` = tile id in the banded order.
-// sk_c < 0: a whole tile.  sk_c >= 0: this block is tail block sk_c; a range that does not start at K tile 0 ends
-// with its fp32 accumulators dumped to slot sk_c (+ flag); the range that starts at 0 OWNS the tile: it adds the
-// partials of the blocks sk_c+1.. that cover the rest of the tile's K and runs the epilogue.
+struct TileCoord {
+    int pi, m0, n0;
+};
+// tile id in the banded order -> problem and tile origin.  Band = `band` M tiles x all N tiles, N-major inside a band, so a
+// run of consecutive ids (what one XCD's 32 CUs work on at a time) covers band x (32 / band) tiles.
+PE_DEV TileCoord decode_tile(const GemmArgs& args, int bid) {
+    TileCoord c;
+    c.pi = bid >= args.tiles0 ? 1 : 0;
+    const GemmProblem& P = args.p[c.pi];
+    bid -= c.pi ? args.tiles0 : 0;
+    const int tilesM = P.tilesM, tilesN = P.tilesN;
+    const int per_band = args.band * tilesN;
+    const int band = bid / per_band;
+    const int rem = bid - band * per_band;
+    const int gm = min(args.band, tilesM - band * args.band);
+    const int tn = rem / gm;
+    const int tm = band * args.band + (rem - tn * gm);
+    c.m0 = tm * BM;
+    c.n0 = tn * BN;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// epilogue of one 256x256 tile.  acc[mi][ni][4q+r] = C[m0 + wm*64 + mi*32 + l31][n0 + wn*128 + ni*32 + 8q + 4h + r]
+// The wave's 64 x 128 bf16 block goes through LDS as two 32-row halves (mi = 0, 1) of 8 KiB at E0 / E1: 16-B chunk c of row
+// r sits at chunk c ^ (r & 15), and its two 8-B halves are swapped when r & 8 (rows r and r ^ 8 would otherwise land on the
+// same banks in one ds_write_b64 lane group).  A wave reads back only what it wrote, and one wave's LDS accesses execute in
+// order: no barrier.  TWO_PASS (schedule 17, E0 == E1): stage half 0, emit it, stage half 1, emit it.
+// ------------------------------------------------------------------------------------------
+template <int EPI, bool FP8, bool TWO_PASS>
+__device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16 (&acc)[2][4], int m0, int n0, char* E0, char* E1,
+                                              int lane, int w, long long* stamp4) {
+    const int M = P.M, N = P.N;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    auto unswap = [](bf16x8 v, int row) -> bf16x8 {
+        return (row & 8) ? __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3) : v;
+    };
+    const int nw0 = n0 + wn * 128;
+    const int mw0 = m0 + wm * 64;
+    bf16x8 rv16[EPI == EPI_GATE_RES ? 16 : 1];   // residual rows of the gated-residual epilogue, prefetched
+    const bf16* bias = (const bf16*)P.bias;
+    const bf16* pre = (const bf16*)P.pre;   // hot LoRA: `out + x @ A.T @ B.T` (vram_management/layers.py:179-180)
+    float sa[2] = {1.f, 1.f};               // FP8: per-row activation scale (fp8_linear's scale_a)
+    if constexpr (FP8) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[min(mw0 + mi * 32 + l31, M - 1)];
+    }
+    // bias first, then (EPI_GATE_RES) all 16 residual rows of this lane: 16-B loads that stay in flight under the LDS
+    // staging below (issued 4 at a time inside the store loop they cost 15-21k cycles of exposed latency)
+    bf16x4 bvs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = nw0 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h;
+        bvs[i] = bf16x4{0, 0, 0, 0};
+        if (bias != nullptr && n < N) bvs[i] = *(const bf16x4*)(bias + n);
+    }
+    if constexpr (EPI == EPI_GATE_RES) {
+        const int n = nw0 + (lane & 15) * 8;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = mw0 + it * 4 + (lane >> 4);
+            rv16[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < M && n < N) rv16[it] = *(const bf16x8*)((const bf16*)P.res + (size_t)m * P.ldr + n);
+        }
+    }
+    // gate vector / q-k norm weight of this lane's 8 columns: loaded BEFORE any store (vmcnt retires in order: a load issued
+    // behind the first half's stores could only be consumed after they have drained)
+    bf16x8 gate_v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EPI == EPI_GATE_RES) {
+        const int n = nw0 + (lane & 15) * 8;
+        if (P.gate != nullptr && n < N) gate_v = *(const bf16x8*)((const bf16*)P.gate + n);
+    }
+    // y = bf16(acc + bias) (+ pre) of the row halves [mi_lo, mi_hi) -> LDS
+    auto stage_rows = [&](int mi_lo, int mi_hi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nw0 + ni * 32 + 8 * q + 4 * h;
+                float b[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = (float)bvs[ni * 4 + q][r];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    if (mi < mi_lo || mi >= mi_hi) continue;
+                    bf16x4 y;
+                    if constexpr (FP8) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] * sa[mi] + b[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] + b[r]);
+                    }
+                    const int row = mi * 32 + l31;
+                    if (pre != nullptr && n < N && mw0 + row < M) {
+                        // y = pre + y : the linear's own (already rounded) output plus this low-rank product
+                        const bf16x4 pv = *(const bf16x4*)(pre + (size_t)(mw0 + row) * P.ldp + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = (bf16)((float)pv[r] + (float)y[r]);
+                    }
+                    const int c = ni * 4 + q;
+                    char* Eb = mi == 0 ? E0 : E1;
+                    *(bf16x4*)(Eb + l31 * 256 + ((c ^ (l31 & 15)) << 4) + ((h ^ ((l31 >> 3) & 1)) << 3)) = y;
+                }
+            }
+    };
+
+    // read the staged half `mi` back row-wise, apply the epilogue proper, store
+    auto emit_rows = [&](int mi) __attribute__((always_inline)) {
+        const char* Eb = mi == 0 ? E0 : E1;
+        if constexpr (EPI == EPI_QKV) {
+            const int HD = N / 3;
+            const int section = nw0 / HD;  // wave-uniform: the wave's 128 columns are exactly one head
+            const int head = (nw0 - section * HD) >> 7;
+            const int S_pad = P.S_pad;
+            if (section < 2) {
+                const bf16* nw = (const bf16*)(section == 0 ? P.norm_q_w : P.norm_k_w);
+                bf16* dst = (bf16*)(section == 0 ? P.q_out : P.k_out);
+                const int c = lane & 15;
+                const bf16x8 wv = *(const bf16x8*)(nw + c * 8);
+#pragma unroll 4
+                for (int j8 = 0; j8 < 8; ++j8) {
+                    const int lrow = j8 * 4 + (lane >> 4);
+                    const int m = mw0 + mi * 32 + lrow;
+                    const bf16x8 v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
+                    float y[8];
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        y[j] = (float)v[j];
+                        ss += y[j] * y[j];
+                    }
+                    ss += __shfl_xor(ss, 1, 64);
+                    ss += __shfl_xor(ss, 2, 64);
+                    ss += __shfl_xor(ss, 4, 64);
+                    ss += __shfl_xor(ss, 8, 64);
+                    // RMSNorm(128, eps 1e-6): models/utils.py:250-257
+                    const float rs = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+                    if (m < M) {
+                        const f32x4 cs = *(const f32x4*)(P.rope_cos + (size_t)m * 64 + c * 4);
+                        const f32x4 sn = *(const f32x4*)(P.rope_sin + (size_t)m * 64 + c * 4);
+                        bf16x8 o;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const float x0 = bf16r(bf16r(y[2 * jj] * rs) * (float)wv[2 * jj]);
+                            const float x1 = bf16r(bf16r(y[2 * jj + 1] * rs) * (float)wv[2 * jj + 1]);
+                            // apply_rotary_emb_qwen: fp32 complex multiply (qwen_image_dit.py:51-57)
+                            o[2 * jj] = (bf16)(x0 * cs[jj] - x1 * sn[jj]);
+                            o[2 * jj + 1] = (bf16)(x0 * sn[jj] + x1 * cs[jj]);
+                        }
+                        *(bf16x8*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
+                    }
+                }
+            } else {
+                // V: written TRANSPOSED, Vt[head][d][pos(token)], tokens permuted inside aligned 16-groups
+                // (pos = perm16) so the attention kernel's P.V MFMA needs no cross-lane shuffle.
+                bf16* vt = (bf16*)P.vt_out + (size_t)head * 128 * S_pad;
+                const int seq0 = P.seq_off + mw0;
+                const int valid = min(64, M - mw0);
+                if ((seq0 & 15) == 0) {
+                    // this half holds the 16-token groups 2 mi and 2 mi + 1 of the wave's 64 tokens: 128 d x 2 groups x 2 halves
+#pragma unroll 2
+                    for (int it = 0; it < 8; ++it) {
+                        const int id = it * 64 + lane;
+                        const int d = id >> 2, tg = id & 3;
+                        const int gl = tg >> 1, hh = tg & 1;       // group inside this half, 8-token half of the group
+                        const int gi = mi * 2 + gl;
+                        unsigned short e[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int lrow = gl * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
+                            e[j] = *(const unsigned short*)(Eb + lrow * 256 + (((d >> 3) ^ (lrow & 15)) << 4) + ((((d & 7) * 2) ^ (lrow & 8))));
+                        }
+                        bf16* dstp = vt + (size_t)d * S_pad + seq0 + gi * 16 + hh * 8;
+                        if (gi * 16 + 16 <= valid) {
+                            u32x4 pk;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pk[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+                            *(u32x4*)dstp = pk;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int tok = gi * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
+                                if (tok < valid) ((unsigned short*)dstp)[j] = e[j];
+                            }
+                        }
+                    }
+                } else {
+                    // unaligned joint offset (text stream behind an odd-sized image stream): element-wise, lane = token
+                    const int s = seq0 + lane;
+                    const int pos = (s & ~15) | perm16(s & 15);
+                    const int lrow = lane & 31;
+                    if (lane < valid && (lane >> 5) == mi) {
+                        for (int d = 0; d < 128; ++d) {
+                            const unsigned short e =
+                                *(const unsigned short*)(Eb + lrow * 256 + (((d >> 3) ^ (lrow & 15)) << 4) + (((d & 7) * 2) ^ (lrow & 8)));
+                            ((unsigned short*)vt)[(size_t)d * S_pad + pos] = e;
+                        }
+                    }
+                }
+            }
+        } else {
+            const int c = lane & 15;
+            const int n = nw0 + c * 8;
+            bf16* out = (bf16*)P.out;
+            float g[8];
+            if constexpr (EPI == EPI_GATE_RES) {
+                const float gs = P.has_gate_scalar ? P.gate_scalar : 1.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = gs;
+                if (P.gate != nullptr && n < N) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = (float)gate_v[j];
+                }
+            }
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) {
+                const int lrow = j8 * 4 + (lane >> 4);
+                const int m = mw0 + mi * 32 + lrow;
+                if (m >= M || n >= N) continue;
+                const bf16x8 v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
+                bf16x8 o;
+                if constexpr (EPI == EPI_BIAS) {
+                    o = v;
+                } else if constexpr (EPI == EPI_GELU_SIG) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = (float)v[j];
+                        const float t = bf16r(1.702f * y);
+                        const float sg = bf16r(__builtin_amdgcn_rcpf(1.0f + __expf(-t)));   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide
+                        o[j] = (bf16)(y * sg);
+                    }
+                } else if constexpr (EPI == EPI_GELU_ERF) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = (float)v[j];
+                        o[j] = (bf16)(0.5f * y * (1.0f + erff(y * 0.70710678118654752440f)));
+                    }
+                } else if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = (float)v[j];
+                        o[j] = (bf16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
+                    }
+                } else if constexpr (EPI == EPI_GATE_RES) {
+                    const bf16x8 rv = rv16[mi * 8 + j8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)rv[j] + bf16r(g[j] * (float)v[j]));
+                }
+                *(bf16x8*)(out + (size_t)m * P.ldo + n) = o;
+            }
+        }
+    };
+
+    if constexpr (TWO_PASS) {
+        stage_rows(0, 1);
+        emit_rows(0);
+        stage_rows(1, 2);
+        emit_rows(1);
+    } else {
+        stage_rows(0, 2);
+        if (stamp4 != nullptr && threadIdx.x == 0) *stamp4 = (long long)__builtin_readcyclecounter();
+        emit_rows(0);
+        emit_rows(1);
+    }
+}
+
+// One output tile per work-group (schedules 10 and 15): `bid` = tile id in the banded order.
 template <int EPI, int VAR, bool FP8>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int bid, int k_lo, int k_hi, int sk_c) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int bid) {
     constexpr int ES = FP8 ? 1 : 2;        // bytes per operand element
     constexpr int KT_BYTES = 128;          // one K tile of a row, in bytes (64 bf16 / 128 e4m3)
-    int lane_ = lane_id();
-    if constexpr (VAR == 16)
-        asm volatile("" : "+v"(lane_));    // opaque per call: keeps LICM from hoisting the epilogue's per-lane address math out
-    const int lane = lane_;                // of the caller's (<= 2 iteration) range loop and spilling it across the main loop
+    const int lane = lane_id();
     const int w = wave_id();
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
 
     PE_STAMP(0);
-    const int pi = bid >= args.tiles0 ? 1 : 0;
-    const GemmProblem& P = args.p[pi];
-    bid -= pi ? args.tiles0 : 0;
+    const TileCoord tc0 = decode_tile(args, bid);
+    const GemmProblem& P = args.p[tc0.pi];
     const int M = P.M, N = P.N, K = P.K;
-    int m0, n0;
-    {
-        const int tilesM = P.tilesM, tilesN = P.tilesN;
-        const int per_band = BAND * tilesN;
-        const int band = bid / per_band;
-        const int rem = bid - band * per_band;
-        const int gm = min(BAND, tilesM - band * BAND);
-        const int tn = rem / gm;
-        const int tm = band * BAND + (rem - tn * gm);
-        m0 = tm * BM;
-        n0 = tn * BN;
-    }
+    const int m0 = tc0.m0, n0 = tc0.n0;
 
     // ---- staging sources: wave w moves pieces w*4..w*4+3 (1 KiB = 8 rows x 128 B) of A and of W
     const char* a_src[4];
@@ -129,11 +369,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
         const int rin = lane >> 3, slot = lane & 7;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // piece (1 KiB = 8 rows) i of this wave.  VAR 0/8/10: whole tiles, piece 4w + i.  VAR 12-14: 128-row half
-            // tiles, piece = half*16 + 2w + j.  VAR 15: A pieces come from the wave group's OWN half (the only one it
-            // reads), piece = grp*16 + 4(w&3) + i; W pieces 4w + i.
-            const int piece_a = VAR >= 15 ? (w >> 2) * 16 + (w & 3) * 4 + i : VAR >= 12 ? (i >> 1) * 16 + w * 2 + (i & 1) : w * 4 + i;
-            const int piece_w = VAR >= 15 ? w * 4 + i : piece_a;
+            // piece (1 KiB = 8 rows) i of this wave.  VAR 10: whole tiles, piece 4w + i.  VAR 15: A pieces come from the wave
+            // group's OWN half (the only one it reads), piece = grp*16 + 4(w&3) + i; W pieces 4w + i.
+            const int piece_a = VAR >= 15 ? (w >> 2) * 16 + (w & 3) * 4 + i : w * 4 + i;
+            const int piece_w = w * 4 + i;
             const int row_a = piece_a * 8 + rin, row_w = piece_w * 8 + rin;
             const int gr = min(m0 + row_a, M - 1);
             const int gn = min(n0 + row_w, N - 1);
@@ -141,14 +380,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
             w_src[i] = W + (size_t)gn * K * ES + (slot ^ ((row_w >> 1) & 7)) * 16;
         }
     }
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE_BYTES + w * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(a_src[i] + kt * KT_BYTES, base + i * 1024);
-            glds16(w_src[i] + kt * KT_BYTES, base + BM * BK * 2 + i * 1024);
-        }
-    };
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -162,25 +393,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
     const int sw = (l31 >> 1) & 7;
 
     const int nk = K * ES / KT_BYTES;
-    if constexpr (!FP8 && VAR < 12) stage(0, 0);
-    if constexpr (VAR >= 12) {
+    if constexpr (VAR >= 15) {
         // "Ping-pong" schedule: the two wave groups (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; waves w and w+4
-        // share a SIMD) run the SAME instruction stream one barrier apart.  Each K tile is four phases per wave, one per
-        // 32x64 quadrant of the wave's 64x128 C tile:
-        //     load part : ds_read the quadrant's missing fragments, issue 2 LDS-DMA pieces (one 128-row half tile per phase
-        //                 and work-group), barrier
-        //     MFMA part : 8 (bf16) / 4 (e4m3) MFMAs under s_setprio 1, barrier
-        // so at any time every SIMD has one wave in its MFMA part and one in its load part: LDS latency, the DMA issue
-        // and the barrier skew of one group hide under the other group's MFMAs (v10 interleaves them inside each wave).
-        //     phase  quadrant (mi, nj)   fragment reads               stages (for tile t+2)
-        //     p0     (0, 0)              A[mi 0] x KS, W[ni 0,1] x KS  W half 0 -> W ring slot (t+2)%3
-        //     p1     (1, 0)              A[mi 1] x KS                  W half 1
-        //     p2     (1, 1)              W[ni 2,3] x KS                A half 0 -> A buffer t&1 (its last read: p1)
-        //     p3     (0, 1)              -                             A half 1 ; then s_waitcnt vmcnt(8)
-        // LDS: A 2 x 32 KiB + W 3 x 32 KiB (v10's rings).  RAW: a wave's pieces of tile t+1 were issued during tile t-1;
-        // vmcnt(8) in p3 of tile t retires them (8 younger pieces = tile t+2's) and both groups pass >= 1 barrier
-        // between that wait and the first ds_read of tile t+1.  WAR: every restaged region was last read >= 2 barriers
-        // earlier (A half g only by group g in p0/p1; W ring slot of tile t-1).
+        // share a SIMD) run the SAME instruction stream one barrier apart, so at any time every SIMD has one wave in its MFMA
+        // part and one in its load part: LDS latency, the DMA issue and the barrier skew of one group hide under the other
+        // group's MFMAs (v10 interleaves them inside each wave).  Two phases of 16 MFMAs per K tile; phase p = row block
+        // mi = p of the wave's C tile against all four column blocks:
+        //     p0: reads A[mi 0] x KS + W[ni 0..3] x KS (20 ds_read_b128), stages this wave's 4 pieces of A(kt+1)
+        //     p1: reads A[mi 1] x KS                                    , stages its 4 pieces of W(kt+2), vmcnt(4)
+        // A half tiles are staged by the group that reads them (piece_a above), so "every wave of my group passed
+        // the barrier behind its lgkmcnt(0)" is all the WAR protection A's two buffers need: A(kt+1) overwrites
+        // A(kt-1), last read in p1 of tile kt-1.  W(kt+2) overwrites W(kt-1) (3-deep ring), last read by group 1 in
+        // p0 of tile kt-1, i.e. >= 4 barriers earlier.  RAW: vmcnt(4) in p1 retires A(kt+1), W(kt+1); both groups
+        // pass a barrier between that wait and the first read of tile kt+1.
         using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
         constexpr int KS = FP8 ? 2 : 4;            // MFMA k-steps per K tile
         constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
@@ -205,60 +430,41 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
         __builtin_amdgcn_s_barrier();              \
         __builtin_amdgcn_sched_barrier(0);         \
     } while (0)
-#define PE_MMA(a, mi, nj)                          \
-    do {                                           \
-        PE_BAR();                                  \
-        __builtin_amdgcn_s_setprio(1);             \
-        mma(a, mi, nj);                            \
-        __builtin_amdgcn_s_setprio(0);             \
-        PE_BAR();                                  \
-    } while (0)
-        if constexpr (VAR >= 15) {
-            // Two phases of 16 MFMAs per K tile (half the barriers of VAR 12: the ~60-cycle barrier/turn-around cost per
-            // phase is paid per 512 instead of per 256 MFMA cycles).  Phase p = row block mi = p of the wave's C tile
-            // against all four column blocks:
-            //     p0: reads A[mi 0] x KS + W[ni 0..3] x KS (20 ds_read_b128), stages this wave's 4 pieces of A(kt+1)
-            //     p1: reads A[mi 1] x KS                                    , stages its 4 pieces of W(kt+2), vmcnt(4)
-            // A half tiles are staged by the group that reads them (piece_a above), so "every wave of my group passed
-            // the barrier behind its lgkmcnt(0)" is all the WAR protection A's two buffers need: A(kt+1) overwrites
-            // A(kt-1), last read in p1 of tile kt-1.  W(kt+2) overwrites W(kt-1) (3-deep ring), last read by group 1 in
-            // p0 of tile kt-1, i.e. >= 4 barriers earlier.  RAW: vmcnt(4) in p1 retires A(kt+1), W(kt+1); both groups
-            // pass a barrier between that wait and the first read of tile kt+1.
-            FragT fa[KS], fw4[4][KS];
-            auto rd_a1 = [&](const char* Sa, int mi) {
+        FragT fa[KS], fw4[4][KS];
+        auto rd_a1 = [&](const char* Sa, int mi) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
-            };
-            auto rd_w4 = [&](const char* Sw) {
+            for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
+        };
+        auto rd_w4 = [&](const char* Sw) {
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) fw4[ni][ks] = rd(Sw + w_off + ni * 4096, ks);
-            };
-            auto mma16 = [&](int mi) {
+                for (int ks = 0; ks < KS; ++ks) fw4[ni][ks] = rd(Sw + w_off + ni * 4096, ks);
+        };
+        auto mma16 = [&](int mi) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        if constexpr (FP8)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                                fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                        else
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
-                    }
-            };
-            auto st_a4 = [&](int i) {          // i = K tile index relative to k_lo
-                const int tc = min(k_lo + i, nk - 1);
-                char* base = a_base + (i & 1) * A_BYTES + (grp * 16 + (w & 3) * 4) * 1024;
+                for (int ni = 0; ni < 4; ++ni) {
+                    if constexpr (FP8)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                            fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    else
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
+                }
+        };
+        auto st_a4 = [&](int i) {
+            const int tc = min(i, nk - 1);
+            char* base = a_base + (i & 1) * A_BYTES + (grp * 16 + (w & 3) * 4) * 1024;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) glds16(a_src[j] + tc * KT_BYTES, base + j * 1024);
-            };
-            auto st_w4 = [&](int i, int slot) {
-                const int tc = min(k_lo + i, nk - 1);
-                char* base = w_base + slot * W_BYTES + w * 4096;
+            for (int j = 0; j < 4; ++j) glds16(a_src[j] + tc * KT_BYTES, base + j * 1024);
+        };
+        auto st_w4 = [&](int i, int slot) {
+            const int tc = min(i, nk - 1);
+            char* base = w_base + slot * W_BYTES + w * 4096;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) glds16(w_src[j] + tc * KT_BYTES, base + j * 1024);
-            };
+            for (int j = 0; j < 4; ++j) glds16(w_src[j] + tc * KT_BYTES, base + j * 1024);
+        };
 #define PE_MMA16(mi)                               \
     do {                                           \
         PE_BAR();                                  \
@@ -267,115 +473,30 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
         __builtin_amdgcn_s_setprio(0);             \
         PE_BAR();                                  \
     } while (0)
-            st_a4(0); st_w4(0, 0); st_w4(1, 1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
-            PE_BAR();
-            if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger
-            PE_STAMP(1);
-            int ws = 0;
-            const int nloc = k_hi - k_lo;
-            for (int kt = 0; kt < nloc; ++kt) {
-                const char* Sa = a_base + (kt & 1) * A_BYTES;
-                const int ws_n1 = ws == 2 ? 0 : ws + 1;
-                const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
-                // p0
-                rd_a1(Sa, 0); rd_w4(w_base + ws * W_BYTES);
-                st_a4(kt + 1);
-                PE_MMA16(0);
-                // p1
-                rd_a1(Sa, 1);
-                st_w4(kt + 2, ws_n2);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's pieces of A(kt+1), W(kt+1) landed
-                PE_MMA16(1);
-                ws = ws_n1;
-            }
-            if (grp == 0) __builtin_amdgcn_s_barrier();        // re-align the two groups
-            PE_STAMP(2);
-#undef PE_MMA16
-        } else {
-            constexpr bool BAL = VAR == 13;   // 13: A[mi 0] of the next tile is pre-read in p3 (reads 8/4/8/4 instead of 12/4/8/0)
-            FragT fa0[KS], fa0b[KS], fa1[KS], fw[2][KS];
-            auto rd_a = [&](const char* Sa, int mi, FragT (&f)[KS]) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) f[ks] = rd(Sa + a_off + mi * 4096, ks);
-            };
-            auto rd_w = [&](const char* Sw, int nj) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) fw[j][ks] = rd(Sw + w_off + (nj * 2 + j) * 4096, ks);
-            };
-            auto mma = [&](FragT (&a)[KS], int mi, int nj) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if constexpr (FP8)
-                            acc[mi][nj * 2 + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                                fw[j][ks], a[ks], acc[mi][nj * 2 + j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                        else
-                            acc[mi][nj * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j][ks], a[ks], acc[mi][nj * 2 + j], 0, 0, 0);
-                    }
-            };
-            auto st_a = [&](int t, int half) {
-                const int tc = min(t, nk - 1);
-                char* base = a_base + (t & 1) * A_BYTES + (half * 16 + w * 2) * 1024;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) glds16(a_src[half * 2 + j] + tc * KT_BYTES, base + j * 1024);
-            };
-            auto st_w = [&](int t, int slot, int half) {
-                const int tc = min(t, nk - 1);
-                char* base = w_base + slot * W_BYTES + (half * 16 + w * 2) * 1024;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) glds16(w_src[half * 2 + j] + tc * KT_BYTES, base + j * 1024);
-            };
-            st_a(0, 0); st_a(0, 1); st_w(0, 0, 0); st_w(0, 0, 1);
-            st_a(1, 0); st_a(1, 1); st_w(1, 1, 0); st_w(1, 1, 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed; tile 1 may still fly
-            PE_BAR();
-            if constexpr (BAL) rd_a(a_base, 0, fa0);
-            if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind group 0
-            PE_STAMP(1);
-            // one K tile; BAL: `cur` holds A[mi 0] of tile kt (read during the previous tile), `nxt` receives tile kt+1's
-            auto tile = [&](int kt, int ws_cur, FragT (&cur)[KS], FragT (&nxt)[KS]) __attribute__((always_inline)) {
-                const char* Sa = a_base + (kt & 1) * A_BYTES;
-                const char* San = a_base + ((kt + 1) & 1) * A_BYTES;
-                const int ws_n1 = ws_cur == 2 ? 0 : ws_cur + 1;
-                const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
-                const char* Sw = w_base + ws_cur * W_BYTES;
-                // p0
-                if constexpr (!BAL) rd_a(Sa, 0, cur);
-                rd_w(Sw, 0);
-                st_w(kt + 2, ws_n2, 0);
-                PE_MMA(cur, 0, 0);
-                // p1
-                rd_a(Sa, 1, fa1);
-                st_w(kt + 2, ws_n2, 1);
-                PE_MMA(fa1, 1, 0);
-                // p2
-                rd_w(Sw, 1);
-                st_a(kt + 2, 0);
-                if constexpr (BAL) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this wave's pieces of tile kt+1 landed
-                PE_MMA(fa1, 1, 1);
-                // p3
-                if constexpr (BAL) rd_a(San, 0, nxt);   // both groups passed a barrier since every wave's vmcnt(6)
-                st_a(kt + 2, 1);
-                if constexpr (!BAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's pieces of tile kt+1 landed
-                PE_MMA(cur, 0, 1);
-            };
-            int ws = 0;
-            int kt = 0;
-            for (; kt + 1 < nk; kt += 2) {
-                tile(kt, ws, fa0, fa0b);
-                ws = ws == 2 ? 0 : ws + 1;
-                if constexpr (BAL) tile(kt + 1, ws, fa0b, fa0); else tile(kt + 1, ws, fa0, fa0b);
-                ws = ws == 2 ? 0 : ws + 1;
-            }
-            if (kt < nk) tile(kt, ws, fa0, fa0b);
-            if (grp == 0) __builtin_amdgcn_s_barrier();        // re-align the two groups
-            PE_STAMP(2);
+        st_a4(0); st_w4(0, 0); st_w4(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
+        PE_BAR();
+        if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger
+        PE_STAMP(1);
+        int ws = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* Sa = a_base + (kt & 1) * A_BYTES;
+            const int ws_n1 = ws == 2 ? 0 : ws + 1;
+            const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
+            // p0
+            rd_a1(Sa, 0); rd_w4(w_base + ws * W_BYTES);
+            st_a4(kt + 1);
+            PE_MMA16(0);
+            // p1
+            rd_a1(Sa, 1);
+            st_w4(kt + 2, ws_n2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's pieces of A(kt+1), W(kt+1) landed
+            PE_MMA16(1);
+            ws = ws_n1;
         }
-#undef PE_MMA
+        if (grp == 0) __builtin_amdgcn_s_barrier();        // re-align the two groups
+        PE_STAMP(2);
+#undef PE_MMA16
 #undef PE_BAR
     } else if constexpr (FP8) {
         // v10's structure (A 2 x 32 KiB + W 3 x 32 KiB ring, tile barrier with vmcnt(4)) on 64-cycle MFMAs:
@@ -475,7 +596,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
         }
 #undef PE_CLUSTER8
 #undef PE_SGB
-    } else if constexpr (VAR == 10) {
+    } else {
+        static_assert(VAR == 10, "unknown GEMM schedule");
         // v8 + a THREE-deep W ring: the weight matrix is the cold operand of every block GEMM (each of
         // the 40 GB of weights is touched once per forward), the activation tile is cache resident.  LDS:
         // A 2 x 32 KiB + W 3 x 32 KiB = the CU's whole 160 KiB.  W(kt+2) is issued during tile kt, AFTER
@@ -524,10 +646,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
         for (int v_ = 0; v_ < (NVMEM); ++v_) { PE_SGB(0x008, 1); PE_SGB(0x020, 1); } \
         PE_SGB(0x008, 5 - (NVMEM));                               \
     } while (0)
-        // prologue.  The common code above staged tile 0 into the 2-stage layout of the other variants;
-        // wait for it to drain, then restage in this variant's layout (runs once per work-group).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         stage_a(0, 0, 4);
         stage_w(0, 0, 0, 4);
         stage_w(1, 1, 0, 4);
@@ -574,318 +692,219 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
 #undef PE_CLUSTER_SCHED
 #undef PE_SGB
     }
-    static_assert(FP8 || VAR == 0 || VAR == 8 || VAR == 10 || VAR == 12 || VAR == 13 || VAR == 14 || VAR == 15 || VAR == 16, "unknown GEMM schedule");
 
-    // ------------------------------------------------------------------------------------------
-    // epilogue.  acc[mi][ni][4q+r] = C[m0 + wm*64 + mi*32 + l31][n0 + wn*128 + ni*32 + 8q + 4h + r]
-    // ------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain every LDS-DMA (incl. the clamped tail tiles) before LDS is reused
     __syncthreads();
     PE_STAMP(3);
-    if constexpr (VAR == 16) {
-        if (sk_c >= 0) {
-            // partial layout: [wave][mi][ni][quad][lane] f32x4 -- the accumulator registers as they are, 1 KiB per store
-            auto slot_ptr = [&](int c) { return args.sk_ws + (size_t)c * SK_SLOT_FLOATS + ((size_t)w * 32 * 64 + lane) * 4; };
-            if (k_lo > 0) {
-                // not the owner: publish the partial (cdna guide G16: plain stores, every wave drains, barrier, ONE lane
-                // releases at agent scope and only then stores the flag)
-                float* dst = slot_ptr(sk_c);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r];
-                            *(f32x4*)(dst + (size_t)((mi * 4 + ni) * 4 + q) * 64 * 4) = v;
-                        }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(args.sk_flags + sk_c, args.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                return;
-            }
-            if (k_hi < nk) {
-                // owner: the blocks sk_c+1, sk_c+2, .. cover [k_hi, nk) of this tile, each with its FIRST range
-                const long long total = (long long)args.sk_tiles * nk;
-                const long long tile_end = (long long)(bid - args.n_full + 1) * nk;
-                for (int cc = sk_c + 1; cc < SK_WGS && (long long)cc * total / SK_WGS < tile_end; ++cc) {
-                    if (threadIdx.x == 0) {
-                        unsigned spins = 0;
-                        while (__hip_atomic_load(args.sk_flags + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != args.sk_epoch) {
-                            __builtin_amdgcn_s_sleep(8);
-                            if (++spins > (1u << 22)) {          // ~ 1 s: give up loudly instead of hanging the GPU
-                                __hip_atomic_store(args.sk_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    }
-                    __syncthreads();
-                    const float* src = slot_ptr(cc);
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const f32x4 v = *(const f32x4*)(src + (size_t)((mi * 4 + ni) * 4 + q) * 64 * 4);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) acc[mi][ni][4 * q + r] += v[r];
-                            }
-                }
-            }
-        }
-    }
-    // this wave's [64 rows][128 cols] bf16 staging tile: 16-B chunk c of row r sits at chunk c ^ (r & 15), and its two 8-B
-    // halves are swapped when r & 8 (rows r and r ^ 8 would otherwise land on the same banks in one ds_write_b64
-    // lane group: measured 7.3k instead of ~3.5k cycles for the 64 writes per lane)
     char* E = smem + w * 16384;
-    auto unswap = [](bf16x8 v, int row) -> bf16x8 {
-        return (row & 8) ? __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3) : v;
-    };
-    const int nw0 = n0 + wn * 128;
-    const int mw0 = m0 + wm * 64;
-    bf16x8 rv16[EPI == EPI_GATE_RES ? 16 : 1];   // residual rows of the gated-residual epilogue, prefetched
-    {
-        const bf16* bias = (const bf16*)P.bias;
-        const bf16* pre = (const bf16*)P.pre;   // hot LoRA: `out + x @ A.T @ B.T` (vram_management/layers.py:179-180)
-        float sa[2] = {1.f, 1.f};               // FP8: per-row activation scale (fp8_linear's scale_a)
-        if constexpr (FP8) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[min(mw0 + mi * 32 + l31, M - 1)];
-        }
-        // bias first, then (EPI_GATE_RES) all 16 residual rows of this lane: 16-B loads that stay in flight under the LDS
-        // staging below (they used to be issued 4 at a time inside the store loop: 15-21k cycles of exposed latency)
-        bf16x4 bvs[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int n = nw0 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h;
-            bvs[i] = bf16x4{0, 0, 0, 0};
-            if (bias != nullptr && n < N) bvs[i] = *(const bf16x4*)(bias + n);
-        }
-        if constexpr (EPI == EPI_GATE_RES) {
-            const int n = nw0 + (lane & 15) * 8;
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int m = mw0 + it * 4 + (lane >> 4);
-                rv16[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (m < M && n < N) rv16[it] = *(const bf16x8*)((const bf16*)P.res + (size_t)m * P.ldr + n);
-            }
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = nw0 + ni * 32 + 8 * q + 4 * h;
-                float b[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = (float)bvs[ni * 4 + q][r];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    bf16x4 y;
-                    if constexpr (FP8) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] * sa[mi] + b[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] + b[r]);
-                    }
-                    const int row = mi * 32 + l31;
-                    if (pre != nullptr && n < N && mw0 + row < M) {
-                        // y = pre + y : the linear's own (already rounded) output plus this low-rank product
-                        const bf16x4 pv = *(const bf16x4*)(pre + (size_t)(mw0 + row) * P.ldp + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = (bf16)((float)pv[r] + (float)y[r]);
-                    }
-                    const int c = ni * 4 + q;
-                    *(bf16x4*)(E + row * 256 + ((c ^ (row & 15)) << 4) + ((h ^ ((row >> 3) & 1)) << 3)) = y;
-                }
-            }
-    }
-    // no barrier here: a wave reads back only its own staging tile, and one wave's LDS accesses execute in order
-    PE_STAMP(4);
-
-    if constexpr (EPI == EPI_QKV) {
-        const int HD = N / 3;
-        const int section = nw0 / HD;  // wave-uniform: the wave's 128 columns are exactly one head
-        const int head = (nw0 - section * HD) >> 7;
-        const int S_pad = P.S_pad;
-        if (section < 2) {
-            const bf16* nw = (const bf16*)(section == 0 ? P.norm_q_w : P.norm_k_w);
-            bf16* dst = (bf16*)(section == 0 ? P.q_out : P.k_out);
-            const int c = lane & 15;
-            const bf16x8 wv = *(const bf16x8*)(nw + c * 8);
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 4 + (lane >> 4);
-                const int m = mw0 + row;
-                const bf16x8 v = unswap(*(const bf16x8*)(E + row * 256 + ((c ^ (row & 15)) << 4)), it << 2);   // row & 8 == (it << 2) & 8
-                float y[8];
-                float ss = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    y[j] = (float)v[j];
-                    ss += y[j] * y[j];
-                }
-                ss += __shfl_xor(ss, 1, 64);
-                ss += __shfl_xor(ss, 2, 64);
-                ss += __shfl_xor(ss, 4, 64);
-                ss += __shfl_xor(ss, 8, 64);
-                // RMSNorm(128, eps 1e-6): models/utils.py:250-257
-                const float rs = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-                if (m < M) {
-                    const f32x4 cs = *(const f32x4*)(P.rope_cos + (size_t)m * 64 + c * 4);
-                    const f32x4 sn = *(const f32x4*)(P.rope_sin + (size_t)m * 64 + c * 4);
-                    bf16x8 o;
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const float x0 = bf16r(bf16r(y[2 * jj] * rs) * (float)wv[2 * jj]);
-                        const float x1 = bf16r(bf16r(y[2 * jj + 1] * rs) * (float)wv[2 * jj + 1]);
-                        // apply_rotary_emb_qwen: fp32 complex multiply (qwen_image_dit.py:51-57)
-                        o[2 * jj] = (bf16)(x0 * cs[jj] - x1 * sn[jj]);
-                        o[2 * jj + 1] = (bf16)(x0 * sn[jj] + x1 * cs[jj]);
-                    }
-                    *(bf16x8*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
-                }
-            }
-        } else {
-            // V: written TRANSPOSED, Vt[head][d][pos(token)], tokens permuted inside aligned 16-groups
-            // (pos = perm16) so the attention kernel's P.V MFMA needs no cross-lane shuffle.
-            bf16* vt = (bf16*)P.vt_out + (size_t)head * 128 * S_pad;
-            const int seq0 = P.seq_off + mw0;
-            const int valid = min(64, M - mw0);
-            if ((seq0 & 15) == 0) {
-#pragma unroll 2
-                for (int it = 0; it < 16; ++it) {
-                    const int id = it * 64 + lane;
-                    const int d = id >> 3, tg = id & 7;
-                    const int gi = tg >> 1, hh = tg & 1;
-                    unsigned short e[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int row = gi * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
-                        e[j] = *(const unsigned short*)(E + row * 256 + (((d >> 3) ^ (row & 15)) << 4) + ((((d & 7) * 2) ^ (row & 8))));
-                    }
-                    bf16* dstp = vt + (size_t)d * S_pad + seq0 + gi * 16 + hh * 8;
-                    if (gi * 16 + 16 <= valid) {
-                        u32x4 pk;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pk[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
-                        *(u32x4*)dstp = pk;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int tok = gi * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
-                            if (tok < valid) ((unsigned short*)dstp)[j] = e[j];
-                        }
-                    }
-                }
-            } else {
-                // unaligned joint offset (text stream behind an odd-sized image stream): element-wise
-                const int s = seq0 + lane;
-                const int pos = (s & ~15) | perm16(s & 15);
-                if (lane < valid) {
-                    for (int d = 0; d < 128; ++d) {
-                        const unsigned short e =
-                            *(const unsigned short*)(E + lane * 256 + (((d >> 3) ^ (lane & 15)) << 4) + (((d & 7) * 2) ^ (lane & 8)));
-                        ((unsigned short*)vt)[(size_t)d * S_pad + pos] = e;
-                    }
-                }
-            }
-        }
-    } else {
-        const int c = lane & 15;
-        const int n = nw0 + c * 8;
-        bf16* out = (bf16*)P.out;
-        float g[8];
-        if constexpr (EPI == EPI_GATE_RES) {
-            const float gs = P.has_gate_scalar ? P.gate_scalar : 1.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = gs;
-            if (P.gate != nullptr && n < N) {
-                const bf16x8 gv = *(const bf16x8*)((const bf16*)P.gate + n);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) g[j] = (float)gv[j];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 4 + (lane >> 4);
-            const int m = mw0 + row;
-            if (m >= M || n >= N) continue;
-            const bf16x8 v = unswap(*(const bf16x8*)(E + row * 256 + ((c ^ (row & 15)) << 4)), it << 2);   // row & 8 == (it << 2) & 8
-            bf16x8 o;
-            if constexpr (EPI == EPI_BIAS) {
-                o = v;
-            } else if constexpr (EPI == EPI_GELU_SIG) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float y = (float)v[j];
-                    const float t = bf16r(1.702f * y);
-                    const float sg = bf16r(__builtin_amdgcn_rcpf(1.0f + __expf(-t)));   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide
-                    o[j] = (bf16)(y * sg);
-                }
-            } else if constexpr (EPI == EPI_GELU_ERF) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float y = (float)v[j];
-                    o[j] = (bf16)(0.5f * y * (1.0f + erff(y * 0.70710678118654752440f)));
-                }
-            } else if constexpr (EPI == EPI_SILU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float y = (float)v[j];
-                    o[j] = (bf16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
-                }
-            } else if constexpr (EPI == EPI_GATE_RES) {
-                const bf16x8 rv = rv16[it];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)rv[j] + bf16r(g[j] * (float)v[j]));
-            }
-            *(bf16x8*)(out + (size_t)m * P.ldo + n) = o;
-        }
-    }
+    long long* stamp4 = nullptr;
+    if constexpr (VAR == 15) stamp4 = args.dbg != nullptr ? args.dbg + (size_t)blockIdx.x * 8 + 4 : nullptr;
+    gemm_epilogue<EPI, FP8, false>(P, acc, m0, n0, E, E + 8192, lane, w, stamp4);
     PE_STAMP(5);
-    if constexpr (VAR == 14) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PE_STAMP(6);
-        if (args.dbg != nullptr && threadIdx.x == 0) args.dbg[(size_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime();
+}
+
+// ------------------------------------------------------------------------------------------
+// Schedule 17: persistent work-groups.  Work-group b (one per CU) computes the tiles b, b + G, b + 2G, ... of the XCD-aware
+// banded order (G = grid size, a multiple of 8: the tiles of a work-group stay on its XCD's chunk).  Its LDS-DMA requests form
+// ONE stream over its tiles: stream index i < nk is K tile i of the current tile; i = nk and nk + 1 -- the requests that
+// schedule 15 issues as clamped dummies in its last two iterations -- are K tiles 0 and 1 of the NEXT tile (same problem, both
+// tiles complete: their source rows are this tile's plus a wave-uniform offset).  A(i) lives in buffer (ab + i) & 1, W(i) in
+// ring slot (ws + i) % 3; ab and ws run on across tiles.  When the main loop ends, A(nk), W(nk) have landed (the last
+// iteration's vmcnt(4)), W(nk + 1) is in flight, and the two regions that held K tile nk - 1 are dead: the epilogue stages
+// the wave's 64 x 128 block there in two 32-row passes (8 KiB per wave: waves 0-3 in the A buffer, 4-7 in the W slot).  Its
+// global stores are not waited for: they retire under the next tile's first K tiles (vmcnt is in order, so that tile's first
+// vmcnt(4) also covers them).  What this removes per tile: the work-group launch, the cold prologue (HBM / L2 latency of the
+// first K tiles with an idle matrix pipe) and most of the store drain.
+// ------------------------------------------------------------------------------------------
+template <int EPI, bool FP8>
+__device__ __forceinline__ void gemm_persistent(const GemmArgs& args, char* smem) {
+    constexpr int ES = FP8 ? 1 : 2;
+    constexpr int KT_BYTES = 128;
+    using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
+    constexpr int KS = FP8 ? 2 : 4;
+    constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
+    const int w = wave_id();
+    const int wm = w >> 1, wn = w & 1;
+    const int grp = w >> 2;
+    char* const a_base = smem;
+    char* const w_base = smem + 2 * A_BYTES;
+    const int G = (int)gridDim.x;
+    const int ntiles = args.ntiles;
+
+#define PE_BAR()                                   \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+
+    int ab = 0, ws = 0;     // A buffer / W ring slot of K tile 0 of the current tile
+    bool have = false;      // K tiles 0 (A, W) and 1 (W) of the current tile were requested by the previous tile
+    for (int t = (int)blockIdx.x; t < ntiles; t += G) {
+        // the lane id is made opaque per tile: everything lane-dependent (staging sources, fragment and epilogue addresses) is
+        // then recomputed per tile instead of being hoisted out of this loop and kept live across the main loop (spills)
+        int lane_ = lane_id();
+        asm volatile("" : "+v"(lane_));
+        const int lane = lane_;
+        const int l31 = lane & 31, h = lane >> 5;
+        const int sw = (l31 >> 1) & 7;
+        const int a_off = (wm * 64 + l31) * 128;
+        const int w_off = (wn * 128 + l31) * 128;
+        const TileCoord tc0 = decode_tile(args, xcd_remap(t, ntiles));
+        const GemmProblem& P = args.p[tc0.pi];
+        const int M = P.M, N = P.N, K = P.K;
+        const int m0 = tc0.m0, n0 = tc0.n0;
+        const int nk = K * ES / KT_BYTES;
+        // next tile of this work-group: prefetchable iff same problem, both tiles complete, and the stream has room (nk >= 2)
+        bool have_next = false;
+        long long a_next = 0, w_next = 0;      // byte offset from this tile's source rows to the next tile's
+        if (t + G < ntiles) {
+            const TileCoord tn = decode_tile(args, xcd_remap(t + G, ntiles));
+            have_next = tn.pi == tc0.pi && nk >= 2 && m0 + BM <= M && tn.m0 + BM <= M && n0 + BN <= N && tn.n0 + BN <= N;
+            a_next = (long long)(tn.m0 - m0) * P.lda * ES;
+            w_next = (long long)(tn.n0 - n0) * K * ES;
+        }
+        // staging sources of this tile (recomputed per tile: nothing lane-dependent is carried across the epilogue)
+        const char* a_src[4];
+        const char* w_src[4];
+        {
+            const char* A = (const char*)P.A;
+            const char* W = (const char*)P.W;
+            const int rin = lane >> 3, slot = lane & 7;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece_a = grp * 16 + (w & 3) * 4 + i;     // A pieces of the wave group's OWN 128-row half
+                const int piece_w = w * 4 + i;
+                const int row_a = piece_a * 8 + rin, row_w = piece_w * 8 + rin;
+                const int gr = min(m0 + row_a, M - 1);
+                const int gn = min(n0 + row_w, N - 1);
+                a_src[i] = A + (size_t)gr * P.lda * ES + (slot ^ ((row_a >> 1) & 7)) * 16;
+                w_src[i] = W + (size_t)gn * K * ES + (slot ^ ((row_w >> 1) & 7)) * 16;
+            }
+        }
+        // byte offset of stream index i (wave-uniform, branch-free): K tile i of this tile; past its end K tile i - nk of the
+        // next tile, or (no prefetchable next tile) a clamped dummy re-read of this tile's last K tile
+        const int i_lim = have_next ? 0x7fffffff : nk - 1;
+        const long long a_adj = have_next ? a_next - (long long)nk * KT_BYTES : 0;
+        const long long w_adj = have_next ? w_next - (long long)nk * KT_BYTES : 0;
+        auto off_a = [&](int i) -> long long { return (long long)min(i, i_lim) * KT_BYTES + (a_adj & -(long long)(i >= nk)); };
+        auto off_w = [&](int i) -> long long { return (long long)min(i, i_lim) * KT_BYTES + (w_adj & -(long long)(i >= nk)); };
+        auto st_a4 = [&](int i, int buf) {
+            long long off = off_a(i);
+            asm volatile("" : "+s"(off));       // one scalar sum, then ONE 64-bit add per piece
+            char* base = a_base + buf * A_BYTES + (grp * 16 + (w & 3) * 4) * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(a_src[j] + off, base + j * 1024);
+        };
+        auto st_w4 = [&](int i, int slot) {
+            long long off = off_w(i);
+            asm volatile("" : "+s"(off));
+            char* base = w_base + slot * W_BYTES + w * 4096;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(w_src[j] + off, base + j * 1024);
+        };
+        auto rd = [&](const char* rowp, int ks) -> FragT {
+            if constexpr (FP8) {
+                const int c0 = 4 * ks + 2 * h;
+                const i32x4 lo = *(const i32x4*)(rowp + ((c0 ^ sw) << 4));
+                const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
+                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+                return *(const bf16x8*)(rowp + (((ks * 2 + h) ^ sw) << 4));
+            }
+        };
+
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+        FragT fa[KS], fw4[4][KS];
+        auto rd_a1 = [&](const char* Sa, int mi) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
+        };
+        auto rd_w4 = [&](const char* Sw) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fw4[ni][ks] = rd(Sw + w_off + ni * 4096, ks);
+        };
+        auto mma16 = [&](int mi) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    if constexpr (FP8)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                            fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    else
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
+                }
+        };
+#define PE_MMA16(mi)                               \
+    do {                                           \
+        PE_BAR();                                  \
+        __builtin_amdgcn_s_setprio(1);             \
+        mma16(mi);                                 \
+        __builtin_amdgcn_s_setprio(0);             \
+        PE_BAR();                                  \
+    } while (0)
+
+        const int ws1 = ws == 2 ? 0 : ws + 1;
+        if (!have) {
+            // cold start of a tile: the regions may still receive the previous tile's clamped dummies, and its epilogue ran in
+            // the other two: drain, meet, then stage as schedule 15 does
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PE_BAR();
+            st_a4(0, ab); st_w4(0, ws); st_w4(1, ws1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
+        }
+        // (have: this wave's pieces of A(0), W(0) were retired by the vmcnt(4) of the previous tile's last iteration)
+        PE_BAR();
+        if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger
+        int abk = ab, wsk = ws;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* Sa = a_base + abk * A_BYTES;
+            const int ws_n1 = wsk == 2 ? 0 : wsk + 1;
+            const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
+            // p0
+            rd_a1(Sa, 0); rd_w4(w_base + wsk * W_BYTES);
+            st_a4(kt + 1, abk ^ 1);
+            PE_MMA16(0);
+            // p1
+            rd_a1(Sa, 1);
+            st_w4(kt + 2, ws_n2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's pieces of A(kt+1), W(kt+1) landed
+            PE_MMA16(1);
+            abk ^= 1;
+            wsk = ws_n1;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();        // re-align the two groups: every fragment read of the tile is done
+        __builtin_amdgcn_sched_barrier(0);
+#undef PE_MMA16
+        // abk / wsk = where stream index nk lives (next tile's K tile 0); the regions of K tile nk - 1 are free
+        const int a_free = abk ^ 1;
+        const int w_free = wsk == 0 ? 2 : wsk - 1;
+        char* E = w < 4 ? a_base + a_free * A_BYTES + w * 8192 : w_base + w_free * W_BYTES + (w - 4) * 8192;
+        gemm_epilogue<EPI, FP8, true>(P, acc, m0, n0, E, E, lane, w, nullptr);
+        ab = abk;
+        ws = wsk;
+        have = have_next;
     }
+#undef PE_BAR
 }
 
 template <int EPI, int VAR, bool FP8>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nk = args.p[0].K * (FP8 ? 1 : 2) / 128;
-    // whole tile: one "range" [0, nk) of tile xcd_remap(block).  Stream-K tail (VAR 15): block b of the tail phase runs on
-    // XCD b % 8; every XCD gets 32 CONSECUTIVE K ranges so that a tile's partials are (mostly) exchanged through one L2.
-    int c = -1, tile = 0, k0 = 0, n_seg = 1;
-    long long r1 = nk;
-    if (VAR == 16 && args.sk_tiles > 0 && (int)blockIdx.x >= args.n_full) {
-        const int b = (int)blockIdx.x - args.n_full;
-        c = (b & 7) * (SK_WGS / 8) + (b >> 3);
-        const long long total = (long long)args.sk_tiles * nk;
-        const long long r0 = (long long)c * total / SK_WGS;
-        r1 = (long long)(c + 1) * total / SK_WGS;
-        const int t0 = (int)(r0 / nk);
-        k0 = (int)(r0 - (long long)t0 * nk);
-        r1 -= (long long)t0 * nk;                 // relative to the first tile's K tile 0
-        n_seg = r1 > nk ? 2 : 1;
-        tile = args.n_full + t0;
-    } else {
-        tile = xcd_remap((int)blockIdx.x, (VAR == 16 && args.sk_tiles > 0) ? args.n_full : (int)gridDim.x);
-    }
-    for (int seg = 0; seg < n_seg; ++seg) {
-        const int lo = seg == 0 ? k0 : 0;
-        const int hi = (int)min((long long)nk, r1 - (long long)seg * nk);
-        gemm_tile<EPI, VAR, FP8>(args, smem, tile + seg, lo, hi, c);
-    }
+    if constexpr (VAR == 17)
+        gemm_persistent<EPI, FP8>(args, smem);
+    else
+        gemm_tile<EPI, VAR, FP8>(args, smem, xcd_remap((int)blockIdx.x, (int)gridDim.x));
 }
 
 static int env_int(const char* name, int dflt) {
@@ -893,41 +912,61 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
+int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
+int g_gemm_persist_wgs = 0;    // 0 = one work-group per CU of the current device
+
+static int persistent_grid() {
+    static std::atomic<int> cus{0};
+    int n = cus.load(std::memory_order_acquire);
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+        n &= ~7;                         // a multiple of 8: a work-group's tiles stay on its XCD's chunk of the order
+        if (n < 8) n = 8;
+        cus.store(n, std::memory_order_release);
+    }
+    if (g_gemm_persist_wgs > 0) return (g_gemm_persist_wgs + 7) & ~7;
+    return n;
+}
 
 template <int EPI, int VAR, bool FP8 = false>
-static int launch_v(const GemmArgs& args, int ntiles, hipStream_t stream) {
+static int launch_v(const GemmArgs& args, int grid, hipStream_t stream) {
     static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
-    constexpr int lds = (FP8 || VAR >= 10) ? GEMM_LDS_V10 : GEMM_LDS;
     if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, VAR, FP8>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR, FP8>), dim3(ntiles), dim3(GEMM_THREADS), lds, stream, args);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR, FP8>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, stream, args);
     return check_launch(FP8 ? "gemm_fp8_kernel" : "gemm_bf16_kernel");
 }
 
 template <int EPI>
-static int launch_t(const GemmArgs& args, int ntiles, bool fp8, hipStream_t stream) {
-    // instantiated schedules: 15 (default), 10 (the round-1 schedule, kept as the A/B reference), 14 (the 4-phase ping-pong with
-    // s_memtime stamps, profiling only), 16 (15 + stream-K tail, a measured negative result kept as a knob).  The other round-1 / 2
-    // experiments (0, 8, 12, 13) are described in profiles/r01_gemm_ablation.md and profiles/r02_gemm_notes.md and were removed.
-    if (fp8) return g_gemm_variant == 10 ? launch_v<EPI, 10, true>(args, ntiles, stream) : launch_v<EPI, 15, true>(args, ntiles, stream);
-    if (g_gemm_variant == 14) return launch_v<EPI, 14>(args, ntiles, stream);
-    if (g_gemm_variant == 16) return launch_v<EPI, 16>(args, ntiles, stream);
-    if (g_gemm_variant == 10) return launch_v<EPI, 10>(args, ntiles, stream);
-    return launch_v<EPI, GEMM_DEFAULT_VARIANT>(args, ntiles, stream);
+static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
+    // instantiated schedules: 17 (default: persistent work-groups; needs more than one round of tiles), 15 (one tile per
+    // work-group: the round-2 default, what 17 falls back to, and the one that can write s_memtime stamps), 10 (the round-1
+    // schedule, kept as the A/B reference).  Everything else that was tried is in profiles/r0*_gemm_*.md.
+    const int ntiles = args.ntiles;
+    int var = g_gemm_variant;
+    const int G = persistent_grid();
+    if (var == 17 && ntiles <= G) var = 15;
+    if (fp8) {
+        if (var == 10) return launch_v<EPI, 10, true>(args, ntiles, stream);
+        if (var == 17) return launch_v<EPI, 17, true>(args, G, stream);
+        return launch_v<EPI, 15, true>(args, ntiles, stream);
+    }
+    if (var == 10) return launch_v<EPI, 10>(args, ntiles, stream);
+    if (var == 17) return launch_v<EPI, 17>(args, G, stream);
+    return launch_v<EPI, 15>(args, ntiles, stream);
 }
 
-int g_gemm_streamk = env_int("PE_GEMM_STREAMK", 1);
-void* g_gemm_sk_ws = nullptr;     // tests / granular operators: a registered stream-K workspace (pe_debug_set_ptr)
-static std::atomic<unsigned> g_sk_epoch{0};
-
-size_t gemm_streamk_ws_bytes() { return (size_t)SK_WGS * SK_SLOT_FLOATS * sizeof(float) + 4096; }
-
-int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, void* sk_ws) {
+int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream) {
     PE_REQUIRE(nproblems >= 1 && nproblems <= 2, "gemm: 1 or 2 problems per launch, got %d", nproblems);
+    PE_REQUIRE(g_gemm_variant == 10 || g_gemm_variant == 15 || g_gemm_variant == 17, "gemm: gemm_variant %d does not exist", g_gemm_variant);
+    PE_REQUIRE(g_gemm_band >= 1 && g_gemm_band <= 64, "gemm: gemm_band %d out of range", g_gemm_band);
     GemmArgs args;
     int tiles[2] = {0, 0};
     const bool fp8 = problems[0].fp8 != 0;
@@ -964,41 +1003,20 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     }
     if (nproblems == 1) args.p[1] = args.p[0];
     args.tiles0 = tiles[0];
+    args.ntiles = tiles[0] + tiles[1];
+    args.band = g_gemm_band;
     args.dbg = g_gemm_dbg;
-    int ntiles = tiles[0] + tiles[1];
-    // stream-K tail: when the last round of work-groups would fill only part of the chip, its tiles are cut along K into
-    // SK_WGS equal ranges instead (gemm_bf16_kernel).  Needs a workspace for the fp32 partials, the default schedule and
-    // one common K; not worth it for a nearly full last round or for very short K.
-    args.n_full = ntiles; args.sk_tiles = 0; args.sk_ws = nullptr; args.sk_flags = nullptr; args.sk_status = nullptr; args.sk_epoch = 0;
-    if (sk_ws == nullptr) sk_ws = g_gemm_sk_ws;
-    {
-        const int nk = problems[0].K / (fp8 ? 128 : BK);
-        const int tail = ntiles % SK_WGS;
-        const bool same_k = nproblems == 1 || problems[0].K == problems[1].K;
-        if (g_gemm_streamk && sk_ws != nullptr && g_gemm_variant == 16 && !fp8 && same_k && tail >= 32 && tail <= 224 &&
-            (long long)tail * nk / SK_WGS >= 6) {
-            args.n_full = ntiles - tail;
-            args.sk_tiles = tail;
-            args.sk_ws = (float*)sk_ws;
-            args.sk_flags = (unsigned*)((char*)sk_ws + (size_t)SK_WGS * SK_SLOT_FLOATS * sizeof(float));
-            args.sk_status = args.sk_flags + SK_WGS;
-            unsigned e = ++g_sk_epoch;
-            if (e == 0) e = ++g_sk_epoch;      // 0 is what a freshly zeroed flag holds
-            args.sk_epoch = e;
-            ntiles = args.n_full + SK_WGS;     // grid: whole tiles, then one tail block per CU
-        }
-    }
     double flops = 0.0;  // algorithmic 2*M*N*K of the launch (what the roofline fraction is quoted on)
     for (int i = 0; i < nproblems; ++i) flops += 2.0 * problems[i].M * (double)problems[i].N * problems[i].K;
     const int slot = prof_begin(PROF_GEMM, flops, stream);
     int rc;
     switch (epilogue) {
-        case EPI_BIAS: rc = launch_t<EPI_BIAS>(args, ntiles, fp8, stream); break;
-        case EPI_GELU_SIG: rc = launch_t<EPI_GELU_SIG>(args, ntiles, fp8, stream); break;
-        case EPI_GELU_ERF: rc = launch_t<EPI_GELU_ERF>(args, ntiles, fp8, stream); break;
-        case EPI_GATE_RES: rc = launch_t<EPI_GATE_RES>(args, ntiles, fp8, stream); break;
-        case EPI_QKV: rc = launch_t<EPI_QKV>(args, ntiles, fp8, stream); break;
-        case EPI_SILU: rc = launch_t<EPI_SILU>(args, ntiles, fp8, stream); break;
+        case EPI_BIAS: rc = launch_t<EPI_BIAS>(args, fp8, stream); break;
+        case EPI_GELU_SIG: rc = launch_t<EPI_GELU_SIG>(args, fp8, stream); break;
+        case EPI_GELU_ERF: rc = launch_t<EPI_GELU_ERF>(args, fp8, stream); break;
+        case EPI_GATE_RES: rc = launch_t<EPI_GATE_RES>(args, fp8, stream); break;
+        case EPI_QKV: rc = launch_t<EPI_QKV>(args, fp8, stream); break;
+        case EPI_SILU: rc = launch_t<EPI_SILU>(args, fp8, stream); break;
         default: rc = set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
     }
     prof_end(slot, stream);

@@ -52,12 +52,9 @@ struct GemmProblem {
     const float* scale_a;   // [M] fp32
 };
 
-// sk_ws: optional stream-K workspace (gemm_streamk_ws_bytes(), flags zeroed once by the owner); null = the registered
-// global one if any, else every tile is computed whole
-int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, void* sk_ws = nullptr);
-size_t gemm_streamk_ws_bytes();
-extern int g_gemm_streamk;
-extern void* g_gemm_sk_ws;
+int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream);
+extern int g_gemm_band;          // M tiles per band of the tile order (default 8)
+extern int g_gemm_persist_wgs;   // schedule 17: work-groups of the persistent grid (0 = one per CU)
 extern int g_gemm_variant;  // experiment knobs (pe_debug_set); production paths use the compiled defaults
 extern int g_attn_variant;
 extern long long* g_attn_dbg;

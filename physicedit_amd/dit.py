@@ -198,6 +198,7 @@ class QwenImageDiTEngine:
         other._step_of = {}
         other.version = self.version
         other.rope = self.rope
+        other._eligen_words = None
         return other
 
     def __del__(self):
@@ -447,12 +448,14 @@ class QwenImageDiTEngine:
         seg_lens = [e.shape[0] for e in ents] + [prompt_emb.shape[-2]]
         # the token words depend on the region masks and the lengths only: built once per image (every step of both CFG branches
         # comes through here), on the host, 4 bytes per token
-        key = (entity_masks.data_ptr(), entity_masks._version, tuple(entity_masks.shape), tuple(seg_lens), tuple(map(tuple, img_shapes)),
-               h8, w8)             # DenoiseLoop also drops the cache at the start of every image
+        # The cache holds a REFERENCE to the masks tensor and is valid only for that very object at that version: a new tensor
+        # for the next image can then never alias it (a freed tensor's address is reused by the caching allocator, and a fresh
+        # tensor's _version is 0 again), whoever the caller is (DenoiseLoop, model_fn_qwen_image, a forked engine).
+        key = (entity_masks._version, tuple(entity_masks.shape), tuple(seg_lens), tuple(map(tuple, img_shapes)), h8, w8)
         cache = getattr(self, "_eligen_words", None)
-        if cache is None or cache[0] != key:
-            self._eligen_words = (key, self._eligen_token_words(entity_masks, n_ent, seg_lens, img_shapes, h8, w8))
-        words = self._eligen_words[1]
+        if cache is None or cache[0] is not entity_masks or cache[1] != key:
+            self._eligen_words = (entity_masks, key, self._eligen_token_words(entity_masks, n_ent, seg_lens, img_shapes, h8, w8))
+        words = self._eligen_words[2]
         prompt_emb_all = torch.cat(ents + [prompt_emb.reshape(-1, prompt_emb.shape[-1])]).unsqueeze(0).contiguous()
         if special_idx is not None and special_idx.numel() > 0:
             # An entity entry that IS the prompt tensor (eligen_enable_on_negative hands the negative prompt_emb out N times,

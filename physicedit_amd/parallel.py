@@ -5,19 +5,25 @@ an image the two CFG branches only meet in the 512 KiB `noise_pred` combine of e
 reference shards by hand with `--start_idx/--end_idx` processes
 (scripts/inference/inference_pica.py:217-220,251-261).  Here:
 
+  * `edit_batch`       the PRODUCT entry: a list of edit jobs (keyword dicts of the pipeline's `__call__`:
+                       prompt, edit_image, seed, height, width, ...) through `QwenImagePhysicPipeline`,
+                       jobs round-robin over the ranks (or over rank PAIRS with the CFG pair of an image
+                       split inside the pair), ONE closing all-gather of the edited images (uint8) or of
+                       the final latents, results in job order on every rank;
   * `shard_units`      static round-robin of work units (images) over ranks; weights are replicated
                        (41.5 GB << 288 GB HBM), seeds/noise belong to the unit, not to the rank, so any
                        world size produces the same images;
-  * `gather_units`     ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) of the decoded
-                       latents / images at the end of the batch, returned in unit order on every rank;
-  * `CfgPairExchange`  optional latency mode for fewer images than GPUs: ranks (2k, 2k+1) run the posi /
-                       nega forward of the SAME image and all-gather `noise_pred` inside the pair each step.
+  * `gather_units`     ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) of per-unit
+                       result tensors, returned in unit order on every rank;
+  * `CfgPairExchange`  latency mode for fewer images than GPUs: ranks (2k, 2k+1) run the posi / nega
+                       forward of the SAME image and all-gather `noise_pred` inside the pair each step
+                       (`DenoiseLoop(cfg_pair=...)` is the product code that uses it).
 
 Backend-agnostic: torch.distributed with "nccl" (= RCCL on ROCm) for device tensors, "gloo" for CPU.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -36,16 +42,38 @@ def shard_units(n_units: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_units, world))
 
 
-def gather_units(local: Sequence[torch.Tensor], n_units: int, group=None) -> List[torch.Tensor]:
+def _gather_by_owner(local: Dict[int, torch.Tensor], ids: Sequence[int], owner: Callable[[int], int], shape, dtype, device,
+                     group=None, always_collective: bool = False) -> Dict[int, torch.Tensor]:
+    """ONE all-gather of the per-unit tensors `ids` (all of `shape` / `dtype`); unit u is contributed by rank owner(u)
+    (every rank evaluates the same `owner`).  Returns {unit: tensor} for all `ids` on every rank.  A single-rank job skips the
+    collective unless `always_collective` (and a process group exists): that is how a 1-GPU box executes the RCCL call."""
+    rank, world = world_info(group)
+    if world == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
+        return {u: local[u] for u in ids}
+    mine = [u for u in ids if owner(u) == rank]
+    per_rank = max(sum(1 for u in ids if owner(u) == r) for r in range(world))
+    buf = torch.zeros((max(per_rank, 1),) + tuple(shape), dtype=dtype, device=device)
+    for i, u in enumerate(mine):
+        buf[i].copy_(local[u].reshape(shape))
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    res, seen = {}, [0] * world
+    for u in ids:
+        r = owner(u)
+        res[u] = out[r][seen[r]]
+        seen[r] += 1
+    return res
+
+
+def gather_units(local: Sequence[torch.Tensor], n_units: int, group=None, always_collective: bool = False) -> List[torch.Tensor]:
     """All-gather per-unit result tensors (same shape/dtype for every unit).  `local` holds this rank's
     units in `shard_units` order.  Returns all `n_units` tensors in unit order on every rank."""
     rank, world = world_info(group)
-    if world == 1:
+    if world == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
         assert len(local) == n_units
         return list(local)
     mine = shard_units(n_units, rank, world)
     assert len(local) == len(mine), (len(local), len(mine))
-    per_rank = (n_units + world - 1) // world
     # shape/dtype agreement: a rank without units still needs a template -> broadcast from rank 0's first unit
     meta = [None]
     if rank == 0:
@@ -54,12 +82,9 @@ def gather_units(local: Sequence[torch.Tensor], n_units: int, group=None) -> Lis
     dist.broadcast_object_list(meta, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     shape, dtype = meta[0]
     dev = local[0].device if len(local) else _default_device()
-    buf = torch.zeros((per_rank,) + tuple(shape), dtype=dtype, device=dev)
-    for i, t in enumerate(local):
-        buf[i].copy_(t.reshape(shape))
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
-    return [out[u % world][u // world] for u in range(n_units)]
+    got = _gather_by_owner(dict(zip(mine, local)), list(range(n_units)), lambda u: u % world, shape, dtype, dev, group,
+                           always_collective)
+    return [got[u] for u in range(n_units)]
 
 
 def _default_device():
@@ -103,3 +128,76 @@ class CfgPairExchange:
         both = [torch.empty_like(pred), torch.empty_like(pred)]
         dist.all_gather(both, pred.contiguous(), group=self.group)
         return both[0], both[1]
+
+
+def edit_batch(pipe, jobs: Sequence[dict], group=None, split_cfg: bool = False, gather: str = "image",
+               cfg_pair: Optional[CfgPairExchange] = None) -> List:
+    """Edit a batch of images on all ranks of the job (the multi-GPU form of scripts/inference/inference_pica.py's
+    `for idx in range(start_idx, end_idx): image = pipe(prompt, edit_image=..., seed=..., ...)`, :251-296, which the
+    reference spreads over GPUs by starting one process per index range by hand, :217-220).
+
+    `pipe`   a `diffsynth.pipelines.qwen_image_physical.QwenImagePhysicPipeline` (same weights on every rank);
+    `jobs`   one keyword dict per image for `pipe.__call__` (every rank passes the SAME list); job j is unit j: its seed,
+             prompt and image travel with it, so the edited images do not depend on the world size;
+    `split_cfg`  False: job j runs on rank j % world.  True (even world size): ranks (2k, 2k+1) form pair k, job j runs on pair
+             j % (world / 2), the positive forward on the even rank and the negative one on the odd rank with a per-step
+             all-gather of `noise_pred` inside the pair (`CfgPairExchange`; pass a `cfg_pair` made earlier to reuse its groups);
+             halves the latency of an image when there are fewer images than GPUs;
+    `gather` "image": ONE all-gather of the decoded uint8 images closes the batch -> list of PIL images in job order on every
+             rank;  "latents": the all-gather moves the final latents instead (512 KiB instead of 3 MiB per 1024^2 image, the
+             collective BASELINE.json's north star names) -> list of [1,16,H/8,W/8] tensors;  "none": no collective, this
+             rank's own results only (the reference's behaviour: every process saves its own files) -> {job index: PIL image}.
+    Jobs whose results differ in shape are gathered per shape (one collective per distinct size)."""
+    from PIL import Image
+    rank, world = world_info(group)
+    if gather not in ("image", "latents", "none"):
+        raise ValueError("gather must be 'image', 'latents' or 'none'")
+    n = len(jobs)
+    if split_cfg and world > 1:
+        if world % 2:
+            raise ValueError("split_cfg needs an even world size")
+        if cfg_pair is None:
+            cfg_pair = CfgPairExchange.make_pairs()
+        lanes, lane = world // 2, rank // 2
+        owner = lambda u: 2 * (u % lanes)            # the pair's even rank contributes the (identical) result
+    else:
+        cfg_pair = None
+        lanes, lane = world, rank
+        owner = lambda u: u % lanes
+    mine = [u for u in range(n) if u % lanes == lane]
+    prev_pair = getattr(pipe, "cfg_pair", None)
+    pipe.cfg_pair = cfg_pair
+    images: Dict[int, torch.Tensor] = {}
+    latents: Dict[int, torch.Tensor] = {}
+    pil: Dict[int, "Image.Image"] = {}
+    try:
+        for u in mine:
+            img = pipe(**jobs[u])
+            pil[u] = img
+            if gather == "latents":
+                latents[u] = pipe.last_latents.detach().clone()
+            elif gather == "image":
+                import numpy as np
+                images[u] = torch.from_numpy(np.asarray(img).copy()).to(pipe.device)
+    finally:
+        pipe.cfg_pair = prev_pair
+    if gather == "none":
+        return pil
+    if world == 1:
+        return [pil[u] for u in range(n)] if gather == "image" else [latents[u] for u in range(n)]
+    # result shapes are a function of the job alone (ShapeChecker, :673-680): every rank groups the units the same way
+    def out_hw(job):
+        h, w = pipe.check_resize_height_width(job.get("height", 1328), job.get("width", 1328))
+        return int(h), int(w)
+    classes: Dict[Tuple[int, int], List[int]] = {}
+    for u in range(n):
+        classes.setdefault(out_hw(jobs[u]), []).append(u)
+    got: Dict[int, torch.Tensor] = {}
+    for (h, w), ids in sorted(classes.items()):
+        if gather == "image":
+            got.update(_gather_by_owner(images, ids, owner, (h, w, 3), torch.uint8, pipe.device, group))
+        else:
+            got.update(_gather_by_owner(latents, ids, owner, (1, 16, h // 8, w // 8), pipe.torch_dtype, pipe.device, group))
+    if gather == "latents":
+        return [got[u] for u in range(n)]
+    return [pil[u] if u in pil else Image.fromarray(got[u].cpu().numpy()) for u in range(n)]

@@ -23,15 +23,19 @@ BF = torch.bfloat16
 
 
 class DenoiseLoop:
-    def __init__(self, dit: QwenImageDiTEngine, dual_stream: bool = False):
+    def __init__(self, dit: QwenImageDiTEngine, dual_stream: bool = False, cfg_pair=None):
         """dual_stream: run the positive and the negative forward of each step concurrently on two HIP streams
         (second workspace on the same weights).  They are independent until the CFG combine (:653-656), and each
-        fills the CUs the other leaves idle in its partial rounds of work-groups."""
+        fills the CUs the other leaves idle in its partial rounds of work-groups.
+        cfg_pair: a `parallel.CfgPairExchange`: THIS rank runs only the forward of its role (0 positive, 1 negative) and the
+        two `noise_pred` tensors are all-gathered inside the rank pair every step (512 KiB over xGMI); both ranks then apply
+        the same CFG combine + Euler update and hold identical latents.  Ignored when cfg_scale == 1."""
         self.dit = dit
         self.device = dit.device
         self.scheduler = qwen_image_scheduler()
         self.torch_dtype = BF
         self.dual_stream = dual_stream
+        self.cfg_pair = cfg_pair
         self._dit_n: Optional[QwenImageDiTEngine] = None
         self._streams = None
 
@@ -68,7 +72,8 @@ class DenoiseLoop:
         if edit_rope_interpolation:                    # (:1367-1368) same tables for both CFG branches
             kw_p["edit_rope_interpolation"] = kw_n["edit_rope_interpolation"] = True
         self.dit._eligen_words = None                  # token words are cached per image (QwenImageDiTEngine._eligen_inputs)
-        dual = self.dual_stream and use_cfg
+        pair = self.cfg_pair if use_cfg else None
+        dual = self.dual_stream and use_cfg and pair is None
         dit_n = self.dit
         if dual:
             if self._dit_n is None or self._dit_n.version != self.dit.version or self._dit_n.fp8 != self.dit.fp8:
@@ -76,6 +81,7 @@ class DenoiseLoop:
                 self._dit_n = self.dit.fork()
                 self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             dit_n = self._dit_n
+            dit_n._eligen_words = None
             dit_n.bind(S_img, T_max, num_inference_steps)
             dit_n.prepare(ts)
         self.dit.bind(S_img, T_max, num_inference_steps)
@@ -86,7 +92,7 @@ class DenoiseLoop:
         nxt = torch.empty_like(latents)
         pred_p = torch.empty_like(latents)
         pred_n = torch.empty_like(latents) if use_cfg else None
-        main = torch.cuda.current_stream(dev)
+        main = torch.cuda.current_stream(dev) if dual else None
         x0 = mask = None
         if inpaint_mask is not None:
             if input_latents is None:
@@ -112,6 +118,14 @@ class DenoiseLoop:
                     dit_n.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl, **kw_n)
                 main.wait_stream(sp)
                 main.wait_stream(sn)
+            elif pair is not None:
+                # split CFG pair: one forward here, the sibling rank runs the other one on the same latents
+                if pair.role == 0:
+                    self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl, **kw_p)
+                    pred_p, pred_n = pair.exchange(pred_p)
+                else:
+                    self.dit.forward(latents, t, prompt_emb_nega, idx_n, edits or None, step=i, out=pred_n, controls=ctl, **kw_n)
+                    pred_p, pred_n = pair.exchange(pred_n)
             else:
                 self.dit.forward(latents, t, prompt_emb_posi, idx_p, edits or None, step=i, out=pred_p, controls=ctl, **kw_p)
                 if use_cfg:

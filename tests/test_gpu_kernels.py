@@ -138,8 +138,27 @@ def test_qkv_rmsnorm_rope(ops, M, seq_off):
     assert torch.count_nonzero(vt[:, :, mask]).item() == 0
 
 
-@pytest.mark.parametrize("S", [64, 100, 256, 700, 1093])
-def test_flash_attn(ops, S):
+ATTN_DEFAULT = 4      # attention.hip g_attn_variant
+
+
+@pytest.fixture
+def attn_variant():
+    """selects a flash-attention kernel variant for one test (pe_debug_set) and restores the default"""
+    from physicedit_amd._lib import lib
+
+    def select(v):
+        assert lib().pe_debug_set(b"attn_variant", v) == 0
+    yield select
+    lib().pe_debug_set(b"attn_variant", ATTN_DEFAULT)
+    lib().pe_debug_set(b"attn_force_split", 0)
+
+
+@pytest.mark.parametrize("S,variant", [(64, 4), (100, 4), (700, 4), (1093, 4), (2208, 4), (256, 0), (1093, 0)])
+def test_flash_attn(ops, attn_variant, S, variant):
+    """The criterion for EVERY variant is the one the repo enforces end to end: the rms distance to the fp32 result must be the
+    bf16 reference's own (torch-CPU bf16 SDPA).  Variant 0 (textbook max update) rounds P at the reference's scale and is
+    also held to <= 3 ulp element-wise; variant 4 (default, lazy max: P <= 2^8 instead of <= 1) rounds P at another scale,
+    so fewer outputs are bit-identical to the reference's (bound 4 ulp) at the SAME distance to fp32."""
     H = 24
     q, k, v = rnd((H, S, 128), 21), rnd((H, S, 128), 22), rnd((H, S, 128), 23)
     ref = F.scaled_dot_product_attention(q[None], k[None], v[None])[0]           # [H,S,128]
@@ -147,15 +166,18 @@ def test_flash_attn(ops, S):
     sp = ops.s_pad_of(S)
     qd = torch.zeros((H, sp, 128), dtype=BF, device="cuda"); qd[:, :S] = q.cuda()
     kd = torch.full((H, sp, 128), float("nan"), dtype=BF, device="cuda"); kd[:, :S] = k.cuda()   # pad rows are masked
+    attn_variant(variant)
     out = ops.flash_attn(qd, kd, ops.pack_vt(v.cuda(), sp), S)
-    # fp32 truth for scale: attention outputs are averages, |o| ~ 0.1; compare on an absolute floor
-    report(f"flash_attn S={S}", out, ref, max_ulp=3.01, max_frac=0.50)   # bf16 P in both; the criterion is the rms below
+    if variant == 0:
+        report(f"flash_attn v0 S={S}", out, ref, max_ulp=3.01, max_frac=0.50)
+    else:
+        report(f"flash_attn v{variant} S={S}", out, ref, max_ulp=4.01, max_frac=0.55)
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0]
     ref32 = ref32.permute(1, 0, 2).reshape(S, H * 128)
     e_gpu = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
     e_cpu = (ref.float() - ref32).pow(2).mean().sqrt().item()
-    print(f"[parity] flash_attn S={S}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
-    assert e_gpu <= 1.5 * e_cpu + 1e-6
+    print(f"[parity] flash_attn v{variant} S={S}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
+    assert e_gpu <= 1.1 * e_cpu + 1e-6
 
 
 @pytest.mark.parametrize("S,force", [(700, 3), (1093, 5), (300, 8)])
@@ -175,7 +197,7 @@ def test_flash_attn_split_kv(ops, S, force):
         out = ops.flash_attn(qd, kd, vt, S, workspace=True)
     finally:
         lib().pe_debug_set(b"attn_force_split", 0)
-    report(f"flash_attn split S={S} x{force} vs reference", out, ref, max_ulp=3.01, max_frac=0.40)
+    report(f"flash_attn split S={S} x{force} vs reference", out, ref, max_ulp=4.01, max_frac=0.55)
     report(f"flash_attn split S={S} x{force} vs unsplit kernel", out, base, max_ulp=2.01, max_frac=0.05)
 
 
@@ -210,18 +232,6 @@ def test_flash_attn_peaked(ops):
     assert e_gpu <= 2.0 * e_cpu + 1e-3
 
 
-@pytest.fixture
-def attn_variant():
-    """selects a flash-attention kernel variant for one test (pe_debug_set) and restores the default"""
-    from physicedit_amd._lib import lib
-
-    def select(v):
-        assert lib().pe_debug_set(b"attn_variant", v) == 0
-    yield select
-    lib().pe_debug_set(b"attn_variant", 0)
-    lib().pe_debug_set(b"attn_force_split", 0)
-
-
 @pytest.mark.parametrize("S,force", [(64, 0), (100, 0), (257, 0), (700, 3), (1093, 5), (2048, 0), (4160, 3)])
 def test_flash_attn_w4_bit_identical(ops, attn_variant, S, force):
     """Variant 3 (4 waves x 64 rows, one wave per SIMD, two 32-MFMA phases per KV tile pipelined across tiles) performs the
@@ -247,25 +257,35 @@ def test_flash_attn_w4_bit_identical(ops, attn_variant, S, force):
         assert torch.equal(ops.flash_attn(qd, kd, vt, S), out)
 
 
-@pytest.mark.parametrize("S", [100, 700, 2048])
-def test_flash_attn_lazy_max(ops, attn_variant, S):
-    """Variant 4 = variant 3 with the running max raised only when a row outgrows it by 2^8 (no O rescale in almost every tile).
-    O / l does not depend on which max was used, but P is rounded to bf16 at another scale than in the reference's SDPA, so fewer
-    outputs are bit-identical to the reference's; the distance to the fp32 truth must stay the reference-bf16's own.  Opt-in."""
-    H = 24
-    q, k, v = rnd((H, S, 128), 21), rnd((H, S, 128), 22), rnd((H, S, 128), 23)
+def test_flash_attn_lazy_max_forced_rescale(ops, attn_variant):
+    """Variant 4 raises a block's running max only when a row outgrows it by 2^8, so on bounded random data its rescale branch
+    almost never runs after the first tile.  Force it (cdna guide T13 / rule 26): spiked keys make chosen rows jump by far more
+    than 2^8 in the middle of the sequence, in tiles where other rows of the same 32-row block do not move; the result must
+    agree with the textbook kernel (variant 0) to rounding and with the fp32 truth as well as the bf16 reference does."""
+    H, S = 24, 1093
+    q, k, v = rnd((H, S, 128), 31), rnd((H, S, 128), 32), rnd((H, S, 128), 33)
+    for (key, row, gain) in ((300, 7, 8.0), (470, 200, 12.0), (700, 7, 16.0), (1000, 1090, 10.0)):
+        k[:, key] = q[:, row] * gain          # score ~ gain * |q|^2 / sqrt(128) ~ 11 * gain  >> 8 / log2(e)
     ref = F.scaled_dot_product_attention(q[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
     sp = ops.s_pad_of(S)
     qd = torch.zeros((H, sp, 128), dtype=BF, device="cuda"); qd[:, :S] = q.cuda()
     kd = torch.full((H, sp, 128), float("nan"), dtype=BF, device="cuda"); kd[:, :S] = k.cuda()
+    vt = ops.pack_vt(v.cuda(), sp)
+    attn_variant(0)
+    base = ops.flash_attn(qd, kd, vt, S).clone()
     attn_variant(4)
-    out = ops.flash_attn(qd, kd, ops.pack_vt(v.cuda(), sp), S)
-    report(f"flash_attn variant 4 S={S}", out, ref, max_ulp=4.01, max_frac=0.55)
-    e_gpu = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
-    e_cpu = (ref.float() - ref32).pow(2).mean().sqrt().item()
-    print(f"[parity] flash_attn variant 4 S={S}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
-    assert e_gpu <= 1.1 * e_cpu + 1e-6
+    out = ops.flash_attn(qd, kd, vt, S)
+    assert torch.isfinite(out.float()).all()
+    report("flash_attn v4 forced rescale vs v0", out, base, max_ulp=4.01, max_frac=0.55)
+    e4 = (out.float().cpu() - ref32).abs().max().item()
+    e0 = (base.float().cpu() - ref32).abs().max().item()
+    ec = (ref.float() - ref32).abs().max().item()
+    print(f"[parity] flash_attn forced rescale: max err vs fp32 truth  v4 {e4:.3e}  v0 {e0:.3e}  cpu-bf16-sdpa {ec:.3e}")
+    assert e4 <= 2.0 * ec + 1e-3
+    r4 = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
+    rc = (ref.float() - ref32).pow(2).mean().sqrt().item()
+    assert r4 <= 1.25 * rc + 1e-6      # peaked rows: the textbook update keeps the dominant P = 1.0 exact, the lazy one does not
 
 
 # ------------------------------------------------------------------------------------------------

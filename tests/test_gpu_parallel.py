@@ -48,32 +48,18 @@ def _worker(rank, world, port, n_units, mode, q):
     torch.cuda.set_device(rank)
     dev = torch.device("cuda", rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    from physicedit_amd import ops, parallel, synth
-    from physicedit_amd.dit import special_indices
+    from physicedit_amd import parallel
     from physicedit_amd.pipeline import DenoiseLoop
-    from physicedit_amd.scheduler import qwen_image_scheduler
     eng = _engine(dev)
     if mode == "dp":
         loop = DenoiseLoop(eng)
         res = parallel.run_data_parallel(n_units, lambda u: _edit_unit(loop, dev, u))
         torch.cuda.synchronize()
         q.put((rank, [r.float().cpu().numpy() for r in res]))
-    else:   # CFG pair split: rank 0 runs the positive forward, rank 1 the negative one, per-step all-gather of noise_pred
+    else:   # CFG pair split through the PRODUCT loop: rank 0 runs the positive forward, rank 1 the negative one, per-step
+        #         all-gather of noise_pred inside DenoiseLoop (pipeline.py)
         ex = parallel.CfgPairExchange.make_pairs()
-        pe_p, pe_n, m_p, m_n = _prompts()
-        pe, mask = (pe_p, m_p) if ex.role == 0 else (pe_n, m_n)
-        pe = pe.to(dev).clone()
-        idx = special_indices(mask, dev)
-        sch = qwen_image_scheduler()
-        sch.set_timesteps(STEPS, dynamic_shift_len=(H // 16) * (W // 16))
-        ts = sch.timesteps.to(BF)
-        eng.bind((H // 16) * (W // 16), max(T_P, T_N), STEPS)
-        eng.prepare(ts)
-        lat = synth.make_noise(100, H, W).to(dev)
-        for i in range(STEPS):
-            pred = eng.forward(lat, ts[i:i + 1], pe, idx, None, step=i)
-            posi, nega = ex.exchange(pred)
-            lat = ops.cfg_euler_step(posi, nega, lat, 4.0, sch.dsigma(i))
+        lat = _edit_unit(DenoiseLoop(eng, cfg_pair=ex), dev, 0)
         torch.cuda.synchronize()
         q.put((rank, lat.float().cpu().numpy()))
     dist.barrier()
@@ -121,3 +107,29 @@ def test_rccl_cfg_pair_split_matches_single_rank():
     dev = torch.device("cuda", 0)
     ref = _edit_unit(DenoiseLoop(_engine(dev)), dev, 0).float().cpu()
     assert torch.equal(torch.from_numpy(got[0]), ref) and torch.equal(torch.from_numpy(got[1]), ref)
+
+
+def test_rccl_path_executes_at_world_1():
+    """The driver's N > 1 scaling runs must not be the first execution of the RCCL path.  On a 1-GPU box everything but the rank
+    count can run: `bench.py --gpus 1 --force-dist` under torch.distributed.run initialises the nccl (= RCCL) process group,
+    closes the batch with the all-gather of the final latents, and takes the max-over-ranks time through barrier + all-reduce.
+    Reduced model (1 layer, 2 steps): the collectives and the launcher are what is under test."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--layers", "1",
+           "--steps", "1", "--warmup", "0", "--inference-steps", "2", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["config"]["rccl_ranks"] == 1
+    assert "all_gather" in out["config"]["batch_closing_collective"]
+    assert len(out["config"]["per_rank_elapsed_s"]) == 1 and out["config"]["finite_outputs"] is True
+    assert out["value"] > 0

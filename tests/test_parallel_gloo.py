@@ -107,3 +107,156 @@ def test_cfg_pair_split_matches_single_process():
     ref = O.denoise_loop(sd, None, synth.make_noise(0, 64, 64), synth.make_prompt_emb(7, 16), synth.make_prompt_emb(8, 12),
                          None, None, 64, 64, 2, cfg_scale=4.0).float()
     assert torch.equal(torch.from_numpy(got[0]), ref) and torch.equal(torch.from_numpy(got[1]), ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# product entry: parallel.edit_batch through a pipeline object, DenoiseLoop(cfg_pair=...)
+# ------------------------------------------------------------------------------------------------
+class OracleEngine:
+    """CPU stand-in for physicedit_amd.dit.QwenImageDiTEngine (same methods DenoiseLoop calls), the oracle as the compute."""
+    device = torch.device("cpu")
+    version, fp8 = 0, False
+
+    def __init__(self):
+        self.sd = synth.make_state_dict(synth.dit_layout(0), 1234)
+        self._eligen_words = None
+        self.forwards = 0
+
+    def bind(self, *a):
+        pass
+
+    def prepare(self, ts):
+        pass
+
+    def forward(self, latents, t, prompt_emb, idx, edits, step=None, out=None, controls=None, **kw):
+        self.forwards += 1
+        h8, w8 = latents.shape[-2:]
+        pred = O.model_fn(self.sd, None, latents, t, prompt_emb, None, h8 * 8, w8 * 8)
+        if out is not None:
+            out.copy_(pred)
+            return out
+        return pred
+
+
+def _cpu_cfg_euler(posi, nega, latents, cfg_scale, dsigma, out=None, **kw):
+    """stand-in for ops.cfg_euler_step (a HIP kernel): any deterministic function of the same inputs serves the plumbing tests"""
+    pred = posi if nega is None else (nega.float() + cfg_scale * (posi.float() - nega.float())).to(BF)
+    res = (latents.float() + pred.float() * dsigma).to(BF)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+class StubPipe:
+    """The attributes / methods of QwenImagePhysicPipeline that parallel.edit_batch touches, over the REAL DenoiseLoop."""
+
+    def __init__(self):
+        import physicedit_amd.pipeline as PL
+        PL.ops.cfg_euler_step = _cpu_cfg_euler
+        self.PL = PL
+        self.device, self.torch_dtype, self.cfg_pair = torch.device("cpu"), BF, None
+        self.dit = OracleEngine()
+        self.last_latents = None
+
+    def check_resize_height_width(self, h, w):
+        return (h + 15) // 16 * 16, (w + 15) // 16 * 16
+
+    def __call__(self, prompt, seed=0, height=64, width=64, num_inference_steps=2, cfg_scale=4.0, **kw):
+        from PIL import Image
+        height, width = self.check_resize_height_width(height, width)
+        loop = self.PL.DenoiseLoop(self.dit, cfg_pair=self.cfg_pair)
+        lat = loop(synth.make_noise(seed, height, width), synth.make_prompt_emb(len(prompt), 16), synth.make_prompt_emb(8, 12),
+                   None, None, height, width, num_inference_steps=num_inference_steps, cfg_scale=cfg_scale)
+        self.last_latents = lat
+        u8 = ((lat.float()[0, :3].clamp(-2, 2) + 2) * 63.75).to(torch.uint8).permute(1, 2, 0)
+        u8 = u8.repeat_interleave(8, 0).repeat_interleave(8, 1).contiguous()
+        return Image.fromarray(u8.numpy())
+
+
+JOBS = [dict(prompt="a" * (3 + i), seed=10 + i, height=64, width=64 if i % 3 else 96) for i in range(5)]
+
+
+def _worker_edit(rank, world, port, split, gather, q):
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    pipe = StubPipe()
+    res = parallel.edit_batch(pipe, JOBS, split_cfg=split, gather=gather)
+    out = [np.asarray(r) if gather == "image" else r.float().numpy() for r in res]
+    q.put((rank, out, pipe.dit.forwards))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,split,gather", [(2, False, "image"), (2, True, "latents"), (4, True, "image")])
+def test_edit_batch_matches_single_process(world, split, gather):
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edit, args=(r, world, port, split, gather, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: (o, f) for r, o, f in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    pipe = StubPipe()
+    single = parallel.edit_batch(pipe, JOBS, gather=gather)        # no process group: this process edits every job
+    single = [np.asarray(r) if gather == "image" else r.float().numpy() for r in single]
+    for rank in range(world):
+        assert len(got[rank][0]) == len(JOBS)
+        for u in range(len(JOBS)):
+            assert np.array_equal(got[rank][0][u], single[u]), (rank, u)        # job order, bit-identical, any world size
+    # work really was divided: 2 steps x 2 forwards per job; a split pair runs ONE forward per step and rank
+    lanes = world // 2 if split else world
+    for rank in range(world):
+        lane = rank // 2 if split else rank
+        n_mine = len([u for u in range(len(JOBS)) if u % lanes == lane])
+        assert got[rank][1] == n_mine * 2 * (1 if split else 2), (rank, got[rank][1])
+
+
+def _worker_loop_pair(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import physicedit_amd.pipeline as PL
+    PL.ops.cfg_euler_step = _cpu_cfg_euler
+    ex = parallel.CfgPairExchange.make_pairs()
+    eng = OracleEngine()
+    loop = PL.DenoiseLoop(eng, cfg_pair=ex)
+    lat = loop(synth.make_noise(3, 64, 64), synth.make_prompt_emb(7, 16), synth.make_prompt_emb(8, 12), None, None, 64, 64,
+               num_inference_steps=3, cfg_scale=4.0)
+    lat1 = loop(synth.make_noise(3, 64, 64), synth.make_prompt_emb(7, 16), synth.make_prompt_emb(8, 12), None, None, 64, 64,
+                num_inference_steps=2, cfg_scale=1.0)            # CFG off: the pair is ignored, every rank runs the one forward
+    q.put((rank, lat.float().numpy(), lat1.float().numpy(), eng.forwards))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_denoise_loop_cfg_pair_is_product_code():
+    """DenoiseLoop(cfg_pair=CfgPairExchange): each rank of a pair runs ONE forward per step and both end with the latents of the
+    unsplit loop."""
+    import physicedit_amd.pipeline as PL
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_loop_pair, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (a, b, f) for r, a, b, f in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    PL.ops.cfg_euler_step = _cpu_cfg_euler
+    eng = OracleEngine()
+    loop = PL.DenoiseLoop(eng)
+    ref = loop(synth.make_noise(3, 64, 64), synth.make_prompt_emb(7, 16), synth.make_prompt_emb(8, 12), None, None, 64, 64,
+               num_inference_steps=3, cfg_scale=4.0).float()
+    ref1 = loop(synth.make_noise(3, 64, 64), synth.make_prompt_emb(7, 16), synth.make_prompt_emb(8, 12), None, None, 64, 64,
+                num_inference_steps=2, cfg_scale=1.0).float()
+    for r in (0, 1):
+        assert torch.equal(torch.from_numpy(got[r][0]), ref) and torch.equal(torch.from_numpy(got[r][1]), ref1)
+        assert got[r][2] == 3 + 2          # one forward per step with the pair, one per step without CFG

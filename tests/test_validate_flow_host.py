@@ -103,7 +103,7 @@ def test_reference_validate_py_runs_unchanged_through_the_facade(tmp_path, monke
             return torch.full((lat.shape[2] * 8, lat.shape[3] * 8, 3), 128, dtype=torch.uint8)
 
     class FakeLoop:
-        def __init__(self, dit, dual_stream=False):
+        def __init__(self, dit, dual_stream=False, cfg_pair=None):
             self.scheduler = None
 
         def __call__(self, latents, pe_p, pe_n, m_p, m_n, height, width, **kw):
