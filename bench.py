@@ -288,6 +288,10 @@ def main():
             out["roofline"]["power_limited_ceiling"] = ceil
             if ceil["random_normal_operands"] > 0:
                 out["roofline"]["frac_of_power_limited_ceiling"] = achieved / ceil["random_normal_operands"]
+            att = attainable_ceiling(dev)
+            out["roofline"]["attainable_ceiling"] = att
+            if att.get("mfma_lds_reads_dma_stream", 0) > 0:
+                out["roofline"]["frac_of_attainable_ceiling"] = achieved / att["mfma_lds_reads_dma_stream"]
         if world == 1 and headline and not args.fp8 and not args.no_secondary:
             out["secondary"] = secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_n, read_prof)
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
@@ -374,6 +378,53 @@ def mfma_power_ceiling(dev):
     return {"what": "pe_mfma_probe: v_mfma_f32_32x32x16_bf16 only, 8 waves/CU, operands in registers, measured in this process "
                     "after the timed region", "unit": "TFLOP/s", "random_normal_operands": res["random_normal"],
             "zero_operands": res["zeros"]}
+
+
+def attainable_ceiling(dev):
+    """How much of the distance to the nominal peak is the schedule's, and how much belongs to the tiling itself: pe_gemm_mix_probe
+    issues the bf16 GEMM main loop's per-MFMA instruction mix -- per K tile and wave 32 MFMAs, 24 ds_read_b128 fragment reads, 8 LDS-DMA
+    pieces from an L2-resident stream -- free-running (no barriers, no waits for arriving data, no epilogue), on N(0,1) operands, after
+    the timed region.  Plus the library GEMM itself with its fixed costs amortised away: one round of 256 tiles with K = 32768."""
+    import ctypes
+    import torch
+    from physicedit_amd import ops
+    from physicedit_amd._lib import check, lib, stream_ptr
+    BF = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(2)
+    src = torch.randn(8 << 20, generator=g, device=dev).to(BF)            # 16 MiB = 8 windows of 2 MiB
+    outb = torch.empty(256 * 512, dtype=torch.float32, device=dev)
+    res = {"what": "pe_gemm_mix_probe (8 waves / CU, 160 KiB LDS, N(0,1) bf16, L2-resident operand stream, no barriers / epilogue); "
+                   "gemm_main_loop_only = pe_gemm_bf16 at 4096 x 4096 x 32768 (one round of tiles, 512 K tiles each)", "unit": "TFLOP/s"}
+    for mode, name in ((0, "mfma_only"), (1, "mfma_lds_reads"), (2, "mfma_lds_reads_dma_stream")):
+        fl = ctypes.c_double(0.0)
+        best = 0.0
+        for iters in (2000, 150000, 150000):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().pe_gemm_mix_probe(mode, src.data_ptr(), src.numel() * 2, outb.data_ptr(), 256, iters, ctypes.byref(fl),
+                                          stream_ptr()), "pe_gemm_mix_probe")
+            e1.record()
+            torch.cuda.synchronize()
+            if iters > 2000:
+                best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        res[name] = best
+    M = N = 4096
+    K = 32768
+    x = torch.randn((M, K), generator=g, device=dev).to(BF)
+    w = (torch.randn((N, K), generator=g, device=dev) * K ** -0.5).to(BF)
+    o = torch.empty((M, N), dtype=BF, device=dev)
+    ops.gemm(x, w, None, out=o)
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(60):
+            ops.gemm(x, w, None, out=o)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 60 * 2.0 * M * N * K / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    res["gemm_main_loop_only"] = best
+    return res
 
 
 def pmc_traffic(args):

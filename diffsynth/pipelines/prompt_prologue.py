@@ -235,6 +235,37 @@ def build_text_encoder(state_dict: Dict[str, torch.Tensor], device, torch_dtype=
     return model.eval()
 
 
+def decode_internals_compatible() -> Tuple[bool, str]:
+    """The q_len = 1 replacements of Qwen2_5_VLAttention.forward / Qwen2_5_VLDecoderLayer.forward below depend on transformers
+    internals: keyword names, the attention returning `(attn_output, attn_weights)`, the decoder layer returning the bare hidden
+    state.  transformers is not pinned by this repo (tested: 5.x), so the contract is checked where it is installed: version
+    range, signatures, and the return statements of the stock methods.  Anything else -> the two classes are left alone and
+    decoding runs through the stock modules (the row-wise Linear / RMSNorm / MLP replacements do not depend on any of this)."""
+    import inspect
+    import re
+    import transformers
+    try:
+        ver = tuple(int(x) for x in re.findall(r"\d+", transformers.__version__)[:2])
+        from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as M
+        if not (5, 0) <= ver < (6, 0) and not os.environ.get("PE_PROLOGUE_ANY_TRANSFORMERS"):
+            return False, f"transformers {transformers.__version__} is outside the tested range 5.x"
+        need = {"Qwen2_5_VLDecoderLayer": ("hidden_states", "attention_mask", "position_ids", "past_key_values", "use_cache",
+                                           "position_embeddings"),
+                "Qwen2_5_VLAttention": ("hidden_states", "attention_mask", "position_ids", "past_key_values", "position_embeddings")}
+        tail = {"Qwen2_5_VLDecoderLayer": r"return\s+hidden_states\s*$", "Qwen2_5_VLAttention": r"return\s+attn_output\s*,\s*attn_weights\s*$"}
+        for name, params in need.items():
+            fwd = getattr(M, name).forward
+            have = inspect.signature(fwd).parameters
+            miss = [p for p in params if p not in have]
+            if miss:
+                return False, f"{name}.forward has no parameter {miss[0]!r}"
+            if not re.search(tail[name], inspect.getsource(fwd).rstrip()):
+                return False, f"{name}.forward no longer ends with the return structure the replacement mirrors"
+    except Exception as e:          # missing module, unreadable source, ...
+        return False, f"{type(e).__name__}: {e}"
+    return True, ""
+
+
 def accelerate_decode(model) -> int:
     """Autoregressive decoding applies every nn.Linear of the language model to ONE row: 15 GB of weights per generated token, an
     HBM-bound GEMV.  On the GPU those calls are routed to the library's pe_gemv_bf16 (fp32 accumulation, one rounding, like
@@ -246,6 +277,9 @@ def accelerate_decode(model) -> int:
     from physicedit_amd import ops
     n = 0
     rope_cache = {"cos": None, "cs": None, "sn": None}      # the section-selected rotary row of the current step, shared by all layers
+    internals_ok, why = decode_internals_compatible()
+    if not internals_ok:
+        print(f"[prompt_prologue] fused decode attention / layer not installed ({why}); single-row Linears, RMSNorms and MLPs only")
     for m in model.modules():
         if (isinstance(m, torch.nn.Linear) and m.weight.is_cuda and m.weight.dtype == torch.bfloat16 and m.weight.is_contiguous()
                 and m.in_features % 8 == 0 and m.in_features <= 32768):
@@ -276,6 +310,8 @@ def accelerate_decode(model) -> int:
                 return _orig(x)
             m.forward = mlp_forward
             n += 1
+        elif not internals_ok:
+            continue
         elif (type(m).__name__ == "Qwen2_5_VLAttention" and getattr(m, "head_dim", 0) == 128 and m.q_proj.weight.is_cuda
               and m.q_proj.weight.dtype == torch.bfloat16 and m.q_proj.in_features % 8 == 0):
             n += _patch_decode_attention(m, ops, rope_cache)
@@ -293,6 +329,8 @@ class GraphDecoder:
     [layer][kv_head][prompt + max_new_tokens][128] that the q/k/v launch appends to (pe_decode_step_*: everything that changes per
     token is read from device memory).  Same kernels, same order, same roundings as `accelerate_decode`, so the tokens are the ones
     the patched `generate()` produces.  EOS is tested on the host every `chunk` tokens; the overshoot is discarded."""
+
+    MAX_CACHE_ROWS = 15360          # rows of the static K / V planes pe_decode_step_attention can walk
 
     def __init__(self, model, chunk: int = 16):
         from physicedit_amd import ops
@@ -348,8 +386,8 @@ class GraphDecoder:
         eos = set() if eos is None else set(eos if isinstance(eos, (list, tuple)) else [eos])
         min_new = int(getattr(gen, "min_new_tokens", 0) or 0)
         cap = Lp + max_new_tokens
-        if cap > 15360:
-            raise ValueError("GraphDecoder.generate: prompt + max_new_tokens exceeds the decode attention's 15360-row cache")
+        if cap > self.MAX_CACHE_ROWS:
+            raise ValueError(f"GraphDecoder.generate: prompt + max_new_tokens exceeds the decode attention's {self.MAX_CACHE_ROWS}-row cache")
         # ---- prefill on transformers (one pass over the prompt; image tokens, mrope positions, rope_deltas are its business)
         try:
             out = model(**model_inputs, use_cache=True, logits_to_keep=1)
@@ -548,7 +586,9 @@ class PromptPrologue:
                         and (getattr(gen, "repetition_penalty", None) or 1.0) == 1.0
                         and not getattr(gen, "no_repeat_ngram_size", 0) and not getattr(gen, "bad_words_ids", None)
                         and not getattr(gen, "suppress_tokens", None) and not getattr(gen, "forced_eos_token_id", None))
-        if self.graph_decoder is not None and plain_greedy and model_inputs["input_ids"].shape[0] == 1:
+        ids = model_inputs["input_ids"]
+        if (self.graph_decoder is not None and plain_greedy and ids.shape[0] == 1
+                and ids.shape[1] + max_new_tokens <= GraphDecoder.MAX_CACHE_ROWS):        # longer: the reference's own path
             return self.graph_decoder.generate(max_new_tokens=max_new_tokens, **model_inputs)
         return self.text_encoder.generate(**model_inputs, max_new_tokens=max_new_tokens)
 

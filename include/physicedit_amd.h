@@ -43,7 +43,7 @@ int pe_abi_version(void);
 const char* pe_build_id(void);
 /* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant", ...).
  * Production callers never need it: the compiled defaults are the validated schedules.
- * "gemm_variant": 17 default (persistent work-groups with cross-tile prefetch; launches of at most one round of tiles run 15);
+ * "gemm_variant": 17 default (persistent work-groups with cross-tile prefetch; launches of fewer than three rounds of tiles run 15);
  * 15 = one tile per work-group (the round-2 default; writes s_memtime stamps when "gemm_stamps" is attached); 10 = the round-1
  * schedule (A/B reference).  "gemm_band": M tiles per band of the XCD-aware tile order (default 8).  "gemm_persist_wgs":
  * work-groups of schedule 17's grid (0 = one per CU).
@@ -108,6 +108,13 @@ int pe_ln_modulate_e4m3(const void* x, void* out_bf16, void* out_e4m3, float* ou
 int pe_gemm_e4m3(int epilogue, const void* Aq, int lda, const float* scale_a, const void* Wq, const void* bias,
                  const void* pre, int ldp, void* out, int ldo, int M, int N, int K, const void* gate, const void* res,
                  int ldr, void* stream);
+/* The MLP-up Linear of a block in e4m3 mode with the NEXT Linear's activation quantisation fused: out = ApproximateGELU(fp8_linear(x))
+ * in bf16 as pe_gemm_e4m3(PE_EPI_GELU_SIG) writes it, plus that output's fp8_linear row quantisation -- q8_out [M,N] e4m3 bytes and
+ * q8_scale [M] -- without a second pass over it: the epilogue stores e4m3(out), exact for every row whose scale is 1 (max|row| <= 447),
+ * and raises q8_flags[m] for the others, which a second, row-wise launch re-quantises from `out` (it also writes every scale and
+ * lowers the flags).  Bit-identical to pe_quantize_rows_e4m3(out).  q8_flags: [M] uint32, zero on entry and on return. */
+int pe_gemm_e4m3_gelu_q8(const void* Aq, int lda, const float* scale_a, const void* Wq, const void* bias, void* out, int ldo,
+                         void* q8_out, float* q8_scale, unsigned* q8_flags, int M, int N, int K, void* stream);
 
 /* Fused QKV projection of one stream (QwenDoubleStreamAttention.forward, qwen_image_dit.py:282-302):
  * x[M,K] @ Wqkv[3*H*128,K]^T + b, per-head RMSNorm(q,k) (weights norm_q_w/norm_k_w [128]), RoPE(q,k)
@@ -442,6 +449,13 @@ int pe_adapter_forward(const pe_adapter_weights* adapter, const void* x, int n, 
  * filled: zeros -> the nominal dense peak; random values -> the rate the chip's POWER LIMIT allows on such operands, the ceiling of
  * every bf16 MFMA kernel on that data).  out: blocks * 512 floats.  *flops receives the FLOPs of the launch; time it with events. */
 int pe_mfma_probe(const void* frags, void* out, int blocks, int iters, double* flops, void* stream);
+/* Measurement aid: the bf16 GEMM main loop's per-MFMA resource mix, free-running (no barriers, no epilogue, no wait for arriving
+ * data): 512-thread work-groups with 160 KiB of LDS, per K tile and wave 32 MFMAs plus -- mode 1 -- the 24 ds_read_b128 fragment
+ * reads of the 64 x 128 wave tile and -- mode 2 -- also the 8 LDS-DMA pieces of the operand stream, read from `src` (src_bytes =
+ * 8 windows of a power-of-two size >= 1 MiB, one per XCD, so the stream is L2 resident).  Mode 0 = MFMAs only in the same
+ * kernel.  On random data the three rates bracket what any schedule of this tiling can reach under the power limit
+ * (bench.py `roofline.attainable_ceiling`).  out: blocks * 512 floats; *flops receives the launch's FLOPs. */
+int pe_gemm_mix_probe(int mode, const void* src, size_t src_bytes, void* out, int blocks, int iters, double* flops, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement: HIP-event timing of sampled launches, recorded on the launch stream.

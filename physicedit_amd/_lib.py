@@ -141,10 +141,13 @@ SIGNATURES = {
     "pe_layernorm_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "pe_perceiver_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "pe_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, C.POINTER(C.c_double), c_void_p]),
+    "pe_gemm_mix_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_int, c_int, C.POINTER(C.c_double), c_void_p]),
     "pe_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_void_p]),
     "pe_cfg_inpaint_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float,
                                           c_int, c_float, c_float, c_void_p]),
     "pe_dit_create": (c_int, [C.POINTER(DitWeights), C.POINTER(AdapterWeights), C.POINTER(c_void_p)]),
+    "pe_gemm_e4m3_gelu_q8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_void_p]),
     "pe_dit_destroy": (None, [c_void_p]),
     "pe_dit_set_hot_lora": (c_int, [c_void_p, C.POINTER(DitBlockLora), c_int]),
     "pe_dit_add_hot_lora": (c_int, [c_void_p, C.POINTER(DitBlockLora), c_int]),

@@ -113,6 +113,21 @@ int pe_gemm_e4m3(int epilogue, const void* Aq, int lda, const float* scale_a, co
     return launch_gemm(epilogue, &p, 1, (hipStream_t)stream);
 }
 
+int pe_gemm_e4m3_gelu_q8(const void* Aq, int lda, const float* scale_a, const void* Wq, const void* bias, void* out, int ldo,
+                         void* q8_out, float* q8_scale, unsigned* q8_flags, int M, int N, int K, void* stream) {
+    PE_REQUIRE(q8_out && q8_scale && q8_flags, "pe_gemm_e4m3_gelu_q8: null e4m3 output");
+    PE_REQUIRE(N % 128 == 0, "pe_gemm_e4m3_gelu_q8: N=%d must be a multiple of 128 (it is the next Linear's K)", N);
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = Aq; p.W = Wq; p.bias = bias; p.out = out;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldo = ldo;
+    p.fp8 = 1; p.scale_a = scale_a;
+    p.q8_out = q8_out; p.ldq8 = N; p.q8_flags = q8_flags;
+    int rc = launch_gemm(EPI_GELU_SIG, &p, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_requant_flagged_rows(out, ldo, M, N, q8_out, N, q8_scale, q8_flags, (hipStream_t)stream);
+}
+
 int pe_qkv_rmsnorm_rope(const void* x, int ldx, const void* Wqkv, const void* bqkv, int M, int H, int K,
                         const void* norm_q_w, const void* norm_k_w, const float* rope_cos,
                         const float* rope_sin, void* q_out, void* k_out, void* vt_out, int seq_off, int S_pad,

@@ -45,6 +45,14 @@ PE_DEV int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// four fp32 -> OCP e4m3fn bytes (v_cvt_pk_fp8_f32 on gfx950, round to nearest even, saturating)
+PE_DEV uint32_t pack4_e4m3(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+
 // exact-erf GELU / sigmoid helpers in fp32
 PE_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 

@@ -44,7 +44,13 @@ struct pe_dit {
     char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
     char* aq;                           // e4m3 mode: quantised activation rows of the Linear being run [S, FF] bytes
     float* asc;                         // e4m3 mode: their per-row scales
-    const void* aq_src = nullptr;       // bf16 operand whose quantised rows currently sit in aq/asc (fused producer), or null
+    char* aq2;                          // e4m3 mode: the MLP-up epilogue's e4m3 output [S, FF] (the MLP-down Linear's operand) ...
+    float* asc2;                        // ... its per-row scales ...
+    unsigned* qflags;                   // ... and the rows that need a scale above 1 (gemm.hip GemmProblem.q8_out), [S], zero at rest
+    // a fused producer left the quantised rows of bf16 operand pre_src in (pre_q, pre_sc): the next dit_linear on it skips its pass
+    const void* pre_src = nullptr;
+    char* pre_q = nullptr;
+    float* pre_sc = nullptr;
     // hot LoRA sets (load_lora(hotload=True) may be called several times: AutoWrappedLinear keeps LISTS of pairs and adds
     // them one after the other, vram_management/layers.py:173-181); each set: operands per block + its padded rank
     static constexpr int MAX_LORA_SETS = 8;
@@ -99,9 +105,13 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     if (h->w.weights_e4m3) {
         take(&h->aq, rows * FF);
         take((char**)&h->asc, rows * sizeof(float));
+        take(&h->aq2, rows * FF);
+        take((char**)&h->asc2, rows * sizeof(float));
+        take((char**)&h->qflags, rows * sizeof(unsigned));
     } else {
-        h->aq = nullptr;
-        h->asc = nullptr;
+        h->aq = h->aq2 = nullptr;
+        h->asc = h->asc2 = nullptr;
+        h->qflags = nullptr;
     }
     return off;
 }
@@ -116,18 +126,20 @@ static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t st
     const bool joint = n == 2 && pp[0].K == pp[1].K && pp[0].lda == pp[1].lda &&
                        (const char*)pp[1].A == (const char*)pp[0].A + (size_t)pp[0].M * pp[0].lda * 2;
     size_t off = 0, row = 0;
-    const bool prequantised = joint && h->aq_src != nullptr && h->aq_src == pp[0].A;   // ln_modulate already wrote aq/asc
-    h->aq_src = nullptr;
+    const bool prequantised = joint && h->pre_src != nullptr && h->pre_src == pp[0].A;   // a fused producer already wrote the rows
+    char* qbuf = prequantised ? h->pre_q : h->aq;
+    float* qsc = prequantised ? h->pre_sc : h->asc;
+    h->pre_src = nullptr;
     for (int s = 0; s < n; ++s) {
         const int Kp = (int)align_up((size_t)pp[s].K, 128);
         if (!prequantised && (s == 0 || !joint)) {
             const int M = joint ? pp[0].M + pp[1].M : pp[s].M;
-            if ((rc = launch_quantize_rows_e4m3(pp[s].A, pp[s].lda, M, pp[s].K, h->aq + off, Kp, h->asc + row, stream)))
+            if ((rc = launch_quantize_rows_e4m3(pp[s].A, pp[s].lda, M, pp[s].K, qbuf + off, Kp, qsc + row, stream)))
                 return rc;
         }
         const int Ms = pp[s].M;
-        pp[s].A = h->aq + off; pp[s].lda = Kp; pp[s].K = Kp;
-        pp[s].scale_a = h->asc + row; pp[s].fp8 = 1;
+        pp[s].A = qbuf + off; pp[s].lda = Kp; pp[s].K = Kp;
+        pp[s].scale_a = qsc + row; pp[s].fp8 = 1;
         off += (size_t)Ms * Kp;
         row += Ms;
     }
@@ -271,6 +283,11 @@ int pe_dit_bind_workspace(pe_dit_handle h, void* workspace, size_t bytes, int S_
     // Q/K pad rows only feed masked scores.  Zero all three once.
     hipError_t e = hipMemsetAsync(h->q, 0, (size_t)(h->attn - h->q), (hipStream_t)stream);
     if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
+    if (h->qflags != nullptr) {
+        const size_t rows = (size_t)S_img_max + T_max > (size_t)n_steps ? (size_t)S_img_max + T_max : (size_t)n_steps;
+        e = hipMemsetAsync(h->qflags, 0, rows * sizeof(unsigned), (hipStream_t)stream);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
+    }
     return PE_OK;
 }
 
@@ -433,7 +450,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                                            sh(mod_txt, 0), sc(mod_txt, 0), 1e-6f, fuse_q ? h->aq : nullptr,
                                            fuse_q ? h->asc : nullptr, stream)))
             return rc;
-        if (fuse_q) h->aq_src = h->xmod;
+        if (fuse_q) { h->pre_src = h->xmod; h->pre_q = h->aq; h->pre_sc = h->asc; }
         // QKV projections + per-head RMSNorm + RoPE, head-major Q/K, transposed V
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {
@@ -470,7 +487,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                                            sh(mod_txt, 1), sc(mod_txt, 1), 1e-6f, fuse_q ? h->aq : nullptr,
                                            fuse_q ? h->asc : nullptr, stream)))   // MLP-up is no LoRA target: no bf16 copy
             return rc;
-        if (fuse_q) h->aq_src = h->xmod;
+        if (fuse_q) { h->pre_src = h->xmod; h->pre_q = h->aq; h->pre_sc = h->asc; }
         // MLP up + ApproximateGELU
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {
@@ -480,7 +497,19 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].out = h->hbuf + (s == 0 ? 0 : (size_t)S_img * FF * 2); pp[s].ldo = FF;
             pp[s].M = s == 0 ? S_img : T; pp[s].N = FF; pp[s].K = D;
         }
+        if (fuse_q) {
+            // the GELU output is the MLP-down Linear's operand: the epilogue also writes it as e4m3 (aq2) and flags the rows whose
+            // scale is not 1; the fix-up pass writes the scales (and redoes flagged rows from hbuf): no second pass over [S, FF]
+            for (int s = 0; s < 2; ++s) {
+                const size_t r0 = s == 0 ? 0 : (size_t)S_img;
+                pp[s].q8_out = h->aq2 + r0 * FF; pp[s].ldq8 = FF; pp[s].q8_flags = h->qflags + r0;
+            }
+        }
         if ((rc = dit_linear(h, EPI_GELU_SIG, pp, 2, stream))) return rc;
+        if (fuse_q) {
+            if ((rc = launch_requant_flagged_rows(h->hbuf, FF, S, FF, h->aq2, FF, h->asc2, h->qflags, stream))) return rc;
+            h->pre_src = h->hbuf; h->pre_q = h->aq2; h->pre_sc = h->asc2;
+        }
         // MLP down + gated residual
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {

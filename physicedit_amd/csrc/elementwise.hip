@@ -7,13 +7,6 @@
 
 namespace pe {
 
-PE_DEV uint32_t pack4_e4m3(float a, float b, float c, float d) {
-    int v = 0;
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);   // v_cvt_pk_fp8_f32: OCP e4m3fn on gfx950, RNE
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-    return (uint32_t)v;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm(elementwise_affine=False, eps) -> x*(1+scale) + shift
@@ -840,6 +833,72 @@ __global__ void __launch_bounds__(256) quantize_rows_e4m3_kernel(const bf16* __r
         }
     }
     for (int c = nch + t; c < (Kp >> 3); c += 256) *(u32x2*)(orow + c * 8) = u32x2{0u, 0u};
+}
+
+// Fix-up pass of the quantisation fused into the producer GEMM's epilogue (GemmProblem.q8_out): the epilogue wrote e4m3(y) for
+// every element, which IS fp8_linear's quantisation whenever the row's scale is 1 (max|row| <= 447 => bf16(max / 448) <= 1 =>
+// clamp(.., min=1) = 1 and x / (1 + 1e-8f) == x in fp32), and flagged the rows holding anything larger.  One block per row:
+// clear flag -> write scale 1 and leave; raised flag -> the full row quantisation from the bf16 row (same arithmetic as
+// quantize_rows_e4m3_kernel), and the flag is lowered for the next launch.
+template <int MAXC>
+__global__ void __launch_bounds__(256) requant_flagged_rows_kernel(const bf16* __restrict__ x, int ldx, int K,
+                                                                   uint8_t* __restrict__ out, int Kp, float* __restrict__ scale,
+                                                                   unsigned* __restrict__ flags) {
+    __shared__ float red[4];
+    const int row = (int)blockIdx.x;
+    const int t = (int)threadIdx.x;
+    if (flags[row] == 0u) {
+        if (t == 0) scale[row] = 1.0f;
+        return;
+    }
+    const bf16* xr = x + (size_t)row * ldx;
+    const int nch = K >> 3;
+    bf16x8 v[MAXC];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 256 + t;
+        if (c < nch) {
+            v[i] = *(const bf16x8*)(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf((float)v[i][j]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = fmaxf(bf16r(mx * (1.0f / 448.0f)), 1.0f);
+    const float dv = sc + 1e-8f;
+    if (t == 0) {
+        scale[row] = sc;
+        flags[row] = 0u;
+    }
+    uint8_t* orow = out + (size_t)row * Kp;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 256 + t;
+        if (c < nch) {
+            u32x2 o;
+            o[0] = pack4_e4m3((float)v[i][0] / dv, (float)v[i][1] / dv, (float)v[i][2] / dv, (float)v[i][3] / dv);
+            o[1] = pack4_e4m3((float)v[i][4] / dv, (float)v[i][5] / dv, (float)v[i][6] / dv, (float)v[i][7] / dv);
+            *(u32x2*)(orow + c * 8) = o;
+        }
+    }
+}
+
+int launch_requant_flagged_rows(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, unsigned* flags,
+                                hipStream_t stream) {
+    PE_REQUIRE(x && out && scale && flags, "requant_flagged_rows: null pointer");
+    PE_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && K <= 12288 && Kp == K && K % 128 == 0,
+               "requant_flagged_rows: M=%d K=%d Kp=%d (K = Kp: multiple of 128, <= 12288)", M, K, Kp);
+    PE_REQUIRE(ldx >= K && ldx % 8 == 0, "requant_flagged_rows: ldx=%d", ldx);
+    const int slot = prof_begin(PROF_ROW, 8.0 * (double)M, stream);   // bytes: flag read + scale write per row
+    hipLaunchKernelGGL((requant_flagged_rows_kernel<6>), dim3(M), dim3(256), 0, stream, (const bf16*)x, ldx, K, (uint8_t*)out, Kp, scale,
+                       flags);
+    prof_end(slot, stream);
+    return check_launch("requant_flagged_rows_kernel");
 }
 
 int launch_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, hipStream_t stream) {

@@ -67,7 +67,7 @@ PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 //   15  (round-2 default) "ping-pong": the two wave groups run the same stream one barrier apart, 2 phases x 16 MFMAs per
 //       K tile, A half tiles staged by the group that reads them; one tile per work-group
 //   17  (default) 15's main loop in persistent work-groups with cross-tile prefetch (gemm_persistent below); launches of
-//       at most one round of tiles run 15
+//       fewer than three rounds of tiles run 15
 //
 // FP8 = true: operands are OCP e4m3 bytes (activation rows quantised by quantize_rows_e4m3, weights stored in e4m3),
 // the K tile is 128 elements (the SAME 128-B LDS rows, staging and swizzle), the MFMA is the CDNA4 block-scaled
@@ -184,8 +184,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
             }
     };
 
-    // read the staged half `mi` back row-wise, apply the epilogue proper, store
-    auto emit_rows = [&](int mi) __attribute__((always_inline)) {
+    // the lane's 8 rows of the staged half `mi` (one 16-B chunk = 8 consecutive columns of each)
+    auto load_rows = [&](int mi, bf16x8 (&rows)[8]) __attribute__((always_inline)) {
+        const char* Eb = mi == 0 ? E0 : E1;
+        const int c = lane & 15;
+#pragma unroll
+        for (int j8 = 0; j8 < 8; ++j8) {
+            const int lrow = j8 * 4 + (lane >> 4);
+            rows[j8] = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
+        }
+    };
+    // read the staged half `mi` back row-wise (held_tag false) or take the rows load_rows fetched earlier (true), apply the
+    // epilogue proper, store
+    auto emit_rows = [&](int mi, auto held_tag, const bf16x8 (&held)[8]) __attribute__((always_inline)) {
+        constexpr bool HELD = decltype(held_tag)::value;
         const char* Eb = mi == 0 ? E0 : E1;
         if constexpr (EPI == EPI_QKV) {
             const int HD = N / 3;
@@ -201,7 +213,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                 for (int j8 = 0; j8 < 8; ++j8) {
                     const int lrow = j8 * 4 + (lane >> 4);
                     const int m = mw0 + mi * 32 + lrow;
-                    const bf16x8 v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
+                    bf16x8 v;
+                    if constexpr (HELD) v = held[j8];
+                    else v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
                     float y[8];
                     float ss = 0.f;
 #pragma unroll
@@ -297,7 +311,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                 const int lrow = j8 * 4 + (lane >> 4);
                 const int m = mw0 + mi * 32 + lrow;
                 if (m >= M || n >= N) continue;
-                const bf16x8 v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
+                bf16x8 v;
+                if constexpr (HELD) v = held[j8];
+                else v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
                 bf16x8 o;
                 if constexpr (EPI == EPI_BIAS) {
                     o = v;
@@ -308,6 +324,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                         const float t = bf16r(1.702f * y);
                         const float sg = bf16r(__builtin_amdgcn_rcpf(1.0f + __expf(-t)));   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide
                         o[j] = (bf16)(y * sg);
+                    }
+                    if constexpr (FP8) {
+                        if (P.q8_out != nullptr) {
+                            // the next Linear's e4m3 operand (fp8_linear's row quantisation with scale 1, GemmProblem.q8_out)
+                            float f[8];
+                            float amax = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                f[j] = (float)o[j];
+                                amax = fmaxf(amax, fabsf(f[j]));
+                            }
+                            u32x2 pk;
+                            pk[0] = pack4_e4m3(f[0], f[1], f[2], f[3]);
+                            pk[1] = pack4_e4m3(f[4], f[5], f[6], f[7]);
+                            *(u32x2*)((uint8_t*)P.q8_out + (size_t)m * P.ldq8 + n) = pk;
+                            if (amax > 447.0f) atomicOr(P.q8_flags + m, 1u);      // rare: the row needs a scale above 1
+                        }
                     }
                 } else if constexpr (EPI == EPI_GELU_ERF) {
 #pragma unroll
@@ -331,16 +364,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
         }
     };
 
+    bf16x8 rows[8];
     if constexpr (TWO_PASS) {
-        stage_rows(0, 1);
-        emit_rows(0);
-        stage_rows(1, 2);
-        emit_rows(1);
+        // One 8 KiB region for both halves.  A wave's LDS operations execute in order, so half 1 may be staged as soon as the
+        // READS of half 0 have been issued: its 32 ds_write_b64 then run under the epilogue maths and stores of half 0 instead of
+        // behind them.
+        // Not for the gated-residual and QKV epilogues: with their 16 prefetched residual rows / RoPE operands the held rows
+        // push the kernel over the 256-register budget (19-31 spilled registers measured).
+        constexpr bool EARLY_STAGE = EPI != EPI_GATE_RES && EPI != EPI_QKV;
+        if constexpr (EARLY_STAGE) {
+            stage_rows(0, 1);
+            load_rows(0, rows);
+            stage_rows(1, 2);
+            emit_rows(0, std::true_type{}, rows);
+            load_rows(1, rows);
+            emit_rows(1, std::true_type{}, rows);
+        } else {
+            stage_rows(0, 1);
+            emit_rows(0, std::false_type{}, rows);
+            stage_rows(1, 2);
+            emit_rows(1, std::false_type{}, rows);
+        }
     } else {
         stage_rows(0, 2);
         if (stamp4 != nullptr && threadIdx.x == 0) *stamp4 = (long long)__builtin_readcyclecounter();
-        emit_rows(0);
-        emit_rows(1);
+        emit_rows(0, std::false_type{}, rows);
+        emit_rows(1, std::false_type{}, rows);
     }
 }
 
@@ -952,7 +1001,9 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     const int ntiles = args.ntiles;
     int var = g_gemm_variant;
     const int G = persistent_grid();
-    if (var == 17 && ntiles <= G) var = 15;
+    // 17 pays from about three rounds of tiles on (measured, profiles/r03_gemm_notes.md: +1.2 ... +1.5 % at 4.8 / 6.4 rounds, -0.7 ... -1.3 %
+    // at 1.6 rounds, where most work-groups own a single tile and only pay for the two-pass epilogue); "gemm_persist_wgs" > 0 forces it
+    if (var == 17 && ntiles < (g_gemm_persist_wgs > 0 ? G + 1 : 3 * G)) var = 15;
     if (fp8) {
         if (var == 10) return launch_v<EPI, 10, true>(args, ntiles, stream);
         if (var == 17) return launch_v<EPI, 17, true>(args, G, stream);

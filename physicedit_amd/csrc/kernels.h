@@ -50,6 +50,13 @@ struct GemmProblem {
     // (lda in elements = bytes, K % 128 == 0); y = bf16(acc * scale_a[m] + bias[n]) before the epilogue proper
     int fp8;
     const float* scale_a;   // [M] fp32
+    // e4m3 operands + EPI_GELU_SIG: the NEXT Linear's activation operand, produced here (fp8_linear's row quantisation of this
+    // output, fused): q8_out [M, ldq8] bytes receives e4m3(out) -- exact whenever the row's scale is 1, i.e. max|row| / 448
+    // rounds to <= 1 -- and q8_flags[m] is raised for rows holding a value above 447 (launch_requant_flagged_rows redoes those
+    // rows from the bf16 output and writes every row's scale).  null: off.
+    void* q8_out;
+    int ldq8;
+    unsigned* q8_flags;     // [M] (indexed like scale_a: row of THIS problem), zero between launches
 };
 
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream);
@@ -83,6 +90,10 @@ int launch_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, f
 // fp8_linear's activation quantisation: scale[m] = max(bf16(max|x[m,:]| * (1/448)), 1); out = e4m3(x / (scale + 1e-8)),
 // columns [K, Kp) zero-filled
 int launch_quantize_rows_e4m3(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, hipStream_t stream);
+// second half of the fused quantisation (GemmProblem.q8_out): scale[m] = 1 for the rows whose flag is clear; flagged rows are
+// quantised from the bf16 row like launch_quantize_rows_e4m3 does, and their flag is cleared
+int launch_requant_flagged_rows(const void* x, int ldx, int M, int K, void* out, int Kp, float* scale, unsigned* flags,
+                                hipStream_t stream);
 int launch_silu(const void* x, void* out, size_t n, hipStream_t stream);
 int launch_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const void* wy, void* out, int rows, int dim, float eps,
                             hipStream_t stream);

@@ -74,11 +74,130 @@ __global__ void __launch_bounds__(512) mfma_probe_kernel(const uint4* __restrict
     out[tid] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Attainable" probe: the GEMM main loop's per-MFMA resource mix without its barriers, its dependencies on arriving data and
+// its epilogue.  8 waves per work-group (two per SIMD), all 160 KiB of LDS, per "K tile" and wave 32 MFMAs fed by
+//   MODE 1: + 24 ds_read_b128 fragment reads (0.75 per MFMA, the 64 x 128 wave tile's ratio) from the swizzled LDS image
+//   MODE 2: + 8 LDS-DMA pieces of 1 KiB (global_load_lds_dwordx4) streamed from an L2-resident window into the ring
+// -- the instructions gemm_bf16_kernel<.., 15 / 17> issues per K tile, free-running (the waves drift, nothing waits for a
+// barrier, counted vmcnt only bounds the DMA queue).  On N(0,1) data the rates of MODE 0 (pe_mfma_probe) / 1 / 2 price the
+// matrix pipe alone, the LDS fragment traffic, and the operand stream under the chip's power limit: what is left between MODE 2
+// and the measured GEMM is schedule (barriers, prologue, epilogue, tile quantisation), what is above MODE 2 is not reachable by
+// a 256 x 256 x 64 tiling with this wave tile at all.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) gemm_mix_probe_kernel(const char* __restrict__ src, unsigned window_bytes /* power of two */,
+                                                               float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char probe_smem[];
+    typedef __attribute__((ext_vector_type(8))) __bf16 probe_bf16x8;
+    typedef __attribute__((ext_vector_type(16))) float probe_f32x16;
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int sw = (l31 >> 1) & 7;
+    // every work-group of an XCD (block b runs on XCD b % 8) streams the same window: the stream is L2 resident
+    const char* win = src + (size_t)(blockIdx.x & 7) * window_bytes;
+    const unsigned wmask = window_bytes - 1u;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    // fill the whole LDS image once (160 pieces of 1 KiB, 20 per wave)
+    for (int i = 0; i < 20; ++i) {
+        const unsigned piece = (unsigned)(w * 20 + i);
+        glds16(win + ((piece * 1024u + lane_off) & wmask), probe_smem + piece * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    probe_f32x16 acc[2][4];
+    for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 4; ++ni)
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int a_off = (wm * 64 + l31) * 128;
+    const int w_off = (wn * 128 + l31) * 128;
+    char* const a_base = probe_smem;
+    char* const w_base = probe_smem + 2 * 32768;
+    probe_bf16x8 fa[4], fw[4][4];
+    // MODE 0 never touches LDS again: fragments are read once
+    for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = *(const probe_bf16x8*)(a_base + a_off + (((ks * 2 + h) ^ sw) << 4));
+        for (int ni = 0; ni < 4; ++ni) fw[ni][ks] = *(const probe_bf16x8*)(w_base + w_off + ni * 4096 + (((ks * 2 + h) ^ sw) << 4));
+    }
+    unsigned stream_off = (unsigned)blockIdx.x * 65536u + (unsigned)w * 8192u;
+    int ab = 0, ws = 0;
+    for (int it = 0; it < iters; ++it) {
+        const char* Sa = a_base + ab * 32768;
+        const char* Sw = w_base + ws * 32768;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            if constexpr (MODE >= 1) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[ks] = *(const probe_bf16x8*)(Sa + a_off + mi * 4096 + (((ks * 2 + h) ^ sw) << 4));
+                if (mi == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            fw[ni][ks] = *(const probe_bf16x8*)(Sw + w_off + ni * 4096 + (((ks * 2 + h) ^ sw) << 4));
+                }
+            }
+            if constexpr (MODE >= 2) {
+                // 4 pieces per half K tile: A pieces into the other A buffer, W pieces into the ring slot two ahead
+                char* dst = mi == 0 ? a_base + (ab ^ 1) * 32768 + w * 4096 : w_base + ((ws + 2) % 3) * 32768 + w * 4096;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    glds16(win + ((stream_off + lane_off) & wmask), dst + j * 1024);
+                    stream_off += 1024u;
+                }
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
+        }
+        stream_off += 65536u - 8192u;
+        ab ^= 1;
+        ws = ws == 2 ? 0 : ws + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+    for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 4; ++ni)
+            for (int r = 0; r < 16; ++r) s += acc[mi][ni][r];
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 }  // namespace pe
 
 using namespace pe;
 
 extern "C" {
+
+int pe_gemm_mix_probe(int mode, const void* src, size_t src_bytes, void* out, int blocks, int iters, double* flops, void* stream) {
+    PE_REQUIRE(src && out && blocks > 0 && blocks <= 4096 && iters > 0, "pe_gemm_mix_probe: bad arguments");
+    PE_REQUIRE(mode >= 0 && mode <= 2, "pe_gemm_mix_probe: mode %d (0 MFMA only, 1 + LDS fragment reads, 2 + LDS-DMA stream)", mode);
+    PE_REQUIRE(src_bytes >= (size_t)8 * (1u << 20) && src_bytes % 8 == 0 && ((src_bytes / 8) & (src_bytes / 8 - 1)) == 0 &&
+                   src_bytes / 8 <= (1u << 30),
+               "pe_gemm_mix_probe: src_bytes must be 8 x a power of two >= 1 MiB (one window per XCD)");
+    const unsigned window = (unsigned)(src_bytes / 8);
+    constexpr int lds = 160 * 1024;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_mix_probe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_mix_probe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_mix_probe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_gemm_mix_probe: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    if (mode == 0)
+        hipLaunchKernelGGL(gemm_mix_probe_kernel<0>, dim3(blocks), dim3(512), lds, (hipStream_t)stream, (const char*)src, window, (float*)out, iters);
+    else if (mode == 1)
+        hipLaunchKernelGGL(gemm_mix_probe_kernel<1>, dim3(blocks), dim3(512), lds, (hipStream_t)stream, (const char*)src, window, (float*)out, iters);
+    else
+        hipLaunchKernelGGL(gemm_mix_probe_kernel<2>, dim3(blocks), dim3(512), lds, (hipStream_t)stream, (const char*)src, window, (float*)out, iters);
+    if (flops) *flops = (double)blocks * 8.0 * (double)iters * 32.0 * (2.0 * 32 * 32 * 16);
+    return check_launch("gemm_mix_probe_kernel");
+}
 
 int pe_mfma_probe(const void* frags, void* out, int blocks, int iters, double* flops, void* stream) {
     PE_REQUIRE(frags && out && blocks > 0 && blocks <= 4096 && iters > 0, "pe_mfma_probe: bad arguments");

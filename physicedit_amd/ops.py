@@ -94,6 +94,21 @@ def gemm_e4m3(xq: torch.Tensor, scale_a: torch.Tensor, wq: torch.Tensor, bias: O
     return out
 
 
+def gemm_e4m3_gelu_q8(xq: torch.Tensor, scale_a: torch.Tensor, wq: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """MLP-up in e4m3 mode with the next Linear's row quantisation fused into the epilogue: -> (out bf16 [M,N], q e4m3 [M,N],
+    scale fp32 [M]); (q, scale) == quantize_rows_e4m3(out) bit for bit."""
+    _chk(xq, "xq", F8), _chk(wq, "wq", F8), _chk(scale_a, "scale_a", torch.float32)
+    M, K = xq.shape
+    N = wq.shape[0]
+    out = torch.empty((M, N), dtype=BF, device=xq.device)
+    q = torch.empty((M, N), dtype=F8, device=xq.device)
+    sc = torch.empty((M,), dtype=torch.float32, device=xq.device)
+    flags = torch.zeros((M,), dtype=torch.int32, device=xq.device)
+    check(lib().pe_gemm_e4m3_gelu_q8(xq.data_ptr(), K, scale_a.data_ptr(), wq.data_ptr(), _ptr(bias), out.data_ptr(), N, q.data_ptr(),
+                                     sc.data_ptr(), flags.data_ptr(), M, N, K, stream_ptr()), "pe_gemm_e4m3_gelu_q8")
+    return out, q, sc, flags
+
+
 def fp8_linear(x: torch.Tensor, wq: torch.Tensor, bias: Optional[torch.Tensor], epilogue: str = "bias", gate=None,
                res=None) -> torch.Tensor:
     """AutoWrappedLinear.fp8_linear: quantise rows, e4m3 GEMM.  wq [N,Kp] e4m3fn (zero padded beyond x.shape[1])."""

@@ -78,6 +78,30 @@ def test_ln_modulate_e4m3_fused_is_bit_identical(ops):
     assert none is None and torch.equal(q2.view(torch.uint8), q.view(torch.uint8)) and torch.equal(s2, s)
 
 
+@pytest.mark.parametrize("M,N,K,gain", [(300, 1024, 512, 1.0), (520, 12288, 3072, 1.0), (300, 1024, 512, 400.0), (2100, 3072, 256, 60.0)])
+def test_gemm_e4m3_gelu_fused_quantisation_is_bit_identical(ops, M, N, K, gain):
+    """The MLP-up epilogue also emits the MLP-down Linear's e4m3 operand (pe_gemm_e4m3_gelu_q8): bf16 output identical to the plain
+    GELU epilogue, (e4m3 bytes, scales) identical to pe_quantize_rows_e4m3 of that output.  gain > 1 scales the weights so that
+    rows exceed 447 (scale > 1): those take the flagged re-quantisation pass, the others the direct one -- both in one call."""
+    x = _acts(M, K, 61)
+    w8 = rnd((N, K), 62, K ** -0.5 * gain).to(F8)
+    if gain > 1.0:
+        w8.view(torch.uint8)[N // 2:] = (rnd((N - N // 2, K), 63, K ** -0.5).to(F8)).view(torch.uint8)    # only half the columns are hot
+    b = rnd((N,), 64, 0.1)
+    xq, sa = ops.quantize_rows_e4m3(x.cuda())
+    ref = ops.gemm_e4m3(xq, sa, w8.cuda(), b.cuda(), "gelu_sigmoid")
+    q_ref, s_ref = ops.quantize_rows_e4m3(ref)
+    out, q, s, flags = ops.gemm_e4m3_gelu_q8(xq, sa, w8.cuda(), b.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert torch.equal(s, s_ref)
+    assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8))
+    assert int(flags.abs().sum().item()) == 0                       # lowered again for the next launch
+    n_scaled = int((s_ref > 1.0).sum().item())
+    print(f"[parity] fused GELU quantisation {M}x{N}x{K} gain {gain}: {n_scaled} of {M} rows with scale > 1")
+    assert 0 < n_scaled < M              # both paths taken in the same call (_acts plants one huge row even at gain 1)
+
+
 def test_e4m3_conversion_all_values(ops):
     """every e4m3 value and every rounding midpoint between neighbours goes through the hardware conversion."""
     vals = torch.arange(0, 256, dtype=torch.uint8).view(F8).float()
