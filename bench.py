@@ -57,10 +57,12 @@ def main():
     ap.add_argument("--t-pos", type=int, default=512)
     ap.add_argument("--t-neg", type=int, default=272)
     ap.add_argument("--lora-rank", type=int, default=128)
-    ap.add_argument("--dual-stream", action="store_true",
-                    help="run the posi and the nega forward of a step concurrently on two HIP streams (+3.7 %% images/s at "
-                         "cfg 2).  Off by default so that the per-kernel launch durations behind `roofline` are those of a "
-                         "kernel that has the chip to itself and agree with the rocprofv3 summary of the same command")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="run the posi and the nega forward of a step one after the other on one HIP stream.  Default since round 3: "
+                         "two streams (DenoiseLoop(dual_stream=True): second workspace on the same weights; the branches are "
+                         "independent until the CFG combine and each fills the CUs the other leaves idle at the end of a kernel: "
+                         "-2.6 %% time per image on the same box, bit-identical images)")
+    ap.add_argument("--dual-stream", action="store_true", help="(default; kept for command lines written before round 3)")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[2]: DiT stored in e4m3 + enable_dit_fp8_computation (every DiT Linear runs "
                          "fp8_linear); NOT the headline configuration, reported with dtype fp8")
@@ -77,9 +79,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (after the headline timed region, N = 1 headline runs also time 2 images each of "
                          "the 1328x1328 / 50-step geometry of configs[4] on this one GPU and of configs[2], the e4m3 Linears)")
+    ap.add_argument("--no-probes", action="store_true",
+                    help="skip the matrix-pipe / GEMM-mix probes after the timed region (profiling runs: keeps them out of the trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     args = ap.parse_args()
+    args.dual_stream = not args.single_stream
 
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_only:
         # `python bench.py --gpus N` without a launcher: become the launcher.  One process per GPU under
@@ -225,9 +230,11 @@ def main():
     # CUs with the sibling branch's kernel, so they understate what a kernel achieves alone.
     prof_excl = None
     if rank == 0:
-        lib().pe_profile_enable(4096, 1)
-        eng.forward(noises[units[0]], torch.tensor([500.0]).to(BF), pe_p0.clone(), None,
-                    [results[0][0]] if False else [vae.encode(edit_img)], step=0)
+        lib().pe_profile_enable(8192, 1)
+        ed = [vae.encode(edit_img)]
+        torch.cuda.synchronize()
+        eng.forward(noises[units[0]], torch.tensor([500.0]).to(BF), pe_p0.clone(), None, ed, step=0)     # the step's positive ...
+        eng.forward(noises[units[0]], torch.tensor([500.0]).to(BF), pe_n0.clone(), None, ed, step=0)     # ... and negative forward
         torch.cuda.synchronize()
         prof_excl = read_prof()
 
@@ -236,7 +243,15 @@ def main():
         value = images / elapsed
         fl = flops_image(H, W, args.inference_steps, args.t_pos, args.t_neg, args.cfg, args.layers)
         g = prof["gemm"]
-        achieved = (g["work"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
+        timed_tf = (g["work"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
+        # Two streams: the event pair around a launch in the timed region also brackets whatever the sibling stream runs on the same
+        # CUs meanwhile, so "work / duration" there is not the kernel's rate.  The roofline then comes from the same process's
+        # single-stream CFG pair of forwards right after the timed region (same kernels, shapes and operands, EVERY launch sampled);
+        # the timed-region figures stay in `roofline.timed_region_two_streams`.  `--single-stream` samples inside the timed region.
+        excl_ok = prof_excl is not None and prof_excl["gemm"]["ms"] > 0
+        use_excl = args.dual_stream and args.cfg != 1.0 and excl_ok
+        gsrc = prof_excl["gemm"] if use_excl else g
+        achieved = (gsrc["work"] / (gsrc["ms"] * 1e-3) / 1e12) if gsrc["ms"] > 0 else 0.0
         traffic, mfma_busy, traffic_src = pmc_traffic(args)
         headline = (H, W, args.inference_steps, args.cfg, args.layers) == (1024, 1024, 40, 4.0, 60)
         cfg_label = f"configs[{2 if args.fp8 else 1}]" if headline else (
@@ -267,12 +282,17 @@ def main():
             "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "mfma_busy": mfma_busy, "traffic_source": traffic_src,
-                         "launches_in_timed_region": g["launches"], "launches_sampled": g["sampled"],
-                         "avg_launch_ms": g["ms"] / max(g["sampled"], 1),
-                         "avg_algorithmic_gflop_per_launch": g["work"] / max(g["sampled"], 1) / 1e9,
-                         "concurrent_streams": 2 if args.dual_stream else 1},
+                         "launches_in_timed_region": g["launches"], "launches_sampled": gsrc["sampled"],
+                         "avg_launch_ms": gsrc["ms"] / max(gsrc["sampled"], 1),
+                         "avg_algorithmic_gflop_per_launch": gsrc["work"] / max(gsrc["sampled"], 1) / 1e9,
+                         "concurrent_streams": 2 if args.dual_stream else 1,
+                         "sampled_in": ("one single-stream CFG pair of forwards in this process right after the timed region, every "
+                                        "launch (the timed region runs the pair on two streams: a launch's event-to-event time there "
+                                        "includes the sibling stream's kernels)") if use_excl else "the timed region (one stream)",
+                         "timed_region_two_streams": ({"work_over_event_time_tflops": timed_tf, "launches_sampled": g["sampled"],
+                                                       "avg_event_ms": g["ms"] / max(g["sampled"], 1)} if use_excl else None)},
             "roofline_exclusive": None if not prof_excl or prof_excl["gemm"]["ms"] <= 0 else {
-                "what": "same GEMM launches of one untimed positive forward alone on the chip (single stream, all launches sampled)",
+                "what": "the GEMM launches of one untimed CFG pair of forwards alone on the chip (single stream, all launches sampled)",
                 "achieved": prof_excl["gemm"]["work"] / (prof_excl["gemm"]["ms"] * 1e-3) / 1e12, "peak": peak,
                 "unit": "TFLOP/s", "frac": prof_excl["gemm"]["work"] / (prof_excl["gemm"]["ms"] * 1e-3) / 1e12 / peak,
                 "flash_attn_tflops": (prof_excl["attn"]["work"] / (prof_excl["attn"]["ms"] * 1e-3) / 1e12) if prof_excl["attn"]["ms"] > 0 else None},
@@ -283,7 +303,7 @@ def main():
                 "vae_conv": {"achieved_tflops": (prof["conv"]["work"] / (prof["conv"]["ms"] * 1e-3) / 1e12) if prof["conv"]["ms"] > 0 else None},
             },
         }
-        if not args.fp8:
+        if not args.fp8 and not args.no_probes:
             ceil = mfma_power_ceiling(dev)
             out["roofline"]["power_limited_ceiling"] = ceil
             if ceil["random_normal_operands"] > 0:
@@ -433,14 +453,16 @@ def pmc_traffic(args):
     passes of tools/pmc_collect.sh (profiles/r02_pmc.json, which records its own command line).  They are per-launch properties
     of (kernel, shape), so they are reported ONLY when this run launches the same kernels on the same shapes -- same layer count,
     geometry, prompt lengths, operand dtype and stream count as the recorded command -- and are null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r02_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r03_pmc.json")
+    if not os.path.exists(path) and not args.fp8:
+        path = os.path.join(ROOT, "profiles", "r02_pmc.json")
     if not os.path.exists(path):
         return None, None, None
     rec = json.load(open(path))
     c = rec.get("config", {})
     same = (c.get("layers") == args.layers and c.get("height") == args.height and c.get("width") == args.width and
-            c.get("t_pos") == args.t_pos and c.get("t_neg") == args.t_neg and bool(c.get("fp8")) == bool(args.fp8) and
-            bool(c.get("dual_stream")) == bool(args.dual_stream))
+            c.get("t_pos") == args.t_pos and c.get("t_neg") == args.t_neg and bool(c.get("fp8")) == bool(args.fp8))
+    # (the passes are collected on one stream: counters per launch of a (kernel, shape) do not depend on what the other stream runs)
     if not same:
         return None, None, f"profiles/{os.path.basename(path)} was collected for another configuration ({rec.get('command')}): not reported"
     # the block GEMMs only (QKV 1224, MLP-up 1632, out-proj / MLP-down 408 work-groups at this geometry): the hoisted modulation

@@ -514,7 +514,15 @@ class QwenImagePhysicPipeline:
         # BlockwiseControlNet unit (:1201-1241)
         ctl_cond = self.controlnet_conditionings(blockwise_controlnet_inputs) if blockwise_controlnet_inputs is not None else None
         # denoise loop + decode (:644-667)
-        loop = DenoiseLoop(self.dit, cfg_pair=getattr(self, "cfg_pair", None))     # cfg_pair: set by physicedit_amd.parallel.edit_batch
+        # One loop object per engine, kept across calls: with two streams (default: the CFG pair's forwards run concurrently, each
+        # filling the CUs the other leaves idle at the end of a kernel; bit-identical images, `pipe.dual_stream = False` turns it
+        # off) it owns the second execution context (0.9 GB workspace at 1024 x 1024), which should not be rebuilt per image.
+        # cfg_pair: set by physicedit_amd.parallel.edit_batch(split_cfg=True); the pair then lives on two GPUs instead.
+        loop = getattr(self, "_loop", None)
+        dual = bool(getattr(self, "dual_stream", True))
+        if loop is None or getattr(loop, "dit", None) is not self.dit or getattr(loop, "dual_stream", None) != dual:
+            loop = self._loop = DenoiseLoop(self.dit, dual_stream=dual)
+        loop.cfg_pair = getattr(self, "cfg_pair", None)
         loop.scheduler = self.scheduler
         latents = loop(latents, pe_p, pe_n, m_p, m_n, height, width, num_inference_steps=num_inference_steps,
                        cfg_scale=cfg_scale, edit_latents=edit_latents or None, exponential_shift_mu=exponential_shift_mu,

@@ -613,18 +613,27 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
         }
         const float inv = 1.0f / l_tot;
         const int q = q0 + b * 32 + l31;
-        if (q < S) {
-            bf16* op = out + (size_t)q * ldo + head * 128 + 4 * h;
+        // A row's 8 consecutive columns 8a .. 8a+7 sit in two lanes (l31 and l31 + 32: 4 columns = 8 bytes each).  One
+        // v_permlane32_swap per dword on the column groups (a, a + 1) -- upper half of group a <-> lower half of group a + 1 --
+        // leaves 16 contiguous bytes of the row in every lane (lower lanes: group a, upper lanes: group a + 1): 8 dwordx4 stores
+        // per 32-row block and lane instead of 16 dwordx2 (the store tail is issue-bound: cdna guide T21).  Same bytes, same values.
+        bf16* op = out + (size_t)min(q, S - 1) * ldo + head * 128 + 8 * h;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    bf16x4 v;
+            for (int a = 0; a < 4; a += 2) {
+                bf16x4 v0, v1;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[b][dt][4 * a + r] * inv);
-                    *(bf16x4*)(op + dt * 32 + 8 * a) = v;
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = (bf16)(o[b][dt][4 * a + r] * inv);
+                    v1[r] = (bf16)(o[b][dt][4 * (a + 1) + r] * inv);
                 }
-        }
+                const u32x2 w0 = __builtin_bit_cast(u32x2, v0), w1 = __builtin_bit_cast(u32x2, v1);
+                const auto sx = __builtin_amdgcn_permlane32_swap(w0[0], w1[0], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(w0[1], w1[1], false, false);
+                const u32x4 pk = {sx[0], sy[0], sx[1], sy[1]};
+                if (q < S) *(u32x4*)(op + dt * 32 + 8 * a) = pk;
+            }
     }
     if (dbg != nullptr && threadIdx.x == 0) {      // profiling only (pe_debug_set_ptr("attn_stamps")): s_memtime of wave 0
         long long* d = dbg + (size_t)blockIdx.x * 10;
