@@ -103,7 +103,7 @@ class QwenImagePhysicPipeline:
         self.height_division_factor = 16
         self.width_division_factor = 16
         self.dinov2_path = dinov2_path          # DINOv2 is only executed when is_train=True (the training-time prior)
-        self.dinov2 = None                      # transformers Dinov2WithRegistersModel (or any module: frames [B,3,224,224] -> [B,L,768])
+        self.dinov2 = None                      # transformers Dinov2WithRegistersModel (weights only: the forward is physicedit_amd.dino) or a Dinov2WithNorm
         self.dino_input_size = 224              # (:213)
         self._prior = None                      # physicedit_amd.prior.PhysicalVisualPrior, built from extra_state on first use
         self.last_pseudo_special_emb = None
@@ -291,19 +291,28 @@ class QwenImagePhysicPipeline:
             return self.vae.encode(self.preprocess_image(image))       # exotic modes: the stand-alone map
         return self.vae.encode(torch.from_numpy(np.ascontiguousarray(u8)).to(self.device))
 
-    # ---- QwenImageUnit_PhysicalVisualEmbedder (:992-1120): the training-time prior.  DINOv2 is `transformers` code on PyTorch-ROCm
-    # (third party, like the text encoder); what follows it runs on the library (physicedit_amd/prior.py).
+    # ---- QwenImageUnit_PhysicalVisualEmbedder (:992-1120): the training-time prior.  `transformers` only READS the DINOv2 checkpoint
+    # (Dinov2WithRegistersModel.from_pretrained, as the reference's Dinov2withNorm does, pipelines/dinov2.py:16-19); the forward runs on
+    # the library (physicedit_amd/dino.py), like everything that follows it (physicedit_amd/prior.py).
     def _load_dinov2(self):
         if self.dinov2 is None:
             if self.dinov2_path is None:
                 raise _lib.PeError("is_train=True needs DINOv2: pass dinov2_path= to from_pretrained() or set pipe.dinov2")
             from transformers import Dinov2WithRegistersModel
-            enc = Dinov2WithRegistersModel.from_pretrained(self.dinov2_path, local_files_only=True)
-            enc.layernorm.elementwise_affine = False          # Dinov2withNorm (pipelines/dinov2.py:21-24)
-            enc.layernorm.weight = None
-            enc.layernorm.bias = None
-            self.dinov2 = enc.to(device=self.device, dtype=self.torch_dtype).eval().requires_grad_(False)
+            self.dinov2 = Dinov2WithRegistersModel.from_pretrained(self.dinov2_path, local_files_only=True).eval().requires_grad_(False)
         return self.dinov2
+
+    def _dino_engine(self):
+        """The library engine for `pipe.dinov2` (a transformers Dinov2WithRegistersModel, or already a physicedit_amd.dino.Dinov2WithNorm);
+        Dinov2withNorm(normalize=True) semantics: the final LayerNorm has no affine (pipelines/dinov2.py:21-24)."""
+        from physicedit_amd.dino import Dinov2WithNorm
+        enc = self._load_dinov2()
+        if isinstance(enc, Dinov2WithNorm):
+            return enc
+        cached = getattr(self, "_dino_cache", None)
+        if cached is None or cached[0] is not enc:
+            cached = self._dino_cache = (enc, Dinov2WithNorm.from_transformers(enc, device=self.device, normalize=True))
+        return cached[1]
 
     def dino_input_preprocess(self, frames, dino_input_size: int = None) -> torch.Tensor:
         """dino_input_preprocess (:1043-1057): torchvision Resize(1.5 * size, BICUBIC) on the shorter edge, RandomCrop(size), ToTensor,
@@ -326,10 +335,8 @@ class QwenImagePhysicPipeline:
         return (x - mean) / std
 
     def _dino_features(self, pixels: torch.Tensor) -> torch.Tensor:
-        enc = self._load_dinov2()
-        out = enc(pixels.to(next(enc.parameters()).dtype))
-        hs = out.last_hidden_state if hasattr(out, "last_hidden_state") else out
-        return hs[:, 5:] if hasattr(out, "last_hidden_state") else hs       # 1 CLS + 4 register tokens dropped (dinov2.py:30-31)
+        """pipe.dinov2(dino_inputs) (:1063): patch features [B, L, 768], CLS + 4 register tokens dropped (dinov2.py:30-31)."""
+        return self._dino_engine()(pixels)
 
     def physical_visual_embedder(self, middle_key_frames, edit_image):
         """-> (pseudo_special_emb_dino, pseudo_special_emb_vae), the targets of model_fn's special-token loss (:1060-1118)."""

@@ -157,6 +157,11 @@ int pe_rmsnorm(const void* x, const void* w, void* out, int rows, int dim, float
 int pe_add_bf16(void* x, const void* y, size_t n, float sign, void* stream);
 int pe_layernorm_affine(const void* x, const void* weight, const void* bias, void* out, int rows, int dim, float eps, void* stream);
 int pe_perceiver_attention(const void* q, const void* kv, void* out, int n_queries, int n_keys, int heads, float scale, void* stream);
+/* Small unmasked attention with heads of 64 and the numerics of torch's scaled_dot_product_attention (DINOv2's self-attention,
+ * pipelines/dinov2.py:8-31 -> transformers Dinov2WithRegistersSelfAttention): fp32 scores and softmax statistics, the un-normalised
+ * P = exp(s - max) rounded to bf16 for the second product, fp32 accumulation, one rounding of O / sum.  Same operand layout as
+ * pe_perceiver_attention: q [n_queries, heads*64], kv [n_keys, 2*heads*64] (keys first), out [n_queries, heads*64]. */
+int pe_sdpa_heads64(const void* q, const void* kv, void* out, int n_queries, int n_keys, int heads, float scale, void* stream);
 
 /* nn.Linear applied to ONE row: y[N] = bf16(W[N,K] . x[K] + bias[N]) (fp32 accumulation, one rounding), bias nullable, K % 8 == 0.
  * The HBM-bound shape of autoregressive decoding: used by the prompt prologue (Qwen2.5-VL `generate`,

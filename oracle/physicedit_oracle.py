@@ -344,6 +344,50 @@ def resampler_adapter(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return F.linear(F.gelu(F.linear(x, sd[p + "net.0.weight"], sd[p + "net.0.bias"])), sd[p + "net.2.weight"], sd[p + "net.2.bias"])
 
 
+def dinov2_features(sd: SD, pixel_values: torch.Tensor, num_heads: int, patch: int = 14, eps: float = 1e-6,
+                    num_register_tokens: int = 4) -> torch.Tensor:
+    """Dinov2withNorm.forward (pipelines/dinov2.py:27-34): transformers' Dinov2WithRegistersModel -- patch embedding, CLS token,
+    position table (resampled when the patch grid differs from the stored one: `interpolate_pos_encoding`, bicubic + antialias in
+    fp32), register tokens behind the CLS token, `num_layers` pre-norm blocks (q / k / v Linears, scaled_dot_product_attention,
+    output Linear, LayerScale, residual; LayerNorm, Linear - GELU(erf) - Linear, LayerScale, residual) -- then the final LayerNorm
+    WITHOUT affine (normalize=True, :21-24) and the 1 + 4 CLS / register tokens dropped (:30-31).  The algorithm lives in a
+    third-party dependency of the reference (transformers 5.x, `models/dinov2_with_registers/modeling_dinov2_with_registers.py`);
+    pinned on the outputs of the reference's own class, fixture G19.  sd: transformers' key names."""
+    x = pixel_values.to(sd["embeddings.patch_embeddings.projection.weight"].dtype)
+    B, _, Hh, Ww = x.shape
+    emb = F.conv2d(x, sd["embeddings.patch_embeddings.projection.weight"], sd["embeddings.patch_embeddings.projection.bias"],
+                   stride=patch).flatten(2).transpose(1, 2)
+    hidden = emb.shape[-1]
+    emb = torch.cat((sd["embeddings.cls_token"].expand(B, -1, -1), emb), dim=1)
+    pos = sd["embeddings.position_embeddings"]
+    n, n0 = emb.shape[1] - 1, pos.shape[1] - 1
+    if not (n == n0 and Hh == Ww):
+        s0 = int(n0 ** 0.5)
+        grid = pos[:, 1:].reshape(1, s0, s0, hidden).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid.to(torch.float32), size=(Hh // patch, Ww // patch), mode="bicubic", align_corners=False,
+                             antialias=True).to(pos.dtype)
+        pos = torch.cat((pos[:, 0].unsqueeze(0), grid.permute(0, 2, 3, 1).reshape(1, -1, hidden)), dim=1)
+    h = emb + pos
+    h = torch.cat((h[:, :1], sd["embeddings.register_tokens"].expand(B, -1, -1), h[:, 1:]), dim=1)
+    i = 0
+    while f"encoder.layer.{i}.norm1.weight" in sd:
+        L = f"encoder.layer.{i}."
+        y = F.layer_norm(h, (hidden,), sd[L + "norm1.weight"], sd[L + "norm1.bias"], eps)
+        hd = lambda t: t.view(B, -1, num_heads, hidden // num_heads).transpose(1, 2)
+        k = hd(F.linear(y, sd[L + "attention.attention.key.weight"], sd[L + "attention.attention.key.bias"]))
+        v = hd(F.linear(y, sd[L + "attention.attention.value.weight"], sd[L + "attention.attention.value.bias"]))
+        q = hd(F.linear(y, sd[L + "attention.attention.query.weight"], sd[L + "attention.attention.query.bias"]))
+        a = F.scaled_dot_product_attention(q, k, v, scale=(hidden // num_heads) ** -0.5).transpose(1, 2).reshape(B, -1, hidden)
+        a = F.linear(a, sd[L + "attention.output.dense.weight"], sd[L + "attention.output.dense.bias"])
+        h = a * sd[L + "layer_scale1.lambda1"] + h
+        y = F.layer_norm(h, (hidden,), sd[L + "norm2.weight"], sd[L + "norm2.bias"], eps)
+        y = F.linear(F.gelu(F.linear(y, sd[L + "mlp.fc1.weight"], sd[L + "mlp.fc1.bias"])), sd[L + "mlp.fc2.weight"], sd[L + "mlp.fc2.bias"])
+        h = y * sd[L + "layer_scale2.lambda1"] + h
+        i += 1
+    h = F.layer_norm(h, (hidden,), None, None, eps)
+    return h[:, 1 + num_register_tokens:]
+
+
 def visual_prior(sd: SD, dino_middle: torch.Tensor, dino_source: torch.Tensor, lat_middle: torch.Tensor, lat_source: torch.Tensor):
     """QwenImageUnit_PhysicalVisualEmbedder.process (:1071-1118) from the DINOv2 patch features of the key frames [B, L, 768] / of the
     source image [1, L, 768] and their VAE latents [B, 16, h, w] / [1, 16, h, w] on: frame-index embedding, frames concatenated

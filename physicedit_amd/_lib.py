@@ -140,6 +140,7 @@ SIGNATURES = {
     "pe_add_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "pe_layernorm_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "pe_perceiver_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "pe_sdpa_heads64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "pe_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, C.POINTER(C.c_double), c_void_p]),
     "pe_gemm_mix_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_int, c_int, C.POINTER(C.c_double), c_void_p]),
     "pe_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_void_p]),

@@ -181,6 +181,10 @@ int pe_perceiver_attention(const void* q, const void* kv, void* out, int n_queri
     return launch_perceiver_attn(q, kv, out, n_queries, n_keys, heads, scale, (hipStream_t)stream);
 }
 
+int pe_sdpa_heads64(const void* q, const void* kv, void* out, int n_queries, int n_keys, int heads, float scale, void* stream) {
+    return launch_perceiver_attn(q, kv, out, n_queries, n_keys, heads, scale, (hipStream_t)stream, 1);
+}
+
 int pe_gemv_bf16(const void* x, const void* W, const void* bias, void* y, int N, int K, void* stream) {
     return launch_gemv(x, W, bias, y, N, K, (hipStream_t)stream);
 }

@@ -287,6 +287,10 @@ int launch_layernorm_affine(const void* x, const void* w, const void* b, void* o
 // in the last), out [nq, H*64].  The reference materialises every intermediate in bf16, and so does this: dots = bf16(q . k) (fp32
 // accumulation), * scale -> bf16, - row max -> bf16, softmax in fp32 -> bf16, attn . v -> bf16.  One work-group per (head, query): the
 // whole problem is 64 queries x <= 10 k keys.
+// SDPA = true: the numerics of torch's scaled_dot_product_attention instead (DINOv2's self-attention, transformers
+// Dinov2WithRegistersSelfAttention -> F.scaled_dot_product_attention): scores and softmax statistics in fp32, the un-normalised
+// P = exp(s - max) rounded to bf16 for the second product, fp32 accumulation, ONE rounding of O / sum.
+template <bool SDPA>
 __global__ void __launch_bounds__(256) perceiver_attn_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kv,
                                                              bf16* __restrict__ out, int nk, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char pa_smem[];
@@ -308,7 +312,7 @@ __global__ void __launch_bounds__(256) perceiver_attn_kernel(const bf16* __restr
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qs[c * 8 + e], (float)k8[e], acc);
         }
-        const float s = bf16r(bf16r(acc) * scale);
+        const float s = SDPA ? acc * scale : bf16r(bf16r(acc) * scale);
         sc[j] = s;
         mx = fmaxf(mx, s);
     }
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(256) perceiver_attn_kernel(const bf16* __restr
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
     for (int j = t; j < nk; j += 256) {
-        const float p = __expf(bf16r(sc[j] - mx));
+        const float p = SDPA ? __expf(sc[j] - mx) : __expf(bf16r(sc[j] - mx));
         sc[j] = p;
         sum += p;
     }
@@ -328,16 +332,25 @@ __global__ void __launch_bounds__(256) perceiver_attn_kernel(const bf16* __restr
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
     const int d = t & 63, grp = t >> 6;
     float o = 0.f;
-    for (int j = grp; j < nk; j += 4) o = __builtin_fmaf(bf16r(sc[j] * inv), (float)kv[(size_t)j * ldkv + H * 64 + h * 64 + d], o);
+    for (int j = grp; j < nk; j += 4)
+        o = __builtin_fmaf(SDPA ? bf16r(sc[j]) : bf16r(sc[j] * inv), (float)kv[(size_t)j * ldkv + H * 64 + h * 64 + d], o);
     part[grp][d] = o;
     __syncthreads();
-    if (t < 64) out[(size_t)qi * ldq + h * 64 + t] = (bf16)(part[0][t] + part[1][t] + part[2][t] + part[3][t]);
+    if (t < 64) {
+        const float tot = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+        out[(size_t)qi * ldq + h * 64 + t] = (bf16)(SDPA ? tot * inv : tot);
+    }
 }
 
-int launch_perceiver_attn(const void* q, const void* kv, void* out, int nq, int nk, int heads, float scale, hipStream_t stream) {
+int launch_perceiver_attn(const void* q, const void* kv, void* out, int nq, int nk, int heads, float scale, hipStream_t stream,
+                          int sdpa) {
     PE_REQUIRE(q && kv && out && nq > 0 && nk > 0 && nk <= 15360 && heads > 0, "perceiver_attn: bad arguments (nq=%d nk=%d)", nq, nk);
-    hipLaunchKernelGGL(perceiver_attn_kernel, dim3(heads, nq), dim3(256), (size_t)nk * 4, stream, (const bf16*)q, (const bf16*)kv,
-                       (bf16*)out, nk, heads, scale);
+    if (sdpa)
+        hipLaunchKernelGGL((perceiver_attn_kernel<true>), dim3(heads, nq), dim3(256), (size_t)nk * 4, stream, (const bf16*)q,
+                           (const bf16*)kv, (bf16*)out, nk, heads, scale);
+    else
+        hipLaunchKernelGGL((perceiver_attn_kernel<false>), dim3(heads, nq), dim3(256), (size_t)nk * 4, stream, (const bf16*)q,
+                           (const bf16*)kv, (bf16*)out, nk, heads, scale);
     return check_launch("perceiver_attn_kernel");
 }
 

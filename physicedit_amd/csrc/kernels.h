@@ -99,7 +99,8 @@ int launch_dual_rmsnorm_add(const void* x, const void* wx, const void* y, const 
                             hipStream_t stream);
 int launch_add_inplace(void* x, const void* y, size_t n, hipStream_t stream, float sign = 1.0f);
 int launch_layernorm_affine(const void* x, const void* w, const void* b, void* out, int rows, int dim, float eps, hipStream_t stream);
-int launch_perceiver_attn(const void* q, const void* kv, void* out, int nq, int nk, int heads, float scale, hipStream_t stream);
+int launch_perceiver_attn(const void* q, const void* kv, void* out, int nq, int nk, int heads, float scale, hipStream_t stream,
+                          int sdpa = 0);
 int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, int K, hipStream_t stream, const void* res = nullptr,
                 const void* norm_w = nullptr, float eps = 0.f);
 int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void* Wk, const void* bk, const void* Wv,

@@ -420,3 +420,14 @@ def perceiver_attention(q: torch.Tensor, kv: torch.Tensor, heads: int = 8) -> to
     check(lib().pe_perceiver_attention(q.data_ptr(), kv.data_ptr(), out.data_ptr(), nq, nk, heads, 64 ** -0.5, stream_ptr()),
           "pe_perceiver_attention")
     return out
+
+
+def sdpa_heads64(q: torch.Tensor, kv: torch.Tensor, heads: int) -> torch.Tensor:
+    """q [nq, heads*64], kv [nk, 2*heads*64] (keys first) -> [nq, heads*64] with scaled_dot_product_attention's numerics
+    (DINOv2 self-attention, pipelines/dinov2.py:8-31)."""
+    _chk(q, "q"), _chk(kv, "kv")
+    nq, nk = q.shape[0], kv.shape[0]
+    assert q.shape[1] == heads * 64 and kv.shape[1] == 2 * heads * 64
+    out = torch.empty_like(q)
+    check(lib().pe_sdpa_heads64(q.data_ptr(), kv.data_ptr(), out.data_ptr(), nq, nk, heads, 64 ** -0.5, stream_ptr()), "pe_sdpa_heads64")
+    return out

@@ -139,6 +139,31 @@ def prior_layout() -> List[Tuple[str, Shape]]:
     return out
 
 
+def dino_layout(hidden: int = 768, num_layers: int = 12, mlp_ratio: int = 4, patch: int = 14, image_size: int = 224,
+                num_register_tokens: int = 4, final_norm: bool = False) -> List[Tuple[str, Shape]]:
+    """transformers' Dinov2WithRegistersModel state dict (the encoder inside the reference's Dinov2withNorm, pipelines/dinov2.py:8-31;
+    `final_norm`: the affine of the last LayerNorm, which Dinov2withNorm(normalize=True) removes)."""
+    n = (image_size // patch) ** 2
+    out: List[Tuple[str, Shape]] = [
+        ("embeddings.cls_token", (1, 1, hidden)), ("embeddings.mask_token", (1, hidden)),
+        ("embeddings.register_tokens", (1, num_register_tokens, hidden)), ("embeddings.position_embeddings", (1, n + 1, hidden)),
+        ("embeddings.patch_embeddings.projection.weight", (hidden, 3, patch, patch)),
+        ("embeddings.patch_embeddings.projection.bias", (hidden,))]
+    for i in range(num_layers):
+        L = f"encoder.layer.{i}."
+        out += [(L + "norm1.weight", (hidden,)), (L + "norm1.bias", (hidden,))]
+        for nm in ("query", "key", "value"):
+            out += [(L + f"attention.attention.{nm}.weight", (hidden, hidden)), (L + f"attention.attention.{nm}.bias", (hidden,))]
+        out += [(L + "attention.output.dense.weight", (hidden, hidden)), (L + "attention.output.dense.bias", (hidden,)),
+                (L + "layer_scale1.lambda1", (hidden,)), (L + "norm2.weight", (hidden,)), (L + "norm2.bias", (hidden,)),
+                (L + "mlp.fc1.weight", (mlp_ratio * hidden, hidden)), (L + "mlp.fc1.bias", (mlp_ratio * hidden,)),
+                (L + "mlp.fc2.weight", (hidden, mlp_ratio * hidden)), (L + "mlp.fc2.bias", (hidden,)),
+                (L + "layer_scale2.lambda1", (hidden,))]
+    if final_norm:
+        out += [("layernorm.weight", (hidden,)), ("layernorm.bias", (hidden,))]
+    return out
+
+
 def _vae_res(prefix: str, cin: int, cout: int) -> List[Tuple[str, Shape]]:
     out: List[Tuple[str, Shape]] = [
         (prefix + "norm1.gamma", (cin, 1, 1, 1)),

@@ -625,6 +625,38 @@ def G18_visual_prior():
          meta={"weights_seed": 1818, "inputs_seed": 181, "frames": B, "lat_h": 12, "lat_w": 20})
 
 
+def G19_dinov2():
+    """The reference's Dinov2withNorm (pipelines/dinov2.py:8-31) itself: constructed from a saved random 2-layer / 2-head (2 x 64)
+    Dinov2WithRegistersModel, synthetic weights loaded into its encoder, run in bf16 as the pipeline does (`enable_vram_management`
+    leaves it in torch_dtype) on two seeded image batches: the configured 224 x 224 and a 168 x 112 one (interpolated positions)."""
+    import tempfile
+    from transformers import Dinov2WithRegistersConfig
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_dinov2", "/root/reference/DiffSynth-Studio/diffsynth/pipelines/dinov2.py")
+    ref_dinov2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_dinov2)
+    hidden, layers, heads, patch, size = 128, 2, 2, 14, 224
+    cfg = Dinov2WithRegistersConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, image_size=size,
+                                    patch_size=patch, mlp_ratio=4)
+    with tempfile.TemporaryDirectory() as tmp:
+        Dinov2WithRegistersModel(cfg).save_pretrained(tmp)
+        model = ref_dinov2.Dinov2withNorm(dinov2_path=tmp)
+    sd = synth.make_state_dict(synth.dino_layout(hidden, layers, 4, patch, size), 1919)
+    missing, unexpected = model.encoder.load_state_dict(sd, strict=False)
+    assert not unexpected and all("layernorm" in k for k in missing), (missing, unexpected)
+    model = model.to(BF).eval()
+    g = torch.Generator().manual_seed(191)
+    x224 = torch.randn((2, 3, 224, 224), generator=g)
+    x168 = torch.randn((1, 3, 168, 112), generator=g)
+    y224 = model(x224.to(BF))
+    y168 = model(x168.to(BF))
+    y224_32 = model.float()(x224.to(BF).float())
+    assert y224.shape == (2, 256, hidden) and y168.shape == (1, 12 * 8, hidden)
+    save("G19_dinov2", {"feat_224": y224, "feat_168x112": y168, "feat_224_fp32": y224_32},
+         meta={"weights_seed": 1919, "inputs_seed": 191, "hidden": hidden, "layers": layers, "heads": heads, "patch": patch,
+               "image_size": size, "attn_implementation": str(cfg._attn_implementation)})
+
+
 def G10_image():
     ramp = (np.arange(16 * 16 * 3) % 256).astype("uint8").reshape(16, 16, 3)
     ns = types.SimpleNamespace(torch_dtype=BF, device="cpu")

@@ -583,3 +583,34 @@ def test_model_fn_eligen_G14(golden, eng2):
     e_plain = (x_plain.float().cpu() - ref_text).abs().mean().item()
     print(f"[parity] eligen text stream after the last block: mean|d| with the mask {e_masked:.4e}, same prompts without it {e_plain:.4e}")
     assert e_masked <= 0.02 * ref_text.abs().mean().item() and e_plain > 10 * e_masked
+
+
+def test_dinov2_G19(golden):
+    """DINOv2 feature extraction on the library's kernels (physicedit_amd/dino.py: pe_gemm_bf16 with fused LayerScale + residual /
+    exact-erf GELU epilogues, pe_layernorm_affine, pe_sdpa_heads64) against the outputs of the reference's own Dinov2withNorm
+    (pipelines/dinov2.py:8-31; fixture G19: a random 2-layer instance in bf16, at the configured size and at one with a
+    resampled position table), and against its fp32 run: as close to fp32 as the reference's bf16 run is."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd.dino import Dinov2WithNorm
+    g, meta = golden("G19_dinov2", with_meta=True)
+    sd = synth.make_state_dict(synth.dino_layout(meta["hidden"], meta["layers"], 4, meta["patch"], meta["image_size"]), meta["weights_seed"])
+    enc = Dinov2WithNorm(sd, device="cuda", patch_size=meta["patch"], num_heads=meta["heads"])
+    gen = torch.Generator().manual_seed(meta["inputs_seed"])
+    x224 = torch.randn((2, 3, 224, 224), generator=gen)
+    x168 = torch.randn((1, 3, 168, 112), generator=gen)
+    y224 = enc(x224.to(BF).cuda())
+    y168 = enc(x168.to(BF).cuda())
+    assert y224.shape == (2, 256, meta["hidden"]) and y168.shape == (1, 96, meta["hidden"])
+    assert torch.equal(O.dinov2_features(sd, x168.to(BF), meta["heads"], meta["patch"]), g["feat_168x112"])      # oracle == reference
+    for name, got, ref in (("224x224", y224, g["feat_224"]), ("168x112", y168, g["feat_168x112"])):
+        d = (got.float().cpu() - ref.float()).abs()
+        print(f"[parity] dinov2 {name}: identical {(d == 0).float().mean().item()*100:.1f} % max|d| {d.max().item():.3e} "
+              f"mean|d| {d.mean().item():.3e} (|ref| mean {ref.float().abs().mean().item():.3f})")
+        assert torch.isfinite(got.float()).all()
+        assert d.mean().item() <= 6e-3 and d.max().item() <= 0.13          # normalised features, |x| ~ 0.8: a few bf16 ulps at the worst element
+    r32 = g["feat_224_fp32"]
+    e_hip = (y224.float().cpu() - r32).pow(2).mean().sqrt().item()
+    e_ref = (g["feat_224"].float() - r32).pow(2).mean().sqrt().item()
+    print(f"[parity] dinov2 224x224: rms distance to the fp32 run  hip {e_hip:.3e}  reference-bf16 {e_ref:.3e}")
+    assert e_hip <= 1.25 * e_ref + 1e-6

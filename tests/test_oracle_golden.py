@@ -322,6 +322,21 @@ def test_G18_visual_prior(golden):
     assert_same(pv, g["pseudo_vae"], "pseudo_special_emb_vae")
 
 
+def test_G19_dinov2(golden):
+    """DINOv2 with registers as the reference's Dinov2withNorm runs it (pipelines/dinov2.py:8-31, a random 2-layer instance in bf16):
+    patch features at the configured size and at another one (resampled position table), bit for bit."""
+    g, meta = golden("G19_dinov2", with_meta=True)
+    sd = synth.make_state_dict(synth.dino_layout(meta["hidden"], meta["layers"], 4, meta["patch"], meta["image_size"]), meta["weights_seed"])
+    gen = torch.Generator().manual_seed(meta["inputs_seed"])
+    x224 = torch.randn((2, 3, 224, 224), generator=gen)
+    x168 = torch.randn((1, 3, 168, 112), generator=gen)
+    assert_same(O.dinov2_features(sd, x224.to(BF), meta["heads"], meta["patch"]), g["feat_224"], "dinov2 224x224")
+    assert_same(O.dinov2_features(sd, x168.to(BF), meta["heads"], meta["patch"]), g["feat_168x112"], "dinov2 168x112 (interpolated positions)")
+    sd32 = {k: v.float() for k, v in sd.items()}
+    d = (O.dinov2_features(sd32, x224.to(BF).float(), meta["heads"], meta["patch"]) - g["feat_224_fp32"]).abs().max().item()
+    assert d <= 1e-5, d
+
+
 def test_G7_vae(golden):
     g = golden("G7_vae")
     vs = synth.make_state_dict(synth.vae_layout(), 77)
