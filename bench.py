@@ -251,6 +251,7 @@ def main():
         excl_ok = prof_excl is not None and prof_excl["gemm"]["ms"] > 0
         use_excl = args.dual_stream and args.cfg != 1.0 and excl_ok
         gsrc = prof_excl["gemm"] if use_excl else g
+        psrc = prof_excl if use_excl else prof
         achieved = (gsrc["work"] / (gsrc["ms"] * 1e-3) / 1e12) if gsrc["ms"] > 0 else 0.0
         traffic, mfma_busy, traffic_src = pmc_traffic(args)
         headline = (H, W, args.inference_steps, args.cfg, args.layers) == (1024, 1024, 40, 4.0, 60)
@@ -296,10 +297,11 @@ def main():
                 "achieved": prof_excl["gemm"]["work"] / (prof_excl["gemm"]["ms"] * 1e-3) / 1e12, "peak": peak,
                 "unit": "TFLOP/s", "frac": prof_excl["gemm"]["work"] / (prof_excl["gemm"]["ms"] * 1e-3) / 1e12 / peak,
                 "flash_attn_tflops": (prof_excl["attn"]["work"] / (prof_excl["attn"]["ms"] * 1e-3) / 1e12) if prof_excl["attn"]["ms"] > 0 else None},
-            "other_kernels": {
-                "flash_attn": {"achieved_tflops": (prof["attn"]["work"] / (prof["attn"]["ms"] * 1e-3) / 1e12) if prof["attn"]["ms"] > 0 else None,
-                               "avg_launch_ms": prof["attn"]["ms"] / max(prof["attn"]["sampled"], 1)},
-                "row_kernels(ln_modulate,quantize_rows)": {"achieved_GBps": (prof["row"]["work"] / (prof["row"]["ms"] * 1e-3) / 1e9) if prof["row"]["ms"] > 0 else None},
+            "other_kernels": {        # sampled like `roofline` (two streams: on the single-stream CFG pair after the timed region)
+                "flash_attn": {"achieved_tflops": (psrc["attn"]["work"] / (psrc["attn"]["ms"] * 1e-3) / 1e12) if psrc["attn"]["ms"] > 0 else None,
+                               "frac_of_bf16_mfma_peak": (psrc["attn"]["work"] / (psrc["attn"]["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if psrc["attn"]["ms"] > 0 else None,
+                               "avg_launch_ms": psrc["attn"]["ms"] / max(psrc["attn"]["sampled"], 1)},
+                "row_kernels(ln_modulate,quantize_rows)": {"achieved_GBps": (psrc["row"]["work"] / (psrc["row"]["ms"] * 1e-3) / 1e9) if psrc["row"]["ms"] > 0 else None},
                 "vae_conv": {"achieved_tflops": (prof["conv"]["work"] / (prof["conv"]["ms"] * 1e-3) / 1e12) if prof["conv"]["ms"] > 0 else None},
             },
         }

@@ -602,7 +602,6 @@ def test_dinov2_G19(golden):
     y224 = enc(x224.to(BF).cuda())
     y168 = enc(x168.to(BF).cuda())
     assert y224.shape == (2, 256, meta["hidden"]) and y168.shape == (1, 96, meta["hidden"])
-    assert torch.equal(O.dinov2_features(sd, x168.to(BF), meta["heads"], meta["patch"]), g["feat_168x112"])      # oracle == reference
     for name, got, ref in (("224x224", y224, g["feat_224"]), ("168x112", y168, g["feat_168x112"])):
         d = (got.float().cpu() - ref.float()).abs()
         print(f"[parity] dinov2 {name}: identical {(d == 0).float().mean().item()*100:.1f} % max|d| {d.max().item():.3e} "
