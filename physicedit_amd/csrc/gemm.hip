@@ -49,6 +49,10 @@ struct GemmArgs {
     long long* dbg;   // per work-group s_memtime stamps [grid][8] of schedule 15 (pe_debug_set_ptr("gemm_stamps", p)), or null
 };
 long long* g_gemm_dbg = nullptr;
+// Device code reads the launch arguments where the dispatcher put them: the kernarg segment (constant address space, scalar
+// loads at a wave-uniform problem index).  Through a by-value copy `args.p[pi]` with a run-time pi is an indexed private array:
+// the compiler parks fields in scratch.
+#define KARG __attribute__((address_space(4)))
 
 #define PE_STAMP(k)                                                                                     \
     do {                                                                                                \
@@ -81,10 +85,10 @@ struct TileCoord {
 };
 // tile id in the banded order -> problem and tile origin.  Band = `band` M tiles x all N tiles, N-major inside a band, so a
 // run of consecutive ids (what one XCD's 32 CUs work on at a time) covers band x (32 / band) tiles.
-PE_DEV TileCoord decode_tile(const GemmArgs& args, int bid) {
+PE_DEV TileCoord decode_tile(const KARG GemmArgs& args, int bid) {
     TileCoord c;
     c.pi = bid >= args.tiles0 ? 1 : 0;
-    const GemmProblem& P = args.p[c.pi];
+    const KARG GemmProblem& P = args.p[c.pi];
     bid -= c.pi ? args.tiles0 : 0;
     const int tilesM = P.tilesM, tilesN = P.tilesN;
     const int per_band = args.band * tilesN;
@@ -104,11 +108,35 @@ PE_DEV TileCoord decode_tile(const GemmArgs& args, int bid) {
 // r sits at chunk c ^ (r & 15), and its two 8-B halves are swapped when r & 8 (rows r and r ^ 8 would otherwise land on the
 // same banks in one ds_write_b64 lane group).  A wave reads back only what it wrote, and one wave's LDS accesses execute in
 // order: no barrier.  TWO_PASS (schedule 17, E0 == E1): stage half 0, emit it, stage half 1, emit it.
+//
+// FAST (the tile lies inside M x N and the problem has no hot-LoRA `pre` operand: every tile of the DiT's Linears but the ragged
+// text-stream one): no bounds checks, no per-chunk branches.  The general form costs ~100 exec-mask branches and their scalar
+// chains per wave and tile -- the epilogue is VALU / issue bound (profiles/r03_gemm_notes.md section 6).
 // ------------------------------------------------------------------------------------------
-template <int EPI, bool FP8, bool TWO_PASS>
-__device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16 (&acc)[2][4], int m0, int n0, char* E0, char* E1,
-                                              int lane, int w, long long* stamp4) {
-    const int M = P.M, N = P.N;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+PE_DEV f32x2 up2(uint32_t p) { return f32x2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)}; }   // two packed bf16 -> fp32
+PE_DEV uint32_t pk2(f32x2 v) {                                                                                // v_cvt_pk_bf16_f32
+    const bf16x2 b = {(bf16)v.x, (bf16)v.y};
+    return __builtin_bit_cast(uint32_t, b);
+}
+PE_DEV f32x2 rnd2(f32x2 v) { return up2(pk2(v)); }      // bf16r of a pair: one convert for two values
+// sum over the 16 lanes of a DPP row, result in every lane; the xor-butterfly order (1, 2, 4, 8) with DPP operands instead of
+// ds_bpermute: after the two quad steps a quad's lanes agree, so the half-mirror (lane 7 - l) and mirror (15 - l) partners hold
+// what lanes l ^ 4 and l ^ 8 hold -- same bits as the __shfl_xor form, no LDS round trips, no lane-id register
+PE_DEV float row16_sum(float v) {
+    const auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
+template <int EPI, bool FP8, bool TWO_PASS, bool FAST>
+__device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, const int M, const int N, const f32x16 (&acc)[2][4], int m0, int n0,
+                                                   char* E0, char* E1, int lane, int w, long long* stamp4) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
     auto unswap = [](bf16x8 v, int row) -> bf16x8 {
@@ -122,24 +150,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
     float sa[2] = {1.f, 1.f};               // FP8: per-row activation scale (fp8_linear's scale_a)
     if constexpr (FP8) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[min(mw0 + mi * 32 + l31, M - 1)];
+        for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[FAST ? mw0 + mi * 32 + l31 : min(mw0 + mi * 32 + l31, M - 1)];
     }
     // bias first, then (EPI_GATE_RES) all 16 residual rows of this lane: 16-B loads that stay in flight under the LDS
     // staging below (issued 4 at a time inside the store loop they cost 15-21k cycles of exposed latency)
     bf16x4 bvs[16];
+    if constexpr (FAST) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int n = nw0 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h;
-        bvs[i] = bf16x4{0, 0, 0, 0};
-        if (bias != nullptr && n < N) bvs[i] = *(const bf16x4*)(bias + n);
+        for (int i = 0; i < 16; ++i) bvs[i] = bf16x4{0, 0, 0, 0};
+        if (bias != nullptr) {      // one wave-uniform branch for the 16 loads
+            const bf16* bl = bias + nw0 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bvs[i] = *(const bf16x4*)(bl + (i >> 2) * 32 + 8 * (i & 3));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = nw0 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h;
+            bvs[i] = bf16x4{0, 0, 0, 0};
+            if (bias != nullptr && n < N) bvs[i] = *(const bf16x4*)(bias + n);
+        }
     }
     if constexpr (EPI == EPI_GATE_RES) {
         const int n = nw0 + (lane & 15) * 8;
+        if constexpr (FAST) {
+            const bf16* rl = (const bf16*)P.res + (size_t)(mw0 + (lane >> 4)) * P.ldr + n;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int m = mw0 + it * 4 + (lane >> 4);
-            rv16[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (m < M && n < N) rv16[it] = *(const bf16x8*)((const bf16*)P.res + (size_t)m * P.ldr + n);
+            for (int it = 0; it < 16; ++it) rv16[it] = *(const bf16x8*)(rl + (size_t)(it * 4) * P.ldr);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int m = mw0 + it * 4 + (lane >> 4);
+                rv16[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < M && n < N) rv16[it] = *(const bf16x8*)((const bf16*)P.res + (size_t)m * P.ldr + n);
+            }
         }
     }
     // gate vector / q-k norm weight of this lane's 8 columns: loaded BEFORE any store (vmcnt retires in order: a load issued
@@ -147,37 +191,57 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
     bf16x8 gate_v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (EPI == EPI_GATE_RES) {
         const int n = nw0 + (lane & 15) * 8;
-        if (P.gate != nullptr && n < N) gate_v = *(const bf16x8*)((const bf16*)P.gate + n);
+        if (P.gate != nullptr && (FAST || n < N)) gate_v = *(const bf16x8*)((const bf16*)P.gate + n);
     }
-    // y = bf16(acc + bias) (+ pre) of the row halves [mi_lo, mi_hi) -> LDS
+    // y = bf16(acc + bias) (+ pre) of the lane's four columns 8q + 4h .. + 3 of block ni, row half mi
+    auto y_chunk = [&](int mi, int ni, int q) __attribute__((always_inline)) -> bf16x4 {
+        const int n = nw0 + ni * 32 + 8 * q + 4 * h;
+        float b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = (float)bvs[ni * 4 + q][r];
+        bf16x4 y;
+        if constexpr (FP8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] * sa[mi] + b[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] + b[r]);
+        }
+        const int row = mi * 32 + l31;
+        if (!FAST && pre != nullptr && n < N && mw0 + row < M) {
+            // y = pre + y : the linear's own (already rounded) output plus this low-rank product
+            const bf16x4 pv = *(const bf16x4*)(pre + (size_t)(mw0 + row) * P.ldp + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (bf16)((float)pv[r] + (float)y[r]);
+        }
+        return y;
+    };
+    // PACK_FIRST (schedule 17's two-pass form on full tiles): both halves are rounded and packed before anything is staged --
+    // 64 registers of bf16 pairs instead of 128 accumulators + 32 of bias live while the first half is emitted, which is what
+    // lets the second half's operands (RoPE tables, residual rows) be requested BEFORE the first half's stores
+    constexpr bool PACK_FIRST = TWO_PASS && FAST;
+    bf16x4 ypk[PACK_FIRST ? 2 : 1][PACK_FIRST ? 16 : 1];
+    if constexpr (PACK_FIRST) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) ypk[mi][ni * 4 + q] = y_chunk(mi, ni, q);
+    }
+    // the row halves [mi_lo, mi_hi) -> LDS
     auto stage_rows = [&](int mi_lo, int mi_hi) __attribute__((always_inline)) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = nw0 + ni * 32 + 8 * q + 4 * h;
-                float b[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = (float)bvs[ni * 4 + q][r];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     if (mi < mi_lo || mi >= mi_hi) continue;
-                    bf16x4 y;
-                    if constexpr (FP8) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] * sa[mi] + b[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi][ni][4 * q + r] + b[r]);
-                    }
-                    const int row = mi * 32 + l31;
-                    if (pre != nullptr && n < N && mw0 + row < M) {
-                        // y = pre + y : the linear's own (already rounded) output plus this low-rank product
-                        const bf16x4 pv = *(const bf16x4*)(pre + (size_t)(mw0 + row) * P.ldp + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = (bf16)((float)pv[r] + (float)y[r]);
-                    }
                     const int c = ni * 4 + q;
+                    bf16x4 y;
+                    if constexpr (PACK_FIRST) y = ypk[mi][c];
+                    else y = y_chunk(mi, ni, q);
                     char* Eb = mi == 0 ? E0 : E1;
                     *(bf16x4*)(Eb + l31 * 256 + ((c ^ (l31 & 15)) << 4) + ((h ^ ((l31 >> 3) & 1)) << 3)) = y;
                 }
@@ -216,7 +280,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                 f32x4 cs8[8], sn8[8];
 #pragma unroll
                 for (int j8 = 0; j8 < 8; ++j8) {
-                    const int mc = min(mw0 + mi * 32 + j8 * 4 + (lane >> 4), M - 1);
+                    const int mr = mw0 + mi * 32 + j8 * 4 + (lane >> 4);
+                    const int mc = FAST ? mr : min(mr, M - 1);
                     cs8[j8] = *(const f32x4*)(P.rope_cos + (size_t)mc * 64 + c * 4);
                     sn8[j8] = *(const f32x4*)(P.rope_sin + (size_t)mc * 64 + c * 4);
                 }
@@ -227,31 +292,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                     bf16x8 v;
                     if constexpr (HELD) v = held[j8];
                     else v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
-                    float y[8];
+                    // pairs of columns as f32x2 (packed fp32 maths, one bf16 convert per pair); the operations and their order are
+                    // those of the scalar form this replaces: squares summed left to right, every op rounded where the reference rounds
+                    const u32x4 vp = __builtin_bit_cast(u32x4, v);
+                    const u32x4 wp = __builtin_bit_cast(u32x4, wv);
+                    f32x2 y2[4];
                     float ss = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        y[j] = (float)v[j];
-                        ss += y[j] * y[j];
+                    for (int jj = 0; jj < 4; ++jj) {
+                        y2[jj] = up2(vp[jj]);
+                        const f32x2 sq = y2[jj] * y2[jj];
+                        ss += sq.x;
+                        ss += sq.y;
                     }
-                    ss += __shfl_xor(ss, 1, 64);
-                    ss += __shfl_xor(ss, 2, 64);
-                    ss += __shfl_xor(ss, 4, 64);
-                    ss += __shfl_xor(ss, 8, 64);
+                    ss = row16_sum(ss);
                     // RMSNorm(128, eps 1e-6): models/utils.py:250-257
-                    const float rs = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-                    if (m < M) {
+                    const float rs = __builtin_amdgcn_rsqf(ss * (1.0f / 128.0f) + 1e-6f);   // v_rsq_f32: the argument is a normal number >= 1e-6
+                    if (FAST || m < M) {
                         const f32x4 cs = cs8[j8], sn = sn8[j8];
-                        bf16x8 o;
+                        u32x4 o;
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
-                            const float x0 = bf16r(bf16r(y[2 * jj] * rs) * (float)wv[2 * jj]);
-                            const float x1 = bf16r(bf16r(y[2 * jj + 1] * rs) * (float)wv[2 * jj + 1]);
+                            const f32x2 x = rnd2(rnd2(y2[jj] * f32x2{rs, rs}) * up2(wp[jj]));
                             // apply_rotary_emb_qwen: fp32 complex multiply (qwen_image_dit.py:51-57)
-                            o[2 * jj] = (bf16)(x0 * cs[jj] - x1 * sn[jj]);
-                            o[2 * jj + 1] = (bf16)(x0 * sn[jj] + x1 * cs[jj]);
+                            const f32x2 a = x * f32x2{cs[jj], cs[jj]};
+                            const f32x2 b = f32x2{x.y, x.x} * f32x2{sn[jj], sn[jj]};
+                            o[jj] = pk2(f32x2{a.x - b.x, a.y + b.y});
                         }
-                        *(bf16x8*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
+                        *(u32x4*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
                     }
                 }
             } else {
@@ -259,7 +327,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                 // (pos = perm16) so the attention kernel's P.V MFMA needs no cross-lane shuffle.
                 bf16* vt = (bf16*)P.vt_out + (size_t)head * 128 * S_pad;
                 const int seq0 = P.seq_off + mw0;
-                const int valid = min(64, M - mw0);
+                const int valid = FAST ? 64 : min(64, M - mw0);
                 if ((seq0 & 15) == 0) {
                     // this half holds the 16-token groups 2 mi and 2 mi + 1 of the wave's 64 tokens: 128 d x 2 groups x 2 halves
 #pragma unroll 2
@@ -275,7 +343,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                             e[j] = *(const unsigned short*)(Eb + lrow * 256 + (((d >> 3) ^ (lrow & 15)) << 4) + ((((d & 7) * 2) ^ (lrow & 8))));
                         }
                         bf16* dstp = vt + (size_t)d * S_pad + seq0 + gi * 16 + hh * 8;
-                        if (gi * 16 + 16 <= valid) {
+                        if (FAST || gi * 16 + 16 <= valid) {
                             u32x4 pk;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) pk[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
@@ -320,7 +388,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
             for (int j8 = 0; j8 < 8; ++j8) {
                 const int lrow = j8 * 4 + (lane >> 4);
                 const int m = mw0 + mi * 32 + lrow;
-                if (m >= M || n >= N) continue;
+                if (!FAST && (m >= M || n >= N)) continue;
                 bf16x8 v;
                 if constexpr (HELD) v = held[j8];
                 else v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
@@ -328,13 +396,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                 if constexpr (EPI == EPI_BIAS) {
                     o = v;
                 } else if constexpr (EPI == EPI_GELU_SIG) {
+                    // x * sigmoid(1.702 x) with the reference's three bf16 roundings (qwen_image_dit.py:44-49), two columns at a time:
+                    // packed fp32 multiplies / adds, one bf16 convert per pair and rounding; exp(-t) = v_exp_f32(-t log2 e) as
+                    // __expf evaluates it, v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide
+                    const u32x4 vp = __builtin_bit_cast(u32x4, v);
+                    u32x4 op;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float y = (float)v[j];
-                        const float t = bf16r(1.702f * y);
-                        const float sg = bf16r(__builtin_amdgcn_rcpf(1.0f + __expf(-t)));   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide
-                        o[j] = (bf16)(y * sg);
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x2 y = up2(vp[jj]);
+                        const f32x2 t = rnd2(f32x2{1.702f, 1.702f} * y);
+                        const f32x2 a = t * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + f32x2{1.0f, 1.0f};
+                        const f32x2 sg = rnd2(f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)});
+                        op[jj] = pk2(y * sg);
                     }
+                    o = __builtin_bit_cast(bf16x8, op);
                     if constexpr (FP8) {
                         if (P.q8_out != nullptr) {
                             // the next Linear's e4m3 operand (fp8_linear's row quantisation with scale 1, GemmProblem.q8_out)
@@ -365,9 +441,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
                         o[j] = (bf16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
                     }
                 } else if constexpr (EPI == EPI_GATE_RES) {
-                    const bf16x8 rv = rv16[mi * 8 + j8];
+                    const u32x4 rp = __builtin_bit_cast(u32x4, rv16[mi * 8 + j8]);
+                    const u32x4 vp = __builtin_bit_cast(u32x4, v);
+                    u32x4 op;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)rv[j] + bf16r(g[j] * (float)v[j]));
+                    for (int jj = 0; jj < 4; ++jj) op[jj] = pk2(up2(rp[jj]) + rnd2(f32x2{g[2 * jj], g[2 * jj + 1]} * up2(vp[jj])));
+                    o = __builtin_bit_cast(bf16x8, op);
                 }
                 *(bf16x8*)(out + (size_t)m * P.ldo + n) = o;
             }
@@ -403,9 +482,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const f32x16
     }
 }
 
+template <int EPI, bool FP8, bool TWO_PASS>
+__device__ __forceinline__ void gemm_epilogue(const KARG GemmProblem& P, const int M, const int N, const f32x16 (&acc)[2][4], int m0, int n0,
+                                              char* E0, char* E1, int lane, int w, long long* stamp4) {
+    if (m0 + BM <= M && n0 + BN <= N && P.pre == nullptr)      // wave-uniform
+        gemm_epilogue_body<EPI, FP8, TWO_PASS, true>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
+    else
+        gemm_epilogue_body<EPI, FP8, TWO_PASS, false>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
+}
+
 // One output tile per work-group (schedules 10 and 15): `bid` = tile id in the banded order.
 template <int EPI, int VAR, bool FP8>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int bid) {
+__device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem, int bid) {
     constexpr int ES = FP8 ? 1 : 2;        // bytes per operand element
     constexpr int KT_BYTES = 128;          // one K tile of a row, in bytes (64 bf16 / 128 e4m3)
     const int lane = lane_id();
@@ -415,7 +503,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
 
     PE_STAMP(0);
     const TileCoord tc0 = decode_tile(args, bid);
-    const GemmProblem& P = args.p[tc0.pi];
+    const KARG GemmProblem& P = args.p[tc0.pi];
     const int M = P.M, N = P.N, K = P.K;
     const int m0 = tc0.m0, n0 = tc0.n0;
 
@@ -758,7 +846,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
     char* E = smem + w * 16384;
     long long* stamp4 = nullptr;
     if constexpr (VAR == 15) stamp4 = args.dbg != nullptr ? args.dbg + (size_t)blockIdx.x * 8 + 4 : nullptr;
-    gemm_epilogue<EPI, FP8, false>(P, acc, m0, n0, E, E + 8192, lane, w, stamp4);
+    gemm_epilogue<EPI, FP8, false>(P, M, N, acc, m0, n0, E, E + 8192, lane, w, stamp4);
     PE_STAMP(5);
 }
 
@@ -776,7 +864,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, char* smem, int 
 // first K tiles with an idle matrix pipe) and most of the store drain.
 // ------------------------------------------------------------------------------------------
 template <int EPI, bool FP8>
-__device__ __forceinline__ void gemm_persistent(const GemmArgs& args, char* smem) {
+__device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char* smem) {
     constexpr int ES = FP8 ? 1 : 2;
     constexpr int KT_BYTES = 128;
     using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
@@ -802,15 +890,17 @@ __device__ __forceinline__ void gemm_persistent(const GemmArgs& args, char* smem
     for (int t = (int)blockIdx.x; t < ntiles; t += G) {
         // the lane id is made opaque per tile: everything lane-dependent (staging sources, fragment and epilogue addresses) is
         // then recomputed per tile instead of being hoisted out of this loop and kept live across the main loop (spills)
-        int lane_ = lane_id();
-        asm volatile("" : "+v"(lane_));
+        // (read from the hardware with mbcnt, not from threadIdx.x: that VGPR would have to stay live -- or be spilled and
+        // reloaded here behind an s_waitcnt vmcnt(0), which waits for the previous tile's stores and the prefetch in flight)
+        int lane_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
         const int lane = lane_;
         const int l31 = lane & 31, h = lane >> 5;
         const int sw = (l31 >> 1) & 7;
         const int a_off = (wm * 64 + l31) * 128;
         const int w_off = (wn * 128 + l31) * 128;
         const TileCoord tc0 = decode_tile(args, xcd_remap(t, ntiles));
-        const GemmProblem& P = args.p[tc0.pi];
+        const KARG GemmProblem& P = args.p[tc0.pi];
         const int M = P.M, N = P.N, K = P.K;
         const int m0 = tc0.m0, n0 = tc0.n0;
         const int nk = K * ES / KT_BYTES;
@@ -949,7 +1039,7 @@ __device__ __forceinline__ void gemm_persistent(const GemmArgs& args, char* smem
         const int a_free = abk ^ 1;
         const int w_free = wsk == 0 ? 2 : wsk - 1;
         char* E = w < 4 ? a_base + a_free * A_BYTES + w * 8192 : w_base + w_free * W_BYTES + (w - 4) * 8192;
-        gemm_epilogue<EPI, FP8, true>(P, acc, m0, n0, E, E, lane, w, nullptr);
+        gemm_epilogue<EPI, FP8, true>(P, M, N, acc, m0, n0, E, E, lane, w, nullptr);
         ab = abk;
         ws = wsk;
         have = have_next;
@@ -958,8 +1048,10 @@ __device__ __forceinline__ void gemm_persistent(const GemmArgs& args, char* smem
 }
 
 template <int EPI, int VAR, bool FP8>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmArgs args) {
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmArgs args_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the only kernel argument sits at offset 0 of the kernarg segment
+    const KARG GemmArgs& args = *(const KARG GemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (VAR == 17)
         gemm_persistent<EPI, FP8>(args, smem);
     else
