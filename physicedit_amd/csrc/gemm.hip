@@ -113,7 +113,6 @@ PE_DEV TileCoord decode_tile(const KARG GemmArgs& args, int bid) {
 // text-stream one): no bounds checks, no per-chunk branches.  The general form costs ~100 exec-mask branches and their scalar
 // chains per wave and tile -- the epilogue is VALU / issue bound (profiles/r03_gemm_notes.md section 6).
 // ------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 PE_DEV f32x2 up2(uint32_t p) { return f32x2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)}; }   // two packed bf16 -> fp32
 PE_DEV uint32_t pk2(f32x2 v) {                                                                                // v_cvt_pk_bf16_f32
     const bf16x2 b = {(bf16)v.x, (bf16)v.y};
