@@ -352,6 +352,19 @@ def secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n_images
         prof = read_prof()
+        sampled_in = "the timed images (one stream)"
+        if args.dual_stream and args.cfg != 1.0:
+            # as for the headline: with two streams a launch's event time includes the sibling stream's kernels, so the rates come
+            # from one single-stream CFG pair of forwards of this geometry right after the timed images, every launch sampled
+            lib().pe_profile_enable(8192, 1)
+            ed = [vae.encode(edit_img)]
+            t500 = torch.tensor([500.0]).to(torch.bfloat16)
+            torch.cuda.synchronize()
+            eng.forward(noises[0], t500, pe_p0.clone(), None, ed, step=0)
+            eng.forward(noises[0], t500, pe_n0.clone(), None, ed, step=0)
+            torch.cuda.synchronize()
+            prof = read_prof()
+            sampled_in = "one single-stream CFG pair of forwards right after the timed images, every launch"
         g = prof["gemm"]
         fl = flops_image(H, W, steps, args.t_pos, args.t_neg, args.cfg, args.layers)
         gemm_tf = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else None
@@ -360,7 +373,7 @@ def secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_
                       "algorithmic_pflop_per_image": fl / 1e15, "achieved_tflops": fl / dt / 1e12,
                       "frac_of_bf16_mfma_peak": fl / dt / 1e12 / PEAK_BF16_TFLOPS,
                       "roofline": {"kernel": "gemm (all epilogues)", "bound": "mfma", "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s",
-                                   "frac": (gemm_tf / peak) if gemm_tf else None, "launches_sampled": g["sampled"]},
+                                   "frac": (gemm_tf / peak) if gemm_tf else None, "launches_sampled": g["sampled"], "sampled_in": sampled_in},
                       "flash_attn_tflops": (prof["attn"]["work"] / (prof["attn"]["ms"] * 1e-3) / 1e12) if prof["attn"]["ms"] > 0 else None,
                       "finite_outputs": all(torch.isfinite(x.float()).all().item() for x in imgs)}
 
