@@ -445,7 +445,8 @@ class QwenImagePhysicPipeline:
         if blockwise_controlnet_inputs is not None and self.blockwise_controlnet is None:
             raise _lib.PeError("blockwise_controlnet_inputs given but no block-wise ControlNet checkpoint was loaded")
         if enable_fp8_attention:
-            raise _lib.PeError("enable_fp8_attention (FlashAttention-3 fp8 on Hopper in the reference) is not implemented")
+            from physicedit_amd.dit import _warn_fp8_attention_once
+            _warn_fp8_attention_once()       # accepted; bf16 attention, as the reference without FlashAttention-3 (qwen_image_dit.py:14-39)
         if is_train and self.use_special_tokens and (middle_key_frames is None or not isinstance(edit_image, Image.Image)):
             raise _lib.PeError("is_train=True runs the training-time prior (PhysicalVisualEmbedder, :992-1120) and needs "
                                "middle_key_frames and one edit_image; inference scripts pass is_train=False")

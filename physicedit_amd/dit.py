@@ -538,6 +538,22 @@ def special_indices(special_token_mask: Optional[torch.Tensor], device) -> Optio
     return idx.to(device)
 
 
+_FP8_ATTN_WARNED = False
+
+
+def _warn_fp8_attention_once():
+    """`enable_fp8_attention=True` in the reference selects FlashAttention-3's e4m3 kernel ONLY where `flash_attn_interface`
+    imports (Hopper); everywhere else qwen_image_flash_attention falls through to bf16 SDPA and the flag does nothing
+    (qwen_image_dit.py:14-39: the `else` branch never reads it).  That second behaviour is what this package mirrors: the flag is
+    accepted, attention stays the bf16 flash kernel, and the caller is told once."""
+    global _FP8_ATTN_WARNED
+    if not _FP8_ATTN_WARNED:
+        _FP8_ATTN_WARNED = True
+        import warnings
+        warnings.warn("enable_fp8_attention=True: no e4m3 attention kernel here; attention runs in bf16, as the reference does "
+                      "wherever FlashAttention-3 is not installed (qwen_image_dit.py:14-39)", stacklevel=3)
+
+
 def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=None, visual_thinking_adapter=None,
                         latents=None, timestep=None, prompt_emb=None, prompt_emb_mask=None, special_token_mask=None,
                         height=None, width=None, blockwise_controlnet_conditioning=None,
@@ -548,7 +564,7 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
                         pseudo_special_emb_dino=None, pseudo_special_emb_vae=None, **kwargs):
     """Drop-in for the reference operator of the same name (qwen_image_physical.py:1302-1403),
     inference subset: returns (noise_pred, 0).  Unsupported reference features raise instead of
-    silently differing."""
+    silently differing; `enable_fp8_attention` behaves as in the reference without FlashAttention-3 (accepted, bf16 attention)."""
     if entity_prompt_emb is not None and entity_masks is None:
         raise _lib.PeError("model_fn_qwen_image: entity_prompt_emb without entity_masks")
     want_loss = bool(is_train) and special_token_mask is not None
@@ -556,7 +572,7 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
         raise _lib.PeError("model_fn_qwen_image: is_train=True needs pseudo_special_emb_dino / pseudo_special_emb_vae (the targets of "
                            "get_loss, produced by the training-time PhysicalVisualEmbedder); inference passes is_train=False")
     if enable_fp8_attention:
-        raise _lib.PeError("model_fn_qwen_image: fp8 attention (FlashAttention-3 on Hopper in the reference) is not implemented")
+        _warn_fp8_attention_once()
     edits = []
     if context_latents is not None:
         edits.append(context_latents)      # context tokens come right after the noise tokens (:1348-1351)

@@ -103,3 +103,16 @@ def test_layout_fingerprints_match_the_reference_detector_table():
     assert detect_model_name(dit) == "qwen_image_dit" and detect_model_name(vae) == "qwen_image_vae"
     small = {k: torch.empty(shape, device="meta") for k, shape in synth.dit_layout(2)}
     assert detect_model_name(small) == "qwen_image_dit"          # reduced depth: key-signature fallback
+
+
+def test_fp8_attention_flag_warns_once():
+    """`enable_fp8_attention=True` is accepted like the reference accepts it without FlashAttention-3 (bf16 attention,
+    qwen_image_dit.py:14-39); the caller is told exactly once."""
+    import warnings
+    import physicedit_amd.dit as D
+    D._FP8_ATTN_WARNED = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        D._warn_fp8_attention_once()
+        D._warn_fp8_attention_once()
+    assert len(rec) == 1 and "FlashAttention-3" in str(rec[0].message)

@@ -122,6 +122,20 @@ def test_model_fn_G5(golden, eng2):
                                  edit_latents=None, is_train=False)
     d, u = stats("model_fn plain (no adapter, no edit)", lat, g["latents_plain"])
     assert u.max().item() <= 16.0 and d.mean().item() <= 4e-3
+    # enable_fp8_attention: accepted, one warning, and -- as in the reference wherever FlashAttention-3 is absent
+    # (qwen_image_dit.py:14-39: the SDPA branch never reads the flag) -- the same bf16 attention, bit for bit
+    import physicedit_amd.dit as D
+    import warnings
+    D._FP8_ATTN_WARNED = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lat8, _ = model_fn_qwen_image(dit=eng2, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF),
+                                      prompt_emb=pe.cuda().clone(), special_token_mask=None, height=256, width=256,
+                                      edit_latents=None, is_train=False, enable_fp8_attention=True)
+        model_fn_qwen_image(dit=eng2, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF), prompt_emb=pe.cuda().clone(),
+                            special_token_mask=None, height=256, width=256, edit_latents=None, is_train=False, enable_fp8_attention=True)
+    assert torch.equal(lat8, lat)
+    assert sum("enable_fp8_attention" in str(w.message) for w in rec) == 1
 
 
 def test_loop_dual_stream_is_bit_identical(eng2):
