@@ -47,19 +47,9 @@ def _inputs(h, w, eh, ew, T, nsp, seed):
     return noise, edit, pe, mask
 
 
-def test_60_layers_depth_meets_length():
-    """Depth AND sequence length together (VERDICT r02 item 4): the FULL 60-layer DiT + adapter on a 512x512 target with a 512x512
-    edit image (S_img = 2048) and T = 160 with 16 special tokens: S = 2208 -> 9 query blocks and 35 KV tiles per head in the flash
-    kernel (multi-tile, split-KV leftovers), 9 M tiles per GEMM (432 / 324 tiles for MLP-up / QKV: several rounds of work-groups,
-    the persistent schedule 17 walks tiles).  One `model_fn` call at the first timestep of the 40-step schedule (t ~ 1000: the
-    adapter's in-place update of the special rows included) against the oracle in bf16 and in fp32
-    (`qwen_image_physical.py:1302-1403`).  The fp32 evaluation is what costs time on the host (its element-wise passes over
-    [S, 12288] fp32 tensors), which is why this is one forward and not a CFG step: the CFG combine / Euler kernel is pinned on the
-    reference's own tensors elsewhere (G6, G15).  Run for BOTH attention variants: the default (4, lazy max) must be as close
-    to the fp32 evaluation as the reference's own bf16 run, and no further from it than the textbook kernel (0) -- the repo's
-    criterion for choosing it (profiles/r03_attention_notes.md)."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
+def _depth_meets_length(HW, T, nsp, case):
+    """60-layer DiT + adapter, one `model_fn` call at the first timestep of the 40-step schedule, both attention variants, against the
+    oracle in bf16 and fp32; returns the two parity records."""
     import os
     from physicedit_amd._lib import lib
     from physicedit_amd.dit import QwenImageDiTEngine, special_indices
@@ -68,8 +58,7 @@ def test_60_layers_depth_meets_length():
     sd_dev = synth.make_state_dict_device(synth.dit_layout(60), 1234, dev)
     ad = synth.make_state_dict(synth.adapter_layout(), 4321)
     eng = QwenImageDiTEngine(sd_dev, ad, device=dev)
-    HW, T = 512, 160
-    noise, edit, pe, mask = _inputs(HW, HW, HW, HW, T, 16, 0)
+    noise, edit, pe, mask = _inputs(HW, HW, HW, HW, T, nsp, 0)
     sch = qwen_image_scheduler()
     sch.set_timesteps(40, dynamic_shift_len=(HW // 16) * (HW // 16))
     t = sch.timesteps[0:1].to(BF)
@@ -93,7 +82,6 @@ def test_60_layers_depth_meets_length():
                            edit.float(), t_min, t_max)
     finally:
         torch.set_num_threads(threads)
-    case = "60 layers, 512x512 + 512x512 edit (S = 2208), T 160, one model_fn call (first of 40 steps)"
     st4 = record("configs[1]", case + " [attention variant 4 = default]", got[4], ref, ref32)
     st0 = record("configs[1]", case + " [attention variant 0]", got[0], ref, ref32)
     assert torch.isfinite(ref.float()).all() and torch.isfinite(got[4].float()).all() and torch.isfinite(got[0].float()).all()
@@ -103,6 +91,36 @@ def test_60_layers_depth_meets_length():
         assert st["max_to_fp32_hip"] <= 1.5 * st["max_to_fp32_reference_bf16"] + 1e-3, st
     # the decision rule for the default attention kernel: not measurably further from fp32 than the textbook update
     assert st4["fp32_distance_ratio"] <= st0["fp32_distance_ratio"] * 1.02 + 1e-3, (st4, st0)
+    return st4, st0
+
+
+def test_60_layers_depth_meets_length():
+    """Depth AND sequence length together (VERDICT r02 item 4): the FULL 60-layer DiT + adapter on a 512x512 target with a 512x512
+    edit image (S_img = 2048) and T = 160 with 16 special tokens: S = 2208 -> 9 query blocks and 35 KV tiles per head in the flash
+    kernel (multi-tile, split-KV leftovers), 9 M tiles per GEMM (432 / 324 tiles for MLP-up / QKV: several rounds of work-groups,
+    the persistent schedule 17 walks tiles).  One `model_fn` call at the first timestep of the 40-step schedule (t ~ 1000: the
+    adapter's in-place update of the special rows included) against the oracle in bf16 and in fp32
+    (`qwen_image_physical.py:1302-1403`).  The fp32 evaluation is what costs time on the host (its element-wise passes over
+    [S, 12288] fp32 tensors), which is why this is one forward and not a CFG step: the CFG combine / Euler kernel is pinned on the
+    reference's own tensors elsewhere (G6, G15).  Run for BOTH attention variants: the default (4, lazy max) must be as close
+    to the fp32 evaluation as the reference's own bf16 run, and no further from it than the textbook kernel (0) -- the repo's
+    criterion for choosing it (profiles/r03_attention_notes.md)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _depth_meets_length(512, 160, 16, "60 layers, 512x512 + 512x512 edit (S = 2208), T 160, one model_fn call (first of 40 steps)")
+
+
+def test_60_layers_headline_geometry():
+    """The same at BASELINE configs[1]'s own geometry: 1024x1024 target + 1024x1024 edit image, T = 512 with 64 special tokens,
+    S = 8704 (34 query blocks x 136 KV tiles per head; 1632 / 1224 / 408-tile GEMM launches).  ~10 minutes of host oracle time
+    (bf16 + fp32, 60 layers at S = 8704), so it only runs when PE_PARITY_FULL=1; its numbers are committed in
+    profiles/r03_parity.json."""
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if os.environ.get("PE_PARITY_FULL") != "1":
+        pytest.skip("set PE_PARITY_FULL=1 (about 10 minutes of CPU oracle time)")
+    _depth_meets_length(1024, 512, 64, "60 layers, 1024x1024 + 1024x1024 edit (S = 8704), T 512, one model_fn call (first of 40 steps)")
 
 
 def test_vae_decode_1024_vs_oracle():
