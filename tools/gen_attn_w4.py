@@ -22,7 +22,8 @@ N = the reads issued after the second fragment by then (2, or 0 at the end of th
 """
 import os
 
-EARLY_PAIRS = 5          # per block: pairs 0..4 of softmax(i+1) run in phase 2 of iteration i, pairs 5..15 in phase 1 of i+1
+DMA_SLOTS = int(os.environ.get("W4_DMA_SLOTS", "3"))      # issue slots an LDS-DMA piece (address + m0 + buffer_load ... lds) is booked with
+EARLY_PAIRS = int(os.environ.get("W4_EARLY_PAIRS", "5"))   # per block: pairs 0..4 of softmax(i+1) run in phase 2 of iteration i, pairs 5..15 in phase 1 of i+1
 KT_BYTES = 64 * 256
 
 
@@ -71,35 +72,104 @@ def add_read(st, kind, slot, idx):
     st.ins.append(f'[ra] "v"({addr})')
 
 
-def add_pair_a(st, P, b, q, tag):
-    """exp2 of scores 2q, 2q+1 of block b into fresh temporaries"""
+class Ins:
+    """one filler instruction of the softmax stream: asm text over %[name] operands, and what it does to the C++ variables behind them"""
+
+    def __init__(self, text, defs=(), uses=(), rmw=(), slots=1, after=None, sreg=()):
+        self.text, self.defs, self.uses, self.rmw, self.slots, self.after, self.sreg = text, dict(defs), dict(uses), dict(rmw), slots, after, set(sreg)
+
+
+def pair_stream(pairs, P, tagp):
+    """The softmax of `pairs` = [(b, q)] (scores 2q, 2q+1 of block b, tile parity P) as ONE instruction stream, software-pipelined one
+    pair deep:   fma fma | add' exp add' exp cvt'   (' = the pair before), so that no instruction reads the result of the one right
+    before it.  Issue slots: v_exp_f32 2 (transcendental rate), everything else 1 (tools/microbench/valu_rate.hip)."""
     if os.environ.get("W4_NO_PAIRS"):       # timing experiment only
-        return
-    st.lines += [f"v_fma_f32 %[t0], %[s0], %[sl], -%[suba]", f"v_fma_f32 %[t1], %[s1], %[sl], -%[suba]"]
-    st.tail_a = [f"v_exp_f32 %[t0], %[t0]", f"v_exp_f32 %[t1], %[t1]"]
-    st.outs += [f'[t0] "=&v"(e0_{tag})', f'[t1] "=&v"(e1_{tag})']
-    st.ins += [f'[s0] "v"({score(P, b, 2 * q)})', f'[s1] "v"({score(P, b, 2 * q + 1)})', '[sl] "s"(scale_log2)',
-               f'[suba] "v"(sm_sub[{b}])']
+        return []
+
+    def parts(k):
+        b, q = pairs[k]
+        T = f"{tagp}{k}"
+        F = [Ins(f"v_fma_f32 %[e{j}_{T}], %[sc{j}_{T}], %[sl], -%[sub{b}]", defs={f"e{j}_{T}": f"e{j}_{T}"},
+                 uses={f"sc{j}_{T}": score(P, b, 2 * q + j), "sl": "scale_log2", f"sub{b}": f"sm_sub[{b}]"}, sreg=("sl",)) for j in (0, 1)]
+        E = [Ins(f"v_exp_f32 %[e{j}_{T}], %[e{j}_{T}]", rmw={f"e{j}_{T}": f"e{j}_{T}"}, slots=2) for j in (0, 1)]
+        S = [Ins(f"v_add_f32 %[ps{b}], %[ps{b}], %[e{j}_{T}]", rmw={f"ps{b}": f"sm_psum[{b}]"}, uses={f"e{j}_{T}": f"e{j}_{T}"}) for j in (0, 1)]
+        C = Ins(f"v_cvt_pk_bf16_f32 %[pw_{T}], %[e0_{T}], %[e1_{T}]", defs={f"pw_{T}": f"pw_{T}"},
+                uses={f"e0_{T}": f"e0_{T}", f"e1_{T}": f"e1_{T}"}, after=f"{pk_slot(P, b, q)} = pw_{T};")
+        return F, E, S, C
+    out = []
+    prev = None
+    for k in range(len(pairs)):
+        F, E, S, C = parts(k)
+        if prev is None:
+            out += [F[0], F[1], E[0], E[1]]
+        else:
+            pS, pC = prev
+            out += [F[0], F[1], pS[0], E[0], pS[1], E[1], pC]
+        prev = (S, C)
+    if prev is not None:
+        out += [prev[0][0], prev[0][1], prev[1]]
+    return out
 
 
-def add_pair_b(st, P, b, q, tag):
-    """row sum (score order) and bf16 pack of a pair whose exp2 ran in an earlier gap"""
-    if os.environ.get("W4_NO_PAIRS"):
-        return
-    st.lines_b = [f"v_add_f32 %[ps], %[ps], %[u0]", f"v_add_f32 %[ps], %[ps], %[u1]", f"v_cvt_pk_bf16_f32 %[pkd], %[u0], %[u1]"]
-    st.outs += [f'[ps] "+v"(sm_psum[{b}])', f'[pkd] "=v"(pw_{tag})']
-    st.ins += [f'[u0] "v"(e0_{tag})', f'[u1] "v"(e1_{tag})']
-    st.after.append(f"{pk_slot(P, b, q)} = pw_{tag};")
+def spread(stream, fixed, first_gap, last_gap):
+    """Cut `stream` into the gaps first_gap..last_gap so that every gap carries about the same number of issue slots, counting what
+    the gap holds already (`fixed[g]`: its LDS reads, max3s, ...).  Returns {gap: [Ins]}.  An MFMA gap hides ~5-7 slots; a gap
+    loaded beyond that stretches the MFMA cadence, and a lighter gap next to it gives nothing back (the matrix pipe cannot run
+    ahead), so the level matters more than the sum."""
+    gaps = list(range(first_gap, last_gap + 1))
+    total = sum(i.slots for i in stream) + sum(fixed.get(g, 0) for g in gaps)
+    res = {g: [] for g in gaps}
+    k = 0
+    used_total = 0.0
+    for n, g in enumerate(gaps):
+        # cumulative target after this gap
+        target = total * (n + 1) / len(gaps)
+        used_total += fixed.get(g, 0)
+        while k < len(stream) and (used_total + stream[k].slots / 2.0 <= target or n == len(gaps) - 1):
+            res[g].append(stream[k])
+            used_total += stream[k].slots
+            k += 1
+    assert k == len(stream)
+    return res
 
 
-def finish_pairs(st):
-    """interleave the two halves so that no instruction reads a result produced by the instruction right before it"""
-    a = getattr(st, "tail_a", [])
-    b = getattr(st, "lines_b", [])
-    if a and b:            # fma fma (already in lines) | add exp add exp cvt
-        st.lines += [b[0], a[0], b[1], a[1], b[2]]
-    else:
-        st.lines += a + b
+def add_stream(st, instrs):
+    """append `instrs` to statement st: every C++ variable becomes ONE operand -- "=&v" if the statement defines it before any
+    read, "+v" if it reads and writes it, "v" / "s" if it only reads it"""
+    state = {}      # name -> [cexpr, first_access ('def' | 'use'), written]
+    order = []
+    for i in instrs:
+        for nm, ce in i.uses.items():
+            if nm not in state:
+                state[nm] = [ce, "use", False, nm in i.sreg]
+                order.append(nm)
+        for nm, ce in i.rmw.items():
+            if nm not in state:
+                state[nm] = [ce, "use", True, False]
+                order.append(nm)
+            else:
+                state[nm][2] = True
+        for nm, ce in i.defs.items():
+            if nm not in state:
+                state[nm] = [ce, "def", True, False]
+                order.append(nm)
+            else:
+                state[nm][2] = True
+        st.lines.append(i.text)
+        if i.after:
+            st.after.append(i.after)
+    for nm in order:
+        ce, first, written, sreg = state[nm]
+        if first == "def":
+            st.outs.append(f'[{nm}] "=&v"({ce})')
+        elif written:
+            st.outs.append(f'[{nm}] "+v"({ce})')
+        else:
+            st.ins.append(f'[{nm}] "{"s" if sreg else "v"}"({ce})')
+
+
+def fixed_slots(st):
+    return sum(0 if ln.startswith("s_waitcnt") or ln.startswith("v_mfma") else 1 for ln in st.lines)
 
 
 def add_max(st, P, g):
@@ -154,12 +224,6 @@ def pair_list(lo, hi):
     return [(b, q) for q in range(lo, hi) for b in (0, 1)]
 
 
-def schedule_pairs(pairs, first_gap, last_gap):
-    """gap of the exp2 half and of the sum/pack half of every pair; the sum/pack half is one gap behind"""
-    ga = distribute(len(pairs), first_gap, last_gap - 1)
-    return ga, [g + 1 for g in ga]
-
-
 def gen_iter(ST, out):
     PC, PN = ST & 1, (ST & 1) ^ 1
     slot_v, slot_k1, slot_k2, slot_d = ST, (ST + 1) & 3, (ST + 2) & 3, (ST + 3) & 3
@@ -176,21 +240,21 @@ def gen_iter(ST, out):
         w(ind + "if (stamp) stamp_it[0] = (long long)__builtin_readcyclecounter();")
         w("#endif")
     late = pair_list(EARLY_PAIRS, 16)
-    ga, gb = schedule_pairs(late, 0, 31)
     w(ind + "float " + ", ".join(f"e0_l{k}, e1_l{k}" for k in range(len(late))) + ";")
     w(ind + "uint32_t " + ", ".join(f"pw_l{k}" for k in range(len(late))) + ";")
     w(ind + "// ---- phase 1")
+    stmts = []
     for g in range(32):
         st = qk_stmt(PN, g, slot_k1)
         if g >= 28:
             add_read(st, "v", slot_v, g - 28)
-        for k, (b, q) in enumerate(late):
-            if ga[k] == g:
-                add_pair_a(st, PC, b, q, f"l{k}")
-        for k, (b, q) in enumerate(late):
-            if gb[k] == g:
-                add_pair_b(st, PC, b, q, f"l{k}")
-        finish_pairs(st)
+        stmts.append(st)
+    fixed = {g: fixed_slots(stmts[g]) for g in range(32)}
+    fixed[2] += 2; fixed[3] += 2            # the (rarely taken) O rescale branches sit behind these gaps
+    placed = spread(pair_stream(late, PC, "l"), fixed, 0, 31)
+    for g in range(32):
+        st = stmts[g]
+        add_stream(st, placed[g])
         out.extend(st.emit(ind))
         if g == 2:
             w(ind + "rescale(0);")
@@ -215,10 +279,10 @@ def gen_iter(ST, out):
         w(ind + "if (stamp) stamp_it[2] = (long long)__builtin_readcyclecounter();")
         w("#endif")
     early = pair_list(0, EARLY_PAIRS)
-    ga, gb = schedule_pairs(early, 11, 31)
     w(ind + "float " + ", ".join(f"e0_e{k}, e1_e{k}" for k in range(len(early))) + ";")
     w(ind + "uint32_t " + ", ".join(f"pw_e{k}" for k in range(len(early))) + ";")
     w(ind + "// ---- phase 2")
+    stmts = []
     for g in range(32):
         st = pv_stmt(PC, g)
         f = g >> 1
@@ -226,17 +290,20 @@ def gen_iter(ST, out):
             add_read(st, "v", slot_v, f + 4)
         if g >= 28:
             add_read(st, "k", slot_k2, g - 28)
-        if g == 0:
-            w(ind + f"if (mask_next) mask_scores(std::integral_constant<int, {PN}>{{}}, t_next);")
         if g < 8:
             add_max(st, PN, g)
-        for k, (b, q) in enumerate(early):
-            if ga[k] == g:
-                add_pair_a(st, PN, b, q, f"e{k}")
-        for k, (b, q) in enumerate(early):
-            if gb[k] == g:
-                add_pair_b(st, PN, b, q, f"e{k}")
-        finish_pairs(st)
+        stmts.append(st)
+    fixed = {g: fixed_slots(stmts[g]) for g in range(32)}
+    for g in range(32):
+        if g & 3 == 1:
+            fixed[g] += DMA_SLOTS           # an LDS-DMA piece is issued behind these gaps
+    first_pair_gap = int(os.environ.get("W4_FIRST_EARLY_GAP", "10"))        # sm_state runs behind gaps 8 and 9
+    placed = spread(pair_stream(early, PN, "e"), fixed, first_pair_gap, 31)
+    for g in range(32):
+        st = stmts[g]
+        if g == 0:
+            w(ind + f"if (mask_next) mask_scores(std::integral_constant<int, {PN}>{{}}, t_next);")
+        add_stream(st, placed.get(g, []))
         out.extend(st.emit(ind))
         if g & 3 == 1 and not os.environ.get("W4_NO_DMA"):       # W4_NO_DMA: timing experiment only (results are garbage)
             j = g >> 3
@@ -293,22 +360,12 @@ def gen_prologue(out):
     w(ind2 + "sm_state(0, true);")
     w(ind2 + "sm_state(1, true);")
     w(ind2 + "W4_FENCE();")
-    for k, (b, q) in enumerate(early):
+    stream = pair_stream(early, 0, "p")
+    for k in range(0, len(stream), 7):          # one pipeline step per statement
         st = Stmt()
-        add_pair_a(st, 0, b, q, f"p{k}")
-        finish_pairs(st)
+        add_stream(st, stream[k:k + 7])
         out.extend(st.emit(ind2))
-        if k > 0:
-            st = Stmt()
-            add_pair_b(st, 0, early[k - 1][0], early[k - 1][1], f"p{k - 1}")
-            finish_pairs(st)
-            out.extend(st.emit(ind2))
         w(ind2 + "W4_FENCE();")
-    st = Stmt()
-    add_pair_b(st, 0, early[-1][0], early[-1][1], f"p{len(early) - 1}")
-    finish_pairs(st)
-    out.extend(st.emit(ind2))
-    w(ind2 + "W4_FENCE();")
     w(ind + "}")
     w("")
 
