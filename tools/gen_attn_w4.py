@@ -11,10 +11,12 @@ say which work rides in which gap; the C++ around the statements (register array
 
 Iteration i of the KV loop (ring slot ST = i & 3, score buffer P = ST & 1 holds tile i, P^1 tile i+1):
   phase 1, gap g: QK^T MFMA g of tile i+1  | K(i+1) fragment reads two k-steps ahead (gaps 4kk, 4kk+1), Vt(i) fragments
-                  0..3 (gaps 28..31)       | the LATE score pairs of softmax(i): exp2 in gap G, row sum + bf16 pack a gap later
+                  0..3 (gaps 28..31)       | the LATE score pairs of softmax(i) as one software-pipelined instruction stream
+                                           | (pair_stream) cut evenly over the 32 gaps by issue slots (spread)
                                            | O rescale of blocks 0 / 1 in gaps 2 / 3 when the running max was raised
   phase 2, gap g: P.V MFMA g of tile i     | Vt(i) fragment f+4 in gap 2f, K(i+2) fragments 0..3 (gaps 28..31), LDS-DMA of
-                  tile i+3 (gaps 4j+1)     | softmax(i+1): row max (gaps 0..7), m / alpha (gaps 8, 9), the EARLY pairs
+                  tile i+3 (gaps 4j+1)     | softmax(i+1): row max (gaps 0..7), m / alpha (gaps 8, 9), the EARLY pairs' stream
+                                           | over gaps 10..31
 LDS reads are asm and not counted by the compiler; the queue is, in issue order: phase 1  [K0..K3 issued at the end of the
 phase 2 before] K4 K5 (gaps 0,1) K6 K7 (4,5) .. K14 K15 (20,21) Vt0..Vt3 (28..31); phase 2  Vt(f+4) in gap 2f (f = 0..11),
 K0..K3 of the next tile (28..31).  One wait per two fragments opens the MFMA statement that first uses them: lgkmcnt(N) with
