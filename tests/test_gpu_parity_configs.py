@@ -47,7 +47,7 @@ def _inputs(h, w, eh, ew, T, nsp, seed):
     return noise, edit, pe, mask
 
 
-def _depth_meets_length(HW, T, nsp, case):
+def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]"):
     """60-layer DiT + adapter, one `model_fn` call at the first timestep of the 40-step schedule, both attention variants, against the
     oracle in bf16 and fp32; returns the two parity records."""
     import os
@@ -58,7 +58,8 @@ def _depth_meets_length(HW, T, nsp, case):
     sd_dev = synth.make_state_dict_device(synth.dit_layout(60), 1234, dev)
     ad = synth.make_state_dict(synth.adapter_layout(), 4321)
     eng = QwenImageDiTEngine(sd_dev, ad, device=dev)
-    noise, edit, pe, mask = _inputs(HW, HW, HW, HW, T, nsp, 0)
+    EH = HW if edit_hw is None else edit_hw
+    noise, edit, pe, mask = _inputs(HW, HW, EH, EH, T, nsp, 0)
     sch = qwen_image_scheduler()
     sch.set_timesteps(40, dynamic_shift_len=(HW // 16) * (HW // 16))
     t = sch.timesteps[0:1].to(BF)
@@ -82,8 +83,8 @@ def _depth_meets_length(HW, T, nsp, case):
                            edit.float(), t_min, t_max)
     finally:
         torch.set_num_threads(threads)
-    st4 = record("configs[1]", case + " [attention variant 4 = default]", got[4], ref, ref32)
-    st0 = record("configs[1]", case + " [attention variant 0]", got[0], ref, ref32)
+    st4 = record(config, case + " [attention variant 4 = default]", got[4], ref, ref32)
+    st0 = record(config, case + " [attention variant 0]", got[0], ref, ref32)
     assert torch.isfinite(ref.float()).all() and torch.isfinite(got[4].float()).all() and torch.isfinite(got[0].float()).all()
     # as close to the fp32 evaluation of the same graph as the reference's own bf16 run is
     for st in (st4, st0):
@@ -121,6 +122,18 @@ def test_60_layers_headline_geometry():
     if os.environ.get("PE_PARITY_FULL") != "1":
         pytest.skip("set PE_PARITY_FULL=1 (about 10 minutes of CPU oracle time)")
     _depth_meets_length(1024, 512, 64, "60 layers, 1024x1024 + 1024x1024 edit (S = 8704), T 512, one model_fn call (first of 40 steps)")
+
+
+def test_60_layers_configs4_geometry():
+    """And at BASELINE configs[4]'s per-GPU geometry: 1328x1328 target (83 x 83 = 6889 noise tokens, odd) + the 1024x1024 edit image,
+    T = 512: S = 11497, 60 layers.  ~15 minutes of host oracle time: PE_PARITY_FULL=1 only; numbers in profiles/r03_parity.json."""
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if os.environ.get("PE_PARITY_FULL") != "1":
+        pytest.skip("set PE_PARITY_FULL=1 (about 15 minutes of CPU oracle time)")
+    _depth_meets_length(1328, 512, 64, "60 layers, 1328x1328 + 1024x1024 edit (S = 11497), T 512, one model_fn call (first of 40 steps)",
+                        edit_hw=1024, config="configs[4]")
 
 
 def test_vae_decode_1024_vs_oracle():
