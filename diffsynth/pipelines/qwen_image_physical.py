@@ -360,7 +360,8 @@ class QwenImagePhysicPipeline:
         """mask.convert("RGB").resize((W/8, H/8)) -> [0, 1] in the pipeline dtype -> mean over RGB -> optional Gaussian blur
         (torchvision.transforms.GaussianBlur(kernel_size = 2 * blur_size + 1, sigma) in the reference; restated here from its
         published algorithm -- reflect padding, separable normalised kernel in the tensor's dtype -- because torchvision is not
-        part of this image: parity of the BLUR is unpinned, the rest is pinned by tests/golden G15)."""
+        part of this image: parity of the BLUR with torchvision itself is unpinned -- tests/test_oracle_golden.py cross-checks it against
+        scipy.ndimage's independent implementation of the same algorithm -- the rest is pinned by tests/golden G15)."""
         if inpaint_mask is None:
             return None
         u8 = np.array(inpaint_mask.convert("RGB").resize((width // 8, height // 8)), dtype=np.float32)

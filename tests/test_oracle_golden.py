@@ -241,6 +241,17 @@ def test_G15_inpaint(golden):
     assert_same(pipe.preprocess_inpaint_mask(Image.fromarray(m_u8, mode="L"), h, w), g["mask"], "facade inpaint mask")
     blurred = pipe.preprocess_inpaint_mask(Image.fromarray(m_u8, mode="L"), h, w, 2, 1.5)
     assert blurred.shape == mask.shape and abs(blurred.float().mean().item() - mask.float().mean().item()) < 0.02
+    # The blur is torchvision's GaussianBlur in the reference (:726-727), and torchvision is not in this image: no fixture.  An
+    # INDEPENDENT implementation of the same published algorithm (normalised exp(-x^2 / 2 sigma^2) taps over 2 * size + 1 pixels,
+    # mirror padding without edge repeat) in float64 cross-checks the restatement -- parity with torchvision itself stays unpinned.
+    from scipy import ndimage
+    pipe.torch_dtype = torch.float32
+    for size, sigma in ((2, 1.5), (4, 2.0), (1, 0.8)):
+        plain = pipe.preprocess_inpaint_mask(Image.fromarray(m_u8, mode="L"), h, w).double().numpy()[0, 0]
+        got = pipe.preprocess_inpaint_mask(Image.fromarray(m_u8, mode="L"), h, w, size, sigma).double().numpy()[0, 0]
+        want = ndimage.gaussian_filter(plain, sigma=sigma, mode="mirror", truncate=(size + 0.25) / sigma)   # radius = int(truncate * sigma + 0.5) = size
+        assert np.abs(got - want).max() < 2e-6, (size, sigma, np.abs(got - want).max())
+    pipe.torch_dtype = BF
     sd = synth.make_state_dict(synth.dit_layout(2), 1234)
     ad = synth.make_state_dict(synth.adapter_layout(), 4321)
     noise, edit, pe_p, mask_p = _model_fn_inputs(h, w, 40, 16, 0)
