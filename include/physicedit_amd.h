@@ -129,6 +129,19 @@ int pe_qkv_rmsnorm_rope(const void* x, int ldx, const void* Wqkv, const void* bq
  * Q,K [H][S_pad][128], Vt [H][128][S_pad] as written by pe_qkv_rmsnorm_rope; out [S][ldo] "s (h d)". */
 int pe_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo,
                   float scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The default attention kernel (round 4) takes Q PRE-MULTIPLIED by scale * log2(e): the factor leaves the softmax's instruction
+ * stream and is applied where Q is produced, in fp32, before Q's one rounding to bf16 (same number of roundings as the reference's
+ * q; qwen_image_dit.py:293-302 then :14-39).  pe_attn_q_prescale(scale) = that factor for the selected kernel (1 when it wants a
+ * plain Q); pe_qkv_rmsnorm_rope_scaled = pe_qkv_rmsnorm_rope storing bf16(rope(q) * q_scale); pe_flash_attn_prescaled =
+ * pe_flash_attn on such a Q (error when pe_attn_q_prescale(scale) == 1).  pe_dit_forward uses this trio; pe_flash_attn itself
+ * keeps taking a plain Q (it runs the same schedule's exact form). */
+float pe_attn_q_prescale(float scale);
+int pe_qkv_rmsnorm_rope_scaled(const void* x, int ldx, const void* Wqkv, const void* bqkv, int M, int H, int K,
+                               const void* norm_q_w, const void* norm_k_w, const float* rope_cos,
+                               const float* rope_sin, void* q_out, void* k_out, void* vt_out, int seq_off, int S_pad,
+                               float q_scale, void* stream);
+int pe_flash_attn_prescaled(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo,
+                            float scale, void* workspace, size_t workspace_bytes, void* stream);
 /* Optional scratch for pe_flash_attn (16-B aligned).  With it, the (head, q-block) items that do not fill a
  * whole round of the 256 CUs are split along KV and merged by a second small kernel (load balance); without
  * it (NULL) the launch is a single kernel. */

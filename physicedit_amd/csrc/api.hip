@@ -146,6 +146,29 @@ int pe_flash_attn(const void* q, const void* k, const void* vt, void* out, int H
     return launch_flash_attn(q, k, vt, out, H, S, S_pad, ldo, scale, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+float pe_attn_q_prescale(float scale) { return attn_q_prescale(scale); }
+
+int pe_qkv_rmsnorm_rope_scaled(const void* x, int ldx, const void* Wqkv, const void* bqkv, int M, int H, int K,
+                               const void* norm_q_w, const void* norm_k_w, const float* rope_cos,
+                               const float* rope_sin, void* q_out, void* k_out, void* vt_out, int seq_off, int S_pad,
+                               float q_scale, void* stream) {
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.W = Wqkv; p.bias = bqkv;
+    p.M = M; p.N = 3 * H * 128; p.K = K; p.lda = ldx;
+    p.norm_q_w = norm_q_w; p.norm_k_w = norm_k_w; p.rope_cos = rope_cos; p.rope_sin = rope_sin;
+    p.q_out = q_out; p.k_out = k_out; p.vt_out = vt_out; p.seq_off = seq_off; p.S_pad = S_pad;
+    p.q_scale = q_scale;
+    return launch_gemm(EPI_QKV, &p, 1, (hipStream_t)stream);
+}
+
+int pe_flash_attn_prescaled(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo,
+                            float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    if (attn_q_prescale(scale) == 1.0f)
+        return pe::set_error(PE_ERR_INVALID_ARG, "pe_flash_attn_prescaled: the selected attention variant takes a plain Q (pe_attn_q_prescale() == 1)");
+    return launch_flash_attn(q, k, vt, out, H, S, S_pad, ldo, scale, workspace, workspace_bytes, (hipStream_t)stream, nullptr, 0, true);
+}
+
 int pe_flash_attn_masked(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, float scale,
                          void* workspace, size_t workspace_bytes, const void* token_words, int n_img, void* stream) {
     if (token_words == nullptr) return pe::set_error(PE_ERR_INVALID_ARG, "pe_flash_attn_masked: null token_words");

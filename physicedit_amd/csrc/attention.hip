@@ -43,7 +43,11 @@ long long* g_attn_dbg = nullptr;   // device buffer for the s_memtime stamps of 
 // reference-bf16's own, at 60 layers x S = 2208 (tests/test_gpu_parity_configs.py; profiles/r03_attention_notes.md).
 // 0: flash_attn_kernel, 8 waves x 32 query rows, textbook update (P rounded at the scale of the reference's SDPA; the A/B knob,
 // and always the kernel of the masked EliGen form);  3: flash_attn_w4_kernel with the textbook update, bit-identical to 0.
-int g_attn_variant = 4;
+// 5 (default since round 4) / 6: the same kernel with the scale and the running max folded out of the softmax stream (FOLD
+// below): 5 = lazy max like 4, 6 = textbook raise on every new maximum (exercises the raise path on every tile: the test form).
+int g_attn_variant = 5;
+// what the QKV epilogue multiplies Q by (GemmProblem.q_scale) for the current variant: scale . log2(e), or 1
+float attn_q_prescale(float scale) { return g_attn_variant >= 5 ? scale * 1.44269504088896340736f : 1.0f; }
 
 // Work decomposition.  total = H * nqb equal (head, q-block) items never divide evenly over the 256 CUs
 // (cfg 2: 816 items = 3.19 rounds -> 4 rounds, 80 % efficiency).  So the first n_full = floor(total/slots)
@@ -411,6 +415,14 @@ PE_DEV float sum_with_lane_xor32(float x) {
 //                                  first part of softmax(i+1): mask, row max, m / alpha, the first SM_EARLY exp2 per block
 //   every (MFMA, fillers) pair is fenced with sched_barrier(0): source order is the schedule (~5 fillers per MFMA gap).
 //   The arithmetic (and its order) is that of flash_attn_kernel: results are bit-identical.
+// lane id recomputed where it is needed (asm volatile: not hoisted, not merged with the kernel-entry copy): a lane constant that
+// lives across the KV loop for the sake of a rarely taken branch or of the epilogue is spilled to scratch and reloaded IN the loop
+// behind a vmcnt(0) (cdna guide, "4-wave structure" pitfalls)
+PE_DEV int lane_id_fresh() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 namespace w4 {
 constexpr int SM_EARLY = 12;      // exp2 of a block's first SM_EARLY scores run in phase 2 (of the iteration before)
 // softmax(i) is cut in PAIRS of scores (one bf16x2 of P each; 16 per block): the first SM_EARLY / 2 pairs of a block run in
@@ -426,6 +438,18 @@ constexpr int k_wait2(int kk) { return kk <= 6 ? 2 : 0; }      // before MFMA 4k
 constexpr int v_wait2(int f) { return f <= 12 ? 2 : 0; }       // before MFMA 2f (f even): fragments f, f+1
 }  // namespace w4
 
+// FOLD (variants 5 / 6, round 4): the two v_fma_f32 per score pair (s . scale_log2 - m) leave the softmax stream.  Q arrives already
+// multiplied by scale . log2(e) (the QKV epilogue applies it in fp32 BEFORE its one bf16 rounding: GemmProblem.q_scale), and the
+// running max enters through the matrix pipe: the first k-step MFMA of every 32 x 32 score tile accumulates onto negm[b] (16
+// registers holding -m of the lane's query row) instead of 0, so the accumulator IS the exp2 argument.  The row max of a tile is then
+// measured relative to m: block b is "raised" when some row's max exceeds tau, by delta = max(row max, 0) per row -- m += delta,
+// negm = -m, the tile's 32 scores -= delta, alpha = exp2(-delta) for O and l -- a wave-uniform branch that bounded data takes on the
+// first tiles only.  P is single buffered (the registers negm takes): a 16-key chunk of P(i+1) is packed only after the last P.V MFMA
+// of tile i that reads the chunk (asserted by the generator).
+#ifndef PE_W4_PK2
+#define PE_W4_PK2 0      // experiment (with W4_PK2=1 at generation): FOLD with the double-buffered P of the exact form
+#endif
+template <bool FOLD>
 __global__ void __launch_bounds__(256, 1)
 flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
                      bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
@@ -511,7 +535,7 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(o[b][dt][r]));
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float m_run[2] = {FOLD ? 0.f : -INFINITY, FOLD ? 0.f : -INFINITY}, l_run[2] = {0.f, 0.f};
     int kaddr[8], vaddr[4];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) kaddr[kk] = l31 * 256 + (((kk * 2 + h) ^ (l31 & 15)) << 4);
@@ -519,7 +543,8 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
     for (int c = 0; c < 4; ++c) vaddr[c] = V_BASE + l31 * 128 + (((c * 2 + h) ^ ((l31 >> 1) & 7)) << 4);
 
     f32x16 sc[2][2][2];      // [tile parity][q block][key half]
-    u32x4 pk[2][2][4];       // P, bf16 pairs: [tile parity][q block][16-key chunk]
+    std::conditional_t<FOLD && !PE_W4_PK2, u32x4[2][4], u32x4[2][2][4]> pk;       // P, bf16 pairs: [tile parity (not FOLD)][q block][16-key chunk]
+    f32x16 negm[2];          // FOLD: -m of the lane's row of block b, 16 copies = the C operand of the tile's first MFMAs
     u32x4 kf[16], vf[16];    // K / Vt fragments, accumulator half: ~6 / ~4 live at a time
     float sm_mx[2], sm_sub[2], sm_alpha[2], sm_psum[2];
     bool sm_moved[2];
@@ -541,17 +566,48 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
         sm_psum[b] = 0.f;
         asm volatile("" : "+v"(sm_alpha[b]), "+v"(sm_sub[b]), "+v"(m_run[b]), "+v"(sm_psum[b]));
     };
-    // keys past S -> -inf: the ragged last tile, and every tile past the end of the sequence (iterations are issued in fours; such a
-    // tile re-reads the last one, whose pad rows may hold anything, NaN included)
-    auto mask_scores = [&](auto p_tag, int t) __attribute__((always_inline)) {
+    // FOLD form of sm_state for the scores sc[P][b] = s . c - m of one tile.  FIRST (the work item's first tile, m = 0 so far): m
+    // becomes the row max whatever its sign and nothing is rescaled (O = l = 0).  A tile past the end arrives fully masked: row max
+    // -inf, no move, P = exp2(-inf) = 0.
+    auto sm_state_f = [&](auto p_tag, int b, auto first_tag) __attribute__((always_inline)) {
         constexpr int P = decltype(p_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const float mx = max_with_lane_xor32(sm_mx[b]);
+        const bool fix = FIRST || __any(mx > tau);
+        sm_moved[b] = !FIRST && fix;
+        float alpha = 1.0f;
+        if (fix) {
+            const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+            if constexpr (!FIRST) alpha = __builtin_amdgcn_exp2f(-delta);
+            m_run[b] += delta;
+            const float nm = -m_run[b];
+            // the 16 copies are written by ONE instruction that defines the whole tuple: the exact-fp32 MFMA D = A . B with
+            // A[i][k] = (k == 0), B[0][j] = -m of query row j (lane halves h = 0 / 1 carry k = 0 / 1 and hold the same m): 1 x nm + 0 x nm.
+            // (16 C++ assignments make the register allocator keep two copies of the tuple and move it on the path that does NOT
+            // raise; 16 tied asm operands spill)
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(negm[b]) : "v"(lane_id_fresh() < 32 ? 1.0f : 0.0f), "v"(nm));
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[P][b][s2][r] -= delta;
+        }
+        sm_alpha[b] = alpha;
+        sm_psum[b] = 0.f;
+        asm volatile("" : "+v"(sm_alpha[b]), "+v"(m_run[b]), "+v"(sm_psum[b]));
+    };
+    // keys at or past s_lim -> -inf: the ragged last tile, and every tile past the end of the sequence (iterations are issued in
+    // fours; such a tile re-reads the last one, whose pad rows may hold anything, NaN included).  s_lim = S, or 0 (FOLD: a tile past
+    // the end of a split-KV part holds real keys that are not this item's)
+    auto mask_scores = [&](auto p_tag, int t, int s_lim) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_tag)::value;
+        const int hf = FOLD ? lane_id_fresh() >> 5 : h;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int f = 0; f < 32; ++f) {
                 const int s2 = f >> 4, r = f & 15;
-                const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                if (key >= S) sc[P][b][s2][r] = -INFINITY;
+                const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                if (key >= s_lim) sc[P][b][s2][r] = -INFINITY;
             }
     };
     auto rescale = [&](int b) __attribute__((always_inline)) {     // O(block b) *= alpha, after the P.V of the tile before is done
@@ -582,19 +638,34 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
 #define PE_W4_STAMPS 0
 #endif
     // the instruction schedule: lambdas iter0..iter3 (one per ring slot) and the prologue, generated by tools/gen_attn_w4.py
+    long long stamp_loop;
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[b][r] = 0.f;
+#include "attention_w5_body.inc"
+        stamp_loop = (long long)__builtin_readcyclecounter();
+        for (int i = 0; i < n; i += 4) {
+            iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
+        }
+    } else {
 #include "attention_w4_body.inc"
-    const long long stamp_loop = (long long)__builtin_readcyclecounter();
-    for (int i = 0; i < n; i += 4) {
-        iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
+        stamp_loop = (long long)__builtin_readcyclecounter();
+        for (int i = 0; i < n; i += 4) {
+            iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
+        }
     }
     const long long stamp_loop_end = (long long)__builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // stray DMA / K reads; last P.V -> reads of O
 
+    const int lane_e = FOLD ? lane_id_fresh() : lane;      // FOLD: nothing lane-derived lives across the loop for the epilogue's sake
+    const int l31e = lane_e & 31, he = lane_e >> 5;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const float l_tot = sum_with_lane_xor32(l_run[b]);
         if (part_slot >= 0) {
-            float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 32 + l31) * 128 + 4 * h;
+            float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 32 + l31e) * 128 + 4 * he;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -604,20 +675,20 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
                     for (int r = 0; r < 4; ++r) v[r] = o[b][dt][4 * a + r];
                     *(f32x4*)(po + dt * 32 + 8 * a) = v;
                 }
-            if (h == 0) {
-                float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 32 + l31) * 2;
+            if (he == 0) {
+                float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 32 + l31e) * 2;
                 pm[0] = m_run[b];
                 pm[1] = l_tot;
             }
             continue;
         }
         const float inv = 1.0f / l_tot;
-        const int q = q0 + b * 32 + l31;
-        // A row's 8 consecutive columns 8a .. 8a+7 sit in two lanes (l31 and l31 + 32: 4 columns = 8 bytes each).  One
+        const int q = q0 + b * 32 + l31e;
+        // A row's 8 consecutive columns 8a .. 8a+7 sit in two lanes (l31e and l31e + 32: 4 columns = 8 bytes each).  One
         // v_permlane32_swap per dword on the column groups (a, a + 1) -- upper half of group a <-> lower half of group a + 1 --
         // leaves 16 contiguous bytes of the row in every lane (lower lanes: group a, upper lanes: group a + 1): 8 dwordx4 stores
         // per 32-row block and lane instead of 16 dwordx2 (the store tail is issue-bound: cdna guide T21).  Same bytes, same values.
-        bf16* op = out + (size_t)min(q, S - 1) * ldo + head * 128 + 8 * h;
+        bf16* op = out + (size_t)min(q, S - 1) * ldo + head * 128 + 8 * he;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -709,7 +780,7 @@ size_t flash_attn_workspace_bytes(int H, int S) {
 
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
                       int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream, const void* words,
-                      int n_img) {
+                      int n_img, bool q_prescaled) {
     PE_REQUIRE(q && k && vt && out, "flash_attn: null pointer");
     PE_REQUIRE(words == nullptr || (n_img >= 0 && n_img <= S && ((uintptr_t)words & 15) == 0),
                "flash_attn: token words need 0 <= n_img <= S and a 16-byte aligned buffer");      // always the 8-wave masked kernel
@@ -717,14 +788,21 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
                S_pad, KV_TILE, S);
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
-    PE_REQUIRE(g_attn_variant == 0 || g_attn_variant == 3 || g_attn_variant == 4, "flash_attn: attn_variant %d does not exist", g_attn_variant);
+    PE_REQUIRE(g_attn_variant == 0 || (g_attn_variant >= 3 && g_attn_variant <= 6), "flash_attn: attn_variant %d does not exist", g_attn_variant);
+    // variants 5 / 6 need Q = q . scale . log2(e) (attn_q_prescale()); a caller with a plain Q gets the same schedule's exact form
+    int variant = g_attn_variant;
+    if (variant >= 5 && !q_prescaled) variant -= 2;
+    // the one-wave-per-SIMD kernels store 16-byte vectors: rows must be 16-byte aligned (the 8-wave kernel needs 8)
+    if (variant >= 3 && (ldo % 8 != 0 || ((uintptr_t)out & 15) != 0)) variant = 0;
     static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
     if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+            e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
@@ -738,15 +816,18 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(plan.split == 1 || n_short <= slots, "flash_attn: internal plan error");
     float* part_o = (float*)workspace;
     float* part_ml = part_o ? part_o + (size_t)g_attn_slots * 256 * 128 : nullptr;
-    const float scale_log2 = scale * 1.44269504088896340736f;
+    const float scale_log2 = q_prescaled ? 1.0f : scale * 1.44269504088896340736f;     // s . 1 - m is exact: Q carries the factor
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);  // QK^T + PV
     const dim3 grid(plan.n_full + (plan.split > 1 ? n_short : 0));
     if (words != nullptr)
         hipLaunchKernelGGL((flash_attn_kernel<8, true>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
                            (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)words, n_img);
-    else if (g_attn_variant == 3 || g_attn_variant == 4)
-        hipLaunchKernelGGL(flash_attn_w4_kernel, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                           (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, g_attn_variant == 4 ? 8.0f : 0.0f, g_attn_dbg);
+    else if (variant >= 5)
+        hipLaunchKernelGGL(flash_attn_w4_kernel<true>, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                           (bf16*)out, S, S_pad, ldo, 1.0f, plan, part_o, part_ml, variant == 5 ? 8.0f : 0.0f, g_attn_dbg);
+    else if (variant >= 3)
+        hipLaunchKernelGGL(flash_attn_w4_kernel<false>, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                           (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, variant == 4 ? 8.0f : 0.0f, g_attn_dbg);
     else
         hipLaunchKernelGGL((flash_attn_kernel<8, false>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
                            (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)nullptr, 0);

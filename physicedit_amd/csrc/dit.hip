@@ -430,6 +430,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
     char* xm_img = h->xmod;
     char* xm_txt = h->xmod + (size_t)S_img * D * 2;
     const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+    const float q_scale = attn_q_prescale(scale);   // attention variants 5 / 6: Q is written pre-multiplied by scale . log2(e)
 
     // ---- 3. transformer blocks  (qwen_image_dit.py:359-401)
     for (int l = 0; l < L; ++l) {
@@ -464,11 +465,12 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].rope_sin = s == 0 ? c->rope_sin_img : c->rope_sin_txt;
             pp[s].q_out = h->q; pp[s].k_out = h->k; pp[s].vt_out = h->vt;
             pp[s].seq_off = s == 0 ? 0 : S_img; pp[s].S_pad = S_pad;
+            pp[s].q_scale = q_scale;
         }
         if ((rc = hot_linear(h, l, 0, EPI_QKV, pp, h->hbuf, 3 * D, stream))) return rc;
         // joint attention
         if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream,
-                                    c->attn_words, S_img)))
+                                    c->attn_words, S_img, q_scale != 1.0f)))
             return rc;
         // output projections + gated residual (in place on x)
         memset(pp, 0, sizeof(pp));

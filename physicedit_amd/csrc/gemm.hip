@@ -272,6 +272,9 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
                 bf16* dst = (bf16*)(section == 0 ? P.q_out : P.k_out);
                 const int c = lane & 15;
                 const bf16x8 wv = *(const bf16x8*)(nw + c * 8);
+                // Q may carry the attention's scale . log2(e) (attention variants 5 / 6): multiplied in fp32 before the one rounding
+                const float qs1 = (section == 0 && P.q_scale != 0.f) ? P.q_scale : 1.0f;
+                const f32x2 qs = f32x2{qs1, qs1};
                 // RoPE operands of the lane's 8 rows, loaded UNCONDITIONALLY (row clamped) and before the first store of this half:
                 // vmcnt retires in order, so a load issued behind a store is only usable once that store has drained -- with the
                 // loads inside the per-row `if (m < M)` every group of rows paid a store round trip (s_memtime stamps: 17k ticks
@@ -316,7 +319,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
                             // apply_rotary_emb_qwen: fp32 complex multiply (qwen_image_dit.py:51-57)
                             const f32x2 a = x * f32x2{cs[jj], cs[jj]};
                             const f32x2 b = f32x2{x.y, x.x} * f32x2{sn[jj], sn[jj]};
-                            o[jj] = pk2(f32x2{a.x - b.x, a.y + b.y});
+                            o[jj] = pk2(f32x2{a.x - b.x, a.y + b.y} * qs);
                         }
                         *(u32x4*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
                     }

@@ -43,6 +43,7 @@ struct GemmProblem {
     void* q_out;            // [H][S_pad][128] bf16
     void* k_out;            // [H][S_pad][128]
     void* vt_out;           // [H][128][S_pad], tokens permuted inside 16-groups (see attention.hip)
+    float q_scale;          // Q is stored as bf16(rope(q) * q_scale), the factor applied in fp32 before that one rounding; 0 = 1
     int seq_off;            // joint-sequence row of this problem's row 0
     int S_pad;
     int tilesM, tilesN;     // filled by the launcher
@@ -72,7 +73,9 @@ extern long long* g_gemm_dbg;   // device buffer for the time stamps of the prof
 // ---------------------------------------------------------------------------------------------
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
                       int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                      const void* words = nullptr, int n_img = 0);   // words: EliGen token words (attention.hip), or null
+                      const void* words = nullptr, int n_img = 0,    // words: EliGen token words (attention.hip), or null
+                      bool q_prescaled = false);                      // Q was written with GemmProblem.q_scale = attn_q_prescale(scale)
+float attn_q_prescale(float scale);   // scale * log2(e) when the current attention variant wants it folded into Q, else 1
 size_t flash_attn_workspace_bytes(int H, int S);
 extern int g_attn_slots, g_attn_force_split;
 

@@ -128,11 +128,24 @@ def alloc_qkv(H: int, S: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch
     return q, k, vt
 
 
-def qkv_rmsnorm_rope(x, wqkv, bqkv, norm_q_w, norm_k_w, rope_cos, rope_sin, q, k, vt, seq_off: int) -> None:
+def attn_q_prescale() -> float:
+    """what Q must be multiplied by (in fp32, before its rounding to bf16) for flash_attn(q_prescaled=True): scale * log2(e) for the
+    default attention kernel, 1.0 for the variants that take a plain Q"""
+    return float(lib().pe_attn_q_prescale(1.0 / math.sqrt(128.0)))
+
+
+def qkv_rmsnorm_rope(x, wqkv, bqkv, norm_q_w, norm_k_w, rope_cos, rope_sin, q, k, vt, seq_off: int, q_scale: float = 0.0) -> None:
+    """q_scale != 0: Q is stored as bf16(rope(q) * q_scale) (pe_qkv_rmsnorm_rope_scaled; pair it with flash_attn(q_prescaled=True))"""
     _chk(x, "x"), _chk(wqkv, "wqkv")
     _chk(rope_cos, "rope_cos", torch.float32), _chk(rope_sin, "rope_sin", torch.float32)
     M, K = x.shape
     H = wqkv.shape[0] // 384
+    if q_scale != 0.0:
+        check(lib().pe_qkv_rmsnorm_rope_scaled(x.data_ptr(), K, wqkv.data_ptr(), _ptr(bqkv), M, H, K, norm_q_w.data_ptr(),
+                                                norm_k_w.data_ptr(), rope_cos.data_ptr(), rope_sin.data_ptr(), q.data_ptr(),
+                                                k.data_ptr(), vt.data_ptr(), seq_off, q.shape[1], q_scale, stream_ptr()),
+              "pe_qkv_rmsnorm_rope_scaled")
+        return
     check(lib().pe_qkv_rmsnorm_rope(x.data_ptr(), K, wqkv.data_ptr(), _ptr(bqkv), M, H, K, norm_q_w.data_ptr(),
                                      norm_k_w.data_ptr(), rope_cos.data_ptr(), rope_sin.data_ptr(), q.data_ptr(),
                                      k.data_ptr(), vt.data_ptr(), seq_off, q.shape[1], stream_ptr()),
@@ -163,9 +176,10 @@ def unpack_vt(vt: torch.Tensor, S: int) -> torch.Tensor:
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, S: int,
                out: Optional[torch.Tensor] = None, workspace: bool = True, token_words: Optional[torch.Tensor] = None,
-               n_img: int = 0) -> torch.Tensor:
+               n_img: int = 0, q_prescaled: bool = False) -> torch.Tensor:
     """q,k [H,S_pad,128], vt [H,128,S_pad] -> [S, H*128].  token_words (int32 [S_pad], zero beyond S) + n_img: the EliGen mask,
-    tokens a, b attend iff token_words[a] & token_words[b] != 0 (rows [0, n_img) are image tokens)."""
+    tokens a, b attend iff token_words[a] & token_words[b] != 0 (rows [0, n_img) are image tokens).  q_prescaled: q already
+    carries attn_q_prescale() (pe_flash_attn_prescaled: the default kernel's own form)."""
     _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
     H, sp, _ = q.shape
     if out is None:
@@ -176,13 +190,14 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, S: int,
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
     if token_words is not None:
         _chk(token_words, "token_words", torch.int32)
-        assert token_words.numel() == sp
+        assert token_words.numel() == sp and not q_prescaled
         check(lib().pe_flash_attn_masked(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128,
                                          1.0 / math.sqrt(128.0), _ptr(ws), nbytes, token_words.data_ptr(), n_img, stream_ptr()),
               "pe_flash_attn_masked")
         return out
-    check(lib().pe_flash_attn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128,
-                              1.0 / math.sqrt(128.0), _ptr(ws), nbytes, stream_ptr()), "pe_flash_attn")
+    fn, name = (lib().pe_flash_attn_prescaled, "pe_flash_attn_prescaled") if q_prescaled else (lib().pe_flash_attn, "pe_flash_attn")
+    check(fn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, 1.0 / math.sqrt(128.0), _ptr(ws), nbytes,
+             stream_ptr()), name)
     return out
 
 

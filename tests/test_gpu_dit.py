@@ -41,9 +41,12 @@ def stats(name, got, ref):
     return d, u
 
 
-def test_block_G4(golden):
+@pytest.mark.parametrize("prescaled", [True, False])
+def test_block_G4(golden, prescaled):
     """One QwenImageTransformerBlock (qwen_image_dit.py:359-401) composed from the granular C-ABI
-    operators exactly as dit.hip sequences them, vs the reference's own output (G4) and its fp32 run."""
+    operators exactly as dit.hip sequences them, vs the reference's own output (G4) and its fp32 run.
+    prescaled: the trio pe_dit_forward uses (Q stored with the attention's scale . log2 e folded in, pe_flash_attn_prescaled);
+    otherwise the plain-Q operators."""
     from physicedit_amd import ops
     from physicedit_amd.rope import RopeCache
     g = golden("G4_block")
@@ -67,12 +70,14 @@ def test_block_G4(golden):
 
     xm = ops.ln_modulate(x, ch(mod_i, 0), ch(mod_i, 1), S_img, ch(mod_t, 0), ch(mod_t, 1))
     q, k, vt = ops.alloc_qkv(24, S, "cuda")
+    qs = ops.attn_q_prescale() if prescaled else 0.0
+    assert not prescaled or qs > 0.12          # the default kernel is the folded one
     ops.qkv_rmsnorm_rope(xm[:S_img].contiguous(), wq(("to_q", "to_k", "to_v")), bq(("to_q", "to_k", "to_v")),
-                         cu[p + "attn.norm_q.weight"], cu[p + "attn.norm_k.weight"], ci, si, q, k, vt, 0)
+                         cu[p + "attn.norm_q.weight"], cu[p + "attn.norm_k.weight"], ci, si, q, k, vt, 0, q_scale=qs)
     ops.qkv_rmsnorm_rope(xm[S_img:].contiguous(), wq(("add_q_proj", "add_k_proj", "add_v_proj")),
                          bq(("add_q_proj", "add_k_proj", "add_v_proj")), cu[p + "attn.norm_added_q.weight"],
-                         cu[p + "attn.norm_added_k.weight"], ct, stt, q, k, vt, S_img)
-    att = ops.flash_attn(q, k, vt, S)
+                         cu[p + "attn.norm_added_k.weight"], ct, stt, q, k, vt, S_img, q_scale=qs)
+    att = ops.flash_attn(q, k, vt, S, q_prescaled=prescaled)
     xi = ops.gemm(att[:S_img].contiguous(), cu[p + "attn.to_out.0.weight"], cu[p + "attn.to_out.0.bias"], "gate_res",
                   gate=ch(mod_i, 2), res=x[:S_img].contiguous())
     xt = ops.gemm(att[S_img:].contiguous(), cu[p + "attn.to_add_out.weight"], cu[p + "attn.to_add_out.bias"], "gate_res",

@@ -163,7 +163,28 @@ def test_qkv_rmsnorm_rope(ops, M, seq_off):
     assert torch.count_nonzero(vt[:, :, mask]).item() == 0
 
 
-ATTN_DEFAULT = 4      # attention.hip g_attn_variant
+def test_qkv_rmsnorm_rope_scaled(ops):
+    """pe_qkv_rmsnorm_rope_scaled: Q = bf16(rope(q) . q_scale) with the factor applied in fp32 before the one rounding -- within one
+    ulp of bf16(q_plain . q_scale), which rounds twice; K and Vt are untouched by the factor; q_scale = 1 is the plain operator."""
+    M, K = 300, 3072
+    x, w, b = rnd((M, K), 11), rnd((9216, K), 12, K ** -0.5), rnd((9216,), 13, 0.1)
+    nq, nk = synth.make_tensor(5, "norm_q.weight", (128,)), synth.make_tensor(5, "norm_k.weight", (128,))
+    _, txt = O.rope_tables([(1, 8, 8)], M)
+    args = (x.cuda(), w.cuda(), b.cuda(), nq.cuda(), nk.cuda(), txt.real.contiguous().cuda(), txt.imag.contiguous().cuda())
+    q0, k0, vt0 = ops.alloc_qkv(24, M, "cuda")
+    ops.qkv_rmsnorm_rope(*args, q0, k0, vt0, 0)
+    q1, k1, vt1 = ops.alloc_qkv(24, M, "cuda")
+    ops.qkv_rmsnorm_rope(*args, q1, k1, vt1, 0, q_scale=1.0)
+    assert torch.equal(q0, q1) and torch.equal(k0, k1) and torch.equal(vt0, vt1)
+    c = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    q2, k2, vt2 = ops.alloc_qkv(24, M, "cuda")
+    ops.qkv_rmsnorm_rope(*args, q2, k2, vt2, 0, q_scale=c)
+    assert torch.equal(k0, k2) and torch.equal(vt0, vt2)
+    report("qkv.q scaled vs bf16(q . c)", q2[:, :M], (q0[:, :M].float() * c).to(BF), 1.01, 0.60)
+    assert not torch.equal(q2, q0)
+
+
+ATTN_DEFAULT = 5      # attention.hip g_attn_variant
 
 
 @pytest.fixture
@@ -315,6 +336,135 @@ def test_flash_attn_lazy_max_forced_rescale(ops, attn_variant):
     r4 = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
     rc = (ref.float() - ref32).pow(2).mean().sqrt().item()
     assert r4 <= 1.25 * rc + 1e-6      # peaked rows: the textbook update keeps the dominant P = 1.0 exact, the lazy one does not
+
+
+# --- the folded form (variants 5 / 6): Q arrives multiplied by scale . log2(e), the running max goes through the MFMA C operand ---
+def _fold_case(S, seed, H=24, spikes=()):
+    """fp32 q0 (what the QKV epilogue holds before its one rounding), its two roundings -- bf16(q0) for the reference form and
+    bf16(q0 . c) for the folded kernel -- and the references: torch-CPU bf16 SDPA on bf16(q0), fp32 SDPA on q0."""
+    g = torch.Generator().manual_seed(seed)
+    q0 = torch.randn((H, S, 128), generator=g)
+    k = torch.randn((H, S, 128), generator=g).to(BF)
+    v = torch.randn((H, S, 128), generator=g).to(BF)
+    for (key, row, gain) in spikes:
+        k[:, key] = (q0[:, row] * gain).to(BF)
+    c = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    ref = F.scaled_dot_product_attention(q0.to(BF)[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
+    ref32 = F.scaled_dot_product_attention(q0[None], k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
+    return q0.to(BF), (q0 * c).to(BF), k, v, ref, ref32
+
+
+def _dev_qkv(ops, q, k, v, S, nan_pad=True):
+    H = q.shape[0]
+    sp = ops.s_pad_of(S)
+    qd = torch.zeros((H, sp, 128), dtype=BF, device="cuda"); qd[:, :S] = q.cuda()
+    kd = torch.full((H, sp, 128), float("nan") if nan_pad else 0.0, dtype=BF, device="cuda"); kd[:, :S] = k.cuda()   # pad rows are masked
+    return qd, kd, ops.pack_vt(v.cuda(), sp)
+
+
+def _rms(a, b):
+    return (a.float().cpu() - b.float().cpu()).pow(2).mean().sqrt().item()
+
+
+@pytest.mark.parametrize("S,variant", [(64, 5), (100, 5), (257, 5), (700, 5), (1093, 5), (2208, 5), (100, 6), (1093, 6)])
+def test_flash_attn_fold(ops, attn_variant, S, variant):
+    """Same criterion as test_flash_attn: the rms distance to the fp32 result must be the bf16 reference's own.  The folded kernel
+    sees bf16(q . c) where the reference sees bf16(q) -- one rounding each of the same fp32 q, at different bits -- so element-wise
+    it is compared with the fp32 truth at the reference's own worst error, not bit-wise with the reference.  Variant 6 (raise on every
+    new maximum) runs the raise path -- score fix-up, negm rewrite, O rescale -- on nearly every tile."""
+    qb, qc, k, v, ref, ref32 = _fold_case(S, 500 + S)
+    qd, kd, vt = _dev_qkv(ops, qc, k, v, S)
+    attn_variant(variant)
+    assert ops.attn_q_prescale() > 0.12
+    out = ops.flash_attn(qd, kd, vt, S, q_prescaled=True)
+    assert torch.isfinite(out.float()).all()
+    e_gpu, e_cpu = _rms(out, ref32), _rms(ref, ref32)
+    m_gpu = (out.float().cpu() - ref32).abs().max().item()
+    m_cpu = (ref.float() - ref32).abs().max().item()
+    print(f"[parity] flash_attn v{variant} S={S}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e};  max {m_gpu:.3e} / {m_cpu:.3e}")
+    assert e_gpu <= 1.1 * e_cpu + 1e-6
+    assert m_gpu <= 1.5 * m_cpu + 1e-4
+    for _ in range(10):                                       # race screen
+        assert torch.equal(ops.flash_attn(qd, kd, vt, S, q_prescaled=True), out)
+
+
+@pytest.mark.parametrize("S,force,variant", [(700, 3, 5), (1093, 5, 5), (300, 8, 5), (1093, 5, 6)])
+def test_flash_attn_fold_split_kv(ops, attn_variant, S, force, variant):
+    """split-KV partials of the folded kernel: every part starts from its own first tile (m = that tile's row max) and ends on up to
+    three fully masked dummy tiles; the merged result must agree with the unsplit kernel to rounding."""
+    from physicedit_amd._lib import lib
+    qb, qc, k, v, ref, ref32 = _fold_case(S, 900 + S)
+    qd, kd, vt = _dev_qkv(ops, qc, k, v, S)
+    attn_variant(variant)
+    base = ops.flash_attn(qd, kd, vt, S, workspace=False, q_prescaled=True)
+    try:
+        lib().pe_debug_set(b"attn_force_split", force)
+        out = ops.flash_attn(qd, kd, vt, S, workspace=True, q_prescaled=True)
+    finally:
+        lib().pe_debug_set(b"attn_force_split", 0)
+    assert torch.isfinite(out.float()).all()
+    report(f"flash_attn v{variant} split S={S} x{force} vs unsplit kernel", out, base, max_ulp=3.51, max_frac=0.06)
+    assert _rms(out, ref32) <= 1.1 * _rms(ref, ref32) + 1e-6
+
+
+def test_flash_attn_fold_forced_raise(ops, attn_variant):
+    """The lazy raise of variant 5 on data that forces it mid-sequence (cdna guide T13 / rule 26): spiked keys make chosen rows jump
+    by far more than 2^8 in tiles where the other rows of the 32-row block do not move, and one spike is NEGATIVE for its row's
+    first tile (m must follow a first-tile maximum of either sign).  Against the fp32 truth as well as the bf16 reference does, and
+    variant 5 == variant 6 == the exact form (variant 4 on a plain Q) to rounding."""
+    S = 1093
+    spikes = ((300, 7, 8.0), (470, 200, 12.0), (700, 7, 16.0), (1000, 1090, 10.0), (5, 900, -6.0))
+    qb, qc, k, v, ref, ref32 = _fold_case(S, 77, spikes=spikes)
+    qd, kd, vt = _dev_qkv(ops, qc, k, v, S)
+    qp, _, _ = _dev_qkv(ops, qb, k, v, S)
+    outs = {}
+    for variant in (5, 6):
+        attn_variant(variant)
+        outs[variant] = ops.flash_attn(qd, kd, vt, S, q_prescaled=True).clone()
+    attn_variant(4)
+    outs[4] = ops.flash_attn(qp, kd, vt, S).clone()
+    ec_max = (ref.float() - ref32).abs().max().item()
+    ec_rms = _rms(ref, ref32)
+    for variant, out in outs.items():
+        assert torch.isfinite(out.float()).all()
+        e_max = (out.float().cpu() - ref32).abs().max().item()
+        print(f"[parity] flash_attn forced raise v{variant}: max err vs fp32 truth {e_max:.3e} (cpu-bf16-sdpa {ec_max:.3e}), rms {_rms(out, ref32):.3e} / {ec_rms:.3e}")
+        assert e_max <= 2.0 * ec_max + 1e-3
+        assert _rms(out, ref32) <= 1.25 * ec_rms + 1e-6
+    assert _rms(outs[5], outs[6]) <= 1.5 * ec_rms
+    assert _rms(outs[5], outs[4]) <= 1.5 * ec_rms
+
+
+def test_flash_attn_fold_full_size(ops, attn_variant):
+    """BASELINE cfg 2 geometry with the folded kernel (816 items -> 768 whole + 48 x 5 split)."""
+    H, S = 24, 8704
+    qb, qc, k, v, ref, ref32 = _fold_case(S, 6)
+    attn_variant(5)
+    vt = ops.pack_vt(v.cuda(), S)
+    out = ops.flash_attn(qc.cuda(), k.cuda(), vt, S, q_prescaled=True)
+    out1 = ops.flash_attn(qc.cuda(), k.cuda(), vt, S, workspace=False, q_prescaled=True)
+    e_gpu, e_cpu = _rms(out, ref32), _rms(ref, ref32)
+    print(f"[parity] flash_attn v5 full size: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
+    assert e_gpu <= 1.1 * e_cpu + 1e-6
+    report("flash_attn v5 full size: balanced vs single-kernel", out, out1, max_ulp=3.01, max_frac=0.05)
+
+
+def test_flash_attn_plain_q_takes_exact_form(ops, attn_variant):
+    """pe_flash_attn on a plain Q with the folded variants selected runs the same schedule's exact form (5 -> 4, 6 -> 3): bit-identical
+    to selecting those directly; pe_flash_attn_prescaled refuses when the selected variant wants a plain Q."""
+    from physicedit_amd._lib import lib
+    S = 700
+    qb, qc, k, v, ref, ref32 = _fold_case(S, 3)
+    qp, kd, vt = _dev_qkv(ops, qb, k, v, S)
+    for fold, exact in ((5, 4), (6, 3)):
+        attn_variant(fold)
+        a = ops.flash_attn(qp, kd, vt, S).clone()
+        attn_variant(exact)
+        assert torch.equal(a, ops.flash_attn(qp, kd, vt, S))
+    assert ops.attn_q_prescale() == 1.0
+    with pytest.raises(Exception):
+        ops.flash_attn(qp, kd, vt, S, q_prescaled=True)
 
 
 # ------------------------------------------------------------------------------------------------

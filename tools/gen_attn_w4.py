@@ -24,8 +24,12 @@ N = the reads issued after the second fragment by then (2, or 0 at the end of th
 """
 import os
 
+FOLD = False      # set by main(): False -> attention_w4_body.inc (variants 3 / 4), True -> attention_w5_body.inc (variants 5 / 6)
 DMA_SLOTS = int(os.environ.get("W4_DMA_SLOTS", "3"))      # issue slots an LDS-DMA piece (address + m0 + buffer_load ... lds) is booked with
 EARLY_PAIRS = int(os.environ.get("W4_EARLY_PAIRS", "5"))   # per block: pairs 0..4 of softmax(i+1) run in phase 2 of iteration i, pairs 5..15 in phase 1 of i+1
+# FOLD: where in phase 1 the O rescale branches sit (a knob: any gap of phase 1 is legal -- after P.V(i), before P.V(i+1))
+PK2 = bool(os.environ.get("W4_PK2"))       # experiment: FOLD with the double-buffered P of the exact form
+RESCALE_GAP = int(os.environ.get("W4_RESCALE_GAP", "2"))
 KT_BYTES = 64 * 256
 
 
@@ -58,7 +62,14 @@ def score(P, b, f):
 def pk_slot(P, b, q):
     f = 2 * q
     s2, r0 = f >> 4, f & 15
+    if FOLD and not PK2:        # P is single buffered: a chunk is rewritten only after the last P.V MFMA that reads it (checked in gen_iter)
+        return f"pk[{b}][{s2 * 2 + (r0 >> 3)}][{(r0 & 7) >> 1}]"
     return f"pk[{P}][{b}][{s2 * 2 + (r0 >> 3)}][{(r0 & 7) >> 1}]"
+
+
+def pk_chunk(q):
+    f = 2 * q
+    return (f >> 4) * 2 + ((f & 15) >> 3)
 
 
 def add_read(st, kind, slot, idx):
@@ -83,17 +94,22 @@ class Ins:
 
 def pair_stream(pairs, P, tagp):
     """The softmax of `pairs` = [(b, q)] (scores 2q, 2q+1 of block b, tile parity P) as ONE instruction stream, software-pipelined one
-    pair deep:   fma fma | add' exp add' exp cvt'   (' = the pair before), so that no instruction reads the result of the one right
-    before it.  Issue slots: v_exp_f32 2 (transcendental rate), everything else 1 (tools/microbench/valu_rate.hip)."""
+    pair deep:   fma fma | add' exp add' exp cvt'   (' = the pair before; FOLD: exp add' exp add' cvt', the fmas are gone), so that no
+    instruction reads the result of the one right before it.  Issue slots: v_exp_f32 2 (transcendental rate), everything else 1 (tools/microbench/valu_rate.hip)."""
     if os.environ.get("W4_NO_PAIRS"):       # timing experiment only
         return []
 
     def parts(k):
         b, q = pairs[k]
         T = f"{tagp}{k}"
-        F = [Ins(f"v_fma_f32 %[e{j}_{T}], %[sc{j}_{T}], %[sl], -%[sub{b}]", defs={f"e{j}_{T}": f"e{j}_{T}"},
-                 uses={f"sc{j}_{T}": score(P, b, 2 * q + j), "sl": "scale_log2", f"sub{b}": f"sm_sub[{b}]"}, sreg=("sl",)) for j in (0, 1)]
-        E = [Ins(f"v_exp_f32 %[e{j}_{T}], %[e{j}_{T}]", rmw={f"e{j}_{T}": f"e{j}_{T}"}, slots=2) for j in (0, 1)]
+        if FOLD:        # the accumulator already holds s . c - m (Q pre-scaled by c, -m fed through the MFMA's C operand)
+            F = []
+            E = [Ins(f"v_exp_f32 %[e{j}_{T}], %[sc{j}_{T}]", defs={f"e{j}_{T}": f"e{j}_{T}"}, uses={f"sc{j}_{T}": score(P, b, 2 * q + j)}, slots=2)
+                 for j in (0, 1)]
+        else:
+            F = [Ins(f"v_fma_f32 %[e{j}_{T}], %[sc{j}_{T}], %[sl], -%[sub{b}]", defs={f"e{j}_{T}": f"e{j}_{T}"},
+                     uses={f"sc{j}_{T}": score(P, b, 2 * q + j), "sl": "scale_log2", f"sub{b}": f"sm_sub[{b}]"}, sreg=("sl",)) for j in (0, 1)]
+            E = [Ins(f"v_exp_f32 %[e{j}_{T}], %[e{j}_{T}]", rmw={f"e{j}_{T}": f"e{j}_{T}"}, slots=2) for j in (0, 1)]
         S = [Ins(f"v_add_f32 %[ps{b}], %[ps{b}], %[e{j}_{T}]", rmw={f"ps{b}": f"sm_psum[{b}]"}, uses={f"e{j}_{T}": f"e{j}_{T}"}) for j in (0, 1)]
         C = Ins(f"v_cvt_pk_bf16_f32 %[pw_{T}], %[e0_{T}], %[e1_{T}]", defs={f"pw_{T}": f"pw_{T}"},
                 uses={f"e0_{T}": f"e0_{T}", f"e1_{T}": f"e1_{T}"}, after=f"{pk_slot(P, b, q)} = pw_{T};")
@@ -103,10 +119,10 @@ def pair_stream(pairs, P, tagp):
     for k in range(len(pairs)):
         F, E, S, C = parts(k)
         if prev is None:
-            out += [F[0], F[1], E[0], E[1]]
+            out += F + [E[0], E[1]]
         else:
             pS, pC = prev
-            out += [F[0], F[1], pS[0], E[0], pS[1], E[1], pC]
+            out += [E[0], pS[0], E[1], pS[1], pC] if FOLD else F + [pS[0], E[0], pS[1], E[1], pC]
         prev = (S, C)
     if prev is not None:
         out += [prev[0][0], prev[0][1], prev[1]]
@@ -191,14 +207,21 @@ def add_max(st, P, g):
                      "v_max3_f32 %[mx0], %[mx0], %[m02], %[m03]", "v_max3_f32 %[mx1], %[mx1], %[m12], %[m13]"]
 
 
-def qk_stmt(P, g, slot_k, ahead=True):
-    """QK^T MFMA g of the tile whose K sits in ring slot slot_k: kk = g >> 2, q block (g >> 1) & 1, key half g & 1"""
+def qk_stmt(P, g, slot_k, ahead=True, negm=None):
+    """QK^T MFMA g of the tile whose K sits in ring slot slot_k: kk = g >> 2, q block (g >> 1) & 1, key half g & 1.
+    negm (FOLD, main loop): the first k-step accumulates onto negm[b] -- 16 registers holding -m of the lane's row -- instead of 0"""
+    if negm is None:
+        negm = FOLD
     st = Stmt()
     kk, b, s2 = g >> 2, (g >> 1) & 1, g & 1
     if g & 3 == 0:
         st.lines.append(f"s_waitcnt lgkmcnt({2 if kk <= 6 else 0})")
     acc = f"sc[{P}][{b}][{s2}]"
-    if kk == 0:
+    if kk == 0 and negm:
+        st.lines.append("v_mfma_f32_32x32x16_bf16 %[acc], %[fa], %[fb], %[nm]")
+        st.outs.append(f'[acc] "=&v"({acc})')
+        st.ins.append(f'[nm] "v"(negm[{b}])')
+    elif kk == 0:
         st.lines.append("v_mfma_f32_32x32x16_bf16 %[acc], %[fa], %[fb], 0")
         st.outs.append(f'[acc] "=&v"({acc})')
     else:
@@ -218,7 +241,7 @@ def pv_stmt(PC, g):
         st.lines.append(f"s_waitcnt lgkmcnt({2 if f <= 12 else 0})")
     st.lines.append("v_mfma_f32_32x32x16_bf16 %[acc], %[fa], %[fb], %[acc]")
     st.outs.append(f'[acc] "+a"(o[{b}][{f & 3}])')
-    st.ins += [f'[fa] "a"(vf[{f}])', f'[fb] "v"(pk[{PC}][{b}][{f >> 2}])']
+    st.ins += [f'[fa] "a"(vf[{f}])', f'[fb] "v"(pk[{b}][{f >> 2}])' if FOLD and not PK2 else f'[fb] "v"(pk[{PC}][{b}][{f >> 2}])']
     return st
 
 
@@ -252,15 +275,16 @@ def gen_iter(ST, out):
             add_read(st, "v", slot_v, g - 28)
         stmts.append(st)
     fixed = {g: fixed_slots(stmts[g]) for g in range(32)}
-    fixed[2] += 2; fixed[3] += 2            # the (rarely taken) O rescale branches sit behind these gaps
+    rg = RESCALE_GAP if FOLD else 2         # the (rarely taken) O rescale branches sit behind gaps rg, rg + 1
+    fixed[rg] += 2; fixed[rg + 1] += 2
     placed = spread(pair_stream(late, PC, "l"), fixed, 0, 31)
     for g in range(32):
         st = stmts[g]
         add_stream(st, placed[g])
         out.extend(st.emit(ind))
-        if g == 2:
+        if g == rg:
             w(ind + "rescale(0);")
-        if g == 3:
+        if g == rg + 1:
             w(ind + "rescale(1);")
         if g == 31:
             w(ind + "l_run[0] = __builtin_fmaf(l_run[0], sm_alpha[0], sm_psum[0]);")
@@ -301,16 +325,26 @@ def gen_iter(ST, out):
             fixed[g] += DMA_SLOTS           # an LDS-DMA piece is issued behind these gaps
     first_pair_gap = int(os.environ.get("W4_FIRST_EARLY_GAP", "10"))        # sm_state runs behind gaps 8 and 9
     placed = spread(pair_stream(early, PN, "e"), fixed, first_pair_gap, 31)
+    if FOLD and not PK2:        # single-buffered P: chunk c of tile i is last read by P.V MFMA 8c + 7; tile i+1's packs into it must sit in a later gap
+        for g, instrs in placed.items():
+            for ins in instrs:
+                if ins.after:
+                    c = int(ins.after.split("]")[1][1:])
+                    assert g > 8 * c + 7, f"early pack into chunk {c} in gap {g}: P.V still reads it"
     for g in range(32):
         st = stmts[g]
-        if g == 0:
-            w(ind + f"if (mask_next) mask_scores(std::integral_constant<int, {PN}>{{}}, t_next);")
+        if g == 0 and FOLD:     # a tile past the end of this work item (iterations come in fours) has no sm_sub = inf to zero its P: every key is masked
+            w(ind + f"if (mask_next || !live_next) mask_scores(std::integral_constant<int, {PN}>{{}}, t_next, live_next ? S : 0);")
+        elif g == 0:
+            w(ind + f"if (mask_next) mask_scores(std::integral_constant<int, {PN}>{{}}, t_next, S);")
         add_stream(st, placed.get(g, []))
         out.extend(st.emit(ind))
         if g & 3 == 1 and not os.environ.get("W4_NO_DMA"):       # W4_NO_DMA: timing experiment only (results are garbage)
             j = g >> 3
             w(ind + (f"stage_v({slot_d}, i + 3, {j});" if (g >> 2) & 1 else f"stage_k({slot_d}, i + 3, {j});"))
-        if g in (8, 9):
+        if g in (8, 9) and FOLD:
+            w(ind + f"sm_state_f(std::integral_constant<int, {PN}>{{}}, {g - 8}, std::false_type{{}});")
+        elif g in (8, 9):
             w(ind + f"sm_state({g - 8}, live_next);")
         w(ind + "W4_FENCE();")
     if ST == 0:
@@ -336,7 +370,7 @@ def gen_prologue(out):
         out.extend(st.emit(ind))
     w(ind + "W4_FENCE();")
     for g in range(32):
-        out.extend(qk_stmt(0, g, 0).emit(ind))
+        out.extend(qk_stmt(0, g, 0, negm=False).emit(ind))
         w(ind + "W4_FENCE();")
     w(ind + 'asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // tile 1 landed')
     w(ind + "W4_FENCE();")
@@ -348,7 +382,7 @@ def gen_prologue(out):
         out.extend(st.emit(ind))
     w(ind + 'asm volatile("s_nop 15");                           // last QK^T MFMAs -> the score reads below')
     w(ind + "W4_FENCE();")
-    w(ind + "if ((t_begin + 1) * KV_TILE > S) mask_scores(std::integral_constant<int, 0>{}, t_begin);")
+    w(ind + "if ((t_begin + 1) * KV_TILE > S) mask_scores(std::integral_constant<int, 0>{}, t_begin, S);")
     early = pair_list(0, EARLY_PAIRS)
     w(ind + "{")
     ind2 = ind + "    "
@@ -359,11 +393,15 @@ def gen_prologue(out):
         add_max(st, 0, g)
         out.extend(st.emit(ind2))
         w(ind2 + "W4_FENCE();")
-    w(ind2 + "sm_state(0, true);")
-    w(ind2 + "sm_state(1, true);")
+    if FOLD:
+        w(ind2 + "sm_state_f(std::integral_constant<int, 0>{}, 0, std::true_type{});")
+        w(ind2 + "sm_state_f(std::integral_constant<int, 0>{}, 1, std::true_type{});")
+    else:
+        w(ind2 + "sm_state(0, true);")
+        w(ind2 + "sm_state(1, true);")
     w(ind2 + "W4_FENCE();")
     stream = pair_stream(early, 0, "p")
-    for k in range(0, len(stream), 7):          # one pipeline step per statement
+    for k in range(0, len(stream), 5 if FOLD else 7):          # one pipeline step per statement
         st = Stmt()
         add_stream(st, stream[k:k + 7])
         out.extend(st.emit(ind2))
@@ -373,15 +411,23 @@ def gen_prologue(out):
 
 
 def main():
-    out = ["// GENERATED by tools/gen_attn_w4.py -- do not edit; the schedule tables and their rationale are in that script.",
-           "// Included inside flash_attn_w4_kernel (attention.hip), which declares every name used here.", ""]
-    for st in range(4):
-        gen_iter(st, out)
-    gen_prologue(out)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "physicedit_amd", "csrc", "attention_w4_body.inc")
-    with open(path, "w") as f:
-        f.write("\n".join(out) + "\n")
-    print(f"wrote {os.path.normpath(path)}: {len(out)} lines")
+    global FOLD
+    here = os.path.dirname(os.path.abspath(__file__))
+    only = os.environ.get("W4_ONLY")        # "w4" / "w5": regenerate one of the two bodies (knob sweeps)
+    for fold, name, kern in ((False, "attention_w4_body.inc", "flash_attn_w4_kernel<false> (variants 3 / 4)"),
+                             (True, "attention_w5_body.inc", "flash_attn_w4_kernel<true> (variants 5 / 6: folded scale and max)")):
+        if only and only != name[10:12]:
+            continue
+        FOLD = fold
+        out = ["// GENERATED by tools/gen_attn_w4.py -- do not edit; the schedule tables and their rationale are in that script.",
+               f"// Included inside {kern} (attention.hip), which declares every name used here.", ""]
+        for st in range(4):
+            gen_iter(st, out)
+        gen_prologue(out)
+        path = os.path.join(here, "..", "physicedit_amd", "csrc", name)
+        with open(path, "w") as f:
+            f.write("\n".join(out) + "\n")
+        print(f"wrote {os.path.normpath(path)}: {len(out)} lines")
 
 
 if __name__ == "__main__":
