@@ -401,9 +401,10 @@ def gen_prologue(out):
         w(ind2 + "sm_state(1, true);")
     w(ind2 + "W4_FENCE();")
     stream = pair_stream(early, 0, "p")
-    for k in range(0, len(stream), 5 if FOLD else 7):          # one pipeline step per statement
+    step = 5 if FOLD else 7                     # one pipeline step per statement
+    for k in range(0, len(stream), step):
         st = Stmt()
-        add_stream(st, stream[k:k + 7])
+        add_stream(st, stream[k:k + step])
         out.extend(st.emit(ind2))
         w(ind2 + "W4_FENCE();")
     w(ind + "}")
