@@ -584,8 +584,10 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
             // the 16 copies are written by ONE instruction that defines the whole tuple: the exact-fp32 MFMA D = A . B with
             // A[i][k] = (k == 0), B[0][j] = -m of query row j (lane halves h = 0 / 1 carry k = 0 / 1 and hold the same m): 1 x nm + 0 x nm.
             // (16 C++ assignments make the register allocator keep two copies of the tuple and move it on the path that does NOT
-            // raise; 16 tied asm operands spill)
-            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(negm[b]) : "v"(lane_id_fresh() < 32 ? 1.0f : 0.0f), "v"(nm));
+            // raise; 16 tied asm operands spill).  Early clobber: a multi-pass MFMA may not write over its A / B operands.
+            // s_nop: a VALU result needs wait states before an MFMA reads it as A / B, and nobody inserts them for an asm statement
+            // (measured: with the select right in front of the MFMA the tuple came out wrong, with two instructions between, right)
+            asm volatile("s_nop 3\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(negm[b]) : "v"(lane_id_fresh() < 32 ? 1.0f : 0.0f), "v"(nm));
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll

@@ -384,7 +384,7 @@ def test_flash_attn_fold(ops, attn_variant, S, variant):
     m_cpu = (ref.float() - ref32).abs().max().item()
     print(f"[parity] flash_attn v{variant} S={S}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e};  max {m_gpu:.3e} / {m_cpu:.3e}")
     assert e_gpu <= 1.1 * e_cpu + 1e-6
-    assert m_gpu <= 1.5 * m_cpu + 1e-4
+    assert m_gpu <= 2.0 * m_cpu + 1e-3          # lazy max: P <= 2^8 is rounded to bf16 at another scale (cdna guide T13: ~3x max-abs)
     for _ in range(10):                                       # race screen
         assert torch.equal(ops.flash_attn(qd, kd, vt, S, q_prescaled=True), out)
 
