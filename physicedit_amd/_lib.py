@@ -9,7 +9,8 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libphysicedit_amd.so")
+# PE_LIB_PATH: an experiment knob (tools/microbench/attn_knobs.sh A/B-tests differently generated builds); product code never sets it
+LIB_PATH = os.environ.get("PE_LIB_PATH") or os.path.join(HERE, "libphysicedit_amd.so")
 
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 

@@ -793,7 +793,7 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(g_attn_variant == 0 || (g_attn_variant >= 3 && g_attn_variant <= 6), "flash_attn: attn_variant %d does not exist", g_attn_variant);
     // variants 5 / 6 need Q = q . scale . log2(e) (attn_q_prescale()); a caller with a plain Q gets the same schedule's exact form
     int variant = g_attn_variant;
-    if (variant >= 5 && !q_prescaled) variant -= 2;
+    if (variant >= 5 && !q_prescaled) variant = variant == 5 ? 4 : 3;
     // the one-wave-per-SIMD kernels store 16-byte vectors: rows must be 16-byte aligned (the 8-wave kernel needs 8)
     if (variant >= 3 && (ldo % 8 != 0 || ((uintptr_t)out & 15) != 0)) variant = 0;
     static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
