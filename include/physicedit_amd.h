@@ -70,6 +70,11 @@ enum {
     PE_EPI_SILU = 5       /* Linear + SiLU    models/utils.py:267-269                                 */
 };
 
+/* Bytes of the stream-K scratch of the GEMM (schedule 19: a launch's tiles x K tiles are cut into equal ranges per CU, a tile
+ * split between two CUs hands its fp32 accumulators over through this buffer; outputs are bit-identical to the unsplit schedules).
+ * pe_dit_workspace_bytes() includes one per handle.  The granular pe_gemm_* calls run the unsplit schedules unless a test installs
+ * a zeroed buffer with pe_debug_set_ptr("gemm_workspace", p). */
+size_t pe_gemm_workspace_bytes(void);
 /* out[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias[N]); bf16, fp32 accumulate.
  * gate[N] (nullable => 1) and res[M,N] (row stride ldr, may alias out) only for PE_EPI_GATE_RES.
  * Requires K % 64 == 0, N % 8 == 0, lda/ldo/ldr % 8 == 0. */

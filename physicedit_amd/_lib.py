@@ -118,6 +118,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_flash_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                               c_size_t, c_void_p]),
+    "pe_gemm_workspace_bytes": (c_size_t, []),
     "pe_attn_q_prescale": (c_float, [c_float]),
     "pe_qkv_rmsnorm_rope_scaled": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -42,6 +42,7 @@ int pe_debug_set(const char* key, int value) {
     PE_REQUIRE(key != nullptr, "pe_debug_set: null key");
     if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return PE_OK; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
+    if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return PE_OK; }
     if (!strcmp(key, "gemm_band")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_band out of range"); g_gemm_band = value; return PE_OK; }
     if (!strcmp(key, "gemm_persist_wgs")) { PE_REQUIRE(value >= 0 && value <= 1024, "gemm_persist_wgs out of range"); g_gemm_persist_wgs = value; return PE_OK; }
     if (!strcmp(key, "attn_slots")) { PE_REQUIRE(value > 0 && value <= 256, "attn_slots out of range"); g_attn_slots = value; return PE_OK; }
@@ -53,8 +54,12 @@ int pe_debug_set_ptr(const char* key, void* p) {
     PE_REQUIRE(key != nullptr, "pe_debug_set_ptr: null key");
     if (!strcmp(key, "gemm_stamps")) { g_gemm_dbg = (long long*)p; return PE_OK; }
     if (!strcmp(key, "attn_stamps")) { g_attn_dbg = (long long*)p; return PE_OK; }
+    // tests: a zeroed device buffer of pe_gemm_workspace_bytes() bytes (256-byte aligned) for the granular pe_gemm_* calls, or null
+    if (!strcmp(key, "gemm_workspace")) { g_gemm_ws.sync = p; g_gemm_ws.bytes = p ? gemm_workspace_bytes() : 0; return PE_OK; }
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set_ptr: unknown key %s", key);
 }
+
+size_t pe_gemm_workspace_bytes(void) { return gemm_workspace_bytes(); }
 
 int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
                  int M, int N, int K, const void* gate, const void* res, int ldr, void* stream) {

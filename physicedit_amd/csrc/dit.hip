@@ -41,6 +41,8 @@ struct pe_dit {
     char *sp_in, *sp_hid, *sp_dino, *sp_vae;
     char* attn_ws;
     size_t attn_ws_bytes = 0;
+    char* gemm_ws;                      // stream-K scratch of the block Linears (gemm.hip schedule 19): zeroed once, private to this handle
+    GemmWorkspace gws = {nullptr, 0};
     char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
     char* aq;                           // e4m3 mode: quantised activation rows of the Linear being run [S, FF] bytes
     float* asc;                         // e4m3 mode: their per-row scales
@@ -100,6 +102,9 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->sp_vae, (size_t)MAX_SPECIAL * TXT * 2);
     h->attn_ws_bytes = flash_attn_workspace_bytes(HEADS, (int)S);
     take(&h->attn_ws, h->attn_ws_bytes);
+    take(&h->gemm_ws, gemm_workspace_bytes());
+    h->gws.sync = h->gemm_ws;
+    h->gws.bytes = gemm_workspace_bytes();
     const size_t rows = S > (size_t)n_steps ? S : (size_t)n_steps;
     take(&h->lora_t, rows * 3 * 128 * 2);
     if (h->w.weights_e4m3) {
@@ -121,7 +126,7 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
 // activation rows (per-row scale), then the e4m3 GEMM.  K is padded to the GEMM's 128 granule (only img_in, K = 64:
 // its weight arrives zero-padded to [3072,128]).
 static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t stream) {
-    if (!h->w.weights_e4m3) return launch_gemm(epi, pp, n, stream);
+    if (!h->w.weights_e4m3) return launch_gemm(epi, pp, n, stream, &h->gws);
     int rc;
     const bool joint = n == 2 && pp[0].K == pp[1].K && pp[0].lda == pp[1].lda &&
                        (const char*)pp[1].A == (const char*)pp[0].A + (size_t)pp[0].M * pp[0].lda * 2;
@@ -143,7 +148,7 @@ static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t st
         off += (size_t)Ms * Kp;
         row += Ms;
     }
-    return launch_gemm(epi, pp, n, stream);
+    return launch_gemm(epi, pp, n, stream, &h->gws);
 }
 
 // does any hot LoRA set carry group g (0 qkv, 1 out, 2 down, 3 mod) of block l (both streams)?
@@ -201,8 +206,8 @@ static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], ch
             tb[s].pre = ybuf + row0[s] * ldy * 2; tb[s].ldp = ldy;
             if (!last) { tb[s].out = ybuf + row0[s] * ldy * 2; tb[s].ldo = ldy; }   // in place: a lane reads pre before the tile is stored
         }
-        if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
-        if ((rc = launch_gemm(last ? epi : EPI_BIAS, tb, 2, stream))) return rc;
+        if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, &h->gws))) return rc;
+        if ((rc = launch_gemm(last ? epi : EPI_BIAS, tb, 2, stream, &h->gws))) return rc;
     }
     return PE_OK;
 }
@@ -283,6 +288,8 @@ int pe_dit_bind_workspace(pe_dit_handle h, void* workspace, size_t bytes, int S_
     // Q/K pad rows only feed masked scores.  Zero all three once.
     hipError_t e = hipMemsetAsync(h->q, 0, (size_t)(h->attn - h->q), (hipStream_t)stream);
     if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
+    e = hipMemsetAsync(h->gemm_ws, 0, 4096, (hipStream_t)stream);       // ticket counter and flags; the kernels leave them zero
+    if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
     if (h->qflags != nullptr) {
         const size_t rows = (size_t)S_img_max + T_max > (size_t)n_steps ? (size_t)S_img_max + T_max : (size_t)n_steps;
         e = hipMemsetAsync(h->qflags, 0, rows * sizeof(unsigned), (hipStream_t)stream);
@@ -341,8 +348,8 @@ int pe_dit_prepare(pe_dit_handle h, const void* sinusoid_bf16, int n_steps, void
                 tb[s].M = n_steps; tb[s].N = MOD; tb[s].K = r;
             }
             if (!have) continue;
-            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream))) return rc;
-            if ((rc = launch_gemm(EPI_BIAS, tb, 2, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, &h->gws))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, tb, 2, stream, &h->gws))) return rc;
         }
     }
     memset(&p, 0, sizeof(p));
@@ -395,11 +402,11 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             memset(&p, 0, sizeof(p));
             p.A = h->sp_in; p.lda = TXT; p.W = w0; p.bias = b0; p.out = h->sp_hid; p.ldo = AD_HID;
             p.M = ns; p.N = AD_HID; p.K = TXT;
-            if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream))) return rc;
+            if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream, &h->gws))) return rc;
             memset(&p, 0, sizeof(p));
             p.A = h->sp_hid; p.lda = AD_HID; p.W = w2; p.bias = b2; p.out = head == 0 ? h->sp_dino : h->sp_vae;
             p.ldo = TXT; p.M = ns; p.N = TXT; p.K = AD_HID;
-            if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream))) return rc;
+            if ((rc = launch_gemm(EPI_BIAS, &p, 1, stream, &h->gws))) return rc;
         }
         if ((rc = launch_adapter_mix_scatter(h->sp_dino, h->sp_vae, c->alpha, c->one_minus_alpha, c->special_idx,
                                              c->prompt_emb, ns, TXT, stream)))
@@ -542,11 +549,11 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                     return rc;
                 memset(&p, 0, sizeof(p));
                 p.A = h->xmod; p.lda = D; p.W = cb.in_w; p.bias = cb.in_b; p.out = h->attn; p.ldo = D; p.M = S0; p.N = D; p.K = D;
-                if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream))) return rc;
+                if ((rc = launch_gemm(EPI_GELU_ERF, &p, 1, stream, &h->gws))) return rc;
                 memset(&p, 0, sizeof(p));
                 p.A = h->attn; p.lda = D; p.W = cb.out_w; p.bias = cb.out_b; p.out = acc; p.ldo = D; p.res = acc; p.ldr = D;
                 p.has_gate_scalar = 1; p.gate_scalar = c->control[ci].scale; p.M = S0; p.N = D; p.K = D;
-                if ((rc = launch_gemm(EPI_GATE_RES, &p, 1, stream))) return rc;
+                if ((rc = launch_gemm(EPI_GATE_RES, &p, 1, stream, &h->gws))) return rc;
             }
             if (!single && (rc = launch_add_inplace(x_img, acc, (size_t)S0 * D, stream))) return rc;
         }

@@ -47,7 +47,11 @@ struct GemmArgs {
     int ntiles;       // all tiles of the launch (schedule 17: the grid is smaller)
     int band;         // M tiles per band of the tile order
     long long* dbg;   // per work-group s_memtime stamps [grid][8] of schedule 15 (pe_debug_set_ptr("gemm_stamps", p)), or null
+    unsigned* sk_sync;   // schedule 19: [0] ticket counter, [SK_FLAG0 + pos] flag of the seam behind position pos; all zero at rest
+    char* sk_part;       // schedule 19: fp32 accumulator images, SK_PART_BYTES per seam
 };
+constexpr int SK_FLAG0 = 32;                          // flags start on their own 128-byte line
+constexpr size_t SK_PART_BYTES = (size_t)BM * BN * 4;   // one 256 x 256 fp32 accumulator tile
 long long* g_gemm_dbg = nullptr;
 // Device code reads the launch arguments where the dispatcher put them: the kernarg segment (constant address space, scalar
 // loads at a wave-uniform problem index).  Through a by-value copy `args.p[pi]` with a run-time pi is an indexed private array:
@@ -865,7 +869,21 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
 // vmcnt(4) also covers them).  What this removes per tile: the work-group launch, the cold prologue (HBM / L2 latency of the
 // first K tiles with an idle matrix pipe) and most of the store drain.
 // ------------------------------------------------------------------------------------------
-template <int EPI, bool FP8>
+//
+// Schedule 19 (SK, round 4) = the same work-groups, "stream-K": a launch of T tiles x nk K tiles is T . nk units of equal work; the
+// tile order's chunk of XCD x (T / 8 tiles) is cut into G / 8 equal unit ranges, one per work-group, so every CU does the same
+// amount of work whatever T mod G is (the block Linears of the headline geometry are 1.6 / 4.8 / 6.4 rounds of 256 tiles: one-tile-
+// per-work-group forms run 2 / 5 / 7).  A range covers the END of one tile (its "tail": K tiles [k1, nk)), whole tiles, and the
+// BEGINNING of another (its "head": K tiles [0, k1)); ranges are at least one tile long, so a tile has at most two parts.  The
+// head's holder computes it FIRST and publishes the fp32 accumulators (256 KiB, write-through stores, then a flag); the tail's
+// holder runs its tail LAST, starting its accumulators from that image instead of from zero -- the K tiles are accumulated in the
+// same order by the same instructions as in an unsplit tile, so the output is BIT-IDENTICAL to schedules 15 / 17 -- and runs
+// the epilogue.  Positions are handed out by an atomic ticket in start order (ticket t -> chunk t & 7, range t >> 3), and a
+// work-group only ever waits for the holder of ticket t - 8, which has started by construction: no assumption about dispatch
+// order or co-residency (cdna guide, "placement-independent protocols"), and since it publishes first thing, the wait is over
+// long before it is reached.  The ticket taker G - 1 zeroes the counter and every consumer its flag: the workspace is all zero
+// again when the launch ends (hipGraph-safe: no host-side generation number).
+template <int EPI, bool FP8, bool SK>
 __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char* smem) {
     constexpr int ES = FP8 ? 1 : 2;
     constexpr int KT_BYTES = 128;
@@ -887,9 +905,52 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
         __builtin_amdgcn_sched_barrier(0);         \
     } while (0)
 
-    int ab = 0, ws = 0;     // A buffer / W ring slot of K tile 0 of the current tile
-    bool have = false;      // K tiles 0 (A, W) and 1 (W) of the current tile were requested by the previous tile
-    for (int t = (int)blockIdx.x; t < ntiles; t += G) {
+    // The work list of this work-group as segments (tile of the banded order, K tiles [ka, kb)), visited s = 0, 1, ...
+    //   17: tiles b, b + G, ... whole;   19: the unit range [u0, u1) of its chunk, LAST tile first (see above)
+    int sk_base = 0, sk_tf = 0, sk_tl = -1, sk_kf = 0, sk_kl = 0, sk_nk = 0, sk_pos = 0;
+    if constexpr (SK) {
+        if (threadIdx.x == 0) {
+            const unsigned tk = __hip_atomic_fetch_add(args.sk_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk == (unsigned)(G - 1)) __hip_atomic_store(args.sk_sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all G tickets are out
+            *(volatile unsigned*)smem = tk;
+        }
+        __syncthreads();
+        const int tk = __builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)smem);
+        // (the first segment's cold start passes a barrier before anything is staged into this LDS word)
+        const int Gc = G >> 3, xc = tk & 7, idx = tk >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        sk_base = xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q;
+        const int cnt = q + (xc < r ? 1 : 0);
+        sk_nk = args.p[0].K * ES / KT_BYTES;                 // the launcher checked: both problems have this K
+        const int Uc = cnt * sk_nk;
+        const int u0 = (int)((long long)idx * Uc / Gc), u1 = (int)((long long)(idx + 1) * Uc / Gc);
+        sk_tf = u0 / sk_nk; sk_kf = u0 - sk_tf * sk_nk;
+        sk_tl = (u1 - 1) / sk_nk; sk_kl = u1 - sk_tl * sk_nk;
+        sk_pos = xc * Gc + idx;
+    }
+    struct Seg { int tile, ka, kb; bool valid; };
+    auto seg_at = [&](int s_) -> Seg {
+        Seg g;
+        if constexpr (SK) {
+            const int ti = sk_tl - s_;
+            g.valid = ti >= sk_tf;
+            g.tile = sk_base + ti;
+            g.ka = ti == sk_tf ? sk_kf : 0;
+            g.kb = ti == sk_tl ? sk_kl : sk_nk;
+        } else {
+            const int t = (int)blockIdx.x + s_ * G;
+            g.valid = t < ntiles;
+            g.tile = g.valid ? xcd_remap(t, ntiles) : 0;
+            g.ka = 0; g.kb = -1;           // kb < 0: the tile's whole K
+        }
+        return g;
+    };
+
+    int ab = 0, ws = 0;     // A buffer / W ring slot of K tile 0 of the current segment
+    bool have = false;      // K tiles 0 (A, W) and 1 (W) of the current segment were requested by the previous one
+    for (int sidx = 0;; ++sidx) {
+        const Seg cur = seg_at(sidx);
+        if (!cur.valid) break;
         // the lane id is made opaque per tile: everything lane-dependent (staging sources, fragment and epilogue addresses) is
         // then recomputed per tile instead of being hoisted out of this loop and kept live across the main loop (spills)
         // (read from the hardware with mbcnt, not from threadIdx.x: that VGPR would have to stay live -- or be spilled and
@@ -901,19 +962,24 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
         const int sw = (l31 >> 1) & 7;
         const int a_off = (wm * 64 + l31) * 128;
         const int w_off = (wn * 128 + l31) * 128;
-        const TileCoord tc0 = decode_tile(args, xcd_remap(t, ntiles));
+        const TileCoord tc0 = decode_tile(args, cur.tile);
         const KARG GemmProblem& P = args.p[tc0.pi];
         const int M = P.M, N = P.N, K = P.K;
         const int m0 = tc0.m0, n0 = tc0.n0;
-        const int nk = K * ES / KT_BYTES;
-        // next tile of this work-group: prefetchable iff same problem, both tiles complete, and the stream has room (nk >= 2)
+        const int ka = cur.ka;
+        const int nk = (cur.kb < 0 ? K * ES / KT_BYTES : cur.kb) - ka;      // K tiles of this segment
+        const bool sk_publish = SK && cur.kb < sk_nk;      // a head: its accumulators go to the tail's holder
+        const bool sk_consume = SK && ka > 0;              // a tail: its accumulators start from the head's
+        // next segment of this work-group: prefetchable iff same problem, both tiles complete, and the streams have room (>= 2 K tiles)
         bool have_next = false;
-        long long a_next = 0, w_next = 0;      // byte offset from this tile's source rows to the next tile's
-        if (t + G < ntiles) {
-            const TileCoord tn = decode_tile(args, xcd_remap(t + G, ntiles));
-            have_next = tn.pi == tc0.pi && nk >= 2 && m0 + BM <= M && tn.m0 + BM <= M && n0 + BN <= N && tn.n0 + BN <= N;
-            a_next = (long long)(tn.m0 - m0) * P.lda * ES;
-            w_next = (long long)(tn.n0 - n0) * K * ES;
+        long long a_next = 0, w_next = 0;      // byte offset from this segment's source rows / first K tile to the next one's
+        const Seg nxt = seg_at(sidx + 1);
+        if (nxt.valid) {
+            const TileCoord tn = decode_tile(args, nxt.tile);
+            const int nk_next = (nxt.kb < 0 ? K * ES / KT_BYTES : nxt.kb) - nxt.ka;
+            have_next = tn.pi == tc0.pi && nk >= 2 && nk_next >= 2 && m0 + BM <= M && tn.m0 + BM <= M && n0 + BN <= N && tn.n0 + BN <= N;
+            a_next = (long long)(tn.m0 - m0) * P.lda * ES + (long long)(nxt.ka - ka) * KT_BYTES;
+            w_next = (long long)(tn.n0 - n0) * K * ES + (long long)(nxt.ka - ka) * KT_BYTES;
         }
         // staging sources of this tile (recomputed per tile: nothing lane-dependent is carried across the epilogue)
         const char* a_src[4];
@@ -929,12 +995,12 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
                 const int row_a = piece_a * 8 + rin, row_w = piece_w * 8 + rin;
                 const int gr = min(m0 + row_a, M - 1);
                 const int gn = min(n0 + row_w, N - 1);
-                a_src[i] = A + (size_t)gr * P.lda * ES + (slot ^ ((row_a >> 1) & 7)) * 16;
-                w_src[i] = W + (size_t)gn * K * ES + (slot ^ ((row_w >> 1) & 7)) * 16;
+                a_src[i] = A + (size_t)gr * P.lda * ES + (slot ^ ((row_a >> 1) & 7)) * 16 + (size_t)ka * KT_BYTES;
+                w_src[i] = W + (size_t)gn * K * ES + (slot ^ ((row_w >> 1) & 7)) * 16 + (size_t)ka * KT_BYTES;
             }
         }
-        // byte offset of stream index i (wave-uniform, branch-free): K tile i of this tile; past its end K tile i - nk of the
-        // next tile, or (no prefetchable next tile) a clamped dummy re-read of this tile's last K tile
+        // byte offset of stream index i (wave-uniform, branch-free): K tile ka + i of this tile; past the segment's end K tile i - nk
+        // of the next segment, or (no prefetchable next segment) a clamped dummy re-read of this segment's last K tile
         const int i_lim = have_next ? 0x7fffffff : nk - 1;
         const long long a_adj = have_next ? a_next - (long long)nk * KT_BYTES : 0;
         const long long w_adj = have_next ? w_next - (long long)nk * KT_BYTES : 0;
@@ -966,12 +1032,38 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
         };
 
         f32x16 acc[2][4];
+        // image of a tile's accumulators in the stream-K workspace: quad j = (mi * 4 + ni) * 4 + q of thread tid at ((j * 512 + tid) * 16
+        // bytes: every store / load instruction of a wave covers 1 KiB contiguous
+        auto sk_image = [&](int seam) -> char* { return args.sk_part + (size_t)seam * SK_PART_BYTES + (size_t)(w * 64 + lane) * 16; };
+        if (sk_consume) {
+            // the head of this tile was published by the holder of ticket - 8 when it STARTED (its first segment): normally long ago
+            unsigned* flag = args.sk_sync + SK_FLAG0 + (sk_pos - 1);
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+                __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // at rest again for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                            // this CU's L1 (one lane + barrier: guide G16)
+            }
+            __syncthreads();
+            const char* img = sk_image(sk_pos - 1);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v = *(const f32x4*)(img + (size_t)((mi * 4 + ni) * 4 + q4) * (GEMM_THREADS * 16));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[mi][ni][4 * q4 + r] = v[r];
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the main loop counts its own LDS-DMA requests only
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
 
         FragT fa[KS], fw4[4][KS];
         auto rd_a1 = [&](const char* Sa, int mi) {
@@ -1041,7 +1133,26 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
         const int a_free = abk ^ 1;
         const int w_free = wsk == 0 ? 2 : wsk - 1;
         char* E = w < 4 ? a_base + a_free * A_BYTES + w * 8192 : w_base + w_free * W_BYTES + (w - 4) * 8192;
-        gemm_epilogue<EPI, FP8, true>(P, M, N, acc, m0, n0, E, E, lane, w, nullptr);
+        if (sk_publish) {
+            // a head: write-through (sc1) 16-byte stores of the accumulators, every wave's drained, then the flag (guide: publish-large /
+            // handoff-flag); the tail's holder acquires and reads them with plain loads
+            char* img = sk_image(sk_pos);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v = {acc[mi][ni][4 * q4], acc[mi][ni][4 * q4 + 1], acc[mi][ni][4 * q4 + 2], acc[mi][ni][4 * q4 + 3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(img + (size_t)((mi * 4 + ni) * 4 + q4) * (GEMM_THREADS * 16)), "v"(v)
+                                     : "memory");
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(args.sk_sync + SK_FLAG0 + sk_pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            gemm_epilogue<EPI, FP8, true>(P, M, N, acc, m0, n0, E, E, lane, w, nullptr);
+        }
         ab = abk;
         ws = wsk;
         have = have_next;
@@ -1054,8 +1165,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmAr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the only kernel argument sits at offset 0 of the kernarg segment
     const KARG GemmArgs& args = *(const KARG GemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    if constexpr (VAR == 17)
-        gemm_persistent<EPI, FP8>(args, smem);
+    if constexpr (VAR == 17 || VAR == 19)
+        gemm_persistent<EPI, FP8, VAR == 19>(args, smem);
     else
         gemm_tile<EPI, VAR, FP8>(args, smem, xcd_remap((int)blockIdx.x, (int)gridDim.x));
 }
@@ -1067,6 +1178,9 @@ static int env_int(const char* name, int dflt) {
 int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_persist_wgs = 0;    // 0 = one work-group per CU of the current device
+int g_gemm_sk = env_int("PE_GEMM_SK", 1);     // schedule 19 where it applies (A/B knob "gemm_sk")
+GemmWorkspace g_gemm_ws = {nullptr, 0};
+constexpr size_t SK_SYNC_BYTES = 4096;        // ticket + flags (<= 992 work-groups), then the accumulator images
 
 static int persistent_grid() {
     static std::atomic<int> cus{0};
@@ -1083,6 +1197,8 @@ static int persistent_grid() {
     if (g_gemm_persist_wgs > 0) return (g_gemm_persist_wgs + 7) & ~7;
     return n;
 }
+
+size_t gemm_workspace_bytes() { return SK_SYNC_BYTES + (size_t)persistent_grid() * SK_PART_BYTES; }
 
 template <int EPI, int VAR, bool FP8 = false>
 static int launch_v(const GemmArgs& args, int grid, hipStream_t stream) {
@@ -1105,6 +1221,18 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     const int ntiles = args.ntiles;
     int var = g_gemm_variant;
     const int G = persistent_grid();
+    // 19 (stream-K) wherever it applies -- a workspace was given, more than one round of tiles that do not fill whole rounds, one K --
+    // because it is the only schedule whose time does not round T / G up; it only exists for the epilogues of the DiT block's Linears.
+    // "gemm_variant" 19 forces it on every launch it can run (tests), 17 / 15 / 10 never take it.
+    constexpr bool SK_EPI = EPI == EPI_QKV || EPI == EPI_GELU_SIG || EPI == EPI_GATE_RES || EPI == EPI_BIAS;
+    const int nk = args.p[0].K / (fp8 ? 128 : BK);
+    const bool sk_can = SK_EPI && args.sk_sync != nullptr && args.sk_part != nullptr && ntiles >= G && nk >= 2 && args.p[0].K == args.p[1].K &&
+                        g_gemm_persist_wgs == 0;
+    const bool sk_want = var == 19 || (var == 17 && g_gemm_sk != 0 && ntiles % G != 0);
+    if (sk_can && sk_want) {
+        if constexpr (SK_EPI) return fp8 ? launch_v<EPI, 19, true>(args, G, stream) : launch_v<EPI, 19>(args, G, stream);
+    }
+    if (var == 19) var = 17;
     // 17 pays from about three rounds of tiles on (measured, profiles/r03_gemm_notes.md: +1.2 ... +1.5 % at 4.8 / 6.4 rounds, -0.7 ... -1.3 %
     // at 1.6 rounds, where most work-groups own a single tile and only pay for the two-pass epilogue); "gemm_persist_wgs" > 0 forces it
     if (var == 17 && ntiles < (g_gemm_persist_wgs > 0 ? G + 1 : 3 * G)) var = 15;
@@ -1118,9 +1246,10 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     return launch_v<EPI, 15>(args, ntiles, stream);
 }
 
-int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream) {
+int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace) {
     PE_REQUIRE(nproblems >= 1 && nproblems <= 2, "gemm: 1 or 2 problems per launch, got %d", nproblems);
-    PE_REQUIRE(g_gemm_variant == 10 || g_gemm_variant == 15 || g_gemm_variant == 17, "gemm: gemm_variant %d does not exist", g_gemm_variant);
+    PE_REQUIRE(g_gemm_variant == 10 || g_gemm_variant == 15 || g_gemm_variant == 17 || g_gemm_variant == 19, "gemm: gemm_variant %d does not exist",
+               g_gemm_variant);
     PE_REQUIRE(g_gemm_band >= 1 && g_gemm_band <= 64, "gemm: gemm_band %d out of range", g_gemm_band);
     GemmArgs args;
     int tiles[2] = {0, 0};
@@ -1161,6 +1290,13 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     args.ntiles = tiles[0] + tiles[1];
     args.band = g_gemm_band;
     args.dbg = g_gemm_dbg;
+    args.sk_sync = nullptr;
+    args.sk_part = nullptr;
+    if (workspace == nullptr && g_gemm_ws.sync != nullptr) workspace = &g_gemm_ws;      // tests: pe_debug_set_ptr("gemm_workspace", p)
+    if (workspace != nullptr && workspace->sync != nullptr && workspace->bytes >= gemm_workspace_bytes() && ((uintptr_t)workspace->sync & 255) == 0) {
+        args.sk_sync = (unsigned*)workspace->sync;
+        args.sk_part = (char*)workspace->sync + SK_SYNC_BYTES;
+    }
     double flops = 0.0;  // algorithmic 2*M*N*K of the launch (what the roofline fraction is quoted on)
     for (int i = 0; i < nproblems; ++i) flops += 2.0 * problems[i].M * (double)problems[i].N * problems[i].K;
     const int slot = prof_begin(PROF_GEMM, flops, stream);

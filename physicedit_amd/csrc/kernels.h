@@ -60,7 +60,16 @@ struct GemmProblem {
     unsigned* q8_flags;     // [M] (indexed like scale_a: row of THIS problem), zero between launches
 };
 
-int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream);
+// scratch of the stream-K schedule (gemm.hip, schedule 19): `bytes` >= gemm_workspace_bytes(), 256-byte aligned, ZERO when first used
+// (the kernels leave it zero), private to one stream at a time.  Without it the launch runs schedules 15 / 17.
+struct GemmWorkspace {
+    void* sync;
+    size_t bytes;
+};
+size_t gemm_workspace_bytes();
+extern GemmWorkspace g_gemm_ws;
+extern int g_gemm_sk;
+int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace = nullptr);
 extern int g_gemm_band;          // M tiles per band of the tile order (default 8)
 extern int g_gemm_persist_wgs;   // schedule 17: work-groups of the persistent grid (0 = one per CU)
 extern int g_gemm_variant;  // experiment knobs (pe_debug_set); production paths use the compiled defaults

@@ -119,6 +119,64 @@ def test_gemm_persistent_schedule_bit_identical(ops, M, N, K):
         lib().pe_debug_set(b"gemm_persist_wgs", 0)
 
 
+@pytest.fixture
+def gemm_workspace():
+    """a zeroed stream-K workspace installed for the granular pe_gemm_* calls of one test (pe_debug_set_ptr), removed afterwards"""
+    from physicedit_amd._lib import lib
+    n = lib().pe_gemm_workspace_bytes()
+    buf = torch.zeros((n + 256,), dtype=torch.uint8, device="cuda")
+    off = (-buf.data_ptr()) % 256
+    ws = buf[off:off + n]
+    assert lib().pe_debug_set_ptr(b"gemm_workspace", ws.data_ptr()) == 0
+    yield ws
+    lib().pe_debug_set_ptr(b"gemm_workspace", None)
+    lib().pe_debug_set(b"gemm_variant", 17)
+
+
+@pytest.mark.parametrize("M,N,K", [(8704, 3072, 3072), (8464, 3072, 12288), (8704, 9216, 3072), (8704, 12288, 3072), (8200, 2048, 128),
+                                   (16500, 1288, 192)])
+def test_gemm_stream_k_bit_identical(ops, gemm_workspace, M, N, K):
+    """Schedule 19 (stream-K: every CU gets the same number of (tile, K tile) units; a tile cut in two hands its fp32 accumulators
+    over through the workspace and the second part continues the SAME accumulation) against schedule 15, one tile per work-group:
+    bit-identical for every epilogue of the block's Linears, on the four block shapes of the headline geometry (1.6 / 1.6 / 4.8 /
+    6.4 rounds of tiles), a 2-K-tile shape (every segment is one or two K tiles long: the no-prefetch paths) and a ragged one;
+    repeated (race screen: uneven arrival of the two parts of a tile), and the workspace's ticket and flags are zero afterwards."""
+    from physicedit_amd._lib import lib
+    x, w, b = rnd((M, K), 1).cuda(), rnd((N, K), 2, K ** -0.5).cuda(), rnd((N,), 3, 0.1).cuda()
+    gate, res = rnd((N,), 7, 0.5).cuda(), rnd((M, N), 8).cuda()
+    for epi in ("bias", "gelu_sigmoid", "gate_res"):
+        kw = dict(gate=gate, res=res) if epi == "gate_res" else {}
+        assert lib().pe_debug_set(b"gemm_variant", 15) == 0
+        a = ops.gemm(x, w, b, epi, **kw)
+        assert lib().pe_debug_set(b"gemm_variant", 19) == 0
+        for _ in range(6):
+            c = ops.gemm(x, w, b, epi, **kw)
+            assert torch.equal(a, c), epi
+        torch.cuda.synchronize()
+        assert torch.count_nonzero(gemm_workspace[:4096]).item() == 0
+
+
+def test_qkv_stream_k_bit_identical(ops, gemm_workspace):
+    """the QKV epilogue (RMSNorm + RoPE + transposed V, scaled Q) under schedule 19 at the headline shape: bit-identical to schedule 15"""
+    from physicedit_amd._lib import lib
+    M, K = 8704, 3072
+    x, w, b = rnd((M, K), 11).cuda(), rnd((9216, K), 12, K ** -0.5).cuda(), rnd((9216,), 13, 0.1).cuda()
+    nq, nk = synth.make_tensor(5, "norm_q.weight", (128,)).cuda(), synth.make_tensor(5, "norm_k.weight", (128,)).cuda()
+    _, txt = O.rope_tables([(1, 8, 8)], M)
+    cos, sin = txt.real.contiguous().cuda(), txt.imag.contiguous().cuda()
+    outs = {}
+    for var in (15, 19, 19):
+        assert lib().pe_debug_set(b"gemm_variant", var) == 0
+        q, k, vt = ops.alloc_qkv(24, M, "cuda")
+        ops.qkv_rmsnorm_rope(x, w, b, nq, nk, cos, sin, q, k, vt, 0, q_scale=0.1275)
+        if var in outs:
+            assert all(torch.equal(u, v) for u, v in zip(outs[var], (q, k, vt)))
+        outs[var] = (q, k, vt)
+    assert all(torch.equal(u, v) for u, v in zip(outs[15], outs[19]))
+    torch.cuda.synchronize()
+    assert torch.count_nonzero(gemm_workspace[:4096]).item() == 0
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from physicedit_amd._lib import PeError
     x, w = rnd((8, 100), 1).cuda(), rnd((16, 100), 2).cuda()
