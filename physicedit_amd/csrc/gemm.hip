@@ -47,7 +47,7 @@ struct GemmArgs {
     int ntiles;       // all tiles of the launch (schedule 17: the grid is smaller)
     int band;         // M tiles per band of the tile order
     long long* dbg;   // per work-group s_memtime stamps [grid][8] of schedule 15 (pe_debug_set_ptr("gemm_stamps", p)), or null
-    unsigned* sk_sync;   // schedule 19: [0] ticket counter, [SK_FLAG0 + pos] flag of the seam behind position pos; all zero at rest
+    unsigned* sk_sync;   // schedule 19: [0] arrivals, [1 + c] position counter of chunk c, [SK_FLAG0 + pos] flag of the seam behind position pos; zero at rest
     char* sk_part;       // schedule 19: fp32 accumulator images, SK_PART_BYTES per seam
 };
 constexpr int SK_FLAG0 = 32;                          // flags start on their own 128-byte line
@@ -878,11 +878,29 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
 // head's holder computes it FIRST and publishes the fp32 accumulators (256 KiB, write-through stores, then a flag); the tail's
 // holder runs its tail LAST, starting its accumulators from that image instead of from zero -- the K tiles are accumulated in the
 // same order by the same instructions as in an unsplit tile, so the output is BIT-IDENTICAL to schedules 15 / 17 -- and runs
-// the epilogue.  Positions are handed out by an atomic ticket in start order (ticket t -> chunk t & 7, range t >> 3), and a
-// work-group only ever waits for the holder of ticket t - 8, which has started by construction: no assumption about dispatch
+// the epilogue.  Positions (chunk, index) are handed out by the chunk's atomic counter in start order, and a
+// work-group only ever waits for the holder of (chunk, index - 1), which has started by construction: no assumption about dispatch
 // order or co-residency (cdna guide, "placement-independent protocols"), and since it publishes first thing, the wait is over
-// long before it is reached.  The ticket taker G - 1 zeroes the counter and every consumer its flag: the workspace is all zero
+// long before it is reached.  The last work-group to take a position zeroes the counters and every consumer its flag: the workspace is all zero
 // again when the launch ends (hipGraph-safe: no host-side generation number).
+// One lane takes the work-group's position: index = the next free one of chunk `first` or, should that chunk be full (an XCD that runs
+// more than its share of the work-groups), of the chunks after it; the last of the G work-groups to arrive zeroes the counters.
+// (Not inlined: inside the kernel this retry loop trips "illegal VGPR to SGPR copy" in hipcc 7.2.)
+__device__ __attribute__((noinline)) unsigned sk_take_position(unsigned* sync, unsigned first, unsigned per_chunk, unsigned G) {
+    unsigned chunk = first, idx = 0;
+    for (int k = 0; k < 8; ++k) {
+        idx = __hip_atomic_fetch_add(sync + 1 + chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (idx < per_chunk) break;
+        chunk = (chunk + 1) & 7u;
+    }
+    // every work-group of the launch holds a position once G have arrived
+    const unsigned arrived = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == G - 1) {
+        for (int c = 0; c < 9; ++c) __hip_atomic_store(sync + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return chunk | (idx << 3);
+}
+
 template <int EPI, bool FP8, bool SK>
 __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char* smem) {
     constexpr int ES = FP8 ? 1 : 2;
@@ -909,10 +927,14 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
     //   17: tiles b, b + G, ... whole;   19: the unit range [u0, u1) of its chunk, LAST tile first (see above)
     int sk_base = 0, sk_tf = 0, sk_tl = -1, sk_kf = 0, sk_kl = 0, sk_nk = 0, sk_pos = 0;
     if constexpr (SK) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // hwreg(HW_REG_XCC_ID, 0, 4): the XCD this work-group runs on
         if (threadIdx.x == 0) {
-            const unsigned tk = __hip_atomic_fetch_add(args.sk_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tk == (unsigned)(G - 1)) __hip_atomic_store(args.sk_sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all G tickets are out
-            *(volatile unsigned*)smem = tk;
+            // position = (chunk, index) from the chunk's own counter, in start order.  The chunk is the XCD this work-group RUNS on (XCC_ID:
+            // its L2 then serves one chunk's tiles, as the XCD-aware order of schedules 15 / 17 arranges -- with positions taken from one
+            // global ticket the 32 work-groups of an XCD worked all over the matrix and the launch took 1.2 - 1.5 x as long).  Placement
+            // is speed only: should an XCD run more than G / 8 work-groups, the surplus takes the next chunk with a free position.
+            const unsigned pos = sk_take_position(args.sk_sync, xcc & 7u, (unsigned)(G >> 3), (unsigned)G);
+            *(volatile unsigned*)smem = pos;
         }
         __syncthreads();
         const int tk = __builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)smem);
@@ -1036,7 +1058,7 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
         // bytes: every store / load instruction of a wave covers 1 KiB contiguous
         auto sk_image = [&](int seam) -> char* { return args.sk_part + (size_t)seam * SK_PART_BYTES + (size_t)(w * 64 + lane) * 16; };
         if (sk_consume) {
-            // the head of this tile was published by the holder of ticket - 8 when it STARTED (its first segment): normally long ago
+            // the head of this tile was published by the holder of the position before this one when it STARTED (its first segment): normally long ago
             unsigned* flag = args.sk_sync + SK_FLAG0 + (sk_pos - 1);
             if (threadIdx.x == 0) {
                 while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
@@ -1178,7 +1200,8 @@ static int env_int(const char* name, int dflt) {
 int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_persist_wgs = 0;    // 0 = one work-group per CU of the current device
-int g_gemm_sk = env_int("PE_GEMM_SK", 1);     // schedule 19 where it applies (A/B knob "gemm_sk")
+int g_gemm_sk = env_int("PE_GEMM_SK", 0);     // schedule 19 where it applies (A/B knob "gemm_sk"; measured slower: profiles/r04_gemm_notes.md)
+int g_gemm_persist_min_rounds = 3;            // schedule 17 from this many rounds of tiles on (knob "gemm_persist_min_rounds"; G + 1 tiles at least)
 GemmWorkspace g_gemm_ws = {nullptr, 0};
 constexpr size_t SK_SYNC_BYTES = 4096;        // ticket + flags (<= 992 work-groups), then the accumulator images
 
@@ -1235,7 +1258,7 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     if (var == 19) var = 17;
     // 17 pays from about three rounds of tiles on (measured, profiles/r03_gemm_notes.md: +1.2 ... +1.5 % at 4.8 / 6.4 rounds, -0.7 ... -1.3 %
     // at 1.6 rounds, where most work-groups own a single tile and only pay for the two-pass epilogue); "gemm_persist_wgs" > 0 forces it
-    if (var == 17 && ntiles < (g_gemm_persist_wgs > 0 ? G + 1 : 3 * G)) var = 15;
+    if (var == 17 && ntiles < (g_gemm_persist_wgs > 0 || g_gemm_persist_min_rounds <= 1 ? G + 1 : g_gemm_persist_min_rounds * G)) var = 15;
     if (fp8) {
         if (var == 10) return launch_v<EPI, 10, true>(args, ntiles, stream);
         if (var == 17) return launch_v<EPI, 17, true>(args, G, stream);
