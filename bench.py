@@ -66,12 +66,12 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[2]: DiT stored in e4m3 + enable_dit_fp8_computation (every DiT Linear runs "
                          "fp8_linear); NOT the headline configuration, reported with dtype fp8")
-    ap.add_argument("--attn-variant", type=int, default=4, choices=[0, 3, 4],
-                    help="flash-attention kernel: 4 = library default since round 3 (4 waves x 64 rows, one wave per SIMD, running max "
-                         "raised only when a row outgrows it by 2^8: the same rms distance to an fp32 evaluation as the reference's bf16 "
-                         "SDPA, measured at 60 layers x S = 2208, profiles/r03_attention_notes.md); 3 = the same kernel with the textbook "
-                         "max update, bit-identical to 0; 0 = 8 waves x 32 rows, textbook update (the round-1/2 default).  Values other "
-                         "than 4 are A/B knobs, reported in config.attn_variant")
+    ap.add_argument("--attn-variant", type=int, default=5, choices=[0, 3, 4, 5, 6],
+                    help="flash-attention kernel: 5 = library default since round 4 (4 waves x 64 rows, one wave per SIMD, lazy running max; "
+                         "the softmax scale is folded into Q by the QKV epilogue and the max enters through the MFMA C operand: "
+                         "profiles/r04_attention_notes.md); 4 = round 3's default (same schedule, scale and max applied per score); 6 / 3 = "
+                         "5 / 4 with the textbook max update; 0 = 8 waves x 32 rows (the round-1/2 default).  Values other than 5 are "
+                         "A/B knobs, reported in config.attn_variant")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (backend nccl = RCCL) and run the batch-closing all-gather, the barriers and "
                          "the max-over-ranks all-reduce even at --gpus 1, so that the only thing a 1-GPU box leaves unexecuted of "
@@ -81,6 +81,12 @@ def main():
                          "the 1328x1328 / 50-step geometry of configs[4] on this one GPU and of configs[2], the e4m3 Linears)")
     ap.add_argument("--no-probes", action="store_true",
                     help="skip the matrix-pipe / GEMM-mix probes after the timed region (profiling runs: keeps them out of the trace)")
+    ap.add_argument("--no-prologue", action="store_true",
+                    help="skip the `prologue` block (N = 1 headline runs time the text-encoder prologue at its real size after the timed "
+                         "region: prefill seconds, captured decode tokens/s and achieved HBM TB/s; SURVEY.md section 8(d))")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="skip the determinism self-check (N = 1 headline runs re-run the first timed image on ONE stream with GEMM "
+                         "schedule 15 -- one tile per work-group -- and require bit-identical final latents and pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     args = ap.parse_args()
@@ -153,7 +159,7 @@ def main():
         torch.cuda.empty_cache()
     vae = QwenImageVAE(synth.make_state_dict(synth.vae_layout(), 77), device=dev)
     loop = DenoiseLoop(eng, dual_stream=args.dual_stream)
-    if args.attn_variant != 4:
+    if args.attn_variant != 5:
         from physicedit_amd._lib import lib
         assert lib().pe_debug_set(b"attn_variant", args.attn_variant) == 0
     torch.cuda.synchronize()
@@ -176,10 +182,10 @@ def main():
     noises = {u: synth.make_noise(u, H, W).to(dev) for u in warm_units + units}
     results = []
 
-    def one_image(i):
+    def one_image(i, loop_=None):
         edit_latents = vae.encode(edit_img)
-        lat = loop(noises[i], pe_p0.clone(), pe_n0.clone(), mask_p, mask_n, H, W,
-                   num_inference_steps=args.inference_steps, cfg_scale=args.cfg, edit_latents=edit_latents)
+        lat = (loop_ or loop)(noises[i], pe_p0.clone(), pe_n0.clone(), mask_p, mask_n, H, W,
+                              num_inference_steps=args.inference_steps, cfg_scale=args.cfg, edit_latents=edit_latents)
         img = vae.decode(lat)
         return lat, img
 
@@ -225,6 +231,30 @@ def main():
         return out_
 
     prof = read_prof()
+    # The bench proves its own outputs (outside the timed region, N = 1 headline runs): the first timed image again on ONE stream
+    # with GEMM schedule 15 (one tile per work-group: no persistent work-groups, no cross-tile prefetch).  Every schedule performs
+    # the same arithmetic in the same order, so the final latents and the decoded pixels must be BIT-IDENTICAL to the timed
+    # two-stream / schedule-17 result; a race in the persistent GEMM, the attention ring or the two-stream loop shows up here at
+    # 60 layers x 40 steps.  A mismatch fails the run.
+    determinism = None
+    if rank == 0 and world == 1 and not args.no_self_check and args.steps > 0:
+        t_chk = time.perf_counter()
+        assert lib().pe_debug_set(b"gemm_variant", 15) == 0
+        try:
+            lat1, img1 = one_image(units[0], DenoiseLoop(eng, dual_stream=False))
+            torch.cuda.synchronize()
+        finally:
+            lib().pe_debug_set(b"gemm_variant", 17)
+        same_lat = bool(torch.equal(lat1, results[0][0]))
+        same_img = bool(torch.equal(img1, results[0][1]))
+        determinism = {"bit_identical": same_lat and same_img, "latents_equal": same_lat, "pixels_equal": same_img,
+                       "what": "timed image 0 (two streams, GEMM schedule 17) vs the same unit on one stream with GEMM schedule 15, "
+                               f"{args.layers} layers x {args.inference_steps} steps", "seconds": round(time.perf_counter() - t_chk, 2)}
+        if not (same_lat and same_img):
+            d = (lat1.float() - results[0][0].float()).abs()
+            determinism["max_abs_latent_diff"] = float(d.max().item())
+            determinism["latent_elements_differing"] = int((d > 0).sum().item())
+        del lat1, img1
     # diagnostic, OUTSIDE the timed region: the same kernels with the chip to themselves (one positive forward on
     # one stream, every launch sampled).  With two streams the timed-region launch durations include sharing the
     # CUs with the sibling branch's kernel, so they understate what a kernel achieves alone.
@@ -274,6 +304,8 @@ def main():
                        "batch_closing_collective": ("one RCCL all_gather of the final latents, inside the timed region" if dist is not None else None),
                        "per_rank_elapsed_s": [round(float(t), 4) for t in per_rank],
                        "finite_outputs": ok},
+            "determinism": (determinism or {}).get("bit_identical"),
+            "self_check": determinism,
             "whole_path": {"algorithmic_pflop_per_image": fl / 1e15,
                            "achieved_tflops_per_gpu": fl * value / world / 1e12,
                            "frac_of_bf16_mfma_peak": fl * value / world / 1e12 / PEAK_BF16_TFLOPS,
@@ -316,9 +348,17 @@ def main():
                 out["roofline"]["frac_of_attainable_ceiling"] = achieved / att["mfma_lds_reads_dma_stream"]
         if world == 1 and headline and not args.fp8 and not args.no_secondary:
             out["secondary"] = secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_n, read_prof)
+        if world == 1 and headline and not args.fp8 and not args.no_prologue:
+            out["prologue"] = prologue_block(dev)
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
+        if determinism is not None and not determinism["bit_identical"]:
+            print("[bench] SELF-CHECK FAILED: the single-stream / schedule-15 re-run of timed image 0 is not bit-identical "
+                  f"({determinism})", file=sys.stderr)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -383,6 +423,31 @@ def secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_
     run("configs[2] (DiT Linears in e4m3: fp8_linear; attention, norms, adapter, VAE bf16)", args.height, args.width,
         args.inference_steps, PEAK_FP8_TFLOPS, "fp8_e4m3")
     return res
+
+
+def prologue_block(dev):
+    """"report prologue (text encoder) separately".  The Qwen2.5-VL-7B text encoder at its real shape with
+    random weights (tools/prologue_time.py, quick form): the two embedding passes of an edit, the prefill of the physical-text
+    generation, and the captured greedy decode step -- tokens/s and the HBM rate of the weights it streams per token."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import prologue_time
+        t0 = time.perf_counter()
+        r = prologue_time.measure(decode_tokens=128, quick=True)
+        g = r.get("generate_captured_decode_step") or {}
+        return {"what": "text-encoder prologue (Qwen2.5-VL-7B shape, random weights, synthetic byte-level tokenizer), timed after the "
+                        "headline region in this process; NOT part of `value` (the reference computes it once per prompt, outside the "
+                        "denoising loop: qwen_image_physical.py:859-873, 943-967)",
+                "embed_positive_seconds": r["embed_positive"]["seconds"], "embed_positive_tokens": r["embed_positive"]["tokens_after_drop"],
+                "embed_negative_seconds": r["embed_negative"]["seconds"], "embed_negative_tokens": r["embed_negative"]["tokens_after_drop"],
+                "generate_prompt_tokens": r["prompt_tokens"], "prefill_plus_1_token_seconds": g.get("prefill_plus_1_token_seconds"),
+                "decode_tokens_per_second": g.get("decode_tokens_per_second"), "decode_tokens_timed": r["new_tokens_timed"],
+                "weight_bytes_streamed_per_token": g.get("weight_bytes_streamed_per_token"), "achieved_TBps": g.get("achieved_TBps"),
+                "frac_of_hbm_peak": g.get("frac_of_hbm_peak_8TBps"), "hbm_peak_TBps": 8.0,
+                "seconds_for_1000_new_tokens_extrapolated": g.get("extrapolated_seconds_for_1000_new_tokens"),
+                "token_ids_sha1": g.get("token_ids_sha1"), "block_seconds": round(time.perf_counter() - t0, 1)}
+    except Exception as e:      # the block is a report, not the metric: never lose the line to it
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def mfma_power_ceiling(dev):
@@ -497,9 +562,9 @@ def cpu_baseline(args):
     a BOUNDED sample of the same workload, extrapolated with the layer / step counts:
         t_image = steps * layers * (t_block(T_pos) + t_block(T_neg)) + t_vae_enc + t_vae_dec
     Sample (about a minute of CPU work in total):
-      1. thread sweep on a reduced block (S_img = 2048): torch threads in {8, 16, 32, 64, 128, all}; the best count is used
-         for everything below (256 threads oversubscribe oneDNN: round 1 measured 3-4x slower than 8 vCPUs that way);
-      2. one full-width DiT block at the full configs[1] sequence (S_img = 8192, T = T_pos; T_neg scaled by tokens);
+      1. one full-width DiT block at the full configs[1] sequence (S_img = 8192, T = T_pos; T_neg scaled by tokens), timed once per
+         torch thread count in {8, 16, 32, 64, 128} (stopping past the knee: 256 threads oversubscribe oneDNN, round 1 measured
+         3-4x slower than 8 vCPUs that way); the best count's time is the sample, and that count is used for everything below;
       3. VAE encode + decode TIMED at 256 x 256 and scaled by the pixel count (convolutions are linear in pixels; the
          mid-block attention, 0.41 of 7.6 TFLOP at 1024^2, is scaled the same way, which under-prices it slightly);
       4. configs[0] (c1) end to end: 2-layer DiT, 512 x 512, 4 steps, CFG off, T = 128, edit image NOT auto-resized
@@ -522,15 +587,21 @@ def cpu_baseline(args):
             O.block_forward(sd, 0, image, text, temb, rope)
         return time.perf_counter() - t0
 
+    # thread sweep AT THE SHAPE THAT IS REPORTED (round 3 picked the count on a reduced block): the full-width block at the full
+    # configs[1] sequence, one run per count after a small warm-up of the thread pool; counts whose first quarter already takes
+    # longer than the best full run so far are not run to the end on the reduced block first
+    S_img = (args.height // 16) * (args.width // 16) + 4096
+    full_shapes = [(1, args.height // 16, args.width // 16), (1, 64, 64)]
     sweep = {}
-    for nt in sorted({n for n in (8, 16, 32, 64, 128, cores) if n <= cores}):
+    for nt in sorted({n for n in (8, 16, 32, 64, 128) if n <= cores}):
         torch.set_num_threads(nt)
         time_block(512, 64, [(1, 16, 16), (1, 16, 16)])            # warm the thread pool
-        sweep[nt] = time_block(2048, 128, [(1, 32, 32), (1, 32, 32)])
+        sweep[nt] = time_block(S_img, args.t_pos, full_shapes)
+        if len(sweep) >= 3 and sweep[nt] > 2.5 * min(sweep.values()):
+            break                                                  # past the knee: more threads only oversubscribe oneDNN
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    S_img = (args.height // 16) * (args.width // 16) + 4096
-    t_blk = {args.t_pos: time_block(S_img, args.t_pos, [(1, args.height // 16, args.width // 16), (1, 64, 64)])}
+    t_blk = {args.t_pos: sweep[best]}
     t_blk[args.t_neg] = t_blk[args.t_pos] * (S_img + args.t_neg) / (S_img + args.t_pos)
     S = S_img + args.t_pos
     blk_flops = 226_492_416 * S + 12_288 * S * S + 226_492_416
@@ -554,8 +625,8 @@ def cpu_baseline(args):
         t_c1 = time.perf_counter() - t0
     per_image = args.inference_steps * args.layers * (t_blk[args.t_pos] + (t_blk[args.t_neg] if args.cfg != 1.0 else 0)) + t_enc + t_dec
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": best, "host_logical_cpus": cores, "kind": "port",
-            "sample": f"torch threads swept {{{', '.join(f'{k}: {v:.2f}s' for k, v in sweep.items())}}} on a reduced block -> {best} threads; "
-                      f"1 DiT block fwd at full shape S_img={S_img}: T={args.t_pos} {t_blk[args.t_pos]:.2f}s "
+            "sample": f"1 DiT block fwd at full shape S_img={S_img}, T={args.t_pos}, torch threads swept at that shape "
+                      f"{{{', '.join(f'{k}: {v:.2f}s' for k, v in sweep.items())}}} -> {best} threads: {t_blk[args.t_pos]:.2f}s "
                       f"(T={args.t_neg} scaled by tokens: {t_blk[args.t_neg]:.2f}s) = {cpu_rate/1e12:.3f} TFLOP/s; "
                       f"VAE timed at 256x256 (enc {t_enc256:.2f}s, dec {t_dec256:.2f}s) and scaled by pixels -> enc {t_enc:.1f}s dec {t_dec:.1f}s; "
                       f"extrapolated x{args.inference_steps} steps x{args.layers} layers",

@@ -389,6 +389,47 @@ PE_DEV void stage_row(bf16* __restrict__ xs, const bf16* __restrict__ x, int K, 
     }
     __syncthreads();
 }
+
+// Two rows of W against the staged x: per lane the 16-byte chunks k = lane * 8 + 512 i in ascending i, eight fmas per chunk in element
+// order -- the summation order of the round-2 kernels, so tokens decoded with them are reproduced bit for bit -- but with the weight
+// chunks of four steps requested before the first is used (8 x 16 B in flight per lane instead of 2) and with the non-temporal hint:
+// a decode step reads every weight byte once (cdna guide: nt on weight streams that one CU reads once, -5 ... -10 % per layer).
+PE_DEV void gemv_dot2(const bf16* __restrict__ xs, const bf16* __restrict__ wa, const bf16* __restrict__ wb, int K, int lane, float& sa,
+                      float& sb) {
+    sa = 0.f;
+    sb = 0.f;
+    int k = lane * 8;
+    for (; k + 3 * 512 < K; k += 4 * 512) {
+        bf16x8 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            va[u] = __builtin_nontemporal_load((const bf16x8*)(wa + k + u * 512));
+            vb[u] = __builtin_nontemporal_load((const bf16x8*)(wb + k + u * 512));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bf16x8 xv = *(const bf16x8*)(xs + k + u * 512);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sa = __builtin_fmaf((float)va[u][j], (float)xv[j], sa);
+                sb = __builtin_fmaf((float)vb[u][j], (float)xv[j], sb);
+            }
+        }
+    }
+    for (; k < K; k += 512) {
+        const bf16x8 xv = *(const bf16x8*)(xs + k);
+        const bf16x8 va = __builtin_nontemporal_load((const bf16x8*)(wa + k));
+        const bf16x8 vb = __builtin_nontemporal_load((const bf16x8*)(wb + k));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sa = __builtin_fmaf((float)va[j], (float)xv[j], sa);
+            sb = __builtin_fmaf((float)vb[j], (float)xv[j], sb);
+        }
+    }
+}
+// ROUNDS = 2: 16 rows per work-group (the lm_head: 9504 work-groups); ROUNDS = 1: 8 rows, for the launches of a few thousand rows
+// (o_proj / down_proj, N = 3584: 224 work-groups of 16 rows left 32 CUs idle and four waves per CU to stream up to 600 KiB)
+template <int ROUNDS>
 __global__ void __launch_bounds__(256) gemv_bf16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
                                                         const bf16* __restrict__ bias, const bf16* __restrict__ res,
                                                         bf16* __restrict__ y, int N, int K, const bf16* __restrict__ norm_w, float eps) {
@@ -397,24 +438,15 @@ __global__ void __launch_bounds__(256) gemv_bf16_kernel(const bf16* __restrict__
     stage_row(xs, x, K, norm_w, eps);
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
-    const int row0 = (int)blockIdx.x * GEMV_ROWS + w * 2;
+    const int row0 = (int)blockIdx.x * (8 * ROUNDS) + w * 2;
 #pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
+    for (int rnd = 0; rnd < ROUNDS; ++rnd) {
         const int ra = row0 + rnd * 8, rb = ra + 1;
         if (ra >= N) break;
         const bf16* wa = W + (size_t)ra * K;
         const bf16* wb = W + (size_t)min(rb, N - 1) * K;
-        float sa = 0.f, sb = 0.f;
-        for (int k = lane * 8; k < K; k += 64 * 8) {
-            const bf16x8 xv = *(const bf16x8*)(xs + k);
-            const bf16x8 va = *(const bf16x8*)(wa + k);
-            const bf16x8 vb = *(const bf16x8*)(wb + k);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                sa = __builtin_fmaf((float)va[j], (float)xv[j], sa);
-                sb = __builtin_fmaf((float)vb[j], (float)xv[j], sb);
-            }
-        }
+        float sa, sb;
+        gemv_dot2(xs, wa, wb, K, lane, sa, sb);
         sa = wave_sum(sa);
         sb = wave_sum(sb);
         if (lane == 0) {                           // res: the decoder layer's `residual + linear(x)`, the sum rounded separately
@@ -444,17 +476,8 @@ __global__ void __launch_bounds__(256) gemv_swiglu_kernel(const bf16* __restrict
         if (n >= N) break;
         const bf16* wa = Wg + (size_t)n * K;
         const bf16* wb = Wu + (size_t)n * K;
-        float sa = 0.f, sb = 0.f;
-        for (int k = lane * 8; k < K; k += 64 * 8) {
-            const bf16x8 xv = *(const bf16x8*)(xs + k);
-            const bf16x8 va = *(const bf16x8*)(wa + k);
-            const bf16x8 vb = *(const bf16x8*)(wb + k);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                sa = __builtin_fmaf((float)va[j], (float)xv[j], sa);
-                sb = __builtin_fmaf((float)vb[j], (float)xv[j], sb);
-            }
-        }
+        float sa, sb;
+        gemv_dot2(xs, wa, wb, K, lane, sa, sb);
         sa = wave_sum(sa);
         sb = wave_sum(sb);
         if (lane == 0) {
@@ -501,12 +524,11 @@ __global__ void __launch_bounds__(256) gemv3_kernel(const bf16* __restrict__ x, 
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
     // work item p = a PAIR of rows: for q / k the rows (i, i + 64) of one 128-wide head, which the rotary embedding mixes; for v two
-    // neighbouring rows.  8 pairs per work-group.
+    // neighbouring rows.  4 pairs per work-group (576 work-groups for the 7B text model's q / k / v; 8 pairs left 288).
     const int npairs = (N0 + N1 + N2) / 2;
-#pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
-        const int p = (int)blockIdx.x * 8 + rnd * 4 + w;
-        if (p >= npairs) break;
+    {
+        const int p = (int)blockIdx.x * 4 + w;
+        if (p >= npairs) return;
         const bf16* wr;
         const bf16* br;
         bf16* yr;
@@ -521,17 +543,8 @@ __global__ void __launch_bounds__(256) gemv3_kernel(const bf16* __restrict__ x, 
         else { ra = q2 * 2; rb = ra + 1; }
         const bf16* rowa = wr + (size_t)ra * K;
         const bf16* rowb = wr + (size_t)rb * K;
-        float sa = 0.f, sb = 0.f;
-        for (int k = lane * 8; k < K; k += 64 * 8) {
-            const bf16x8 xv = *(const bf16x8*)(xs + k);
-            const bf16x8 va = *(const bf16x8*)(rowa + k);
-            const bf16x8 vb = *(const bf16x8*)(rowb + k);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                sa = __builtin_fmaf((float)va[j], (float)xv[j], sa);
-                sb = __builtin_fmaf((float)vb[j], (float)xv[j], sb);
-            }
-        }
+        float sa, sb;
+        gemv_dot2(xs, rowa, rowb, K, lane, sa, sb);
         sa = wave_sum(sa);
         sb = wave_sum(sb);
         if (lane == 0) {
@@ -560,7 +573,7 @@ int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void*
     PE_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && K > 0 && K % 8 == 0 && K <= 32768, "decode_qkv: bad shape");
     PE_REQUIRE(!step || (base >= 0 && ld > base), "decode_qkv: cache of %d rows cannot take row %d", ld, base);
     const int N0 = n_q_heads * 128, N1 = n_kv_heads * 128;
-    hipLaunchKernelGGL(gemv3_kernel, dim3(((N0 + 2 * N1) / 2 + 7) / 8), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
+    hipLaunchKernelGGL(gemv3_kernel, dim3(((N0 + 2 * N1) / 2 + 3) / 4), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
                        (const bf16*)Wq, (const bf16*)bq, N0, (const bf16*)Wk, (const bf16*)bk, N1, (const bf16*)Wv, (const bf16*)bv, N1,
                        (bf16*)q, (bf16*)k, (bf16*)v, K, (const bf16*)cos_sel, (const bf16*)sin_sel, step, base, ld,
                        (const bf16*)norm_w, eps);
@@ -596,7 +609,7 @@ __global__ void __launch_bounds__(DEC_NT) attn_decode_kernel(const bf16* __restr
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[c * 8 + j] = (float)t8[j];
         }
-#pragma unroll 2
+#pragma unroll 4
         for (int j = g4; j < L; j += DEC_NT / 4) {
             const bf16* kr = kb + (size_t)j * 128 + s4 * 32;
             float acc = 0.f;
@@ -635,7 +648,7 @@ __global__ void __launch_bounds__(DEC_NT) attn_decode_kernel(const bf16* __restr
     // P.V: lane `sub` owns output channels 8 sub .. 8 sub + 7, group `grp` every (DEC_NT / 16)-th key; the four groups of a wave meet
     // by shuffles, the waves in LDS
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
     for (int j = grp; j < L; j += DEC_NT / 16) {
         const bf16x8 v8 = *(const bf16x8*)(vb + (size_t)j * 128 + sub * 8);
         const float p = sc[j];
@@ -729,9 +742,20 @@ __global__ void __launch_bounds__(1024) argmax_step_kernel(const bf16* __restric
     __shared__ int bi[16];
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = (int)threadIdx.x; i < V; i += 1024) {
+    // 16-byte loads: thread t scans elements 8 t .. 8 t + 7 of every 8192-element stride in ascending order (the first maximum stays),
+    // then the tail; ties across threads go to the lower index below, so the result is the first maximum whatever the partition
+    const int V8 = V & ~7;
+    for (int i = (int)threadIdx.x * 8; i < V8; i += 1024 * 8) {
+        const bf16x8 t8 = *(const bf16x8*)(logits + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (float)t8[j];
+            if (v > best) { best = v; idx = i + j; }
+        }
+    }
+    for (int i = V8 + (int)threadIdx.x; i < V; i += 1024) {
         const float v = (float)logits[i];
-        if (v > best) { best = v; idx = i; }       // ascending i per thread: the first maximum stays
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
@@ -768,8 +792,12 @@ int launch_gemv(const void* x, const void* W, const void* bias, void* y, int N, 
     PE_REQUIRE(x && W && y, "gemv: null pointer");
     PE_REQUIRE(!norm_w || K == 3584, "gemv: the fused RMSNorm is for the text width 3584 (K=%d)", K);
     PE_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && K <= 32768, "gemv: N=%d K=%d (K must be a multiple of 8, at most 32768)", N, K);
-    hipLaunchKernelGGL(gemv_bf16_kernel, dim3((N + GEMV_ROWS - 1) / GEMV_ROWS), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
-                       (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)y, N, K, (const bf16*)norm_w, eps);
+    if (N <= 8192)
+        hipLaunchKernelGGL(gemv_bf16_kernel<1>, dim3((N + 7) / 8), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
+                           (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)y, N, K, (const bf16*)norm_w, eps);
+    else
+        hipLaunchKernelGGL(gemv_bf16_kernel<2>, dim3((N + GEMV_ROWS - 1) / GEMV_ROWS), dim3(256), (size_t)K * 2, stream, (const bf16*)x,
+                           (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)y, N, K, (const bf16*)norm_w, eps);
     return check_launch("gemv_bf16_kernel");
 }
 

@@ -27,7 +27,26 @@ def main():
     ap.add_argument("--decode-tokens", type=int, default=128)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--no-gemv", action="store_true", help="leave the single-row Linears of the decode on torch's BLAS GEMV")
+    ap.add_argument("--quick", action="store_true", help="what bench.py runs: embedding passes, prefill, captured decode step only")
     args = ap.parse_args()
+    print(json.dumps(measure(args.decode_tokens, args.layers, args.no_gemv, args.quick), indent=1))
+
+
+def streamed_bytes_per_token(model):
+    """weight bytes one decode step reads: every Linear of the language model's layers + lm_head (the embedding table contributes one
+    row, the vision tower nothing)"""
+    n = 0
+    for name, p in model.named_parameters():
+        if "visual" in name or "embed_tokens" in name:
+            continue
+        n += p.numel() * p.element_size()
+    return n
+
+
+def measure(decode_tokens=128, layers=28, no_gemv=False, quick=False):
+    """-> dict (see the module docstring).  quick: skips the stock-transformers generate() timings (bench.py's `prologue` block)."""
+    import types
+    args = types.SimpleNamespace(decode_tokens=decode_tokens, layers=layers, no_gemv=no_gemv)
     import torch
     import tiny_vl
     from diffsynth.pipelines import prompt_prologue as pp
@@ -114,9 +133,14 @@ def main():
         with torch.no_grad():
             return model.generate(**mi, max_new_tokens=n, min_new_tokens=n)
 
-    t_gen1, _ = timed(lambda: gen(1), reps=2)             # prefill + 1 token
-    t_genn, out = timed(lambda: gen(n_new), reps=2)
-    rate = (n_new - 1) / max(t_genn - t_gen1, 1e-9)
+    if quick:
+        t_gen1 = t_genn = rate = None
+        out = None
+    else:
+        t_gen1, _ = timed(lambda: gen(1), reps=2)             # prefill + 1 token
+        t_genn, out = timed(lambda: gen(n_new), reps=2)
+        rate = (n_new - 1) / max(t_genn - t_gen1, 1e-9)
+    bytes_tok = streamed_bytes_per_token(model)
     graph = None
     if prologue.graph_decoder is not None:
         # the path physical_text() takes: prefill on transformers, then the captured decode step (GraphDecoder)
@@ -125,10 +149,14 @@ def main():
         tg1, _ = timed(lambda: ggen(1), reps=2)
         tgn, gout = timed(lambda: ggen(n_new), reps=2)
         grate = (n_new - 1) / max(tgn - tg1, 1e-9)
-        same = int((gout[0, -n_new:] == out[0, -n_new:]).sum())
+        same = None if out is None else int((gout[0, -n_new:] == out[0, -n_new:]).sum())
+        import hashlib
         graph = {"prefill_plus_1_token_seconds": round(tg1, 4), "seconds": round(tgn, 3), "decode_tokens_per_second": round(grate, 1),
-                 "includes": "graph capture (once per call) + KV-cache copy into the static planes",
-                 "tokens_identical_to_generate()": f"{same} of {n_new}",
+                 "weight_bytes_streamed_per_token": bytes_tok, "achieved_TBps": round(bytes_tok * grate / 1e12, 3),
+                 "frac_of_hbm_peak_8TBps": round(bytes_tok * grate / 8e12, 4),
+                 "includes": "graph capture (once per (cache length, max_new_tokens)) + KV-cache copy into the static planes",
+                 "tokens_identical_to_generate()": None if same is None else f"{same} of {n_new}",
+                 "token_ids_sha1": hashlib.sha1(gout[0, -n_new:].cpu().numpy().tobytes()).hexdigest()[:16],
                  "extrapolated_seconds_for_1000_new_tokens": round(tg1 + 999 / grate, 1)}
     res = {
         "what": "prompt prologue at real size (Qwen2.5-VL-7B architecture, random weights), stock transformers on PyTorch-ROCm",
@@ -138,13 +166,16 @@ def main():
                                                       "hardest case for a tie-break)",
         "embed_positive": {"tokens_after_drop": int(posi["prompt_emb"].shape[1]), "seconds": round(t_posi, 4)},
         "embed_negative": {"tokens_after_drop": int(nega["prompt_emb"].shape[1]), "seconds": round(t_nega, 4)},
-        "generate": {"prompt_tokens": int(mi["input_ids"].shape[1]), "prefill_plus_1_token_seconds": round(t_gen1, 4),
-                     "new_tokens_timed": n_new, "seconds": round(t_genn, 3), "decode_tokens_per_second": round(rate, 1),
-                     "extrapolated_seconds_for_1000_new_tokens": round(t_gen1 + 999 / rate, 1)},
+        "generate": None if quick else {"prompt_tokens": int(mi["input_ids"].shape[1]), "prefill_plus_1_token_seconds": round(t_gen1, 4),
+                                        "new_tokens_timed": n_new, "seconds": round(t_genn, 3), "decode_tokens_per_second": round(rate, 1),
+                                        "extrapolated_seconds_for_1000_new_tokens": round(t_gen1 + 999 / rate, 1)},
+        "prompt_tokens": int(mi["input_ids"].shape[1]), "new_tokens_timed": n_new,
         "generate_captured_decode_step": graph,
         "torch": torch.__version__, "device": torch.cuda.get_device_name(0),
     }
-    print(json.dumps(res, indent=1))
+    del model, prologue
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":
