@@ -324,7 +324,8 @@ class GraphDecoder:
     """Greedy `generate` of the text encoder (qwen_image_physical.py:859-873: `text_encoder.generate(**model_inputs,
     max_new_tokens=1000)`, greedy by the model's generation config) with the whole decode step -- embedding row, 28 decoder layers
     of 6 launches (q/k/v + rotary + cache append with the input norm fused, attention, o_proj + residual, gate/up + SiLU with the
-    post-attention norm fused, down_proj + residual), lm_head with the final norm fused, arg-max -- captured ONCE per call in a hipGraph and replayed per token: no Python, no
+    post-attention norm fused, down_proj + residual), lm_head with the final norm fused, arg-max -- captured ONCE per cache-capacity bucket (round 4: the
+    capture outlives the call) in a hipGraph and replayed per token: no Python, no
     launch latency, no Cache object in the loop.  The prefill stays on transformers; its DynamicCache is copied into static planes
     [layer][kv_head][prompt + max_new_tokens][128] that the q/k/v launch appends to (pe_decode_step_*: everything that changes per
     token is read from device memory).  Same kernels, same order, same roundings as `accelerate_decode`, so the tokens are the ones
@@ -353,6 +354,8 @@ class GraphDecoder:
         for ly in self.layers:
             if ly.self_attn.o_proj.bias is not None or ly.mlp.down_proj.bias is not None or ly.mlp.gate_proj.bias is not None:
                 raise ValueError("GraphDecoder: unexpected biases in o_proj / the MLP")
+        self._static = {}           # capacity bucket -> static planes, tables, counters and the captured decode step
+        self.captures = 0           # graphs captured so far (tests: calls of one bucket share one)
 
     def _step(self, st):
         """one decode step on the current stream (captured); st: dict of static device tensors"""
@@ -396,8 +399,21 @@ class GraphDecoder:
         first = int(out.logits[0, -1].float().argmax())
         past = out.past_key_values
         L = len(self.layers)
-        kc = torch.zeros((L, self.hkv, cap, 128), dtype=torch.bfloat16, device=dev)
-        vc = torch.zeros_like(kc)
+        # ---- static state, one set per capacity bucket, kept across calls WITH its captured graph: nothing the graph's launches take
+        # as an argument depends on the prompt (the cache row of generated token t is step = Lp + t, read from the device counter;
+        # `base` is 0; the rotary tables are indexed by that same step), so a later call of the same bucket only refills the planes'
+        # first Lp rows, the table rows [Lp, Lp + max_new_tokens) and the counter, and replays
+        bucket = min(self.MAX_CACHE_ROWS, (cap + 1023) // 1024 * 1024)
+        st = self._static.get(bucket)
+        if st is None:
+            st = {"kc": torch.zeros((L, self.hkv, bucket, 128), dtype=torch.bfloat16, device=dev), "base": 0, "cap": bucket,
+                  "cos": torch.zeros((bucket, 128), dtype=torch.bfloat16, device=dev),
+                  "token": torch.zeros(1, dtype=torch.int32, device=dev), "step": torch.zeros(1, dtype=torch.int32, device=dev),
+                  "out_ids": torch.zeros(bucket, dtype=torch.int32, device=dev), "graph": None}
+            st["vc"] = torch.zeros_like(st["kc"])
+            st["sin"] = torch.zeros_like(st["cos"])
+            self._static = {bucket: st}                    # one bucket alive at a time (28 KiB per row of capacity and plane pair)
+        kc, vc = st["kc"], st["vc"]
         for l in range(L):
             if hasattr(past, "layers"):                    # transformers >= 4.54: DynamicCache.layers[l].keys / .values
                 k, v = past.layers[l].keys, past.layers[l].values
@@ -414,30 +430,33 @@ class GraphDecoder:
         pos = (torch.arange(Lp, Lp + max_new_tokens, device=dev) + delta).view(1, 1, -1).expand(3, 1, -1)
         cos, sin = self.lm.rotary_emb(kc.new_zeros(1), pos)               # [3, 1, T, 128]
         ar = torch.arange(128, device=dev)
-        st = {"kc": kc, "vc": vc, "base": Lp,
-              "cos": cos[:, 0].permute(1, 0, 2)[:, self.sel, ar].to(torch.bfloat16).contiguous(),
-              "sin": sin[:, 0].permute(1, 0, 2)[:, self.sel, ar].to(torch.bfloat16).contiguous(),
-              "token": torch.tensor([first], dtype=torch.int32, device=dev), "step": torch.zeros(1, dtype=torch.int32, device=dev),
-              "out_ids": torch.zeros(max(max_new_tokens - 1, 1), dtype=torch.int32, device=dev)}
+        st["cos"][Lp:Lp + max_new_tokens].copy_(cos[:, 0].permute(1, 0, 2)[:, self.sel, ar].to(torch.bfloat16))
+        st["sin"][Lp:Lp + max_new_tokens].copy_(sin[:, 0].permute(1, 0, 2)[:, self.sel, ar].to(torch.bfloat16))
         tokens = [first]
         n_steps = max_new_tokens - 1                       # the prefill produced the first new token
         if n_steps > 0 and not (first in eos and min_new <= 1):
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                self._step(st)                             # warm-up outside the capture (lazy module loads, allocator)
-                side.synchronize()
-                st["step"].zero_()
+                if st["graph"] is None:
+                    st["step"].fill_(Lp)
+                    st["token"].fill_(first)
+                    self._step(st)                         # warm-up outside the capture (lazy module loads, allocator)
+                    side.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side):
+                        self._step(st)
+                    st["graph"] = graph
+                    self.captures += 1
+                graph = st["graph"]
+                st["step"].fill_(Lp)
                 st["token"].fill_(first)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    self._step(st)
                 done = 0
                 while done < n_steps:
                     n = min(self.chunk, n_steps - done)
                     for _ in range(n):
                         graph.replay()
-                    new = st["out_ids"][done:done + n].tolist()            # synchronises
+                    new = st["out_ids"][Lp + done:Lp + done + n].tolist()            # synchronises
                     done += n
                     stop = next((i for i, t in enumerate(new) if t in eos and len(tokens) + i + 1 >= max(min_new, 1)), None)
                     if stop is not None:

@@ -448,13 +448,23 @@ def test_graph_decoder_matches_generate():
         ref2 = m.generate(**inputs, max_new_tokens=40)
     got2 = dec.generate(max_new_tokens=40, **inputs)
     assert ref2.shape[1] == 37 + first + 1 and torch.equal(ref2, got2)
-    # a second call re-captures with another prompt length
+    # another prompt length and token budget in the same capacity bucket: the captured step is REUSED (nothing in it depends on the
+    # prompt: cache row and rotary row come from the device-side step counter), the tokens are still generate()'s
     ids3 = ids[:, :29].contiguous()
     m.generation_config.eos_token_id = None
     with torch.no_grad():
         ref3 = m.generate(input_ids=ids3, attention_mask=torch.ones_like(ids3), max_new_tokens=12, min_new_tokens=12)
     got3 = dec.generate(max_new_tokens=12, input_ids=ids3, attention_mask=torch.ones_like(ids3))
     assert torch.equal(ref3, got3)
+    assert dec.captures == 1
+    # a prompt that needs the next bucket: one more capture, stale rows of the first bucket's planes play no part
+    ids4 = torch.randint(20, 4000, (1, 1030), generator=torch.Generator().manual_seed(4)).cuda()
+    with torch.no_grad():
+        ref4 = m.generate(input_ids=ids4, attention_mask=torch.ones_like(ids4), max_new_tokens=10, min_new_tokens=10)
+    got4 = dec.generate(max_new_tokens=10, input_ids=ids4, attention_mask=torch.ones_like(ids4))
+    assert torch.equal(ref4, got4) and dec.captures == 2
+    got5 = dec.generate(max_new_tokens=40, **inputs)               # back to a short prompt: its bucket was dropped, captured again
+    assert torch.equal(ref, got5)
 
 
 def test_is_train_runs_the_visual_prior_through_the_facade(tmp_path):
