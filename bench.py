@@ -44,6 +44,20 @@ def flops_image(height, width, steps, T_pos, T_neg, cfg, layers=60, edit_hw=(102
     return f + vae
 
 
+def host_threads_per_rank(world, cpus=None):
+    """the ranks of one node share its host: the CPU-side parts of the model build (LoRA / adapter / VAE tensors are generated with torch
+    CPU ops) must not oversubscribe it N-fold, and more than 32 threads do not help a generator-bound build"""
+    cpus = cpus or os.cpu_count() or 8
+    return max(1, min(32, cpus // max(world, 1)))
+
+
+def launcher_command(n_gpus, argv, port, script=None):
+    """the command `python bench.py --gpus N` turns itself into: one rank per GPU under torch.distributed.run on 127.0.0.1 -- the
+    driver's own command line"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,8 +114,7 @@ def main():
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd = launcher_command(args.gpus, sys.argv[1:], port)
         print(f"[bench] spawning {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
@@ -126,9 +139,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
     if world > 1:
-        # the ranks share the host: the CPU-side parts of the model build (LoRA / adapter / VAE tensors are generated with torch CPU
-        # ops) must not oversubscribe it N-fold
-        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+        torch.set_num_threads(host_threads_per_rank(world))
 
     from physicedit_amd import synth, ops
     from physicedit_amd._lib import lib
@@ -147,13 +158,21 @@ def main():
     del sd
     torch.cuda.empty_cache()
     if args.lora_rank > 0:
-        # PhysicEdit LoRA, merged at load like validate.py does (hotload=False), 12 targets x layers
+        # PhysicEdit LoRA, merged at load like validate.py does (hotload=False), 12 targets x layers.  The tensors are generated
+        # with torch CPU ops: at N > 1 the ranks take turns two at a time (rank r starts when rank r - 2 has generated its set), so
+        # that eight processes do not all hammer the host's memory system in the same seconds
+        if dist is not None and world > 2:
+            for turn in range(rank // 2):
+                dist.barrier()
         n = 0
         for i in range(args.layers):
             lora = {k.replace("transformer_blocks.0.", f"transformer_blocks.{i}."): v.to(dev)
                     for k, v in synth.make_lora(4321 + i, 1, args.lora_rank).items()}
             n += eng.load_lora(lora)
         assert n == 12 * args.layers
+        if dist is not None and world > 2:
+            for turn in range(rank // 2, (world - 1) // 2):
+                dist.barrier()
     if args.fp8:
         eng.enable_fp8_computation()
         torch.cuda.empty_cache()
@@ -163,9 +182,17 @@ def main():
         from physicedit_amd._lib import lib
         assert lib().pe_debug_set(b"attn_variant", args.attn_variant) == 0
     torch.cuda.synchronize()
-    if rank == 0:
-        print(f"[bench] model ready in {time.time()-t0:.1f}s ({args.layers} layers, "
-              f"{torch.cuda.memory_allocated()/2**30:.1f} GiB resident)", file=sys.stderr)
+    ready_s = time.time() - t0
+    # every rank says when its model stood (stderr): a slow or failed rank of an N > 1 run is visible from the tail alone
+    print(f"[bench] rank {rank}/{world} (cuda:{local_rank}, {torch.get_num_threads()} host threads): model ready in {ready_s:.1f}s "
+          f"({args.layers} layers, {torch.cuda.memory_allocated()/2**30:.1f} GiB resident)", file=sys.stderr, flush=True)
+    ready_all = [ready_s]
+    if dist is not None:
+        ready_all = [None] * world
+        dist.all_gather_object(ready_all, ready_s)
+        if rank == 0:
+            print(f"[bench] all {dist.get_world_size()} RCCL ranks ready: " + " ".join(f"r{i}={t:.1f}s" for i, t in enumerate(ready_all)),
+                  file=sys.stderr, flush=True)
 
     # ---- inputs (resident in HBM before the timed region)
     n_img = args.warmup + args.steps
@@ -303,6 +330,8 @@ def main():
                        "attn_variant": args.attn_variant,
                        "batch_closing_collective": ("one RCCL all_gather of the final latents, inside the timed region" if dist is not None else None),
                        "per_rank_elapsed_s": [round(float(t), 4) for t in per_rank],
+                       "per_rank_model_ready_s": [round(float(t), 1) for t in ready_all],
+                       "host_threads_per_rank": torch.get_num_threads(),
                        "finite_outputs": ok},
             "determinism": (determinism or {}).get("bit_identical"),
             "self_check": determinism,
@@ -542,7 +571,7 @@ def pmc_traffic(args):
     c = rec.get("config", {})
     same = (c.get("layers") == args.layers and c.get("height") == args.height and c.get("width") == args.width and
             c.get("t_pos") == args.t_pos and c.get("t_neg") == args.t_neg and bool(c.get("fp8")) == bool(args.fp8))
-    # (the passes are collected on one stream: counters per launch of a (kernel, shape) do not depend on what the other stream runs)
+    # (the passes are collected on one stream; `traffic_source` says so when this run times two)
     if not same:
         return None, None, f"profiles/{os.path.basename(path)} was collected for another configuration ({rec.get('command')}): not reported"
     # the block GEMMs only (QKV 1224, MLP-up 1632, out-proj / MLP-down 408 work-groups at this geometry): the hoisted modulation
@@ -554,7 +583,9 @@ def pmc_traffic(args):
     traffic = sum(r["traffic_bytes_per_launch"] * r["launches"] for r in rows) / n
     busy = [r for r in rows if r.get("mfma_busy") is not None]
     mfma = sum(r["mfma_busy"] * r["launches"] for r in busy) / sum(r["launches"] for r in busy) if busy else None
-    return traffic, mfma, f"profiles/{os.path.basename(path)} ({rec.get('command')})"
+    note = " -- counters collected with ONE stream on the chip; the timed region of this run interleaves two, whose kernels share each L2 " \
+           "and the Infinity Cache, so its per-launch L2-miss bytes can differ" if args.dual_stream else ""
+    return traffic, mfma, f"profiles/{os.path.basename(path)} ({rec.get('command')}){note}"
 
 
 def cpu_baseline(args):

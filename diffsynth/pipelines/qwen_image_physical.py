@@ -309,6 +309,9 @@ class QwenImagePhysicPipeline:
         enc = self._load_dinov2()
         if isinstance(enc, Dinov2WithNorm):
             return enc
+        if not (hasattr(enc, "config") and hasattr(enc, "state_dict") and hasattr(getattr(enc, "config"), "num_attention_heads")):
+            # any other module mapping frames [B,3,H,W] to patch features [B,L,768] (documented since round 2): called as it is
+            return enc
         cached = getattr(self, "_dino_cache", None)
         if cached is None or cached[0] is not enc:
             cached = self._dino_cache = (enc, Dinov2WithNorm.from_transformers(enc, device=self.device, normalize=True))

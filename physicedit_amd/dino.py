@@ -32,6 +32,12 @@ class Dinov2WithNorm:
         sd = {k[len("encoder_model."):] if k.startswith("encoder_model.") else k: v for k, v in state_dict.items()}
         p = self.p = {k: v.to(device=self.device, dtype=BF).contiguous() for k, v in sd.items() if v.is_floating_point()}
         self.patch, self.heads, self.eps = int(patch_size), int(num_heads), float(layer_norm_eps)
+        need = ("embeddings.patch_embeddings.projection.weight", "embeddings.register_tokens", "embeddings.position_embeddings",
+                "encoder.layer.0.mlp.fc1.weight", "encoder.layer.0.attention.attention.query.weight")
+        missing = [k for k in need if k not in p]
+        if missing:
+            hint = " (a SwiGLU-MLP checkpoint: mlp.weights_in / weights_out are not supported)" if any("mlp.weights_in" in k for k in p) else ""
+            raise _lib.PeError(f"Dinov2WithNorm: not a DINOv2-with-registers state dict with fc1 / fc2 MLPs, missing {missing}{hint}")
         w = p["embeddings.patch_embeddings.projection.weight"]                      # [hidden, C, patch, patch]
         self.hidden = w.shape[0]
         if self.hidden != self.heads * 64:

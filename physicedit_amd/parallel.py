@@ -112,17 +112,31 @@ class CfgPairExchange:
         self.role = role
 
     @staticmethod
-    def make_pairs() -> "CfgPairExchange":
-        """Collective: every rank must call it.  Ranks (2k, 2k+1) form pair k."""
-        rank, world = world_info()
+    def make_pairs(group=None) -> "CfgPairExchange":
+        """Collective over `group` (default: the world): every rank of it must call it.  Ranks (2k, 2k+1) OF THE GROUP form pair k;
+        the pair groups are built from their global ranks, as dist.new_group wants them.  Creates world / 2 communicators: call it
+        once and keep the result (edit_batch caches it on the pipe)."""
+        rank, world = world_info(group)
         if world % 2:
             raise ValueError("CFG-pair split needs an even world size")
+        to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
         mine = None
         for k in range(world // 2):
-            g = dist.new_group([2 * k, 2 * k + 1])
+            g = dist.new_group([to_global(2 * k), to_global(2 * k + 1)])       # every rank of the default group takes part in every call
             if rank // 2 == k:
                 mine = g
         return CfgPairExchange(mine, rank % 2)
+
+    def agree_on_seed(self, seed):
+        """The two ranks of a pair must draw the SAME noise (and the same RandomCrop in training mode): a job without a seed would
+        take it from each process's own global RNG.  The pair's even rank decides: its seed (a fresh random one when the job has
+        none) is broadcast inside the pair."""
+        if self.role == 0 and seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        box = [seed]
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
 
     def exchange(self, pred: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         both = [torch.empty_like(pred), torch.empty_like(pred)]
@@ -157,7 +171,15 @@ def edit_batch(pipe, jobs: Sequence[dict], group=None, split_cfg: bool = False, 
         if world % 2:
             raise ValueError("split_cfg needs an even world size")
         if cfg_pair is None:
-            cfg_pair = CfgPairExchange.make_pairs()
+            # one set of pair communicators per (pipe, group), not one per call
+            cache = getattr(pipe, "_cfg_pair_cache", None)
+            if cache is None or cache[0] is not group:
+                cache = (group, CfgPairExchange.make_pairs(group))
+                try:
+                    pipe._cfg_pair_cache = cache
+                except AttributeError:
+                    pass
+            cfg_pair = cache[1]
         lanes, lane = world // 2, rank // 2
         owner = lambda u: 2 * (u % lanes)            # the pair's even rank contributes the (identical) result
     else:
@@ -172,7 +194,11 @@ def edit_batch(pipe, jobs: Sequence[dict], group=None, split_cfg: bool = False, 
     pil: Dict[int, "Image.Image"] = {}
     try:
         for u in mine:
-            img = pipe(**jobs[u])
+            job = jobs[u]
+            if cfg_pair is not None:
+                # both ranks of the pair must start from identical latents: an unseeded job gets the even rank's seed
+                job = dict(job, seed=cfg_pair.agree_on_seed(job.get("seed")))
+            img = pipe(**job)
             pil[u] = img
             if gather == "latents":
                 latents[u] = pipe.last_latents.detach().clone()

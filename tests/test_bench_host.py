@@ -27,3 +27,20 @@ def test_gpus_n_spawns_n_ranks_which_check_the_gpu_count():
     import torch
     if torch.cuda.device_count() < 2:
         assert r.returncode != 0 and "--gpus 2 but only" in out          # printed by the spawned ranks, not by the launcher
+
+
+def test_gpus_8_launcher_command_and_thread_cap():
+    """BASELINE configs[3] / the driver's SCALE run: `--gpus 8` becomes `torch.distributed.run --nnodes=1 --nproc-per-node=8` on
+    127.0.0.1 with the caller's flags passed through, and every rank caps its host threads at its share of the node."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29512)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29512"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert bench.host_threads_per_rank(8, cpus=256) == 32 and bench.host_threads_per_rank(8, cpus=64) == 8
+    assert bench.host_threads_per_rank(8, cpus=4) == 1 and bench.host_threads_per_rank(1, cpus=256) == 32
+    r = _run(["--gpus", "8", "--no-cpu-baseline"])
+    out = r.stderr + r.stdout
+    assert "[bench] spawning 8 ranks" in out and "--nproc-per-node=8" in out

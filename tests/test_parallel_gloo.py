@@ -175,28 +175,41 @@ class StubPipe:
 
 
 JOBS = [dict(prompt="a" * (3 + i), seed=10 + i, height=64, width=64 if i % 3 else 96) for i in range(5)]
+# BASELINE configs[3]'s literal shape: 16 images (CFG pairs) for 8 ranks; and fewer images than ranks, split over CFG pairs
+JOBS16 = [dict(prompt="b" * (2 + i % 5), seed=100 + i, height=64, width=64) for i in range(16)]
+JOBS4 = [dict(prompt="c" * (2 + i), seed=200 + i, height=64, width=64) for i in range(4)]
+JOB_SETS = {"5": JOBS, "16": JOBS16, "4": JOBS4}
 
 
-def _worker_edit(rank, world, port, split, gather, q):
+def _worker_edit(rank, world, port, split, gather, q, jobs_key="5"):
     import numpy as np
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    torch.set_num_threads(1 if world > 4 else 2)
     pipe = StubPipe()
-    res = parallel.edit_batch(pipe, JOBS, split_cfg=split, gather=gather)
+    jobs = JOB_SETS[jobs_key]
+    res = parallel.edit_batch(pipe, jobs, split_cfg=split, gather=gather)
+    if split:       # a second batch on the same pipe reuses the pair communicators (one make_pairs per pipe and group)
+        first = getattr(pipe, "_cfg_pair_cache", None)
+        parallel.edit_batch(pipe, jobs[:world // 2], split_cfg=True, gather="none")
+        assert first is not None and pipe._cfg_pair_cache is first
     out = [np.asarray(r) if gather == "image" else r.float().numpy() for r in res]
     q.put((rank, out, pipe.dit.forwards))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,split,gather", [(2, False, "image"), (2, True, "latents"), (4, True, "image")])
-def test_edit_batch_matches_single_process(world, split, gather):
+@pytest.mark.parametrize("world,split,gather,jobs_key", [(2, False, "image", "5"), (2, True, "latents", "5"), (4, True, "image", "5"),
+                                                         (8, False, "latents", "16"), (8, True, "latents", "4")])
+def test_edit_batch_matches_single_process(world, split, gather, jobs_key):
+    """also at world 8: configs[3]'s literal shape (16 jobs, 2 per rank, one closing all-gather of the latents) and 4 jobs on 4 CFG
+    pairs (split_cfg: every rank runs ONE forward per step of its pair's image)"""
     import numpy as np
+    JOBS = JOB_SETS[jobs_key]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_edit, args=(r, world, port, split, gather, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_edit, args=(r, world, port, split, gather, q, jobs_key)) for r in range(world)]
     for p in procs:
         p.start()
     got = {r: (o, f) for r, o, f in (q.get(timeout=600) for _ in range(world))}
@@ -210,12 +223,47 @@ def test_edit_batch_matches_single_process(world, split, gather):
         assert len(got[rank][0]) == len(JOBS)
         for u in range(len(JOBS)):
             assert np.array_equal(got[rank][0][u], single[u]), (rank, u)        # job order, bit-identical, any world size
-    # work really was divided: 2 steps x 2 forwards per job; a split pair runs ONE forward per step and rank
+    # work really was divided: 2 steps x 2 forwards per job; a split pair runs ONE forward per step and rank (+ the second, ungathered
+    # batch of world / 2 jobs the split workers run to check the communicator cache: one more job per pair)
     lanes = world // 2 if split else world
     for rank in range(world):
         lane = rank // 2 if split else rank
-        n_mine = len([u for u in range(len(JOBS)) if u % lanes == lane])
+        n_mine = len([u for u in range(len(JOBS)) if u % lanes == lane]) + (1 if split else 0)
         assert got[rank][1] == n_mine * 2 * (1 if split else 2), (rank, got[rank][1])
+
+
+def _worker_unseeded_pair(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    torch.manual_seed(1000 + rank)               # the two processes' global RNGs disagree, as they do in real life
+    pipe = StubPipe()
+    seen = []
+    orig = StubPipe.__call__
+    pipe_call = lambda **kw: (seen.append(kw.get("seed")), orig(pipe, **kw))[1]
+    pipe.__class__ = type("RecPipe", (StubPipe,), {"__call__": lambda self, **kw: pipe_call(**kw)})
+    res = parallel.edit_batch(pipe, [dict(prompt="abc", seed=None, height=64, width=64)], split_cfg=True, gather="latents")
+    q.put((rank, seen, res[0].float().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_cfg_unseeded_job_gets_one_seed_per_pair():
+    """a job with seed=None (the pipeline default) under split_cfg would draw its noise from each process's own global
+    RNG and the pair would silently combine forwards of different latents.  The pair's even rank now decides the seed."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unseeded_pair, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (s_, lat) for r, s_, lat in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] and got[0][0][0] is not None          # both ranks ran the job with the SAME, concrete seed
+    assert np.array_equal(got[0][1], got[1][1])
 
 
 def _worker_loop_pair(rank, world, port, q):
