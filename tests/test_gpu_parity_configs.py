@@ -136,8 +136,9 @@ def test_60_layers_headline_geometry():
 
 
 def test_60_layers_two_cfg_steps():
-    """Multi-step at depth: TWO CFG-4 steps of the 60-layer loop at S = 2208 / 2128 (512x512 target + 512x512 edit image, T_pos = 160
-    and T_neg = 80, 16 special tokens each) through DenoiseLoop's default form (two streams), against the oracle's loop in bf16
+    """Multi-step at depth: TWO CFG-4 steps of the 60-layer loop at S = 672 / 592 (256x256 target + 256x256 edit image, T_pos = 160
+    and T_neg = 80, 16 special tokens each: four 60-layer oracle forwards have to fit the suite's budget -- at 512x512 they took 238 s
+    of host time; depth x LENGTH is the test above) through DenoiseLoop's default form (two streams), against the oracle's loop in bf16
     (`qwen_image_physical.py:644-661`): the adapter's in-place accumulation on the special rows across steps (the second step's
     prompt embeddings are the first step's outputs), the CFG combine and the Euler update, at the depth where only single forwards
     were compared.  Bound: a 2-step schedule moves the latents by 0.5 pred per step and CFG 4 weighs the two forwards' errors by
@@ -151,20 +152,20 @@ def test_60_layers_two_cfg_steps():
     sd_dev = synth.make_state_dict_device(synth.dit_layout(60), 1234, dev)
     ad = synth.make_state_dict(synth.adapter_layout(), 4321)
     eng = QwenImageDiTEngine(sd_dev, ad, device=dev)
-    noise, edit, pe_p, mask_p = _inputs(512, 512, 512, 512, 160, 16, 3)
+    noise, edit, pe_p, mask_p = _inputs(256, 256, 256, 256, 160, 16, 3)
     pe_n = synth.make_prompt_emb(11, 80)
     mask_n = synth.make_special_token_mask(80, 16)
     loop = DenoiseLoop(eng, dual_stream=True)
     pp, pn = pe_p.cuda().clone(), pe_n.cuda().clone()
-    got = loop(noise.cuda(), pp, pn, mask_p, mask_n, 512, 512, num_inference_steps=2, cfg_scale=4.0, edit_latents=edit.cuda())
+    got = loop(noise.cuda(), pp, pn, mask_p, mask_n, 256, 256, num_inference_steps=2, cfg_scale=4.0, edit_latents=edit.cuda())
     torch.cuda.synchronize()
     threads = torch.get_num_threads()
     try:
         torch.set_num_threads(max(threads, min(32, os.cpu_count() or 16)))
-        ref = O.denoise_loop(HostView(sd_dev), ad, noise, pe_p, pe_n, mask_p, mask_n, 512, 512, 2, cfg_scale=4.0, edit_latents=edit)
+        ref = O.denoise_loop(HostView(sd_dev), ad, noise, pe_p, pe_n, mask_p, mask_n, 256, 256, 2, cfg_scale=4.0, edit_latents=edit)
     finally:
         torch.set_num_threads(threads)
-    st = record("configs[1]", "60 layers, 512x512 + 512x512 edit, TWO CFG-4 steps of the loop (two streams) vs the oracle's loop [bf16 oracle only]",
+    st = record("configs[1]", "60 layers, 256x256 + 256x256 edit, TWO CFG-4 steps of the loop (two streams) vs the oracle's loop [bf16 oracle only]",
                 got, ref)
     assert torch.isfinite(got.float()).all() and torch.isfinite(ref.float()).all()
     assert st["mean_abs_diff"] <= 2e-2 and st["max_abs_diff"] <= 0.25, st

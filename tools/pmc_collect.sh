@@ -2,9 +2,9 @@
 # PMC passes over the HEADLINE kernels and shapes: the 60-layer bench command with 2 denoising steps (4 forwards = 240 launches
 # of every block kernel; per-launch counters do not depend on the step count).  Separate passes as MI355X_MICROARCH.md
 # prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with the sys/hip/hsa trace domains).
-# usage (GPU box, from the repo root):  bash tools/pmc_collect.sh gpurun_out/pmc_r03 [extra bench flags]
+# usage (GPU box, from the repo root):  bash tools/pmc_collect.sh gpurun_out/pmc_r04 [extra bench flags]
 set -u
-OUT=${1:-gpurun_out/pmc_r03}; shift || true
+OUT=${1:-gpurun_out/pmc_r04}; shift || true
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 CMD="python bench.py --layers 60 --inference-steps 2 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-probes --single-stream $*"
 mkdir -p "$OUT"
