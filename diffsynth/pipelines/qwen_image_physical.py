@@ -317,19 +317,26 @@ class QwenImagePhysicPipeline:
             cached = self._dino_cache = (enc, Dinov2WithNorm.from_transformers(enc, device=self.device, normalize=True))
         return cached[1]
 
-    def dino_input_preprocess(self, frames, dino_input_size: int = None) -> torch.Tensor:
+    def dino_input_preprocess(self, frames, dino_input_size: int = None, crop_offsets=None) -> torch.Tensor:
         """dino_input_preprocess (:1043-1057): torchvision Resize(1.5 * size, BICUBIC) on the shorter edge, RandomCrop(size), ToTensor,
         ImageNet mean / std.  torchvision is not in this image: restated with PIL (what torchvision's Resize calls for PIL inputs)
-        and torch.randint for the crop offsets (RandomCrop.get_params) -- parity unpinned, and random by construction."""
+        and torch.randint for the crop offsets (RandomCrop.get_params; random by construction).  crop_offsets: [(top, left)] per frame
+        instead of the random draw -- tests/golden G20 pins the resize rule, PIL's bicubic and the crop / ToTensor / Normalize
+        arithmetic on a fixed offset (generated without torchvision: its RandomCrop itself stays unpinned)."""
         size = dino_input_size or self.dino_input_size
         first = int(size * 1.5)
         out = []
-        for im in frames:
+        for n_, im in enumerate(frames):
             w, h = im.size
             nw, nh = (first, int(first * h / w)) if w <= h else (int(first * w / h), first)
             im = im.convert("RGB").resize((nw, nh), Image.BICUBIC)
-            i = int(torch.randint(0, nh - size + 1, size=(1,)).item())
-            j = int(torch.randint(0, nw - size + 1, size=(1,)).item())
+            if crop_offsets is not None:
+                i, j = crop_offsets[n_]
+                if not (0 <= i <= nh - size and 0 <= j <= nw - size):
+                    raise ValueError(f"crop offset {(i, j)} outside the resized frame {(nh, nw)}")
+            else:
+                i = int(torch.randint(0, nh - size + 1, size=(1,)).item())
+                j = int(torch.randint(0, nw - size + 1, size=(1,)).item())
             t = torch.from_numpy(np.array(im.crop((j, i, j + size, i + size)), dtype=np.uint8)).permute(2, 0, 1).to(torch.float32).div(255)
             out.append(t)
         x = torch.stack(out).to(self.device)

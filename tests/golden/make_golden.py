@@ -667,6 +667,33 @@ def G10_image():
     save("G10_image", {"pre": x, "post_in": y, "post_u8": torch.from_numpy(np.array(img))})
 
 
+def G20_dino_preprocess():
+    """The DINOv2 input preprocessing of the training-time prior (qwen_image_physical.py:1043-1057: Resize(int(1.5 * 224), BICUBIC),
+    RandomCrop(224), ToTensor, Normalize).  torchvision is not installed here, so the reference's transform objects cannot run; this
+    fixture is derived from what they are DEFINED to do for a PIL input -- torchvision.transforms.functional.resize with an int size
+    scales the shorter edge to it and the longer to int(size * long / short), then calls PIL's Image.resize(..., BICUBIC) -- with a
+    FIXED crop offset in place of RandomCrop.get_params' draw.  It pins the size rule, PIL's bicubic kernel on this image and the
+    ToTensor / Normalize arithmetic; RandomCrop's random draw stays unpinned (random by construction)."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tiny_vl
+    outs = {}
+    for name, (w, h, top, left) in {"landscape": (300, 200, 40, 100), "portrait": (180, 260, 77, 5)}.items():
+        im = tiny_vl.make_image(w, h, 3)
+        short, long_ = min(w, h), max(w, h)
+        new_long = int(336 * long_ / short)
+        size = (336, new_long) if w <= h else (new_long, 336)                 # PIL takes (width, height)
+        rs = im.convert("RGB").resize(size, Image.BICUBIC)
+        crop = np.array(rs, dtype=np.uint8)[top:top + 224, left:left + 224]
+        x = torch.from_numpy(crop.copy()).permute(2, 0, 1).to(torch.float32).div(255)
+        mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+        outs[f"{name}.crop_u8"] = torch.from_numpy(crop.copy())
+        outs[f"{name}.normalized_sample"] = ((x - mean) / std)[:, ::16, ::16].contiguous()
+    save("G20_dino_preprocess", outs, meta={"landscape": "w300 h200 seed3 top40 left100", "portrait": "w180 h260 seed3 top77 left5",
+                                            "pil": __import__("PIL").__version__})
+
+
 def G12_prologue():
     """Prompt prologue (QwenImageUnit_PhysicalVerbalEmbedder + QwenImageUnit_PromptEmbedder, qwen_image_physical.py:732-990)
     run by the REFERENCE's units on the synthetic tiny Qwen2.5-VL stack of tests/tiny_vl.py (byte-level tokenizer, seeded

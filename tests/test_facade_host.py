@@ -116,3 +116,31 @@ def test_fp8_attention_flag_warns_once():
         D._warn_fp8_attention_once()
         D._warn_fp8_attention_once()
     assert len(rec) == 1 and "FlashAttention-3" in str(rec[0].message)
+
+
+def test_G20_dino_preprocess_resize_and_crop():
+    """The DINOv2 input preprocessing (qwen_image_physical.py:1043-1057) on fixed crop offsets against tests/golden G20: shorter edge
+    to int(1.5 * 224) by the torchvision size rule, PIL bicubic, crop, ToTensor, ImageNet Normalize.  (torchvision's RandomCrop draw
+    itself cannot be pinned: random by construction, and torchvision is not installed.)"""
+    import os
+    import sys
+    import types
+    from safetensors.torch import load_file
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tiny_vl
+    from diffsynth.pipelines.qwen_image_physical import QwenImagePhysicPipeline
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G20_dino_preprocess.safetensors"))
+    ns = types.SimpleNamespace(dino_input_size=224, device="cpu")
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    for name, (w, h, top, left) in {"landscape": (300, 200, 40, 100), "portrait": (180, 260, 77, 5)}.items():
+        x = QwenImagePhysicPipeline.dino_input_preprocess(ns, [tiny_vl.make_image(w, h, 3)], crop_offsets=[(top, left)])
+        assert x.shape == (1, 3, 224, 224)
+        u8 = ((x[0].float() * std + mean) * 255).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0)
+        assert torch.equal(u8, g[f"{name}.crop_u8"]), name
+        assert torch.allclose(x[0].float()[:, ::16, ::16], g[f"{name}.normalized_sample"], atol=1e-6), name
+    # an offset outside the resized frame is refused, and without offsets two calls draw different crops of the right size
+    with pytest.raises(ValueError):
+        QwenImagePhysicPipeline.dino_input_preprocess(ns, [tiny_vl.make_image(300, 200, 3)], crop_offsets=[(200, 0)])
+    a = QwenImagePhysicPipeline.dino_input_preprocess(ns, [tiny_vl.make_image(300, 200, 3)])
+    assert a.shape == (1, 3, 224, 224)
