@@ -455,9 +455,8 @@ class QwenImagePhysicPipeline:
             raise _lib.PeError("inpaint_mask needs input_image (the reference's step() blends towards the INPUT latents)")
         if blockwise_controlnet_inputs is not None and self.blockwise_controlnet is None:
             raise _lib.PeError("blockwise_controlnet_inputs given but no block-wise ControlNet checkpoint was loaded")
-        if enable_fp8_attention:
-            from physicedit_amd.dit import _warn_fp8_attention_once
-            _warn_fp8_attention_once()       # accepted; bf16 attention, as the reference without FlashAttention-3 (qwen_image_dit.py:14-39)
+        # enable_fp8_attention: the e4m3 attention branch (qwen_image_dit.py:24-35), which the reference only reaches where
+        # FlashAttention-3 imports; here it is the library's own kernel, passed down to every forward of the loop
         if is_train and self.use_special_tokens and (middle_key_frames is None or not isinstance(edit_image, Image.Image)):
             raise _lib.PeError("is_train=True runs the training-time prior (PhysicalVisualEmbedder, :992-1120) and needs "
                                "middle_key_frames and one edit_image; inference scripts pass is_train=False")
@@ -548,7 +547,8 @@ class QwenImagePhysicPipeline:
                        denoising_strength=denoising_strength, blockwise_controlnet=self.blockwise_controlnet,
                        blockwise_controlnet_inputs=blockwise_controlnet_inputs, blockwise_controlnet_conditioning=ctl_cond,
                        eligen_posi=eligen_posi, eligen_nega=eligen_nega, input_latents=x0 if mask8 is not None else None,
-                       inpaint_mask=mask8, edit_rope_interpolation=edit_rope_interpolation)
+                       inpaint_mask=mask8, edit_rope_interpolation=edit_rope_interpolation,
+                       enable_fp8_attention=bool(enable_fp8_attention))
         self.last_latents = latents
         # vae.decode + vae_output_to_image (:664-667) in one composite: the last kernel emits HWC uint8
         u8 = self.vae.decode(latents, output_u8=True, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)

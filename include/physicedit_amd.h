@@ -147,6 +147,15 @@ int pe_qkv_rmsnorm_rope_scaled(const void* x, int ldx, const void* Wqkv, const v
                                float q_scale, void* stream);
 int pe_flash_attn_prescaled(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo,
                             float scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The reference's enable_fp8_attention branch as one operator (it takes it only where FlashAttention-3 exists; here it is this kernel):
+ * q, k, vt in pe_flash_attn's bf16 layouts with a PLAIN Q.  Computes the three global standard deviations (torch.std semantics, bf16),
+ * e4m3(q / q_std), e4m3(k / k_std), e4m3(v / v_std), softmax(q8 k8^T q_std k_std / sqrt(128)) with P cast to e4m3 for the second
+ * e4m3 matmul, and bf16(bf16(out) * v_std).  scratch: pe_flash_attn_fp8_scratch_bytes(H, S_pad) bytes, 256-byte aligned; workspace
+ * as for pe_flash_attn (nullable).  What FlashAttention-3 does INSIDE its kernel is restated from its published design (oracle
+ * flash_attention_fp8): parity of the P quantisation is unpinned. */
+size_t pe_flash_attn_fp8_scratch_bytes(int H, int S_pad);
+int pe_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
+                      size_t scratch_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* Optional scratch for pe_flash_attn (16-B aligned).  With it, the (head, q-block) items that do not fill a
  * whole round of the 256 CUs are split along KV and merged by a second small kernel (load balance); without
  * it (NULL) the launch is a single kernel. */
@@ -327,6 +336,10 @@ typedef struct pe_dit_call {
      * token of prompt i = bit i.  Attention between tokens a, b is allowed iff words[a] & words[b] != 0 -- the reference's
      * additive 0 / -inf mask.  Default attention kernel only. */
     const unsigned int* attn_words;
+    /* != 0: qwen_image_flash_attention(enable_fp8_attention=True) (models/qwen_image_dit.py:24-35): q, k, v / their global std -> e4m3,
+     * both attention matmuls on e4m3 operands, softmax_scale = q_std k_std / sqrt(128), output x v_std (pe_flash_attn_fp8).  Like the
+     * reference, only without a mask: ignored when attn_words is set. */
+    int fp8_attention;
 } pe_dit_call;
 
 /* Runtime ("hot") LoRA operands of one block -- load_lora(hotload=True), qwen_image_physical.py:264-272 +

@@ -229,7 +229,33 @@ def _heads(x: torch.Tensor, h: int = 24) -> torch.Tensor:
     return x.reshape(B, S, h, HD // h).permute(0, 2, 1, 3)
 
 
-def joint_attention(sd: SD, p: str, image, text, rope, attention_mask=None) -> Tuple[torch.Tensor, torch.Tensor]:
+def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dtype=torch.float8_e4m3fn) -> torch.Tensor:
+    """qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35: q, k, v [B, H, S, D] bf16 are divided by their
+    global standard deviations (torch.std: unbiased, over the whole tensor, a bf16 scalar), cast to float8_e4m3fn, handed to
+    FlashAttention-3 with softmax_scale = q_std * k_std / sqrt(D), and the output (bf16) is multiplied by v_std.
+
+    PARITY UNPINNED for the kernel itself: flash_attn_interface (FA3, Hopper) cannot run here or in the reference's CPU path, so
+    what it does INSIDE -- in particular how it quantises P for the second matmul -- is restated from its published design: both
+    matmuls on e4m3 operands with fp32 accumulation, softmax statistics in fp32, P cast to e4m3 (p_dtype=None: P kept in fp32,
+    the upper bound on what any such kernel can reach).  Everything outside the kernel (the three std, the two casts, the scale,
+    the output product and its roundings) is the reference's own arithmetic.  -> [B, H, S, D] bf16."""
+    origin = q.dtype
+    q_std, k_std, v_std = q.std(), k.std(), v.std()
+    q8, k8, v8 = (q / q_std).to(torch.float8_e4m3fn), (k / k_std).to(torch.float8_e4m3fn), (v / v_std).to(torch.float8_e4m3fn)
+    scale = float(q_std * k_std / math.sqrt(q.size(-1)))                 # a bf16 tensor product, then the python float FA3 receives
+    s = torch.matmul(q8.float(), k8.float().transpose(-1, -2)) * scale   # e4m3 products are exact in fp32; fp32 accumulation
+    pr = torch.softmax(s, dim=-1)                                        # FA3: the row max gives P <= 1 before the cast
+    if p_dtype is not None:
+        # the kernel quantises the UN-normalised exp(s - max) and divides the accumulated output by the fp32 row sum afterwards
+        m = s.amax(dim=-1, keepdim=True)
+        e = torch.exp(s - m)
+        x = torch.matmul(e.to(p_dtype).float(), v8.float()) / e.sum(dim=-1, keepdim=True)
+    else:
+        x = torch.matmul(pr, v8.float())
+    return x.to(origin) * v_std
+
+
+def joint_attention(sd: SD, p: str, image, text, rope, attention_mask=None, fp8_attention: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     # QwenDoubleStreamAttention.forward, qwen_image_dit.py:274-316
     a = p + "attn."
     img_q = _linear(sd, a + "to_q", image)
@@ -249,8 +275,11 @@ def joint_attention(sd: SD, p: str, image, text, rope, attention_mask=None) -> T
     q = torch.cat([txt_q, img_q], dim=2)
     k = torch.cat([txt_k, img_k], dim=2)
     v = torch.cat([txt_v, img_v], dim=2)
-    # qwen_image_flash_attention, SDPA branch (:37-38); CPU has no FA3
-    x = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask)
+    # qwen_image_flash_attention, SDPA branch (:37-38); CPU has no FA3.  fp8_attention: the FA3 e4m3 branch (:24-35) as restated above
+    if fp8_attention and attention_mask is None:
+        x = flash_attention_fp8(q, k, v)
+    else:
+        x = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask)
     B, H, S, D = x.shape
     x = x.permute(0, 2, 1, 3).reshape(B, S, H * D).to(q.dtype)
     txt_o, img_o = x[:, :seq_txt, :], x[:, seq_txt:, :]
@@ -266,7 +295,7 @@ def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return _linear(sd, p + "net.2", x)
 
 
-def block_forward(sd: SD, i: int, image, text, temb, rope, attention_mask=None) -> Tuple[torch.Tensor, torch.Tensor]:
+def block_forward(sd: SD, i: int, image, text, temb, rope, attention_mask=None, fp8_attention: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     # QwenImageTransformerBlock.forward, qwen_image_dit.py:359-401.  Returns (text, image).
     p = f"transformer_blocks.{i}."
     D = image.shape[-1]
@@ -278,7 +307,7 @@ def block_forward(sd: SD, i: int, image, text, temb, rope, attention_mask=None) 
 
     img_m, img_gate = _modulate(F.layer_norm(image, (D,), eps=1e-6), img_mod_attn)
     txt_m, txt_gate = _modulate(F.layer_norm(text, (D,), eps=1e-6), txt_mod_attn)
-    img_attn, txt_attn = joint_attention(sd, p, img_m, txt_m, rope, attention_mask)
+    img_attn, txt_attn = joint_attention(sd, p, img_m, txt_m, rope, attention_mask, fp8_attention)
     image = image + img_gate * img_attn
     text = text + txt_gate * txt_attn
 
@@ -515,7 +544,7 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
              height: int, width: int, edit_latents=None,
              t_min: float = 20.0, t_max: float = 1000.0, controlnets=None, progress_id: int = 0,
              num_inference_steps: int = 1, entity_prompt_emb=None, entity_masks=None, capture: Optional[dict] = None,
-             edit_rope_interpolation: bool = False, pseudo_special_emb=None) -> torch.Tensor:
+             edit_rope_interpolation: bool = False, pseudo_special_emb=None, enable_fp8_attention: bool = False) -> torch.Tensor:
     """One DiT forward at inference (is_train=False).  MUTATES `prompt_emb` IN PLACE on the
     special-token rows exactly as the reference does (:1336).
     `controlnets`: list of dicts {"sd": controlnet state dict, "conditioning": latents [1,16|17,h8,w8], "scale", "start", "end"}
@@ -551,7 +580,7 @@ def model_fn(sd: SD, ad: Optional[SD], latents: torch.Tensor, timestep: torch.Te
     processed = [controlnet_preprocess(c["sd"], c["conditioning"]) for c in controlnets] if controlnets else None
 
     for i in range(num_layers_of(sd)):
-        text, image = block_forward(sd, i, image, text, conditioning, (vid_f, txt_f), attention_mask)
+        text, image = block_forward(sd, i, image, text, conditioning, (vid_f, txt_f), attention_mask, enable_fp8_attention)
         if processed is not None:                          # :1389-1396
             image_slice = image[:, :image_seq_len].clone()
             res = 0

@@ -92,11 +92,12 @@ class DitCall(C.Structure):
         ("step", c_int), ("noise_pred", c_void_p),
         ("n_control", c_int), ("control", ControlInput * 4),
         ("attn_words", c_void_p),
+        ("fp8_attention", c_int),
     ]
 
 
 # name -> (restype, argtypes); every symbol include/physicedit_amd.h declares
-ABI_VERSION = 6   # include/physicedit_amd.h: bumped on any signature / struct change
+ABI_VERSION = 7   # include/physicedit_amd.h: bumped on any signature / struct change
 
 SIGNATURES = {
     "pe_last_error": (C.c_char_p, []),
@@ -124,6 +125,9 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "pe_flash_attn_prescaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                         c_size_t, c_void_p]),
+    "pe_flash_attn_fp8_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "pe_flash_attn_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                  c_size_t, c_void_p]),
     "pe_flash_attn_masked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                      c_size_t, c_void_p, c_int, c_void_p]),
     "pe_flash_attn_workspace_bytes": (c_size_t, [c_int, c_int]),

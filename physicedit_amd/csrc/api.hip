@@ -32,7 +32,7 @@ using namespace pe;
 extern "C" {
 
 const char* pe_last_error(void) { return g_err; }
-int pe_abi_version(void) { return 6; }
+int pe_abi_version(void) { return 7; }
 #ifndef PE_SRC_HASH
 #define PE_SRC_HASH "unknown"
 #endif
@@ -182,6 +182,13 @@ int pe_flash_attn_masked(const void* q, const void* k, const void* vt, void* out
 }
 
 size_t pe_flash_attn_workspace_bytes(int H, int S) { return flash_attn_workspace_bytes(H, S); }
+
+size_t pe_flash_attn_fp8_scratch_bytes(int H, int S_pad) { return flash_attn_fp8_scratch_bytes(H, S_pad); }
+
+int pe_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
+                      size_t scratch_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    return launch_flash_attn_fp8(q, k, vt, out, H, S, S_pad, ldo, scratch, scratch_bytes, workspace, workspace_bytes, (hipStream_t)stream);
+}
 
 int pe_ln_modulate(const void* x, void* out, int rows, int dim, int rows_a, const void* shift_a,
                    const void* scale_a, const void* shift_b, const void* scale_b, float eps, void* stream) {

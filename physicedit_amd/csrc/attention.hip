@@ -33,6 +33,8 @@
 
 namespace pe {
 
+typedef __attribute__((ext_vector_type(8))) int i32x8f;
+typedef __attribute__((ext_vector_type(4))) int i32x4f;
 constexpr int KV_TILE = 64;
 constexpr int KDEPTH = 4;   // K-fragment ds_reads kept in flight ahead of the QK^T MFMAs
 constexpr int ATT_STAGE = 2 * KV_TILE * 128 * 2;  // K tile 16 KiB + Vt tile 16 KiB
@@ -718,7 +720,8 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
 // merge the `split` partials of each leftover (head, q-block): O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M)
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o,
                                                            const float* __restrict__ part_ml, bf16* __restrict__ out,
-                                                           int S, int ldo, AttnPlan plan, int Q_BLOCK) {
+                                                           int S, int ldo, AttnPlan plan, int Q_BLOCK,
+                                                           const float* __restrict__ out_scale = nullptr) {
     // one block = 8 query rows x 32 four-column chunks of one leftover item (grid.x = items * Q_BLOCK/8: the merge is a
     // short dependent chain per element, so it wants many small blocks, not a loop)
     const int per_item = Q_BLOCK / 8;
@@ -748,6 +751,11 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
     bf16x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[j] * inv);
+    if (out_scale != nullptr) {                 // the e4m3 form: x.to(bf16) * v_std, a second bf16 rounding
+        const float vs = *out_scale;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)o[j] * vs);
+    }
     *(bf16x4*)(out + (size_t)q * ldo + head * 128 + c * 4) = o;
 }
 
@@ -837,6 +845,368 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     if (rc == PE_OK && plan.split > 1) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3((total - plan.n_full) * (Q_BLOCK / 8)), dim3(256), 0, stream, part_o, part_ml,
                            (bf16*)out, S, ldo, plan, Q_BLOCK);
+        rc = check_launch("attn_combine_kernel");
+    }
+    prof_end(slot, stream);
+    return rc;
+}
+
+// ================================================================================================================
+// e4m3 attention: qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35 -- the branch the reference only takes
+// with FlashAttention-3 on Hopper.  q, k, v are divided by their GLOBAL standard deviations (torch.std over the whole [1,H,S,128]
+// tensor: unbiased, a bf16 scalar), cast to float8_e4m3fn, both matmuls run on e4m3 operands (CDNA4: v_mfma_scale_f32_32x32x64_f8f6f4
+// with unit block scales, 2x the bf16 rate), softmax_scale = q_std * k_std / sqrt(128), and the bf16 output is multiplied by v_std.
+// What FA3 does inside is restated from its published design (oracle/physicedit_oracle.py flash_attention_fp8: P = exp(s - max) cast
+// to e4m3, fp32 row sums and accumulation): parity of the P quantisation itself is UNPINNED -- FA3 cannot run here.
+//
+//   attn_fp8_stats_kernel / _finish : sum and sum of squares of Q, K (rows < S) and Vt, in double from fp32 per-thread partials, in a
+//                                     fixed order -> {q_std, k_std, v_std} rounded to bf16, scale_log2 = bf16r(bf16r(q_std k_std) /
+//                                     sqrt(128)) * log2 e
+//   attn_fp8_quant_kernel           : Q8, K8 [H][S_pad][128] = e4m3(bf16r(x / std)); Vt8 [H][128][S_pad] likewise, keys re-ordered
+//                                     inside every 64-key tile so that the P.V MFMA needs no shuffle (below)
+//   flash_attn_fp8_kernel           : 8 waves x 32 query rows like flash_attn_kernel; a KV tile is 8 KiB of K8 + 8 KiB of Vt8.
+// Operand layout of the e4m3 MFMA (tools/microbench/mfma_scale_f8_layout_probe.hip): lane l supplies row l & 31 and the 32
+// contiguous bytes k = 32 (l >> 5) .. + 31; D as the bf16 MFMA.  S^T = K . Q^T leaves lane (q = l & 31, h = l >> 5) with the scores of
+// keys 32 s2 + 8 a + 4 h + b (r = 4 a + b of accumulator s2): 32 of the tile's 64 keys, i.e. exactly the 32 bytes of ITS half of
+// the P.V MFMA's 64 k-slots once packed to e4m3 -- k-slot 32 h + j (j = 16 s2 + 4 a + b) is key 32 s2 + 8 a + 4 h + b, which is the
+// order Vt8 stores a tile's keys in.
+// ================================================================================================================
+constexpr int F8_STAGE = 2 * KV_TILE * 128;       // K8 tile 8 KiB + Vt8 tile 8 KiB
+constexpr int F8_LDS = 2 * F8_STAGE;
+constexpr int F8_STAT_WGS = 512;
+
+// grid (F8_STAT_WGS, 3): tensor z = Q (rows < S of every head), K (same), Vt (all S_pad columns: the pad columns are zero)
+__global__ void __launch_bounds__(256) attn_fp8_stats_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                             const bf16* __restrict__ Vt, int H, int S, int S_pad,
+                                                             double* __restrict__ part) {
+    __shared__ double red[2][4];
+    const int z = (int)blockIdx.y;
+    const bf16* base = z == 0 ? Q : z == 1 ? K : Vt;
+    // rows of 128 elements; Q / K: row r of head h is valid iff r < S.  Vt: every row d of a head has S_pad columns = S_pad / 128 ... walk
+    // it as [H * 128][S_pad] in chunks of 8 elements
+    const size_t n8 = z < 2 ? (size_t)H * S_pad * 16 : (size_t)H * 128 * (S_pad / 8);
+    float s1 = 0.f, s2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;
+    int cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)F8_STAT_WGS * 256) {
+        if (z < 2) {
+            const size_t row = i >> 4;                      // 16 chunks of 8 per 128-wide row
+            if ((int)(row % (size_t)S_pad) >= S) continue;
+        }
+        const bf16x8 v = *(const bf16x8*)(base + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (float)v[j];
+            s1 += x;
+            s2 = __builtin_fmaf(x, x, s2);
+        }
+        if (++cnt == 64) { d1 += (double)s1; d2 += (double)s2; s1 = s2 = 0.f; cnt = 0; }      // fp32 partials of <= 512 elements
+    }
+    d1 += (double)s1;
+    d2 += (double)s2;
+    for (int o = 32; o > 0; o >>= 1) {
+        d1 += __shfl_xor(d1, o, 64);
+        d2 += __shfl_xor(d2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d1; red[1][threadIdx.x >> 6] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((size_t)z * F8_STAT_WGS + blockIdx.x) * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[((size_t)z * F8_STAT_WGS + blockIdx.x) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+// stats[0..2] = q_std, k_std, v_std (bf16 values as float), stats[3] = softmax scale in the log2 domain
+__global__ void __launch_bounds__(64) attn_fp8_stats_finish_kernel(const double* __restrict__ part, double n, float* __restrict__ stats) {
+    const int z = (int)threadIdx.x;
+    if (z >= 3) return;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < F8_STAT_WGS; ++i) {
+        a += part[((size_t)z * F8_STAT_WGS + i) * 2];
+        b += part[((size_t)z * F8_STAT_WGS + i) * 2 + 1];
+    }
+    const double mean = a / n;
+    const double var = (b - n * mean * mean) / (n - 1.0);           // torch.std: unbiased
+    stats[z] = bf16r((float)sqrt(var > 0.0 ? var : 0.0));
+    __syncthreads();
+    if (z == 0) {
+        const float qk = bf16r(stats[0] * stats[1]);                 // q_std * k_std: a bf16 tensor product ...
+        stats[3] = bf16r(qk / 11.3137084989847603904f) * 1.44269504088896340736f;      // ... / sqrt(128): bf16 again; then log2 e for exp2
+    }
+}
+
+// Q8 / K8: thread = 16 consecutive elements of a row; Vt8: thread = 16 consecutive BYTE positions of a row's tile (two 8-element groups of
+// the perm16 source order: see the layout note above)
+__global__ void __launch_bounds__(256) attn_fp8_quant_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                             const bf16* __restrict__ Vt, uint8_t* __restrict__ Q8,
+                                                             uint8_t* __restrict__ K8, uint8_t* __restrict__ Vt8, int H, int S_pad,
+                                                             const float* __restrict__ stats) {
+    const int z = (int)blockIdx.y;
+    const size_t n16 = (size_t)H * S_pad * 8;          // 16-element groups per tensor
+    const float sd = stats[z];
+    auto q16 = [&](const bf16x8 a, const bf16x8 b) -> u32x4 {
+        float f[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f[j] = bf16r((float)a[j] / sd); f[8 + j] = bf16r((float)b[j] / sd); }      // x / std: a bf16 tensor
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack4_e4m3(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]);
+        return o;
+    };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        if (z < 2) {
+            const bf16* src = (z == 0 ? Q : K) + i * 16;
+            *(u32x4*)((z == 0 ? Q8 : K8) + i * 16) = q16(*(const bf16x8*)src, *(const bf16x8*)(src + 8));
+        } else {
+            // row = i / (S_pad / 16) of [H * 128], p16 = 16-byte slot inside the row: tile = p16 >> 2, hh = (p16 >> 1) & 1, s2 = p16 & 1
+            const int per_row = S_pad / 16;
+            const size_t row = i / per_row;
+            const int p16 = (int)(i - row * per_row);
+            const int tile = p16 >> 2, hh = (p16 >> 1) & 1, s2 = p16 & 1;
+            const bf16* src = Vt + row * S_pad + tile * 64 + (2 * s2) * 16 + 8 * hh;
+            *(u32x4*)(Vt8 + row * S_pad + tile * 64 + 32 * hh + 16 * s2) = q16(*(const bf16x8*)src, *(const bf16x8*)(src + 16));
+        }
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2)
+flash_attn_fp8_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict__ K8, const uint8_t* __restrict__ Vt8,
+                      bf16* __restrict__ out, int S, int S_pad, int ldo, const float* __restrict__ stats, AttnPlan plan,
+                      float* __restrict__ part_o, float* __restrict__ part_ml) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Q_BLOCK = NW * 32;
+    static_assert(NW == 8, "one K8 piece and one Vt8 piece per wave");
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int l31 = lane & 31, h = lane >> 5;
+    const float scale_log2 = stats[3], v_std = stats[2];
+    const int nqb = plan.nqb;
+    const int nt_all = (S + KV_TILE - 1) / KV_TILE;
+    int item, t_begin = 0, t_end = nt_all, part_slot = -1;
+    if ((int)blockIdx.x < plan.n_full) {
+        item = xcd_remap((int)blockIdx.x, plan.n_full);
+    } else {
+        const int j = (int)blockIdx.x - plan.n_full;
+        item = plan.n_full + j / plan.split;
+        const int part = j - (j / plan.split) * plan.split;
+        if (plan.split > 1) {
+            t_begin = (int)((long long)nt_all * part / plan.split);
+            t_end = (int)((long long)nt_all * (part + 1) / plan.split);
+            part_slot = j;
+        }
+    }
+    const int head = item / nqb;
+    const int qb = item - head * nqb;
+    const int q0 = qb * Q_BLOCK + w * 32;
+    const uint8_t* Qh = Q8 + (size_t)head * S_pad * 128;
+    const uint8_t* Kh = K8 + (size_t)head * S_pad * 128;
+    const uint8_t* Vh = Vt8 + (size_t)head * 128 * S_pad;
+
+    i32x8f qf[2];            // Q fragments (B operand): query row l31, bytes 64 kk + 32 h .. + 31
+    {
+        const int qrow = min(q0 + l31, S - 1);
+        const uint8_t* qp = Qh + (size_t)qrow * 128 + h * 32;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const i32x4f lo = *(const i32x4f*)(qp + kk * 64), hi = *(const i32x4f*)(qp + kk * 64 + 16);
+            qf[kk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+    // staging: wave w moves K8 piece w (8 key rows x 128 B) and Vt8 piece w (16 d rows x 64 B): 16-byte chunk c of row r sits at
+    // chunk c ^ (r & 7) (K8) / c ^ ((r >> 1) & 3) (Vt8) of the LDS row
+    const uint8_t* k_src;
+    const uint8_t* v_src;
+    {
+        const int krow = w * 8 + (lane >> 3);
+        k_src = Kh + (size_t)krow * 128 + (((lane & 7) ^ (krow & 7)) << 4);
+        const int vrow = w * 16 + (lane >> 2);
+        v_src = Vh + (size_t)vrow * S_pad + (((lane & 3) ^ ((vrow >> 1) & 3)) << 4);
+    }
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * F8_STAGE + w * 1024;
+        glds16(k_src + (size_t)t * KV_TILE * 128, base);
+        glds16(v_src + t * KV_TILE, base + KV_TILE * 128);
+    };
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ksw = l31 & 7, vsw = (l31 >> 1) & 3;
+
+    auto rd32 = [&](const char* rowp, int c0, int sw) -> i32x8f {      // the 32 bytes at chunks c0, c0 + 1 of a swizzled LDS row
+        const i32x4f lo = *(const i32x4f*)(rowp + ((c0 ^ sw) << 4)), hi = *(const i32x4f*)(rowp + (((c0 + 1) ^ sw) << 4));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto tile = [&](int t, auto buf_tag, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const char* Sb = smem + decltype(buf_tag)::value * F8_STAGE;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 sc[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const i32x8f kf = rd32(Sb + (s2 * 32 + l31) * 128, kk * 4 + 2 * h, ksw);
+                sc[s2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[kk], kk == 0 ? zero : sc[s2], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+        if constexpr (MASK) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (key >= S) sc[s2][r] = -INFINITY;
+                }
+        }
+        float mx = sc[0][0];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[s2][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * scale_log2);
+        const bool moved = m_new != m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        i32x8f pk;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float p[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    p[b] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + b], scale_log2, -m_new));
+                    psum += p[b];
+                }
+                pk[s2 * 4 + a] = (int)pack4_e4m3(p[0], p[1], p[2], p[3]);      // k-slot bytes 16 s2 + 4 a + b of this lane's half
+            }
+        l_run = __builtin_fmaf(l_run, alpha, psum);
+        if (__any(moved)) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const i32x8f vf = rd32(Sb + KV_TILE * 128 + (dt * 32 + l31) * 64, 2 * h, vsw);
+            o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pk, o[dt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    auto sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    const int nt = t_end;
+    const bool tail = (S & (KV_TILE - 1)) != 0 && nt == nt_all;
+    const int nt_loop = tail ? nt - 1 : nt;
+    stage(0, t_begin);
+    int t = t_begin;
+    for (; t + 2 <= nt_loop; t += 2) {
+        sync();
+        stage(1, t + 1);
+        tile(t, B0{}, std::false_type{});
+        sync();
+        if (t + 2 < nt) stage(0, t + 2);
+        tile(t + 1, B1{}, std::false_type{});
+    }
+    if (t < nt_loop) {
+        sync();
+        if (t + 1 < nt) stage(1, t + 1);
+        tile(t, B0{}, std::false_type{});
+        ++t;
+    }
+    if (tail) {
+        sync();
+        if ((t - t_begin) & 1) tile(t, B1{}, std::true_type{});
+        else tile(t, B0{}, std::true_type{});
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (part_slot >= 0) {
+        float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 128 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = o[dt][4 * a + r];
+                *(f32x4*)(po + dt * 32 + 8 * a) = v;
+            }
+        if (h == 0) {
+            float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 2;
+            pm[0] = m_run;
+            pm[1] = l_tot;
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < S) {
+        bf16* op = out + (size_t)q * ldo + head * 128 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16)((float)(bf16)(o[dt][4 * a + r] * inv) * v_std);     // x.to(bf16) * v_std
+                *(bf16x4*)(op + dt * 32 + 8 * a) = v;
+            }
+    }
+}
+
+size_t flash_attn_fp8_scratch_bytes(int H, int S_pad) {
+    return 3 * (size_t)H * S_pad * 128 + 256 + (size_t)3 * F8_STAT_WGS * 2 * sizeof(double) + 256;
+}
+
+int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
+                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    PE_REQUIRE(q && k && vt && out && scratch, "flash_attn_fp8: null pointer");
+    PE_REQUIRE(H > 0 && S > 1 && S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn_fp8: bad shape (H=%d S=%d S_pad=%d)", H, S, S_pad);
+    PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn_fp8: bad ldo=%d", ldo);
+    PE_REQUIRE(scratch_bytes >= flash_attn_fp8_scratch_bytes(H, S_pad) && ((uintptr_t)scratch & 255) == 0,
+               "flash_attn_fp8: scratch of %zu bytes, 256-byte aligned, needed", flash_attn_fp8_scratch_bytes(H, S_pad));
+    static std::atomic<bool> configured{false};
+    if (!configured.load(std::memory_order_acquire)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fp8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured.store(true, std::memory_order_release);
+    }
+    const size_t plane = (size_t)H * S_pad * 128;
+    uint8_t* q8 = (uint8_t*)scratch;
+    uint8_t* k8 = q8 + plane;
+    uint8_t* vt8 = k8 + plane;
+    float* stats = (float*)(vt8 + plane);
+    double* part = (double*)((char*)stats + 256);
+    const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);
+    hipLaunchKernelGGL(attn_fp8_stats_kernel, dim3(F8_STAT_WGS, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                       H, S, S_pad, part);
+    hipLaunchKernelGGL(attn_fp8_stats_finish_kernel, dim3(1), dim3(64), 0, stream, (const double*)part, (double)H * S * 128.0, stats);
+    hipLaunchKernelGGL(attn_fp8_quant_kernel, dim3(1024, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt, q8, k8,
+                       vt8, H, S_pad, (const float*)stats);
+    int rc = check_launch("attn_fp8_quant_kernel");
+    if (rc != PE_OK) { prof_end(slot, stream); return rc; }
+    const bool have_ws = workspace != nullptr && workspace_bytes >= flash_attn_workspace_bytes(H, S) && ((uintptr_t)workspace & 15) == 0;
+    constexpr int Q_BLOCK = 256;
+    const AttnPlan plan = make_plan(H, S, have_ws, Q_BLOCK, g_attn_slots);
+    const int total = H * plan.nqb;
+    const int n_short = (total - plan.n_full) * plan.split;
+    float* part_o = (float*)workspace;
+    float* part_ml = part_o ? part_o + (size_t)g_attn_slots * 256 * 128 : nullptr;
+    hipLaunchKernelGGL((flash_attn_fp8_kernel<8>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
+                       (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan, part_o,
+                       part_ml);
+    rc = check_launch("flash_attn_fp8_kernel");
+    if (rc == PE_OK && plan.split > 1) {
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((total - plan.n_full) * (Q_BLOCK / 8)), dim3(256), 0, stream, part_o, part_ml, (bf16*)out,
+                           S, ldo, plan, Q_BLOCK, (const float*)(stats + 2));
         rc = check_launch("attn_combine_kernel");
     }
     prof_end(slot, stream);

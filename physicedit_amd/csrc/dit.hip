@@ -41,6 +41,8 @@ struct pe_dit {
     char *sp_in, *sp_hid, *sp_dino, *sp_vae;
     char* attn_ws;
     size_t attn_ws_bytes = 0;
+    char* attn_f8;                      // e4m3 attention (pe_dit_call.fp8_attention): e4m3 copies of Q / K / Vt, the three std, partial sums
+    size_t attn_f8_bytes = 0;
     char* gemm_ws;                      // stream-K scratch of the block Linears (gemm.hip schedule 19): zeroed once, private to this handle
     GemmWorkspace gws = {nullptr, 0};
     char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
@@ -102,6 +104,8 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->sp_vae, (size_t)MAX_SPECIAL * TXT * 2);
     h->attn_ws_bytes = flash_attn_workspace_bytes(HEADS, (int)S);
     take(&h->attn_ws, h->attn_ws_bytes);
+    h->attn_f8_bytes = flash_attn_fp8_scratch_bytes(HEADS, (int)S_pad);
+    take(&h->attn_f8, h->attn_f8_bytes);
     take(&h->gemm_ws, gemm_workspace_bytes());
     h->gws.sync = h->gemm_ws;
     h->gws.bytes = gemm_workspace_bytes();
@@ -437,7 +441,10 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
     char* xm_img = h->xmod;
     char* xm_txt = h->xmod + (size_t)S_img * D * 2;
     const float scale = 0.08838834764831845f;  // 1/sqrt(128)
-    const float q_scale = attn_q_prescale(scale);   // attention variants 5 / 6: Q is written pre-multiplied by scale . log2(e)
+    // the reference takes its e4m3 attention branch only without a mask (qwen_image_dit.py:15): EliGen calls stay on the bf16 kernel
+    const bool fp8_attn = c->fp8_attention != 0 && c->attn_words == nullptr;
+    // attention variants 5 / 6: Q is written pre-multiplied by scale . log2(e); the e4m3 branch scales by its own statistics
+    const float q_scale = fp8_attn ? 1.0f : attn_q_prescale(scale);
 
     // ---- 3. transformer blocks  (qwen_image_dit.py:359-401)
     for (int l = 0; l < L; ++l) {
@@ -476,9 +483,13 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         }
         if ((rc = hot_linear(h, l, 0, EPI_QKV, pp, h->hbuf, 3 * D, stream))) return rc;
         // joint attention
-        if ((rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream,
-                                    c->attn_words, S_img, q_scale != 1.0f)))
-            return rc;
+        if (fp8_attn)
+            rc = launch_flash_attn_fp8(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, h->attn_f8, h->attn_f8_bytes, h->attn_ws,
+                                       h->attn_ws_bytes, stream);
+        else
+            rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream,
+                                   c->attn_words, S_img, q_scale != 1.0f);
+        if (rc) return rc;
         // output projections + gated residual (in place on x)
         memset(pp, 0, sizeof(pp));
         for (int s = 0; s < 2; ++s) {

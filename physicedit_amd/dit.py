@@ -361,14 +361,16 @@ class QwenImageDiTEngine:
     def forward(self, latents: torch.Tensor, timestep: torch.Tensor, prompt_emb: torch.Tensor,
                 special_idx: Optional[torch.Tensor] = None, edit_latents=None, step: Optional[int] = None,
                 out: Optional[torch.Tensor] = None, controls=None, entity_prompt_emb=None, entity_masks=None,
-                edit_rope_interpolation: bool = False) -> torch.Tensor:
+                edit_rope_interpolation: bool = False, enable_fp8_attention: bool = False) -> torch.Tensor:
         """One model_fn call.  `timestep`: [1] tensor in the pipeline dtype.  `prompt_emb` [1,T,3584] is
         MUTATED IN PLACE on `special_idx` rows.  Returns noise_pred [1,16,h8,w8].
         `controls`: active block-wise ControlNet inputs, [(QwenImageBlockWiseControlNet, processed conditioning [S0,3072], scale)]
         (physicedit_amd.controlnet).
         `entity_prompt_emb` (list of [1,T_i,3584]) + `entity_masks` ([1,N,1,h8,w8] in {0,1}): EliGen entity control
         (QwenImageDiT.process_entity_masks, qwen_image_dit.py:433-498).
-        `edit_rope_interpolation`: RoPE tables of QwenEmbedRope.forward_sampling (:1367-1368); ignored with EliGen, as in the reference."""
+        `edit_rope_interpolation`: RoPE tables of QwenEmbedRope.forward_sampling (:1367-1368); ignored with EliGen, as in the reference.
+        `enable_fp8_attention`: the e4m3 attention branch of qwen_image_flash_attention (qwen_image_dit.py:24-35; pe_flash_attn_fp8);
+        like the reference's, it is not taken under an attention mask (EliGen)."""
         ops._chk(latents, "latents"), ops._chk(prompt_emb, "prompt_emb")
         h8, w8 = latents.shape[-2:]
         edits: List[torch.Tensor] = []
@@ -407,6 +409,7 @@ class QwenImageDiTEngine:
             c.edit_h8[i], c.edit_w8[i] = e.shape[-2], e.shape[-1]
         c.prompt_emb, c.T = (prompt_emb_all if eligen is not None else prompt_emb).data_ptr(), T
         c.attn_words = words.data_ptr() if eligen is not None else None
+        c.fp8_attention = 1 if enable_fp8_attention else 0
         if special_idx is not None and special_idx.numel() > 0:
             if self.adapter is None:
                 raise _lib.PeError("special tokens given but no visual_thinking_adapter weights loaded")
@@ -538,22 +541,6 @@ def special_indices(special_token_mask: Optional[torch.Tensor], device) -> Optio
     return idx.to(device)
 
 
-_FP8_ATTN_WARNED = False
-
-
-def _warn_fp8_attention_once():
-    """`enable_fp8_attention=True` in the reference selects FlashAttention-3's e4m3 kernel ONLY where `flash_attn_interface`
-    imports (Hopper); everywhere else qwen_image_flash_attention falls through to bf16 SDPA and the flag does nothing
-    (qwen_image_dit.py:14-39: the `else` branch never reads it).  That second behaviour is what this package mirrors: the flag is
-    accepted, attention stays the bf16 flash kernel, and the caller is told once."""
-    global _FP8_ATTN_WARNED
-    if not _FP8_ATTN_WARNED:
-        _FP8_ATTN_WARNED = True
-        import warnings
-        warnings.warn("enable_fp8_attention=True: no e4m3 attention kernel here; attention runs in bf16, as the reference does "
-                      "wherever FlashAttention-3 is not installed (qwen_image_dit.py:14-39)", stacklevel=3)
-
-
 def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=None, visual_thinking_adapter=None,
                         latents=None, timestep=None, prompt_emb=None, prompt_emb_mask=None, special_token_mask=None,
                         height=None, width=None, blockwise_controlnet_conditioning=None,
@@ -564,15 +551,14 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
                         pseudo_special_emb_dino=None, pseudo_special_emb_vae=None, **kwargs):
     """Drop-in for the reference operator of the same name (qwen_image_physical.py:1302-1403),
     inference subset: returns (noise_pred, 0).  Unsupported reference features raise instead of
-    silently differing; `enable_fp8_attention` behaves as in the reference without FlashAttention-3 (accepted, bf16 attention)."""
+    silently differing.  `enable_fp8_attention=True` takes the e4m3 attention branch the reference takes where FlashAttention-3 exists
+    (qwen_image_dit.py:24-35): here that branch is the library's own kernel (pe_flash_attn_fp8), so the flag always acts."""
     if entity_prompt_emb is not None and entity_masks is None:
         raise _lib.PeError("model_fn_qwen_image: entity_prompt_emb without entity_masks")
     want_loss = bool(is_train) and special_token_mask is not None
     if want_loss and (pseudo_special_emb_dino is None or pseudo_special_emb_vae is None):
         raise _lib.PeError("model_fn_qwen_image: is_train=True needs pseudo_special_emb_dino / pseudo_special_emb_vae (the targets of "
                            "get_loss, produced by the training-time PhysicalVisualEmbedder); inference passes is_train=False")
-    if enable_fp8_attention:
-        _warn_fp8_attention_once()
     edits = []
     if context_latents is not None:
         edits.append(context_latents)      # context tokens come right after the noise tokens (:1348-1351)
@@ -594,7 +580,8 @@ def model_fn_qwen_image(dit: QwenImageDiTEngine = None, blockwise_controlnet=Non
                      for ci, c in zip(blockwise_controlnet_inputs, blockwise_controlnet_conditioning)]
         controls = blockwise_controlnet.active_controls(blockwise_controlnet_inputs, processed, progress_id, num_inference_steps)
     pred = dit.forward(latents, timestep, prompt_emb, idx, edits or None, controls=controls,
-                       entity_prompt_emb=entity_prompt_emb, entity_masks=entity_masks, edit_rope_interpolation=edit_rope_interpolation)
+                       entity_prompt_emb=entity_prompt_emb, entity_masks=entity_masks, edit_rope_interpolation=edit_rope_interpolation,
+                       enable_fp8_attention=bool(enable_fp8_attention))
     if want_loss:        # :1337-1338: the loss value of the training path (forward only: this library has no backward)
         return pred, dit.special_token_loss(timestep, idx.numel(), pseudo_special_emb_dino, pseudo_special_emb_vae)
     return pred, 0

@@ -47,7 +47,7 @@ class DenoiseLoop:
                  denoising_strength: float = 1.0, blockwise_controlnet=None, blockwise_controlnet_inputs=None,
                  blockwise_controlnet_conditioning=None, eligen_posi=None, eligen_nega=None,
                  input_latents: Optional[torch.Tensor] = None, inpaint_mask: Optional[torch.Tensor] = None,
-                 edit_rope_interpolation: bool = False) -> torch.Tensor:
+                 edit_rope_interpolation: bool = False, enable_fp8_attention: bool = False) -> torch.Tensor:
         """noise [1,16,H/8,W/8] (for an image-to-image run: already `scheduler.add_noise(input_latents, noise, timesteps[0])`);
         prompt_emb_* [1,T,3584] DEVICE tensors, mutated in place on their special rows across the steps exactly like
         `inputs_posi["prompt_emb"]` in the reference.  `inpaint_mask` [1,1,H/8,W/8] + `input_latents`: the blend of
@@ -71,6 +71,8 @@ class DenoiseLoop:
         kw_n = dict(eligen_nega) if eligen_nega else {}
         if edit_rope_interpolation:                    # (:1367-1368) same tables for both CFG branches
             kw_p["edit_rope_interpolation"] = kw_n["edit_rope_interpolation"] = True
+        if enable_fp8_attention:                       # (:614, :1321) both CFG branches
+            kw_p["enable_fp8_attention"] = kw_n["enable_fp8_attention"] = True
         self.dit._eligen_words = None                  # token words are cached per image (QwenImageDiTEngine._eligen_inputs)
         pair = self.cfg_pair if use_cfg else None
         dual = self.dual_stream and use_cfg and pair is None

@@ -105,17 +105,24 @@ def test_layout_fingerprints_match_the_reference_detector_table():
     assert detect_model_name(small) == "qwen_image_dit"          # reduced depth: key-signature fallback
 
 
-def test_fp8_attention_flag_warns_once():
-    """`enable_fp8_attention=True` is accepted like the reference accepts it without FlashAttention-3 (bf16 attention,
-    qwen_image_dit.py:14-39); the caller is told exactly once."""
-    import warnings
+def test_fp8_attention_flag_reaches_the_engine():
+    """`enable_fp8_attention` is a real switch since round 4 (pe_flash_attn_fp8: the branch the reference takes where FlashAttention-3
+    exists, qwen_image_dit.py:24-35): model_fn_qwen_image hands it to the engine's forward, DenoiseLoop to both CFG branches."""
+    import inspect
     import physicedit_amd.dit as D
-    D._FP8_ATTN_WARNED = False
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter("always")
-        D._warn_fp8_attention_once()
-        D._warn_fp8_attention_once()
-    assert len(rec) == 1 and "FlashAttention-3" in str(rec[0].message)
+    import physicedit_amd.pipeline as P
+    assert "enable_fp8_attention" in inspect.signature(D.QwenImageDiTEngine.forward).parameters
+    assert "enable_fp8_attention" in inspect.signature(P.DenoiseLoop.__call__).parameters
+    seen = {}
+
+    class Eng:
+        def forward(self, *a, **kw):
+            seen.update(kw)
+            return torch.zeros(1)
+    D.model_fn_qwen_image(dit=Eng(), latents=torch.zeros(1, 16, 8, 8), timestep=torch.tensor([500.0]), prompt_emb=torch.zeros(1, 4, 3584),
+                          is_train=False, enable_fp8_attention=True)
+    assert seen["enable_fp8_attention"] is True
+    assert not hasattr(D, "_warn_fp8_attention_once")
 
 
 def test_G20_dino_preprocess_resize_and_crop():

@@ -525,6 +525,51 @@ def test_flash_attn_plain_q_takes_exact_form(ops, attn_variant):
         ops.flash_attn(qp, kd, vt, S, q_prescaled=True)
 
 
+# --- e4m3 attention (qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35) ---
+def _fp8_attn(ops, q, k, v, S, workspace=True):
+    from physicedit_amd._lib import check, lib, stream_ptr
+    H = q.shape[0]
+    qd, kd, vt = _dev_qkv(ops, q, k, v, S, nan_pad=False)
+    sp = qd.shape[1]
+    n = lib().pe_flash_attn_fp8_scratch_bytes(H, sp)
+    scratch = torch.empty((n + 256,), dtype=torch.uint8, device="cuda")
+    base = (scratch.data_ptr() + 255) // 256 * 256
+    out = torch.empty((S, H * 128), dtype=BF, device="cuda")
+    ws, nb = None, 0
+    if workspace:
+        nb = lib().pe_flash_attn_workspace_bytes(H, S)
+        ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    check(lib().pe_flash_attn_fp8(qd.data_ptr(), kd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, base, n,
+                                  ws.data_ptr() if ws is not None else None, nb, stream_ptr()), "pe_flash_attn_fp8")
+    return out
+
+
+@pytest.mark.parametrize("S,scales", [(64, (1.0, 1.0, 1.0)), (100, (1.0, 1.0, 1.0)), (700, (0.7, 1.9, 3.1)), (1093, (2.5, 0.4, 0.05)),
+                                      (2208, (1.0, 1.3, 0.8))])
+def test_flash_attn_fp8(ops, S, scales):
+    """The e4m3 attention operator against the oracle's restatement of the reference branch (global std of q, k, v in bf16, e4m3 casts,
+    softmax_scale = q_std k_std / sqrt(128), P cast to e4m3, output x v_std), on tensors whose three scales differ: what the kernel
+    may differ in is the fp32 summation order and the rounding of P near e4m3 ties -- a small fraction of what e4m3 operands cost
+    against the fp32 truth.  Also: the three standard deviations reproduce torch.std bit for bit (as bf16)."""
+    from physicedit_amd._lib import lib
+    H = 24
+    g = torch.Generator().manual_seed(800 + S)
+    q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in scales)
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    ref = O.flash_attention_fp8(q[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
+    ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
+    out = _fp8_attn(ops, q, k, v, S)
+    assert torch.isfinite(out.float()).all()
+    e_kernel, e_fp8 = _rms(out, ref), _rms(ref, ref32)
+    print(f"[parity] flash_attn_fp8 S={S}: rms hip vs oracle-fp8 {e_kernel:.3e}; oracle-fp8 vs fp32 truth {e_fp8:.3e}; hip vs truth {_rms(out, ref32):.3e}")
+    assert e_kernel <= 0.25 * e_fp8 + 1e-6
+    assert _rms(out, ref32) <= 1.1 * e_fp8 + 1e-6
+    out1 = _fp8_attn(ops, q, k, v, S, workspace=False)
+    report(f"flash_attn_fp8 S={S}: balanced vs single-kernel", out, out1, max_ulp=3.01, max_frac=0.06)
+    for _ in range(5):
+        assert torch.equal(_fp8_attn(ops, q, k, v, S), out)
+
+
 # ------------------------------------------------------------------------------------------------
 # row kernels
 # ------------------------------------------------------------------------------------------------
