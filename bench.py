@@ -405,13 +405,13 @@ def secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_
     from physicedit_amd.pipeline import DenoiseLoop
     res = {}
 
-    def run(label, H, W, steps, peak, dtype):
+    def run(label, H, W, steps, peak, dtype, fp8_attention=False):
         loop = DenoiseLoop(eng, dual_stream=args.dual_stream)
         noises = [synth.make_noise(5000 + i, H, W).to(dev) for i in range(n_images + 1)]
 
         def image(i, n_steps):
             lat = loop(noises[i], pe_p0.clone(), pe_n0.clone(), mask_p, mask_n, H, W, num_inference_steps=n_steps,
-                       cfg_scale=args.cfg, edit_latents=vae.encode(edit_img))
+                       cfg_scale=args.cfg, edit_latents=vae.encode(edit_img), enable_fp8_attention=fp8_attention)
             return vae.decode(lat)
         image(0, 2)
         torch.cuda.synchronize()
@@ -429,8 +429,8 @@ def secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_
             ed = [vae.encode(edit_img)]
             t500 = torch.tensor([500.0]).to(torch.bfloat16)
             torch.cuda.synchronize()
-            eng.forward(noises[0], t500, pe_p0.clone(), None, ed, step=0)
-            eng.forward(noises[0], t500, pe_n0.clone(), None, ed, step=0)
+            eng.forward(noises[0], t500, pe_p0.clone(), None, ed, step=0, enable_fp8_attention=fp8_attention)
+            eng.forward(noises[0], t500, pe_n0.clone(), None, ed, step=0, enable_fp8_attention=fp8_attention)
             torch.cuda.synchronize()
             prof = read_prof()
             sampled_in = "one single-stream CFG pair of forwards right after the timed images, every launch"
@@ -451,6 +451,10 @@ def secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_
     torch.cuda.empty_cache()
     run("configs[2] (DiT Linears in e4m3: fp8_linear; attention, norms, adapter, VAE bf16)", args.height, args.width,
         args.inference_steps, PEAK_FP8_TFLOPS, "fp8_e4m3")
+    # the same with enable_fp8_attention=True: q / k / v scaled by their global std and cast to e4m3, both attention matmuls on e4m3
+    # operands (pe_flash_attn_fp8; `flash_attn_tflops` then covers the statistics, the quantisation pass and the kernel together)
+    run("configs[2] + enable_fp8_attention (e4m3 Linears AND e4m3 attention)", args.height, args.width, args.inference_steps,
+        PEAK_FP8_TFLOPS, "fp8_e4m3", fp8_attention=True)
     return res
 
 

@@ -229,7 +229,7 @@ def _heads(x: torch.Tensor, h: int = 24) -> torch.Tensor:
     return x.reshape(B, S, h, HD // h).permute(0, 2, 1, 3)
 
 
-def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dtype=torch.float8_e4m3fn) -> torch.Tensor:
+def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dtype=torch.float8_e4m3fn, kv_tile: Optional[int] = None) -> torch.Tensor:
     """qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35: q, k, v [B, H, S, D] bf16 are divided by their
     global standard deviations (torch.std: unbiased, over the whole tensor, a bf16 scalar), cast to float8_e4m3fn, handed to
     FlashAttention-3 with softmax_scale = q_std * k_std / sqrt(D), and the output (bf16) is multiplied by v_std.
@@ -237,15 +237,34 @@ def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dty
     PARITY UNPINNED for the kernel itself: flash_attn_interface (FA3, Hopper) cannot run here or in the reference's CPU path, so
     what it does INSIDE -- in particular how it quantises P for the second matmul -- is restated from its published design: both
     matmuls on e4m3 operands with fp32 accumulation, softmax statistics in fp32, P cast to e4m3 (p_dtype=None: P kept in fp32,
-    the upper bound on what any such kernel can reach).  Everything outside the kernel (the three std, the two casts, the scale,
-    the output product and its roundings) is the reference's own arithmetic.  -> [B, H, S, D] bf16."""
+    the upper bound on what any such kernel can reach).  kv_tile=None quantises P = exp(s - row max) against the FINAL row max; a
+    flash kernel cannot know that yet -- it quantises each KV tile's P against the RUNNING max and rescales the accumulator when the
+    max moves -- so kv_tile=n restates that online form with n-key tiles (FA3's own tile size is not observable; the library's is
+    64).  The two differ by e4m3 rounding noise of P only (same size, different rounding points).  Everything outside the kernel
+    (the three std, the two casts, the scale, the output product and its roundings) is the reference's own arithmetic.
+    -> [B, H, S, D] bf16."""
     origin = q.dtype
     q_std, k_std, v_std = q.std(), k.std(), v.std()
     q8, k8, v8 = (q / q_std).to(torch.float8_e4m3fn), (k / k_std).to(torch.float8_e4m3fn), (v / v_std).to(torch.float8_e4m3fn)
     scale = float(q_std * k_std / math.sqrt(q.size(-1)))                 # a bf16 tensor product, then the python float FA3 receives
     s = torch.matmul(q8.float(), k8.float().transpose(-1, -2)) * scale   # e4m3 products are exact in fp32; fp32 accumulation
     pr = torch.softmax(s, dim=-1)                                        # FA3: the row max gives P <= 1 before the cast
-    if p_dtype is not None:
+    if p_dtype is not None and kv_tile:
+        S_ = s.shape[-1]
+        m = torch.full(s.shape[:-1] + (1,), float("-inf"))
+        l = torch.zeros(s.shape[:-1] + (1,))
+        acc = torch.zeros(s.shape[:-1] + (v8.shape[-1],))
+        vf = v8.float()
+        for t0 in range(0, S_, kv_tile):
+            st = s[..., t0:t0 + kv_tile]
+            m_new = torch.maximum(m, st.amax(dim=-1, keepdim=True))
+            alpha = torch.exp(m - m_new)
+            e = torch.exp(st - m_new)
+            l = l * alpha + e.sum(dim=-1, keepdim=True)
+            acc = acc * alpha + torch.matmul(e.to(p_dtype).float(), vf[..., t0:t0 + kv_tile, :])
+            m = m_new
+        x = acc / l
+    elif p_dtype is not None:
         # the kernel quantises the UN-normalised exp(s - max) and divides the accumulated output by the fp32 row sum afterwards
         m = s.amax(dim=-1, keepdim=True)
         e = torch.exp(s - m)

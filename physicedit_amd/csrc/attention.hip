@@ -916,20 +916,28 @@ __global__ void __launch_bounds__(256) attn_fp8_stats_kernel(const bf16* __restr
     }
 }
 // stats[0..2] = q_std, k_std, v_std (bf16 values as float), stats[3] = softmax scale in the log2 domain
-__global__ void __launch_bounds__(64) attn_fp8_stats_finish_kernel(const double* __restrict__ part, double n, float* __restrict__ stats) {
-    const int z = (int)threadIdx.x;
-    if (z >= 3) return;
+__global__ void __launch_bounds__(192) attn_fp8_stats_finish_kernel(const double* __restrict__ part, double n, float* __restrict__ stats) {
+    // wave z reduces tensor z: lane l adds the partials l, l + 64, ... in that order, then the lanes meet in a fixed butterfly
+    __shared__ float sd[3];
+    const int z = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     double a = 0.0, b = 0.0;
-    for (int i = 0; i < F8_STAT_WGS; ++i) {
+    for (int i = lane; i < F8_STAT_WGS; i += 64) {
         a += part[((size_t)z * F8_STAT_WGS + i) * 2];
         b += part[((size_t)z * F8_STAT_WGS + i) * 2 + 1];
     }
-    const double mean = a / n;
-    const double var = (b - n * mean * mean) / (n - 1.0);           // torch.std: unbiased
-    stats[z] = bf16r((float)sqrt(var > 0.0 ? var : 0.0));
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if (lane == 0) {
+        const double mean = a / n;
+        const double var = (b - n * mean * mean) / (n - 1.0);           // torch.std: unbiased
+        sd[z] = bf16r((float)sqrt(var > 0.0 ? var : 0.0));
+        stats[z] = sd[z];
+    }
     __syncthreads();
-    if (z == 0) {
-        const float qk = bf16r(stats[0] * stats[1]);                 // q_std * k_std: a bf16 tensor product ...
+    if (threadIdx.x == 0) {
+        const float qk = bf16r(sd[0] * sd[1]);                           // q_std * k_std: a bf16 tensor product ...
         stats[3] = bf16r(qk / 11.3137084989847603904f) * 1.44269504088896340736f;      // ... / sqrt(128): bf16 again; then log2 e for exp2
     }
 }
@@ -1188,7 +1196,7 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);
     hipLaunchKernelGGL(attn_fp8_stats_kernel, dim3(F8_STAT_WGS, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                        H, S, S_pad, part);
-    hipLaunchKernelGGL(attn_fp8_stats_finish_kernel, dim3(1), dim3(64), 0, stream, (const double*)part, (double)H * S * 128.0, stats);
+    hipLaunchKernelGGL(attn_fp8_stats_finish_kernel, dim3(1), dim3(192), 0, stream, (const double*)part, (double)H * S * 128.0, stats);
     hipLaunchKernelGGL(attn_fp8_quant_kernel, dim3(1024, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt, q8, k8,
                        vt8, H, S_pad, (const float*)stats);
     int rc = check_launch("attn_fp8_quant_kernel");

@@ -557,15 +557,24 @@ def test_flash_attn_fp8(ops, S, scales):
     q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in scales)
     torch.set_num_threads(max(torch.get_num_threads(), 16))
     ref = O.flash_attention_fp8(q[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
+    ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64)[0].permute(1, 0, 2).reshape(S, H * 128)
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
-    out = _fp8_attn(ops, q, k, v, S)
+    out = _fp8_attn(ops, q, k, v, S, workspace=False)
     assert torch.isfinite(out.float()).all()
-    e_kernel, e_fp8 = _rms(out, ref), _rms(ref, ref32)
-    print(f"[parity] flash_attn_fp8 S={S}: rms hip vs oracle-fp8 {e_kernel:.3e}; oracle-fp8 vs fp32 truth {e_fp8:.3e}; hip vs truth {_rms(out, ref32):.3e}")
-    assert e_kernel <= 0.25 * e_fp8 + 1e-6
+    e_tile, e_glob, e_fp8 = _rms(out, ref_t), _rms(out, ref), _rms(ref, ref32)
+    print(f"[parity] flash_attn_fp8 S={S}: rms hip vs oracle-fp8 (online, 64-key tiles) {e_tile:.3e}, (P against the final max) {e_glob:.3e}; "
+          f"oracle-fp8 vs fp32 truth {e_fp8:.3e}; hip vs truth {_rms(out, ref32):.3e}")
+    # against the restatement that quantises P where a flash kernel must (running max of 64-key tiles): summation order and e4m3 ties
+    assert e_tile <= 0.05 * e_fp8 + 1e-6
+    # against the form that knows the final max: the same size of P rounding noise at other rounding points
+    assert e_glob <= 0.6 * e_fp8 + 1e-6
     assert _rms(out, ref32) <= 1.1 * e_fp8 + 1e-6
-    out1 = _fp8_attn(ops, q, k, v, S, workspace=False)
-    report(f"flash_attn_fp8 S={S}: balanced vs single-kernel", out, out1, max_ulp=3.01, max_frac=0.06)
+    out1 = out
+    out = _fp8_attn(ops, q, k, v, S)
+    # the load-balanced form (leftover items split along KV): every part has its own running max, so its P is rounded to e4m3 at other
+    # points than the unsplit kernel's -- the same noise again, not a bf16-ulp matter
+    print(f"[parity] flash_attn_fp8 S={S}: balanced vs single-kernel rms {_rms(out, out1):.3e}; balanced vs truth {_rms(out, ref32):.3e}")
+    assert _rms(out, out1) <= 0.6 * e_fp8 + 1e-6 and _rms(out, ref32) <= 1.1 * e_fp8 + 1e-6
     for _ in range(5):
         assert torch.equal(_fp8_attn(ops, q, k, v, S), out)
 
