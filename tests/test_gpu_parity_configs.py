@@ -72,6 +72,9 @@ def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]", fp3
         for variant in variants:
             assert lib().pe_debug_set(b"attn_variant", variant) == 0
             got[variant] = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, dev), edit.cuda()).clone()
+        if fp32:      # the e4m3 attention branch at depth: reported next to the bf16 kernels' distance to fp32 (no oracle pass of its own)
+            got["fp8"] = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, dev), edit.cuda(),
+                                     enable_fp8_attention=True).clone()
         torch.cuda.synchronize()
     finally:
         lib().pe_debug_set(b"attn_variant", 5)
@@ -91,6 +94,11 @@ def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]", fp3
     names = {5: "attention variant 5 = default", 4: "attention variant 4", 0: "attention variant 0"}
     st = {v: record(config, f"{case} [{names[v]}]" + ("" if fp32 else " [bf16 oracle only]"), got[v], ref, ref32) for v in variants}
     assert torch.isfinite(ref.float()).all() and all(torch.isfinite(g.float()).all() for g in got.values())
+    if "fp8" in got:
+        # enable_fp8_attention=True against the SAME references (the bf16-attention oracle and its fp32 run): what e4m3 attention
+        # operands cost at 60 layers, as a multiple of the bf16 path's own distance to fp32
+        st8 = record(config, f"{case} [enable_fp8_attention: e4m3 attention vs the bf16-attention references]", got["fp8"], ref, ref32)
+        assert st8["fp32_distance_ratio"] <= 6.0, st8
     if not fp32:
         # the numbers of the full form (profiles/r03_parity.json: mean |d| 1.63e-3, 5 ulp at this depth for every variant) with headroom
         assert st[5]["mean_abs_diff"] <= 2e-3 and st[5]["max_ulp"] <= 6.0, st[5]
