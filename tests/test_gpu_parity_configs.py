@@ -18,17 +18,23 @@ BF = torch.bfloat16
 
 
 class HostView:
-    """Read-only state-dict view for the oracle over weights that live on the GPU: one tensor at a time is copied to
-    the host (optionally widened to fp32), so a 60-layer model (41 GB) never has to exist twice in host memory."""
+    """Read-only state-dict view for the oracle over weights that live on the GPU: a tensor is copied to the host when the oracle
+    first asks for it and kept (bf16; widened to fp32 per access when asked), so the seven oracle passes of this module over the
+    60-layer model copy its 41 GB once instead of seven times.  `cache`: a dict shared by the views of one state dict."""
 
-    def __init__(self, dev_sd, dtype=None):
-        self.sd, self.dtype = dev_sd, dtype
+    def __init__(self, dev_sd, dtype=None, cache=None):
+        self.sd, self.dtype, self.cache = dev_sd, dtype, cache
 
     def __contains__(self, k):
         return k in self.sd
 
     def __getitem__(self, k):
-        t = self.sd[k].cpu()
+        if self.cache is not None:
+            t = self.cache.get(k)
+            if t is None:
+                t = self.cache[k] = self.sd[k].cpu()
+        else:
+            t = self.sd[k].cpu()
         return t.to(self.dtype) if self.dtype is not None else t
 
     def get(self, k, default=None):
@@ -47,6 +53,29 @@ def _inputs(h, w, eh, ew, T, nsp, seed):
     return noise, edit, pe, mask
 
 
+_MODEL60 = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _release_model60():
+    yield
+    _MODEL60.clear()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
+def model60():
+    """the 60-layer DiT (+ adapter) of this module's tests: generated on the device and wrapped in an engine ONCE (41 GB), with one host
+    cache for the oracle's views"""
+    if not _MODEL60:
+        from physicedit_amd.dit import QwenImageDiTEngine
+        dev = torch.device("cuda")
+        sd_dev = synth.make_state_dict_device(synth.dit_layout(60), 1234, dev)
+        ad = synth.make_state_dict(synth.adapter_layout(), 4321)
+        _MODEL60.update(sd=sd_dev, ad=ad, eng=QwenImageDiTEngine(sd_dev, ad, device=dev), host={})
+    return _MODEL60["sd"], _MODEL60["ad"], _MODEL60["eng"], _MODEL60["host"]
+
+
 def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]", fp32=True):
     """60-layer DiT + adapter, one `model_fn` call at the first timestep of the 40-step schedule, against the oracle in bf16 and (fp32=True)
     in fp32, for the default attention kernel (5: folded scale and max) and the two it is judged against (4: the same schedule with
@@ -54,12 +83,10 @@ def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]", fp3
     pass is what costs host time), held to the element-wise numbers the full form measured.  Returns the parity records by variant."""
     import os
     from physicedit_amd._lib import lib
-    from physicedit_amd.dit import QwenImageDiTEngine, special_indices
+    from physicedit_amd.dit import special_indices
     from physicedit_amd.scheduler import qwen_image_scheduler
     dev = torch.device("cuda")
-    sd_dev = synth.make_state_dict_device(synth.dit_layout(60), 1234, dev)
-    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
-    eng = QwenImageDiTEngine(sd_dev, ad, device=dev)
+    sd_dev, ad, eng, host = model60()
     EH = HW if edit_hw is None else edit_hw
     noise, edit, pe, mask = _inputs(HW, HW, EH, EH, T, nsp, 0)
     sch = qwen_image_scheduler()
@@ -82,12 +109,12 @@ def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]", fp3
     ref32 = None
     try:
         torch.set_num_threads(max(threads, min(32, os.cpu_count() or 16)))
-        ref = O.model_fn(HostView(sd_dev), ad, noise, t, pe.clone(), mask, HW, HW, edit, t_min, t_max)
+        ref = O.model_fn(HostView(sd_dev, cache=host), ad, noise, t, pe.clone(), mask, HW, HW, edit, t_min, t_max)
         if fp32:
             # the fp32 pass is bound by element-wise traffic on the host: more threads than oneDNN's bf16 GEMMs like
             torch.set_num_threads(max(threads, min(64, os.cpu_count() or 16)))
             ad32 = {k: v.float() for k, v in ad.items()}
-            ref32 = O.model_fn(HostView(sd_dev, torch.float32), ad32, noise.float(), t.float(), pe.clone().float(), mask, HW, HW,
+            ref32 = O.model_fn(HostView(sd_dev, torch.float32, cache=host), ad32, noise.float(), t.float(), pe.clone().float(), mask, HW, HW,
                                edit.float(), t_min, t_max)
     finally:
         torch.set_num_threads(threads)
@@ -154,12 +181,8 @@ def test_60_layers_two_cfg_steps():
     import os
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from physicedit_amd.dit import QwenImageDiTEngine
     from physicedit_amd.pipeline import DenoiseLoop
-    dev = torch.device("cuda")
-    sd_dev = synth.make_state_dict_device(synth.dit_layout(60), 1234, dev)
-    ad = synth.make_state_dict(synth.adapter_layout(), 4321)
-    eng = QwenImageDiTEngine(sd_dev, ad, device=dev)
+    sd_dev, ad, eng, host = model60()
     noise, edit, pe_p, mask_p = _inputs(256, 256, 256, 256, 160, 16, 3)
     pe_n = synth.make_prompt_emb(11, 80)
     mask_n = synth.make_special_token_mask(80, 16)
@@ -170,7 +193,7 @@ def test_60_layers_two_cfg_steps():
     threads = torch.get_num_threads()
     try:
         torch.set_num_threads(max(threads, min(32, os.cpu_count() or 16)))
-        ref = O.denoise_loop(HostView(sd_dev), ad, noise, pe_p, pe_n, mask_p, mask_n, 256, 256, 2, cfg_scale=4.0, edit_latents=edit)
+        ref = O.denoise_loop(HostView(sd_dev, cache=host), ad, noise, pe_p, pe_n, mask_p, mask_n, 256, 256, 2, cfg_scale=4.0, edit_latents=edit)
     finally:
         torch.set_num_threads(threads)
     st = record("configs[1]", "60 layers, 256x256 + 256x256 edit, TWO CFG-4 steps of the loop (two streams) vs the oracle's loop [bf16 oracle only]",
