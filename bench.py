@@ -375,6 +375,12 @@ def main():
             out["roofline"]["attainable_ceiling"] = att
             if att.get("mfma_lds_reads_dma_stream", 0) > 0:
                 out["roofline"]["frac_of_attainable_ceiling"] = achieved / att["mfma_lds_reads_dma_stream"]
+            fa = out["other_kernels"]["flash_attn"]
+            if args.attn_variant >= 5 and fa.get("achieved_tflops"):
+                ac = attention_ceiling(dev, (H // 16) * (W // 16) + 4096 + args.t_pos)
+                fa["attainable_ceiling"] = ac
+                if ac.get("tflops", 0) > 0:
+                    fa["frac_of_attainable_ceiling"] = fa["achieved_tflops"] / ac["tflops"]
         if world == 1 and headline and not args.fp8 and not args.no_secondary:
             out["secondary"] = secondary_configs(args, dev, eng, vae, edit_img, pe_p0, pe_n0, mask_p, mask_n, read_prof)
         if world == 1 and headline and not args.fp8 and not args.no_prologue:
@@ -558,6 +564,40 @@ def attainable_ceiling(dev):
         best = max(best, 60 * 2.0 * M * N * K / (e0.elapsed_time(e1) * 1e-3) / 1e12)
     res["gemm_main_loop_only"] = best
     return res
+
+
+def attention_ceiling(dev, S):
+    """pe_attn_mix_probe: the default flash-attention kernel's own schedule without its softmax (per KV tile and wave 64 MFMAs, 32 LDS
+    fragment reads, 8 LDS-DMA pieces, one barrier) on N(0,1) Q / K / Vt at the headline sequence length, after the timed region."""
+    import ctypes
+    import torch
+    from physicedit_amd import ops
+    from physicedit_amd._lib import check, lib, stream_ptr
+    BF = torch.bfloat16
+    H = 24
+    g = torch.Generator(device=dev).manual_seed(3)
+    sp = ops.s_pad_of(S)
+    q = torch.randn((H, sp, 128), generator=g, device=dev).to(BF)
+    k = torch.randn((H, sp, 128), generator=g, device=dev).to(BF)
+    vt = torch.randn((H, 128, sp), generator=g, device=dev).to(BF)
+    out = torch.empty((S, H * 128), dtype=BF, device=dev)
+    fl = ctypes.c_double(0.0)
+
+    def run(n):
+        for _ in range(n):
+            check(lib().pe_attn_mix_probe(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, ctypes.byref(fl),
+                                          stream_ptr()), "pe_attn_mix_probe")
+    run(3)
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(20)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 20 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return {"what": f"pe_attn_mix_probe at S = {S}, H = 24: flash_attn_w4_kernel's schedule (variant 5) without the softmax instruction stream, "
+                    "N(0,1) operands, whole (head, q-block) items only", "unit": "TFLOP/s", "tflops": best}
 
 
 def pmc_traffic(args):

@@ -492,6 +492,12 @@ int pe_mfma_probe(const void* frags, void* out, int blocks, int iters, double* f
  * kernel.  On random data the three rates bracket what any schedule of this tiling can reach under the power limit
  * (bench.py `roofline.attainable_ceiling`).  out: blocks * 512 floats; *flops receives the launch's FLOPs. */
 int pe_gemm_mix_probe(int mode, const void* src, size_t src_bytes, void* out, int blocks, int iters, double* flops, void* stream);
+/* The attention twin: the default flash-attention kernel's schedule WITHOUT its softmax -- per KV tile and wave the 64 MFMAs, their 32
+ * LDS fragment reads, 8 LDS-DMA pieces and the barrier -- on the caller's Q / K / Vt (pe_flash_attn layouts; N(0,1) data for a
+ * meaningful rate).  *flops = 4 S^2 128 H, the launch's nominal work; `out` receives garbage.  What it sustains is the ceiling of the
+ * tiling and staging; bench.py reports flash attention's rate as a fraction of it (other_kernels.flash_attn). */
+int pe_attn_mix_probe(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, double* flops,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement: HIP-event timing of sampled launches, recorded on the launch stream.

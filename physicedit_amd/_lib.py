@@ -183,6 +183,7 @@ SIGNATURES = {
     "pe_adapter_workspace_bytes": (c_size_t, [c_int]),
     "pe_adapter_forward": (c_int, [C.POINTER(AdapterWeights), c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
+    "pe_attn_mix_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(C.c_double), c_void_p]),
     "pe_profile_enable": (c_int, [c_int, c_int]),
     "pe_profile_disable": (None, []),
     "pe_profile_read": (c_int, [c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double),

@@ -451,7 +451,10 @@ constexpr int v_wait2(int f) { return f <= 12 ? 2 : 0; }       // before MFMA 2f
 #ifndef PE_W4_PK2
 #define PE_W4_PK2 0      // experiment (with W4_PK2=1 at generation): FOLD with the double-buffered P of the exact form
 #endif
-template <bool FOLD>
+// PROBE (pe_attn_mix_probe): the folded schedule without its softmax -- the MFMAs, their LDS fragment reads, the LDS-DMA stream and the
+// barrier of every iteration; P is whatever bf16 data K's first rows hold.  What it sustains on N(0,1) operands is the ceiling of this
+// tiling and staging, as pe_gemm_mix_probe's is for the GEMM.  Its output is meaningless.
+template <bool FOLD, bool PROBE = false>
 __global__ void __launch_bounds__(256, 1)
 flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
                      bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
@@ -643,7 +646,21 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
 #endif
     // the instruction schedule: lambdas iter0..iter3 (one per ring slot) and the prologue, generated by tools/gen_attn_w4.py
     long long stamp_loop;
-    if constexpr (FOLD) {
+    if constexpr (PROBE) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[b][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pk[b][c] = *(const u32x4*)(Kh + (size_t)((b * 4 + c) * 64 + lane) * 8);       // stand-in for P
+            l_run[b] = 1.0f;
+        }
+#include "attention_w5_probe_body.inc"
+        stamp_loop = (long long)__builtin_readcyclecounter();
+        for (int i = 0; i < n; i += 4) {
+            iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
+        }
+    } else if constexpr (FOLD) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -780,6 +797,24 @@ static AttnPlan make_plan(int H, int S, bool have_ws, int Q_BLOCK, int slots) {
         p.split = split;
     }
     return p;
+}
+
+int launch_attn_mix_probe(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, hipStream_t stream) {
+    PE_REQUIRE(q && k && vt && out && H > 0 && S >= 1024 && S_pad % KV_TILE == 0 && S_pad >= S && ldo % 8 == 0 && ldo >= H * 128 &&
+                   ((uintptr_t)out & 15) == 0, "attn_mix_probe: bad arguments");
+    static std::atomic<bool> configured{false};
+    if (!configured.load(std::memory_order_acquire)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "attn_mix_probe: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured.store(true, std::memory_order_release);
+    }
+    AttnPlan plan;
+    plan.nqb = (S + 255) / 256;
+    plan.n_full = H * plan.nqb;
+    plan.split = 1;
+    hipLaunchKernelGGL((flash_attn_w4_kernel<true, true>), dim3(plan.n_full), dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k,
+                       (const bf16*)vt, (bf16*)out, S, S_pad, ldo, 1.0f, plan, (float*)nullptr, (float*)nullptr, 8.0f, (long long*)nullptr);
+    return check_launch("flash_attn_w4_kernel<probe>");
 }
 
 size_t flash_attn_workspace_bytes(int H, int S) {

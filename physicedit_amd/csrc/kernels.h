@@ -86,6 +86,8 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
                       bool q_prescaled = false);                      // Q was written with GemmProblem.q_scale = attn_q_prescale(scale)
 float attn_q_prescale(float scale);   // scale * log2(e) when the current attention variant wants it folded into Q, else 1
 size_t flash_attn_workspace_bytes(int H, int S);
+// the default attention kernel's schedule without its softmax (attainable-ceiling probe; the output is meaningless)
+int launch_attn_mix_probe(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, hipStream_t stream);
 // the reference's enable_fp8_attention branch (attention.hip, "e4m3 attention"): q, k, vt in the bf16 layouts of launch_flash_attn (plain
 // Q); scratch: flash_attn_fp8_scratch_bytes(H, S_pad), 256-byte aligned (e4m3 copies, the three std and their partial sums)
 size_t flash_attn_fp8_scratch_bytes(int H, int S_pad);

@@ -199,6 +199,11 @@ int pe_gemm_mix_probe(int mode, const void* src, size_t src_bytes, void* out, in
     return check_launch("gemm_mix_probe_kernel");
 }
 
+int pe_attn_mix_probe(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, double* flops, void* stream) {
+    if (flops) *flops = 4.0 * (double)S * S * 128.0 * H;
+    return launch_attn_mix_probe(q, k, vt, out, H, S, S_pad, ldo, (hipStream_t)stream);
+}
+
 int pe_mfma_probe(const void* frags, void* out, int blocks, int iters, double* flops, void* stream) {
     PE_REQUIRE(frags && out && blocks > 0 && blocks <= 4096 && iters > 0, "pe_mfma_probe: bad arguments");
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const uint4*)frags, (float*)out, iters);

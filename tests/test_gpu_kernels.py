@@ -762,6 +762,22 @@ def test_decode_attention(ops, L):
     assert torch.isfinite(out.float()).all() and e_gpu <= 1.5 * e_cpu + 1e-4
 
 
+def test_attn_mix_probe_runs(ops):
+    """pe_attn_mix_probe (the default attention schedule without its softmax) launches, reports the launch's nominal FLOPs and leaves
+    the library usable; its output is not a result."""
+    import ctypes
+    from physicedit_amd._lib import check, lib, stream_ptr
+    H, S = 24, 2048
+    q, k = rnd((H, S, 128), 1).cuda(), rnd((H, S, 128), 2).cuda()
+    vt = rnd((H, 128, S), 3).cuda()
+    out = torch.empty((S, H * 128), dtype=BF, device="cuda")
+    fl = ctypes.c_double(0.0)
+    check(lib().pe_attn_mix_probe(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, S, H * 128, ctypes.byref(fl), stream_ptr()),
+          "pe_attn_mix_probe")
+    torch.cuda.synchronize()
+    assert fl.value == 4.0 * S * S * 128 * H
+
+
 def test_mfma_probe(ops):
     """pe_mfma_probe (measurement aid of bench.py's roofline block): launches, reports its FLOP count, zero fragments give zeros."""
     import ctypes

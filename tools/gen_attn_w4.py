@@ -24,6 +24,7 @@ N = the reads issued after the second fragment by then (2, or 0 at the end of th
 """
 import os
 
+PROBE = False     # set by main(): the folded body WITHOUT its softmax (no pairs, max, state, mask, rescale): attention_w5_probe_body.inc
 FOLD = False      # set by main(): False -> attention_w4_body.inc (variants 3 / 4), True -> attention_w5_body.inc (variants 5 / 6)
 DMA_SLOTS = int(os.environ.get("W4_DMA_SLOTS", "3"))      # issue slots an LDS-DMA piece (address + m0 + buffer_load ... lds) is booked with
 EARLY_PAIRS = int(os.environ.get("W4_EARLY_PAIRS", "5"))   # per block: pairs 0..4 of softmax(i+1) run in phase 2 of iteration i, pairs 5..15 in phase 1 of i+1
@@ -96,7 +97,7 @@ def pair_stream(pairs, P, tagp):
     """The softmax of `pairs` = [(b, q)] (scores 2q, 2q+1 of block b, tile parity P) as ONE instruction stream, software-pipelined one
     pair deep:   fma fma | add' exp add' exp cvt'   (' = the pair before; FOLD: exp add' exp add' cvt', the fmas are gone), so that no
     instruction reads the result of the one right before it.  Issue slots: v_exp_f32 2 (transcendental rate), everything else 1 (tools/microbench/valu_rate.hip)."""
-    if os.environ.get("W4_NO_PAIRS"):       # timing experiment only
+    if os.environ.get("W4_NO_PAIRS") or PROBE:       # timing experiment / the mix probe
         return []
 
     def parts(k):
@@ -192,6 +193,8 @@ def fixed_slots(st):
 
 def add_max(st, P, g):
     """running max over scores 4g..4g+3 of both blocks"""
+    if PROBE:
+        return
     for b in (0, 1):
         e = [score(P, b, 4 * g + k) for k in range(4)]
         if g == 0:
@@ -282,11 +285,11 @@ def gen_iter(ST, out):
         st = stmts[g]
         add_stream(st, placed[g])
         out.extend(st.emit(ind))
-        if g == rg:
+        if g == rg and not PROBE:
             w(ind + "rescale(0);")
-        if g == rg + 1:
+        if g == rg + 1 and not PROBE:
             w(ind + "rescale(1);")
-        if g == 31:
+        if g == 31 and not PROBE:
             w(ind + "l_run[0] = __builtin_fmaf(l_run[0], sm_alpha[0], sm_psum[0]);")
             w(ind + "l_run[1] = __builtin_fmaf(l_run[1], sm_alpha[1], sm_psum[1]);")
         w(ind + "W4_FENCE();")
@@ -333,7 +336,9 @@ def gen_iter(ST, out):
                     assert g > 8 * c + 7, f"early pack into chunk {c} in gap {g}: P.V still reads it"
     for g in range(32):
         st = stmts[g]
-        if g == 0 and FOLD:     # a tile past the end of this work item (iterations come in fours) has no sm_sub = inf to zero its P: every key is masked
+        if PROBE:
+            pass
+        elif g == 0 and FOLD:     # a tile past the end of this work item (iterations come in fours) has no sm_sub = inf to zero its P: every key is masked
             w(ind + f"if (mask_next || !live_next) mask_scores(std::integral_constant<int, {PN}>{{}}, t_next, live_next ? S : 0);")
         elif g == 0:
             w(ind + f"if (mask_next) mask_scores(std::integral_constant<int, {PN}>{{}}, t_next, S);")
@@ -342,7 +347,9 @@ def gen_iter(ST, out):
         if g & 3 == 1 and not os.environ.get("W4_NO_DMA"):       # W4_NO_DMA: timing experiment only (results are garbage)
             j = g >> 3
             w(ind + (f"stage_v({slot_d}, i + 3, {j});" if (g >> 2) & 1 else f"stage_k({slot_d}, i + 3, {j});"))
-        if g in (8, 9) and FOLD:
+        if g in (8, 9) and PROBE:
+            pass
+        elif g in (8, 9) and FOLD:
             w(ind + f"sm_state_f(std::integral_constant<int, {PN}>{{}}, {g - 8}, std::false_type{{}});")
         elif g in (8, 9):
             w(ind + f"sm_state({g - 8}, live_next);")
@@ -382,7 +389,8 @@ def gen_prologue(out):
         out.extend(st.emit(ind))
     w(ind + 'asm volatile("s_nop 15");                           // last QK^T MFMAs -> the score reads below')
     w(ind + "W4_FENCE();")
-    w(ind + "if ((t_begin + 1) * KV_TILE > S) mask_scores(std::integral_constant<int, 0>{}, t_begin, S);")
+    if not PROBE:
+        w(ind + "if ((t_begin + 1) * KV_TILE > S) mask_scores(std::integral_constant<int, 0>{}, t_begin, S);")
     early = pair_list(0, EARLY_PAIRS)
     w(ind + "{")
     ind2 = ind + "    "
@@ -393,7 +401,9 @@ def gen_prologue(out):
         add_max(st, 0, g)
         out.extend(st.emit(ind2))
         w(ind2 + "W4_FENCE();")
-    if FOLD:
+    if PROBE:
+        pass
+    elif FOLD:
         w(ind2 + "sm_state_f(std::integral_constant<int, 0>{}, 0, std::true_type{});")
         w(ind2 + "sm_state_f(std::integral_constant<int, 0>{}, 1, std::true_type{});")
     else:
@@ -412,14 +422,16 @@ def gen_prologue(out):
 
 
 def main():
-    global FOLD
+    global FOLD, PROBE
     here = os.path.dirname(os.path.abspath(__file__))
-    only = os.environ.get("W4_ONLY")        # "w4" / "w5": regenerate one of the two bodies (knob sweeps)
-    for fold, name, kern in ((False, "attention_w4_body.inc", "flash_attn_w4_kernel<false> (variants 3 / 4)"),
-                             (True, "attention_w5_body.inc", "flash_attn_w4_kernel<true> (variants 5 / 6: folded scale and max)")):
-        if only and only != name[10:12]:
+    only = os.environ.get("W4_ONLY")        # "w4" / "w5": regenerate one of the bodies (knob sweeps)
+    for fold, probe, name, kern in ((False, False, "attention_w4_body.inc", "flash_attn_w4_kernel<false> (variants 3 / 4)"),
+                                    (True, False, "attention_w5_body.inc", "flash_attn_w4_kernel<true> (variants 5 / 6: folded scale and max)"),
+                                    (True, True, "attention_w5_probe_body.inc", "flash_attn_w4_kernel<true, true>: the folded schedule without "
+                                     "its softmax (pe_attn_mix_probe: MFMAs, LDS fragment reads, LDS-DMA stream, barrier)")):
+        if only and (only != name[10:12] or probe):
             continue
-        FOLD = fold
+        FOLD, PROBE = fold, probe
         out = ["// GENERATED by tools/gen_attn_w4.py -- do not edit; the schedule tables and their rationale are in that script.",
                f"// Included inside {kern} (attention.hip), which declares every name used here.", ""]
         for st in range(4):

@@ -9,7 +9,8 @@ OBJS=$(ls physicedit_amd/_build/*.o | grep -v attention.o)
 for spec in "$@"; do
     tag="${spec%%:*}"; envs="${spec#*:}"
     env $envs W4_ONLY=w5 python tools/gen_attn_w4.py > /dev/null
-    /opt/rocm/bin/hipcc $FLAGS -c physicedit_amd/csrc/attention.hip -o build_ab/attention_$tag.o
+    extra=""; case "$envs" in *W4_STAMPS=1*) extra="-DPE_W4_STAMPS=1";; esac
+    /opt/rocm/bin/hipcc $FLAGS $extra -c physicedit_amd/csrc/attention.hip -o build_ab/attention_$tag.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_ab/libpe_$tag.so $OBJS build_ab/attention_$tag.o
     rm build_ab/attention_$tag.o
     echo "built build_ab/libpe_$tag.so  ($envs)"
