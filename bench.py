@@ -606,9 +606,9 @@ def pmc_traffic(args):
     passes of tools/pmc_collect.sh (profiles/r02_pmc.json, which records its own command line).  They are per-launch properties
     of (kernel, shape), so they are reported ONLY when this run launches the same kernels on the same shapes -- same layer count,
     geometry, prompt lengths, operand dtype and stream count as the recorded command -- and are null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r03_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r04_pmc.json")
     if not os.path.exists(path) and not args.fp8:
-        path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        path = os.path.join(ROOT, "profiles", "r03_pmc.json")
     if not os.path.exists(path):
         return None, None, None
     rec = json.load(open(path))

@@ -164,10 +164,15 @@ def test_60_layers_headline_geometry():
     (mean |d| <= 2e-3, <= 6 ulp); PE_PARITY_FULL=1 adds the fp32 oracle pass and the other attention variants (~10 minutes; numbers
     in profiles/r03_parity.json, r04_parity.json)."""
     import os
+    from conftest import suite_seconds
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    full = os.environ.get("PE_PARITY_FULL") == "1"
+    if not full and suite_seconds() > float(os.environ.get("PE_SUITE_BUDGET_S", "820")):
+        pytest.skip(f"suite time budget: {suite_seconds():.0f} s gone when this ~190 s host-oracle test came up (slow / shared host); "
+                    "its numbers of the last full run are in profiles/r04_parity.json")
     _depth_meets_length(1024, 512, 64, "60 layers, 1024x1024 + 1024x1024 edit (S = 8704), T 512, one model_fn call (first of 40 steps)",
-                        fp32=os.environ.get("PE_PARITY_FULL") == "1")
+                        fp32=full)
 
 
 def test_60_layers_two_cfg_steps():
