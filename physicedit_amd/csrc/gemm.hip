@@ -1201,7 +1201,10 @@ int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_persist_wgs = 0;    // 0 = one work-group per CU of the current device
 int g_gemm_sk = env_int("PE_GEMM_SK", 0);     // schedule 19 where it applies (A/B knob "gemm_sk"; measured slower: profiles/r04_gemm_notes.md)
-int g_gemm_persist_min_rounds = 3;            // schedule 17 from this many rounds of tiles on (knob "gemm_persist_min_rounds"; G + 1 tiles at least)
+// schedule 17 from this many rounds of tiles on (knob "gemm_persist_min_rounds"; G + 1 tiles at least).  Round 3 used 3: in isolation
+// the 1.6-round Linears tie between 15 and 17.  In the two-stream pipeline 1 is 0.9 % faster per image (three interleaved A/B pairs on
+// one box: 11.59 / 11.61 / 11.61 s with 3, 11.50 / 11.49 / 11.50 s with 1; profiles/r04_gemm_notes.md section 5): the default since round 4.
+int g_gemm_persist_min_rounds = 1;
 GemmWorkspace g_gemm_ws = {nullptr, 0};
 constexpr size_t SK_SYNC_BYTES = 4096;        // ticket + flags (<= 992 work-groups), then the accumulator images
 
@@ -1256,8 +1259,8 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
         if constexpr (SK_EPI) return fp8 ? launch_v<EPI, 19, true>(args, G, stream) : launch_v<EPI, 19>(args, G, stream);
     }
     if (var == 19) var = 17;
-    // 17 pays from about three rounds of tiles on (measured, profiles/r03_gemm_notes.md: +1.2 ... +1.5 % at 4.8 / 6.4 rounds, -0.7 ... -1.3 %
-    // at 1.6 rounds, where most work-groups own a single tile and only pay for the two-pass epilogue); "gemm_persist_wgs" > 0 forces it
+    // 17 needs more than one round of tiles (profiles/r03_gemm_notes.md: +1.2 ... +1.5 % at 4.8 / 6.4 rounds, a tie at 1.6 rounds in isolation;
+    // in the two-stream pipeline it also pays at 1.6 rounds: g_gemm_persist_min_rounds above); "gemm_persist_wgs" > 0 forces it
     if (var == 17 && ntiles < (g_gemm_persist_wgs > 0 || g_gemm_persist_min_rounds <= 1 ? G + 1 : g_gemm_persist_min_rounds * G)) var = 15;
     if (fp8) {
         if (var == 10) return launch_v<EPI, 10, true>(args, ntiles, stream);
