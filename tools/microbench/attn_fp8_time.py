@@ -1,0 +1,29 @@
+"""pe_flash_attn_fp8 (statistics + quantisation + e4m3 flash kernel) at S = 8704 / 8464, H = 24: median of 5 x 10 launches.
+python tools/microbench/attn_fp8_time.py  (GPU box, from the repo root; under rocprofv3 --kernel-trace --stats for the per-kernel split)"""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import torch
+from physicedit_amd import ops
+from physicedit_amd._lib import lib, check, stream_ptr
+BF = torch.bfloat16
+g = torch.Generator(device='cuda').manual_seed(0)
+H = 24
+for S in (8704, 8464):
+    sp = ops.s_pad_of(S)
+    q = torch.zeros((H, sp, 128), dtype=BF, device='cuda'); q[:, :S] = torch.randn((H, S, 128), generator=g, device='cuda').to(BF)
+    k = torch.zeros((H, sp, 128), dtype=BF, device='cuda'); k[:, :S] = torch.randn((H, S, 128), generator=g, device='cuda').to(BF)
+    vt = ops.pack_vt(torch.randn((H, S, 128), generator=g, device='cuda').to(BF), sp)
+    out = torch.empty((S, H * 128), dtype=BF, device='cuda')
+    n = lib().pe_flash_attn_fp8_scratch_bytes(H, sp)
+    scratch = torch.empty((n + 256,), dtype=torch.uint8, device="cuda"); base = (scratch.data_ptr() + 255) // 256 * 256
+    nb = lib().pe_flash_attn_workspace_bytes(H, S); ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    def run():
+        check(lib().pe_flash_attn_fp8(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, base, n, ws.data_ptr(), nb, stream_ptr()), "fp8")
+    run(); torch.cuda.synchronize()
+    ts = []
+    for r in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 10)
+    print(f"S={S}: e4m3 attention (stats + quantise + kernel) {sorted(ts)[2]*1e3:.0f} us", flush=True)
