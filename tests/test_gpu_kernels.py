@@ -526,7 +526,7 @@ def test_flash_attn_plain_q_takes_exact_form(ops, attn_variant):
 
 
 # --- e4m3 attention (qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35) ---
-def _fp8_attn(ops, q, k, v, S, workspace=True):
+def _fp8_attn(ops, q, k, v, S, workspace=True, want_stats=False):
     from physicedit_amd._lib import check, lib, stream_ptr
     H = q.shape[0]
     qd, kd, vt = _dev_qkv(ops, q, k, v, S, nan_pad=False)
@@ -541,6 +541,9 @@ def _fp8_attn(ops, q, k, v, S, workspace=True):
         ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
     check(lib().pe_flash_attn_fp8(qd.data_ptr(), kd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, base, n,
                                   ws.data_ptr() if ws is not None else None, nb, stream_ptr()), "pe_flash_attn_fp8")
+    if want_stats:      # the scratch layout: Q8 | K8 | Vt8 planes of H * S_pad * 128 bytes, then {q_std, k_std, v_std, scale_log2} as fp32
+        off = base - scratch.data_ptr() + 3 * H * sp * 128
+        return out, scratch[off:off + 16].view(torch.float32).cpu()
     return out
 
 
@@ -559,8 +562,13 @@ def test_flash_attn_fp8(ops, S, scales):
     ref = O.flash_attention_fp8(q[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
     ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64)[0].permute(1, 0, 2).reshape(S, H * 128)
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
-    out = _fp8_attn(ops, q, k, v, S, workspace=False)
+    out, stats = _fp8_attn(ops, q, k, v, S, workspace=False, want_stats=True)
     assert torch.isfinite(out.float()).all()
+    # the statistics: torch.std of the whole bf16 tensor (unbiased, a bf16 scalar), and the scale FA3 would receive, in the log2 domain
+    q_std, k_std, v_std = q.std(), k.std(), v.std()
+    want = [float(q_std), float(k_std), float(v_std), float(q_std * k_std / math.sqrt(128.0)) * 1.4426950408889634]
+    print(f"[parity] flash_attn_fp8 S={S}: std / scale  hip {[round(x, 6) for x in stats.tolist()]}  torch {[round(x, 6) for x in want]}")
+    assert stats[:3].tolist() == want[:3] and abs(stats[3].item() - want[3]) <= 1e-6 * abs(want[3])
     e_tile, e_glob, e_fp8 = _rms(out, ref_t), _rms(out, ref), _rms(ref, ref32)
     print(f"[parity] flash_attn_fp8 S={S}: rms hip vs oracle-fp8 (online, 64-key tiles) {e_tile:.3e}, (P against the final max) {e_glob:.3e}; "
           f"oracle-fp8 vs fp32 truth {e_fp8:.3e}; hip vs truth {_rms(out, ref32):.3e}")
