@@ -45,7 +45,7 @@ const char* pe_build_id(void);
  * Production callers never need it: the compiled defaults are the validated schedules.
  * "gemm_variant": 17 default (persistent work-groups with cross-tile prefetch; launches of fewer than three rounds of tiles run 15);
  * 15 = one tile per work-group (the round-2 default; writes s_memtime stamps when "gemm_stamps" is attached); 10 = the round-1
- * schedule (A/B reference).  "gemm_band": M tiles per band of the XCD-aware tile order (default 8).  "gemm_persist_wgs":
+ * schedule (A/B reference).  "gemm_band": M tiles per band of the XCD-aware tile order (default 4).  "gemm_persist_wgs":
  * work-groups of schedule 17's grid (0 = one per CU).
  * "attn_variant": 4 default (4 waves x 64 query rows, one wave per SIMD, running softmax max raised only when a row outgrows
  * it by 2^8: same distance to an fp32 result as the reference's own bf16 SDPA, profiles/r03_attention_notes.md); 3 = the same

@@ -38,7 +38,7 @@ namespace pe {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;
 constexpr int GEMM_LDS = 5 * 32768;   // A x2 + W x3 = 160 KiB (all of a CU's LDS)
-constexpr int GEMM_DEFAULT_BAND = 8;
+constexpr int GEMM_DEFAULT_BAND = 4;      // M tiles per band: 8 until round 4; in the two-stream pipeline 4 is 0.45 - 0.6 % faster per image (profiles/r04_gemm_notes.md section 5)
 constexpr int GEMM_DEFAULT_VARIANT = 17;  // see the VAR list below
 
 struct GemmArgs {

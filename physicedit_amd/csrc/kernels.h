@@ -70,7 +70,7 @@ size_t gemm_workspace_bytes();
 extern GemmWorkspace g_gemm_ws;
 extern int g_gemm_sk, g_gemm_persist_min_rounds;
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace = nullptr);
-extern int g_gemm_band;          // M tiles per band of the tile order (default 8)
+extern int g_gemm_band;          // M tiles per band of the tile order (default 4)
 extern int g_gemm_persist_wgs;   // schedule 17: work-groups of the persistent grid (0 = one per CU)
 extern int g_gemm_variant;  // experiment knobs (pe_debug_set); production paths use the compiled defaults
 extern int g_attn_variant;
