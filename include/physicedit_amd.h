@@ -43,17 +43,19 @@ int pe_abi_version(void);
 const char* pe_build_id(void);
 /* Experiment knobs for in-process A/B benchmarking of kernel schedules ("gemm_variant", "attn_variant", ...).
  * Production callers never need it: the compiled defaults are the validated schedules.
- * "gemm_variant": 17 default (persistent work-groups with cross-tile prefetch; launches of fewer than three rounds of tiles run 15);
- * 15 = one tile per work-group (the round-2 default; writes s_memtime stamps when "gemm_stamps" is attached); 10 = the round-1
- * schedule (A/B reference).  "gemm_band": M tiles per band of the XCD-aware tile order (default 4).  "gemm_persist_wgs":
- * work-groups of schedule 17's grid (0 = one per CU).
- * "attn_variant": 4 default (4 waves x 64 query rows, one wave per SIMD, running softmax max raised only when a row outgrows
- * it by 2^8: same distance to an fp32 result as the reference's own bf16 SDPA, profiles/r03_attention_notes.md); 3 = the same
- * kernel with the textbook max update, bit-identical to 0; 0 = 8 waves x 32 query rows, textbook update (the round-1/2 default,
- * and always the kernel of the masked form). */
+ * "gemm_variant": 17 default (persistent work-groups with cross-tile prefetch; launches of at most one round of tiles run 15 --
+ * "gemm_persist_min_rounds", default 1); 15 = one tile per work-group (the round-2 default; writes s_memtime stamps when "gemm_stamps"
+ * is attached); 10 = the round-1 schedule (A/B reference); 19 = stream-K (bit-identical, needs a workspace: pe_gemm_workspace_bytes;
+ * "gemm_sk" = 1 lets 17 take it where tiles do not fill whole rounds; measured slower, default off).  "gemm_band": M tiles per band of
+ * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of schedule 17's grid (0 = one per CU).
+ * "attn_variant": 5 default (4 waves x 64 query rows, one wave per SIMD, lazy running max, the softmax scale folded into Q and the max
+ * fed through the MFMA C operand: pe_attn_q_prescale / pe_flash_attn_prescaled; same distance to an fp32 result as the reference's own
+ * bf16 SDPA, profiles/r04_attention_notes.md); 6 = 5 with the textbook max update; 4 / 3 = the same schedule with scale and max applied
+ * per score (round 3's default / its textbook form, bit-identical to 0); 0 = 8 waves x 32 query rows, textbook update (the round-1/2
+ * default, and always the kernel of the masked form).  "attn_slots", "attn_force_split": load-balancing knobs of the tests. */
 int pe_debug_set(const char* key, int value);
 /* Device buffer for a profiling variant's output ("gemm_stamps": long long [work-groups][8] s_memtime stamps of
- * gemm variant 15; "attn_stamps": long long [work-groups][10] of attention variants 3 / 4 built with -DPE_W4_STAMPS=1);
+ * gemm variant 15; "attn_stamps": long long [work-groups][10] of attention variants 3 - 6 built with -DPE_W4_STAMPS=1; "gemm_workspace": stream-K scratch for the granular pe_gemm_* calls);
  * NULL detaches it. */
 int pe_debug_set_ptr(const char* key, void* device_ptr);
 
