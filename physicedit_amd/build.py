@@ -22,6 +22,9 @@ HEADERS = ["common.h", "kernels.h", "attention_w4_body.inc", "attention_w5_body.
 # into one fma, silently deleting a bf16 rounding the reference performs (measured: 29 % of
 # ln_modulate outputs off by one ulp).  Fusion is written explicitly (fmaf) where it is wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# per-source extras.  attention.hip: no SLP vectorisation -- it turns adjacent fp32 adds / muls / fmas of the softmax into v_pk_*_f32, which
+# on gfx950 costs more than the two plain VALU it replaces when issued beside MFMAs
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -70,7 +73,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ([f'-DPE_SRC_HASH="{src_hash}"'] if src.endswith("api.hip") else []) + ["-c", src, "-o", obj]
+        cmd = ([hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
+               + ([f'-DPE_SRC_HASH="{src_hash}"'] if src.endswith("api.hip") else []) + ["-c", src, "-o", obj])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

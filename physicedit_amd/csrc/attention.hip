@@ -1205,6 +1205,313 @@ flash_attn_fp8_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict_
     }
 }
 
+
+// Variant 1 (default): the same arithmetic in a SOFTWARE-PIPELINED, hand-interleaved order.  In the kernel above the two waves of a SIMD
+// walk a tile in phase (barrier, 4 MFMAs of S, softmax, 4 MFMAs of P.V): while one issues MFMAs the other wants the matrix pipe too, so
+// matrix time and softmax time ADD (measured: 2600 cycles per tile and SIMD = 1024 of MFMA + ~1600 of VALU).  Here iteration t issues
+// S(t+1) = K(t+1) Q^T and O += P(t-1) V(t-1) -- eight MFMAs that do not depend on this iteration's softmax -- one per slice of the
+// softmax of S(t), which the previous iteration left in registers; every (LDS reads, MFMA) and every VALU slice is fenced with
+// sched_barrier(0), so source order is the schedule: each wave's own stream keeps the matrix pipe fed while it issues VALU.
+// K is staged two tiles ahead and V one tile behind it (two 8 KiB rings each: the same 32 KiB), one barrier per tile.
+// The lane halves meet in v_permlane32_swap (no LDS round trip); the row sum runs in two interleaved partial sums per lane, so l differs
+// from variant 0's in the last bits.  No packed fp32 (v_pk_*: slower than two plain VALU beside MFMAs on gfx950; the file is compiled
+// with -fno-slp-vectorize).
+int g_attn_fp8_variant = 1;
+#define F8_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2)
+flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict__ K8, const uint8_t* __restrict__ Vt8,
+                       bf16* __restrict__ out, int S, int S_pad, int ldo, const float* __restrict__ stats, AttnPlan plan,
+                       float* __restrict__ part_o, float* __restrict__ part_ml) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Q_BLOCK = NW * 32;
+    constexpr int RING = KV_TILE * 128;           // one K8 or Vt8 tile: 8 KiB
+    static_assert(NW == 8, "one K8 piece and one Vt8 piece per wave");
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int l31 = lane & 31, h = lane >> 5;
+    const float scale_log2 = stats[3], v_std = stats[2];
+    const int nqb = plan.nqb;
+    const int nt_all = (S + KV_TILE - 1) / KV_TILE;
+    int item, t_begin = 0, t_end = nt_all, part_slot = -1;
+    if ((int)blockIdx.x < plan.n_full) {
+        item = xcd_remap((int)blockIdx.x, plan.n_full);
+    } else {
+        const int j = (int)blockIdx.x - plan.n_full;
+        item = plan.n_full + j / plan.split;
+        const int part = j - (j / plan.split) * plan.split;
+        if (plan.split > 1) {
+            t_begin = (int)((long long)nt_all * part / plan.split);
+            t_end = (int)((long long)nt_all * (part + 1) / plan.split);
+            part_slot = j;
+        }
+    }
+    const int head = item / nqb;
+    const int qb = item - head * nqb;
+    const int q0 = qb * Q_BLOCK + w * 32;
+    const uint8_t* Qh = Q8 + (size_t)head * S_pad * 128;
+    const uint8_t* Kh = K8 + (size_t)head * S_pad * 128;
+    const uint8_t* Vh = Vt8 + (size_t)head * 128 * S_pad;
+
+    i32x8f qf[2];
+    {
+        const int qrow = min(q0 + l31, S - 1);
+        const uint8_t* qp = Qh + (size_t)qrow * 128 + h * 32;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const i32x4f lo = *(const i32x4f*)(qp + kk * 64), hi = *(const i32x4f*)(qp + kk * 64 + 16);
+            qf[kk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+    const uint8_t* k_src;
+    const uint8_t* v_src;
+    {
+        const int krow = w * 8 + (lane >> 3);
+        k_src = Kh + (size_t)krow * 128 + (((lane & 7) ^ (krow & 7)) << 4);
+        const int vrow = w * 16 + (lane >> 2);
+        v_src = Vh + (size_t)vrow * S_pad + (((lane & 3) ^ ((vrow >> 1) & 3)) << 4);
+    }
+    // LDS: K ring (2 x 8 KiB) then V ring (2 x 8 KiB)
+    auto stage_k = [&](int buf, int t) { glds16(k_src + (size_t)t * KV_TILE * 128, smem + buf * RING + w * 1024); };
+    auto stage_v = [&](int buf, int t) { glds16(v_src + t * KV_TILE, smem + (2 + buf) * RING + w * 1024); };
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ksw = l31 & 7, vsw = (l31 >> 1) & 3;
+    const int krow_off = l31 * 128, vrow_off = l31 * 64;
+
+    auto rd32 = [&](const char* rowp, int c0, int sw) -> i32x8f {
+        const i32x4f lo = *(const i32x4f*)(rowp + ((c0 ^ sw) << 4)), hi = *(const i32x4f*)(rowp + (((c0 + 1) ^ sw) << 4));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // matrix slot j of an iteration: 0..3 = S(t+1) pieces (s2 = j & 1, kk = j >> 1: the two accumulators alternate), 4..7 = P(t-1) V(t-1), dt = j - 4
+    auto frag = [&](const char* Kb, const char* Vb, int j) -> i32x8f {
+        return j < 4 ? rd32(Kb + (j & 1) * 32 * 128 + krow_off, (j >> 1) * 4 + 2 * h, ksw) : rd32(Vb + (j - 4) * 32 * 64 + vrow_off, 2 * h, vsw);
+    };
+    // every MFMA is a volatile asm statement: the compiler may neither sink it into the next iteration (its result is only read there) nor
+    // re-order it against the pinned softmax slices.  Operands come from LDS reads (s_waitcnt is inserted by the compiler) or were written
+    // hundreds of cycles earlier; readers of the results are >= 64 cycles downstream (hand-checked: the compiler does not see these hazards)
+    int unit = 0x7f7f7f7f;
+    asm volatile("" : "+v"(unit));
+    // drain: the wait states a 16-pass MFMA needs before anything reads its result, INSIDE the asm statement -- the compiler is free to put
+    // register copies of the result right behind the statement (it did: the two arms of a branch merged their accumulators that way)
+#define F8_MFMA "v_mfma_scale_f32_32x32x64_f8f6f4 "
+#define F8_DRAIN "\n\ts_nop 15\n\ts_nop 7"
+    auto mm = [&](int j, const i32x8f& f, f32x16 (&sn)[2], const i32x8f& p, bool drain = false) {
+        if (j < 2)
+            asm volatile(F8_MFMA "%0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]" : "=&v"(sn[j & 1]) : "v"(f), "v"(qf[0]), "v"(unit));
+        else if (j < 4 && !drain)
+            asm volatile(F8_MFMA "%0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(sn[j & 1]) : "v"(f), "v"(qf[1]), "v"(unit));
+        else if (j < 4)
+            asm volatile(F8_MFMA "%0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" F8_DRAIN : "+v"(sn[j & 1]) : "v"(f), "v"(qf[1]), "v"(unit));
+        else if (!drain)
+            asm volatile(F8_MFMA "%0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(o[j - 4]) : "v"(f), "v"(p), "v"(unit));
+        else
+            asm volatile(F8_MFMA "%0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" F8_DRAIN : "+v"(o[j - 4]) : "v"(f), "v"(p), "v"(unit));
+    };
+    auto sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    const int n = t_end - t_begin;
+    const bool tail = (S & (KV_TILE - 1)) != 0 && t_end == nt_all;
+    // iteration i (tile t = t_begin + i), parity P = i & 1: K(t+1) sits in K ring 1 - P, V(t-1) in V ring 1 - P; K(t+2) -> K ring P, V(t) -> V ring P.
+    // sc: S(t) (in), sn: S(t+1) (out); pq: P(t-1) (in), pc: P(t) (out)
+    auto iter = [&](int t, auto par_tag, auto prev_tag, auto last_tag, f32x16 (&sc)[2], f32x16 (&sn)[2], const i32x8f& pq, i32x8f& pc) {
+        constexpr int P = decltype(par_tag)::value;
+        constexpr bool PREV = decltype(prev_tag)::value, LAST = decltype(last_tag)::value;
+        const char* Kb = smem + (1 - P) * RING;
+        const char* Vb = smem + (2 + 1 - P) * RING;
+        auto on = [](int j) { return j < 4 ? !LAST : PREV; };
+        sync();
+        if constexpr (!LAST) {
+            if (t + 2 < t_end) stage_k(P, t + 2);
+        }
+        stage_v(P, t);
+        i32x8f f[3];
+        if (on(0)) f[0] = frag(Kb, Vb, 0);
+        F8_FENCE();
+        // slot(j): issue MFMA j, then the LDS reads of slot j + 1's fragment (a whole VALU slice ahead of its use).  The MFMA is
+        // asynchronous and the compiler does not know: its A / B registers are "dead" after the asm statement and would be handed to the
+        // very next LDS read or VALU temporary while the matrix pipe still reads them (measured: 4 % rms error).  F8_KEEP holds every
+        // fragment (and P) live until the NEXT MFMA of this wave has issued, i.e. until this one has left the pipe.
+#define F8_KEEP(x) asm volatile("" ::"v"(x))
+#define F8_SLOT(j)                                                   \
+        F8_FENCE();                                                  \
+        if (on(j)) mm(j, f[(j) % 3], sn, pq);                        \
+        if ((j) >= 2 && on((j) - 2)) F8_KEEP(f[((j) - 2) % 3]);      \
+        if ((j) + 1 < 8 && on((j) + 1)) f[((j) + 1) % 3] = frag(Kb, Vb, (j) + 1); \
+        F8_FENCE();
+        if constexpr (LAST) {
+            if (tail) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                        if (key >= S) sc[s2][r] = -INFINITY;
+                    }
+            }
+            F8_FENCE();
+        }
+        float mx0 = sc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx0 = fmaxf(mx0, sc[0][r]);
+        asm volatile("" : "+v"(mx0));            // pins: pure arithmetic is otherwise placed wherever instruction selection likes
+        F8_SLOT(0)
+        float mx = sc[1][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+        mx = fmaxf(mx, mx0);
+        asm volatile("" : "+v"(mx));
+        F8_SLOT(1)
+        mx = max_with_lane_xor32(mx);
+        const float m_new = fmaxf(m_run, mx * scale_log2);
+        const bool moved = m_new != m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        const float nm = -m_new;
+        float ps0 = 0.f, ps1 = 0.f;
+        auto group = [&](int g) {            // scores 4 a .. 4 a + 3 of accumulator s2 -> dword g = 4 s2 + a of this lane's k-slots
+            const int s2 = g >> 2, a = g & 3;
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a], scale_log2, nm));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 1], scale_log2, nm));
+            const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 2], scale_log2, nm));
+            const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 3], scale_log2, nm));
+            ps0 += p0;
+            ps1 += p1;
+            ps0 += p2;
+            ps1 += p3;
+            pc[g] = (int)pack4_e4m3(p0, p1, p2, p3);
+            asm volatile("" : "+v"(pc[g]));          // computed HERE (not sunk to its reader in the next iteration)
+        };
+        group(0);
+        F8_SLOT(2)
+        group(1);
+        F8_SLOT(3)
+        group(2);
+        F8_SLOT(4)
+        group(3);
+        F8_SLOT(5)
+        group(4);
+        F8_SLOT(6)
+        group(5);
+        F8_SLOT(7)
+        group(6);
+        group(7);
+        l_run = __builtin_fmaf(l_run, alpha, ps0 + ps1);
+        asm volatile("" : "+v"(l_run));
+        if (on(7)) {
+            F8_KEEP(f[0]);
+            F8_KEEP(f[1]);
+            F8_KEEP(pq);
+        }
+        F8_FENCE();
+#undef F8_SLOT
+#undef F8_KEEP
+        if (__any(moved)) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using No = std::false_type;
+    using Yes = std::true_type;
+    f32x16 sa[2], sb[2];
+    i32x8f pa, pb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pa[j] = pb[j] = 0;
+    if (n > 0) {                                     // a part of a split item may own no tile at all (more parts than tiles)
+        stage_k(0, t_begin);
+        sync();
+        if (n > 1) stage_k(1, t_begin + 1);
+        {                                                                         // S(t_begin)
+            i32x8f f4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f4[j] = frag(smem, smem, j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm(j, f4[j], sa, pa, j == 3);             // drained: the first iteration reads S
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(f4[j]));            // live while the matrix pipe reads them (see F8_KEEP)
+        }
+        // even iterations: S in sa -> sb, P(t) -> pa (P(t-1) in pb); odd iterations the other way round
+        if (n == 1) {
+            iter(t_begin, P0{}, No{}, Yes{}, sa, sb, pb, pa);
+        } else {
+            iter(t_begin, P0{}, No{}, No{}, sa, sb, pb, pa);
+            int i = 1;
+            for (; i + 2 <= n - 1; i += 2) {
+                iter(t_begin + i, P1{}, Yes{}, No{}, sb, sa, pa, pb);
+                iter(t_begin + i + 1, P0{}, Yes{}, No{}, sa, sb, pb, pa);
+            }
+            if (i < n - 1) {
+                iter(t_begin + i, P1{}, Yes{}, No{}, sb, sa, pa, pb);
+                ++i;
+            }
+            if (i & 1) iter(t_begin + i, P1{}, Yes{}, Yes{}, sb, sa, pa, pb);
+            else iter(t_begin + i, P0{}, Yes{}, Yes{}, sa, sb, pb, pa);
+        }
+        i32x8f pl;                                       // P(t_end - 1), selected before the barrier (a VALU write needs distance to the MFMA)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pl[j] = ((n - 1) & 1) ? pb[j] : pa[j];
+        asm volatile("" : "+v"(pl));
+        sync();                                          // V(t_end - 1) landed
+        {
+            const char* Vb = smem + (2 + ((n - 1) & 1)) * RING;
+            i32x8f f4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f4[j] = frag(Vb, Vb, 4 + j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm(4 + j, f4[j], sa, pl, j == 3);         // drained: the epilogue reads O
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(f4[j]));
+            asm volatile("" ::"v"(pl));
+            asm volatile("" ::"v"(pa), "v"(pb), "v"(qf[0]), "v"(qf[1]), "v"(unit));      // nothing an MFMA reads is ever "dead" before the end
+        }
+    }
+    const float l_tot = sum_with_lane_xor32(l_run);
+    if (part_slot >= 0) {
+        float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 128 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = o[dt][4 * a + r];
+                *(f32x4*)(po + dt * 32 + 8 * a) = v;
+            }
+        if (h == 0) {
+            float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 2;
+            pm[0] = m_run;
+            pm[1] = l_tot;
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < S) {
+        bf16* op = out + (size_t)q * ldo + head * 128 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16)((float)(bf16)(o[dt][4 * a + r] * inv) * v_std);     // x.to(bf16) * v_std
+                *(bf16x4*)(op + dt * 32 + 8 * a) = v;
+            }
+    }
+}
+
 size_t flash_attn_fp8_scratch_bytes(int H, int S_pad) {
     return 3 * (size_t)H * S_pad * 128 + 256 + (size_t)3 * F8_STAT_WGS * 2 * sizeof(double) + 256;
 }
@@ -1218,7 +1525,8 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
                "flash_attn_fp8: scratch of %zu bytes, 256-byte aligned, needed", flash_attn_fp8_scratch_bytes(H, S_pad));
     static std::atomic<bool> configured{false};
     if (!configured.load(std::memory_order_acquire)) {
-        const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fp8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fp8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_fp8p_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
@@ -1243,9 +1551,14 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
     const int n_short = (total - plan.n_full) * plan.split;
     float* part_o = (float*)workspace;
     float* part_ml = part_o ? part_o + (size_t)g_attn_slots * 256 * 128 : nullptr;
-    hipLaunchKernelGGL((flash_attn_fp8_kernel<8>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
-                       (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan, part_o,
-                       part_ml);
+    if (g_attn_fp8_variant == 0)
+        hipLaunchKernelGGL((flash_attn_fp8_kernel<8>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
+                           (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
+                           part_o, part_ml);
+    else
+        hipLaunchKernelGGL((flash_attn_fp8p_kernel<8>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
+                           (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
+                           part_o, part_ml);
     rc = check_launch("flash_attn_fp8_kernel");
     if (rc == PE_OK && plan.split > 1) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3((total - plan.n_full) * (Q_BLOCK / 8)), dim3(256), 0, stream, part_o, part_ml, (bf16*)out,

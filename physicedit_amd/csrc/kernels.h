@@ -93,7 +93,7 @@ int launch_attn_mix_probe(const void* q, const void* k, const void* vt, void* ou
 size_t flash_attn_fp8_scratch_bytes(int H, int S_pad);
 int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
                           size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream);
-extern int g_attn_slots, g_attn_force_split;
+extern int g_attn_slots, g_attn_force_split, g_attn_fp8_variant;
 
 // ---------------------------------------------------------------------------------------------
 // row kernels / elementwise

@@ -19,11 +19,19 @@ for S in (8704, 8464):
     nb = lib().pe_flash_attn_workspace_bytes(H, S); ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
     def run():
         check(lib().pe_flash_attn_fp8(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, base, n, ws.data_ptr(), nb, stream_ptr()), "fp8")
-    run(); torch.cuda.synchronize()
-    ts = []
-    for r in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10): run()
-        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 10)
-    print(f"S={S}: e4m3 attention (stats + quantise + kernel) {sorted(ts)[2]*1e3:.0f} us", flush=True)
+    ref = None
+    for variant in (0, 1):
+        check(lib().pe_debug_set(b"attn_fp8_variant", variant), "knob")
+        run(); torch.cuda.synchronize()
+        if variant == 0:
+            ref = out.float().clone()
+        else:
+            d = out.float() - ref
+            print("  variant 1 vs 0: max abs", float(d.abs().max()), "rms rel", float((d.pow(2).mean() / ref.pow(2).mean()).sqrt()), flush=True)
+        ts = []
+        for r in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): run()
+            e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 10)
+        print(f"S={S} variant {variant}: e4m3 attention (stats + quantise + kernel) {sorted(ts)[2]*1e3:.0f} us", flush=True)
