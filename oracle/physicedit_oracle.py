@@ -229,7 +229,8 @@ def _heads(x: torch.Tensor, h: int = 24) -> torch.Tensor:
     return x.reshape(B, S, h, HD // h).permute(0, 2, 1, 3)
 
 
-def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dtype=torch.float8_e4m3fn, kv_tile: Optional[int] = None) -> torch.Tensor:
+def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dtype=torch.float8_e4m3fn, kv_tile: Optional[int] = None,
+                        lazy_tau_log2: float = 0.0) -> torch.Tensor:
     """qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35: q, k, v [B, H, S, D] bf16 are divided by their
     global standard deviations (torch.std: unbiased, over the whole tensor, a bf16 scalar), cast to float8_e4m3fn, handed to
     FlashAttention-3 with softmax_scale = q_std * k_std / sqrt(D), and the output (bf16) is multiplied by v_std.
@@ -240,7 +241,10 @@ def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dty
     the upper bound on what any such kernel can reach).  kv_tile=None quantises P = exp(s - row max) against the FINAL row max; a
     flash kernel cannot know that yet -- it quantises each KV tile's P against the RUNNING max and rescales the accumulator when the
     max moves -- so kv_tile=n restates that online form with n-key tiles (FA3's own tile size is not observable; the library's is
-    64).  The two differ by e4m3 rounding noise of P only (same size, different rounding points).  Everything outside the kernel
+    64).  lazy_tau_log2 = T > 0 restates the LAZY online form (the library's default kernel; FlashAttention-4 publishes the same
+    trick with T = 8): the reference value m is raised to a tile's maximum only when that exceeds m by more than a factor 2^T,
+    so P = exp(s - m) may reach 2^T (256 for T = 8, below e4m3's 448) and the accumulator is rescaled on a few tiles only.
+    All these forms differ by e4m3 rounding noise of P only (same size, different rounding points).  Everything outside the kernel
     (the three std, the two casts, the scale, the output product and its roundings) is the reference's own arithmetic.
     -> [B, H, S, D] bf16."""
     origin = q.dtype
@@ -257,7 +261,9 @@ def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dty
         vf = v8.float()
         for t0 in range(0, S_, kv_tile):
             st = s[..., t0:t0 + kv_tile]
-            m_new = torch.maximum(m, st.amax(dim=-1, keepdim=True))
+            m_tile = st.amax(dim=-1, keepdim=True)
+            # T = 0: the running maximum.  (m = -inf on the first tile: always raised)
+            m_new = torch.where(m_tile - m > lazy_tau_log2 * math.log(2.0), m_tile, m)
             alpha = torch.exp(m - m_new)
             e = torch.exp(st - m_new)
             l = l * alpha + e.sum(dim=-1, keepdim=True)

@@ -1217,7 +1217,20 @@ flash_attn_fp8_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict_
 // from variant 0's in the last bits.  No packed fp32 (v_pk_*: slower than two plain VALU beside MFMAs on gfx950; the file is compiled
 // with -fno-slp-vectorize).
 int g_attn_fp8_variant = 1;
+constexpr float F8_TAU = 8.0f;
 #define F8_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef PE_F8_EXP
+#define PE_F8_EXP 0
+#endif
+#ifndef PE_F8_NOMFMA
+#define PE_F8_NOMFMA 0
+#endif
+#ifndef PE_F8_NOBAR
+#define PE_F8_NOBAR 0
+#endif
+#ifndef PE_F8_STAMPS      // experiment: per-wave cycles spent waiting in the per-tile barrier / in total, written behind `stats` (work-group 0)
+#define PE_F8_STAMPS 0
+#endif
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 2)
@@ -1316,10 +1329,17 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
     };
     auto sync = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if PE_F8_NOBAR
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#else
         __syncthreads();
+#endif
     };
     const int n = t_end - t_begin;
     const bool tail = (S & (KV_TILE - 1)) != 0 && t_end == nt_all;
+#if PE_F8_STAMPS
+    long long st_wait = 0, st_seg[5] = {0, 0, 0, 0, 0};
+#endif
     // iteration i (tile t = t_begin + i), parity P = i & 1: K(t+1) sits in K ring 1 - P, V(t-1) in V ring 1 - P; K(t+2) -> K ring P, V(t) -> V ring P.
     // sc: S(t) (in), sn: S(t+1) (out); pq: P(t-1) (in), pc: P(t) (out)
     auto iter = [&](int t, auto par_tag, auto prev_tag, auto last_tag, f32x16 (&sc)[2], f32x16 (&sn)[2], const i32x8f& pq, i32x8f& pc) {
@@ -1328,24 +1348,40 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         const char* Kb = smem + (1 - P) * RING;
         const char* Vb = smem + (2 + 1 - P) * RING;
         auto on = [](int j) { return j < 4 ? !LAST : PREV; };
+#if PE_F8_STAMPS
+        const long long st_a = (long long)__builtin_readcyclecounter();
         sync();
+        st_wait += (long long)__builtin_readcyclecounter() - st_a;
+#else
+        sync();
+#endif
         if constexpr (!LAST) {
             if (t + 2 < t_end) stage_k(P, t + 2);
         }
         stage_v(P, t);
-        i32x8f f[3];
-        if (on(0)) f[0] = frag(Kb, Vb, 0);
+#if PE_F8_STAMPS
+        long long st_t = (long long)__builtin_readcyclecounter();
+        st_seg[0] += st_t - st_a;
+#define F8_STAMP(k) { const long long now = (long long)__builtin_readcyclecounter(); st_seg[k] += now - st_t; st_t = now; }
+#else
+#define F8_STAMP(k)
+#endif
+        i32x8f f[4];
+        if (on(0)) {
+            f[0] = frag(Kb, Vb, 0);
+            f[1] = frag(Kb, Vb, 1);
+        }
         F8_FENCE();
-        // slot(j): issue MFMA j, then the LDS reads of slot j + 1's fragment (a whole VALU slice ahead of its use).  The MFMA is
+        // slot(j): issue MFMA j, then the LDS reads of slot j + 2's fragment (two VALU slices ahead of its use).  The MFMA is
         // asynchronous and the compiler does not know: its A / B registers are "dead" after the asm statement and would be handed to the
         // very next LDS read or VALU temporary while the matrix pipe still reads them (measured: 4 % rms error).  F8_KEEP holds every
         // fragment (and P) live until the NEXT MFMA of this wave has issued, i.e. until this one has left the pipe.
 #define F8_KEEP(x) asm volatile("" ::"v"(x))
 #define F8_SLOT(j)                                                   \
         F8_FENCE();                                                  \
-        if (on(j)) mm(j, f[(j) % 3], sn, pq);                        \
-        if ((j) >= 2 && on((j) - 2)) F8_KEEP(f[((j) - 2) % 3]);      \
-        if ((j) + 1 < 8 && on((j) + 1)) f[((j) + 1) % 3] = frag(Kb, Vb, (j) + 1); \
+        if (on(j) && !((PE_F8_NOMFMA >> (j)) & 1)) mm(j, f[(j) & 3], sn, pq); \
+        if ((j) >= 1 && on((j) - 1)) F8_KEEP(f[((j) - 1) & 3]);      \
+        if ((j) + 2 < 8 && on((j) + 2)) f[((j) + 2) & 3] = frag(Kb, Vb, (j) + 2); \
         F8_FENCE();
         if constexpr (LAST) {
             if (tail) {
@@ -1371,29 +1407,47 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         asm volatile("" : "+v"(mx));
         F8_SLOT(1)
         mx = max_with_lane_xor32(mx);
-        const float m_new = fmaxf(m_run, mx * scale_log2);
-        const bool moved = m_new != m_run;
+        // lazily raised reference: m moves to the tile's maximum only when that exceeds it by more than 2^F8_TAU (the first tile always:
+        // m = -inf); otherwise P = exp2(s c - m) <= 2^8 = 256 < 448 = the largest e4m3 and O, l keep their scale: no pass over O
+        const float m_tile = mx * scale_log2;
+        const bool moved = m_tile - m_run > F8_TAU;
+        const float m_new = moved ? m_tile : m_run;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         const float nm = -m_new;
         float ps0 = 0.f, ps1 = 0.f;
         auto group = [&](int g) {            // scores 4 a .. 4 a + 3 of accumulator s2 -> dword g = 4 s2 + a of this lane's k-slots
             const int s2 = g >> 2, a = g & 3;
-            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a], scale_log2, nm));
-            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 1], scale_log2, nm));
-            const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 2], scale_log2, nm));
-            const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 3], scale_log2, nm));
+#if PE_F8_EXP == 1          // experiment: no transcendental
+#define F8_EXP2(x) (x)
+#elif PE_F8_EXP == 2        // experiment: neither exp nor fma
+#define F8_EXP2(x) (x)
+#define __builtin_fmaf(a, b, c) (a)
+#else
+#define F8_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+            const float p0 = F8_EXP2(__builtin_fmaf(sc[s2][4 * a], scale_log2, nm));
+            const float p1 = F8_EXP2(__builtin_fmaf(sc[s2][4 * a + 1], scale_log2, nm));
+            const float p2 = F8_EXP2(__builtin_fmaf(sc[s2][4 * a + 2], scale_log2, nm));
+            const float p3 = F8_EXP2(__builtin_fmaf(sc[s2][4 * a + 3], scale_log2, nm));
+#if PE_F8_EXP == 2
+#undef __builtin_fmaf
+#endif
             ps0 += p0;
             ps1 += p1;
             ps0 += p2;
             ps1 += p3;
-            pc[g] = (int)pack4_e4m3(p0, p1, p2, p3);
+            int v = pc[g];                           // both halves are overwritten: no zero fill
+            v = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, v, false);
+            v = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, v, true);
+            pc[g] = v;
             asm volatile("" : "+v"(pc[g]));          // computed HERE (not sunk to its reader in the next iteration)
         };
         group(0);
         F8_SLOT(2)
         group(1);
         F8_SLOT(3)
+        F8_STAMP(1)
         group(2);
         F8_SLOT(4)
         group(3);
@@ -1402,25 +1456,31 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         F8_SLOT(6)
         group(5);
         F8_SLOT(7)
+        F8_STAMP(2)
         group(6);
         group(7);
         l_run = __builtin_fmaf(l_run, alpha, ps0 + ps1);
         asm volatile("" : "+v"(l_run));
         if (on(7)) {
-            F8_KEEP(f[0]);
-            F8_KEEP(f[1]);
+            F8_KEEP(f[3]);
             F8_KEEP(pq);
         }
         F8_FENCE();
 #undef F8_SLOT
 #undef F8_KEEP
+        F8_STAMP(3)
         if (__any(moved)) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
+        F8_STAMP(4)
+#undef F8_STAMP
     };
+#if PE_F8_STAMPS
+    const long long st_begin = (long long)__builtin_readcyclecounter();
+#endif
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     using No = std::false_type;
@@ -1477,6 +1537,15 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
             asm volatile("" ::"v"(pa), "v"(pb), "v"(qf[0]), "v"(qf[1]), "v"(unit));      // nothing an MFMA reads is ever "dead" before the end
         }
     }
+#if PE_F8_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+        long long* st = (long long*)((char*)stats + 256) + w * 8;
+        st[0] = st_wait;
+        st[1] = (long long)__builtin_readcyclecounter() - st_begin;
+        st[2] = n;
+        for (int k = 0; k < 5; ++k) st[3 + k] = st_seg[k];
+    }
+#endif
     const float l_tot = sum_with_lane_xor32(l_run);
     if (part_slot >= 0) {
         float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 128 + 4 * h;

@@ -547,9 +547,19 @@ def _fp8_attn(ops, q, k, v, S, workspace=True, want_stats=False):
     return out
 
 
+@pytest.fixture
+def fp8_variant(request):
+    """attn_fp8_variant knob for one test: 1 = the default (software-pipelined, lazily raised reference, 2^8), 0 = the plain kernel (running max)"""
+    from physicedit_amd._lib import lib, check
+    check(lib().pe_debug_set(b"attn_fp8_variant", request.param), "attn_fp8_variant")
+    yield request.param
+    check(lib().pe_debug_set(b"attn_fp8_variant", 1), "attn_fp8_variant")
+
+
+@pytest.mark.parametrize("fp8_variant", [1, 0], indirect=True)
 @pytest.mark.parametrize("S,scales", [(64, (1.0, 1.0, 1.0)), (100, (1.0, 1.0, 1.0)), (700, (0.7, 1.9, 3.1)), (1093, (2.5, 0.4, 0.05)),
                                       (2208, (1.0, 1.3, 0.8))])
-def test_flash_attn_fp8(ops, S, scales):
+def test_flash_attn_fp8(ops, S, scales, fp8_variant):
     """The e4m3 attention operator against the oracle's restatement of the reference branch (global std of q, k, v in bf16, e4m3 casts,
     softmax_scale = q_std k_std / sqrt(128), P cast to e4m3, output x v_std), on tensors whose three scales differ: what the kernel
     may differ in is the fp32 summation order and the rounding of P near e4m3 ties -- a small fraction of what e4m3 operands cost
@@ -560,7 +570,8 @@ def test_flash_attn_fp8(ops, S, scales):
     q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in scales)
     torch.set_num_threads(max(torch.get_num_threads(), 16))
     ref = O.flash_attention_fp8(q[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
-    ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64)[0].permute(1, 0, 2).reshape(S, H * 128)
+    tau = 8.0 if fp8_variant == 1 else 0.0      # the default kernel raises its reference lazily (oracle: lazy_tau_log2)
+    ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64, lazy_tau_log2=tau)[0].permute(1, 0, 2).reshape(S, H * 128)
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
     out, stats = _fp8_attn(ops, q, k, v, S, workspace=False, want_stats=True)
     assert torch.isfinite(out.float()).all()
@@ -570,19 +581,21 @@ def test_flash_attn_fp8(ops, S, scales):
     print(f"[parity] flash_attn_fp8 S={S}: std / scale  hip {[round(x, 6) for x in stats.tolist()]}  torch {[round(x, 6) for x in want]}")
     assert stats[:3].tolist() == want[:3] and abs(stats[3].item() - want[3]) <= 1e-6 * abs(want[3])
     e_tile, e_glob, e_fp8 = _rms(out, ref_t), _rms(out, ref), _rms(ref, ref32)
-    print(f"[parity] flash_attn_fp8 S={S}: rms hip vs oracle-fp8 (online, 64-key tiles) {e_tile:.3e}, (P against the final max) {e_glob:.3e}; "
+    print(f"[parity] flash_attn_fp8 S={S} variant {fp8_variant}: rms hip vs oracle-fp8 (online, 64-key tiles, tau 2^{tau:.0f}) {e_tile:.3e}, (P against the final max) {e_glob:.3e}; "
           f"oracle-fp8 vs fp32 truth {e_fp8:.3e}; hip vs truth {_rms(out, ref32):.3e}")
     # against the restatement that quantises P where a flash kernel must (running max of 64-key tiles): summation order and e4m3 ties
     assert e_tile <= 0.05 * e_fp8 + 1e-6
     # against the form that knows the final max: the same size of P rounding noise at other rounding points
-    assert e_glob <= 0.6 * e_fp8 + 1e-6
+    # (the lazy form moves its rounding points further from the final-max form's than the running max does: 0.66 measured, 0.44 for variant 0)
+    noise = 0.8 if fp8_variant == 1 else 0.6
+    assert e_glob <= noise * e_fp8 + 1e-6
     assert _rms(out, ref32) <= 1.1 * e_fp8 + 1e-6
     out1 = out
     out = _fp8_attn(ops, q, k, v, S)
     # the load-balanced form (leftover items split along KV): every part has its own running max, so its P is rounded to e4m3 at other
     # points than the unsplit kernel's -- the same noise again, not a bf16-ulp matter
     print(f"[parity] flash_attn_fp8 S={S}: balanced vs single-kernel rms {_rms(out, out1):.3e}; balanced vs truth {_rms(out, ref32):.3e}")
-    assert _rms(out, out1) <= 0.6 * e_fp8 + 1e-6 and _rms(out, ref32) <= 1.1 * e_fp8 + 1e-6
+    assert _rms(out, out1) <= noise * e_fp8 + 1e-6 and _rms(out, ref32) <= 1.1 * e_fp8 + 1e-6
     for _ in range(5):
         assert torch.equal(_fp8_attn(ops, q, k, v, S), out)
 
