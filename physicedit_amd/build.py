@@ -24,7 +24,7 @@ HEADERS = ["common.h", "kernels.h", "attention_w4_body.inc", "attention_w5_body.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # per-source extras.  attention.hip: no SLP vectorisation -- it turns adjacent fp32 adds / muls / fmas of the softmax into v_pk_*_f32, which
 # on gfx950 costs more than the two plain VALU it replaces when issued beside MFMAs
-EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"] + os.environ.get("PE_ATTN_DEFS", "").split()}
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -1219,18 +1219,6 @@ flash_attn_fp8_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict_
 int g_attn_fp8_variant = 1;
 constexpr float F8_TAU = 8.0f;
 #define F8_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifndef PE_F8_EXP
-#define PE_F8_EXP 0
-#endif
-#ifndef PE_F8_NOMFMA
-#define PE_F8_NOMFMA 0
-#endif
-#ifndef PE_F8_NOBAR
-#define PE_F8_NOBAR 0
-#endif
-#ifndef PE_F8_STAMPS      // experiment: per-wave cycles spent waiting in the per-tile barrier / in total, written behind `stats` (work-group 0)
-#define PE_F8_STAMPS 0
-#endif
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 2)
@@ -1329,17 +1317,10 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
     };
     auto sync = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if PE_F8_NOBAR
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#else
         __syncthreads();
-#endif
     };
     const int n = t_end - t_begin;
     const bool tail = (S & (KV_TILE - 1)) != 0 && t_end == nt_all;
-#if PE_F8_STAMPS
-    long long st_wait = 0, st_seg[5] = {0, 0, 0, 0, 0};
-#endif
     // iteration i (tile t = t_begin + i), parity P = i & 1: K(t+1) sits in K ring 1 - P, V(t-1) in V ring 1 - P; K(t+2) -> K ring P, V(t) -> V ring P.
     // sc: S(t) (in), sn: S(t+1) (out); pq: P(t-1) (in), pc: P(t) (out)
     auto iter = [&](int t, auto par_tag, auto prev_tag, auto last_tag, f32x16 (&sc)[2], f32x16 (&sn)[2], const i32x8f& pq, i32x8f& pc) {
@@ -1348,24 +1329,11 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         const char* Kb = smem + (1 - P) * RING;
         const char* Vb = smem + (2 + 1 - P) * RING;
         auto on = [](int j) { return j < 4 ? !LAST : PREV; };
-#if PE_F8_STAMPS
-        const long long st_a = (long long)__builtin_readcyclecounter();
         sync();
-        st_wait += (long long)__builtin_readcyclecounter() - st_a;
-#else
-        sync();
-#endif
         if constexpr (!LAST) {
             if (t + 2 < t_end) stage_k(P, t + 2);
         }
         stage_v(P, t);
-#if PE_F8_STAMPS
-        long long st_t = (long long)__builtin_readcyclecounter();
-        st_seg[0] += st_t - st_a;
-#define F8_STAMP(k) { const long long now = (long long)__builtin_readcyclecounter(); st_seg[k] += now - st_t; st_t = now; }
-#else
-#define F8_STAMP(k)
-#endif
         i32x8f f[4];
         if (on(0)) {
             f[0] = frag(Kb, Vb, 0);
@@ -1379,7 +1347,7 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
 #define F8_KEEP(x) asm volatile("" ::"v"(x))
 #define F8_SLOT(j)                                                   \
         F8_FENCE();                                                  \
-        if (on(j) && !((PE_F8_NOMFMA >> (j)) & 1)) mm(j, f[(j) & 3], sn, pq); \
+        if (on(j)) mm(j, f[(j) & 3], sn, pq);                        \
         if ((j) >= 1 && on((j) - 1)) F8_KEEP(f[((j) - 1) & 3]);      \
         if ((j) + 2 < 8 && on((j) + 2)) f[((j) + 2) & 3] = frag(Kb, Vb, (j) + 2); \
         F8_FENCE();
@@ -1418,21 +1386,10 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         float ps0 = 0.f, ps1 = 0.f;
         auto group = [&](int g) {            // scores 4 a .. 4 a + 3 of accumulator s2 -> dword g = 4 s2 + a of this lane's k-slots
             const int s2 = g >> 2, a = g & 3;
-#if PE_F8_EXP == 1          // experiment: no transcendental
-#define F8_EXP2(x) (x)
-#elif PE_F8_EXP == 2        // experiment: neither exp nor fma
-#define F8_EXP2(x) (x)
-#define __builtin_fmaf(a, b, c) (a)
-#else
-#define F8_EXP2(x) __builtin_amdgcn_exp2f(x)
-#endif
-            const float p0 = F8_EXP2(__builtin_fmaf(sc[s2][4 * a], scale_log2, nm));
-            const float p1 = F8_EXP2(__builtin_fmaf(sc[s2][4 * a + 1], scale_log2, nm));
-            const float p2 = F8_EXP2(__builtin_fmaf(sc[s2][4 * a + 2], scale_log2, nm));
-            const float p3 = F8_EXP2(__builtin_fmaf(sc[s2][4 * a + 3], scale_log2, nm));
-#if PE_F8_EXP == 2
-#undef __builtin_fmaf
-#endif
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a], scale_log2, nm));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 1], scale_log2, nm));
+            const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 2], scale_log2, nm));
+            const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 3], scale_log2, nm));
             ps0 += p0;
             ps1 += p1;
             ps0 += p2;
@@ -1447,7 +1404,6 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         F8_SLOT(2)
         group(1);
         F8_SLOT(3)
-        F8_STAMP(1)
         group(2);
         F8_SLOT(4)
         group(3);
@@ -1456,7 +1412,6 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         F8_SLOT(6)
         group(5);
         F8_SLOT(7)
-        F8_STAMP(2)
         group(6);
         group(7);
         l_run = __builtin_fmaf(l_run, alpha, ps0 + ps1);
@@ -1468,19 +1423,13 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         F8_FENCE();
 #undef F8_SLOT
 #undef F8_KEEP
-        F8_STAMP(3)
         if (__any(moved)) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
-        F8_STAMP(4)
-#undef F8_STAMP
     };
-#if PE_F8_STAMPS
-    const long long st_begin = (long long)__builtin_readcyclecounter();
-#endif
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     using No = std::false_type;
@@ -1537,15 +1486,6 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
             asm volatile("" ::"v"(pa), "v"(pb), "v"(qf[0]), "v"(qf[1]), "v"(unit));      // nothing an MFMA reads is ever "dead" before the end
         }
     }
-#if PE_F8_STAMPS
-    if (blockIdx.x == 0 && lane == 0) {
-        long long* st = (long long*)((char*)stats + 256) + w * 8;
-        st[0] = st_wait;
-        st[1] = (long long)__builtin_readcyclecounter() - st_begin;
-        st[2] = n;
-        for (int k = 0; k < 5; ++k) st[3 + k] = st_seg[k];
-    }
-#endif
     const float l_tot = sum_with_lane_xor32(l_run);
     if (part_slot >= 0) {
         float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 32 + l31) * 128 + 4 * h;
