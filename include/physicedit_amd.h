@@ -52,7 +52,10 @@ const char* pe_build_id(void);
  * fed through the MFMA C operand: pe_attn_q_prescale / pe_flash_attn_prescaled; same distance to an fp32 result as the reference's own
  * bf16 SDPA, profiles/r04_attention_notes.md); 6 = 5 with the textbook max update; 4 / 3 = the same schedule with scale and max applied
  * per score (round 3's default / its textbook form, bit-identical to 0); 0 = 8 waves x 32 query rows, textbook update (the round-1/2
- * default, and always the kernel of the masked form).  "attn_slots", "attn_force_split": load-balancing knobs of the tests. */
+ * default, and always the kernel of the masked form).  "attn_slots", "attn_force_split": load-balancing knobs of the tests.
+ * "attn_fp8_variant": kernel of pe_flash_attn_fp8: 1 default (software-pipelined: the MFMAs of S(t+1) and P(t-1) V(t-1) ride between the
+ * slices of the softmax of S(t); the softmax reference is raised lazily, by tiles whose maximum exceeds it by 2^8 -- oracle:
+ * flash_attention_fp8(kv_tile=64, lazy_tau_log2=8)); 0 = the plain kernel (running maximum; oracle: kv_tile=64). */
 int pe_debug_set(const char* key, int value);
 /* Device buffer for a profiling variant's output ("gemm_stamps": long long [work-groups][8] s_memtime stamps of
  * gemm variant 15; "attn_stamps": long long [work-groups][10] of attention variants 3 - 6 built with -DPE_W4_STAMPS=1; "gemm_workspace": stream-K scratch for the granular pe_gemm_* calls);
