@@ -1419,6 +1419,8 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         if (on(7)) {
             F8_KEEP(f[3]);
             F8_KEEP(pq);
+        } else if (on(3)) {
+            F8_KEEP(f[3]);                           // no MFMA behind slot 3 in the first iteration: fragment 3 lives to the tail
         }
         F8_FENCE();
 #undef F8_SLOT

@@ -600,6 +600,32 @@ def test_flash_attn_fp8(ops, S, scales, fp8_variant):
         assert torch.equal(_fp8_attn(ops, q, k, v, S), out)
 
 
+@pytest.mark.parametrize("H,S", [(256, 64), (256, 128), (256, 192), (256, 256), (256, 320), (256, 384), (4, 700), (3, 1093)])
+def test_flash_attn_fp8_every_peeled_path(ops, H, S):
+    """The pipelined e4m3 kernel peels its first and last iteration and alternates two S / P buffers: 1 ... 6 tiles per work-group
+    without a KV split (256 items = one round) and split parts of odd and even lengths take every instantiation of the iteration body
+    (an even tile count once returned stale accumulator registers).  Against the plain kernel: the same arithmetic up to the rounding
+    points of P, i.e. far inside what e4m3 operands cost; against the lazy restatement of the oracle for the small ones."""
+    from physicedit_amd._lib import lib, check
+    g = torch.Generator().manual_seed(900 + S)
+    q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in (1.0, 1.2, 0.9))
+    outs = []
+    try:
+        for variant in (0, 1):
+            check(lib().pe_debug_set(b"attn_fp8_variant", variant), "attn_fp8_variant")
+            outs.append(_fp8_attn(ops, q, k, v, S))
+    finally:
+        check(lib().pe_debug_set(b"attn_fp8_variant", 1), "attn_fp8_variant")
+    ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
+    e0, e1, d = _rms(outs[0], ref32), _rms(outs[1], ref32), _rms(outs[1], outs[0])
+    print(f"[parity] flash_attn_fp8 peeled paths H={H} S={S}: vs fp32 truth plain {e0:.3e} pipelined {e1:.3e}; pipelined vs plain {d:.3e}")
+    assert torch.isfinite(outs[1].float()).all()
+    assert e1 <= 1.1 * e0 + 1e-6 and d <= 0.9 * e0 + 1e-6
+    if H == 256 and S <= 192:       # no KV split (every part of a split item starts its own reference sequence), and seconds of CPU
+        ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64, lazy_tau_log2=8.0)[0].permute(1, 0, 2).reshape(S, H * 128)
+        assert _rms(outs[1], ref_t) <= 0.05 * e0 + 1e-6
+
+
 # ------------------------------------------------------------------------------------------------
 # row kernels
 # ------------------------------------------------------------------------------------------------
