@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[2]: DiT stored in e4m3 + enable_dit_fp8_computation (every DiT Linear runs "
                          "fp8_linear); NOT the headline configuration, reported with dtype fp8")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="with --fp8: also enable_fp8_attention=True (e4m3 attention, pe_flash_attn_fp8) in the timed loop -- the third "
+                         "`secondary` line of the default run as the primary workload (profiling); reported in config.workload")
     ap.add_argument("--attn-variant", type=int, default=5, choices=[0, 3, 4, 5, 6],
                     help="flash-attention kernel: 5 = library default since round 4 (4 waves x 64 rows, one wave per SIMD, lazy running max; "
                          "the softmax scale is folded into Q by the QKV epilogue and the max enters through the MFMA C operand: "
@@ -212,7 +215,8 @@ def main():
     def one_image(i, loop_=None):
         edit_latents = vae.encode(edit_img)
         lat = (loop_ or loop)(noises[i], pe_p0.clone(), pe_n0.clone(), mask_p, mask_n, H, W,
-                              num_inference_steps=args.inference_steps, cfg_scale=args.cfg, edit_latents=edit_latents)
+                              num_inference_steps=args.inference_steps, cfg_scale=args.cfg, edit_latents=edit_latents,
+                              enable_fp8_attention=args.fp8_attention)
         img = vae.decode(lat)
         return lat, img
 
@@ -290,8 +294,8 @@ def main():
         lib().pe_profile_enable(8192, 1)
         ed = [vae.encode(edit_img)]
         torch.cuda.synchronize()
-        eng.forward(noises[units[0]], torch.tensor([500.0]).to(BF), pe_p0.clone(), None, ed, step=0)     # the step's positive ...
-        eng.forward(noises[units[0]], torch.tensor([500.0]).to(BF), pe_n0.clone(), None, ed, step=0)     # ... and negative forward
+        eng.forward(noises[units[0]], torch.tensor([500.0]).to(BF), pe_p0.clone(), None, ed, step=0, enable_fp8_attention=args.fp8_attention)     # the step's positive ...
+        eng.forward(noises[units[0]], torch.tensor([500.0]).to(BF), pe_n0.clone(), None, ed, step=0, enable_fp8_attention=args.fp8_attention)     # ... and negative forward
         torch.cuda.synchronize()
         prof_excl = read_prof()
 
@@ -321,7 +325,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8_e4m3" if args.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": f"{cfg_label}{' (DiT Linears in e4m3: fp8_linear; attention, norms, adapter, VAE bf16)' if args.fp8 else ''}: {H}x{W} edit, {args.inference_steps} steps, CFG {args.cfg}, "
+            "config": {"workload": f"{cfg_label}{(' (DiT Linears in e4m3: fp8_linear; ' + ('e4m3 attention: enable_fp8_attention; ' if args.fp8_attention else 'attention, ') + 'norms, adapter, VAE bf16)') if args.fp8 else ''}: {H}x{W} edit, {args.inference_steps} steps, CFG {args.cfg}, "
                                    f"{args.layers}-layer Qwen-Image DiT + merged rank-{args.lora_rank} LoRA + "
                                    f"visual-thinking adapter (64 special tokens), T_pos={args.t_pos} T_neg={args.t_neg}, "
                                    f"VAE encode(1024x1024 edit image)+decode included",

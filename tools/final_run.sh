@@ -10,6 +10,9 @@ python -m pytest tests -m gpu -q --durations=25 > "$OUT/pytest.log" 2>&1
 tail -3 "$OUT/pytest.log"
 python bench.py --steps ${BENCH_STEPS:-5} --warmup 1 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 bash tools/evidence_run.sh "$OUT"
+# the e4m3 attention operator per kernel variant, and the VALU / MFMA co-issue probe behind profiles/r04_attention_notes.md section 5.2
+python tools/microbench/attn_fp8_time.py > "$OUT/attn_fp8_time.log" 2>&1
+hipcc --offload-arch=gfx950 -O3 -o /tmp/coissue tools/microbench/mfma_f8_coissue.hip > /dev/null 2>&1 && /tmp/coissue > "$OUT/mfma_f8_coissue.log" 2>&1
 python - "$OUT" <<'P'
 import json, sys
 o = sys.argv[1]
