@@ -55,7 +55,9 @@ const char* pe_build_id(void);
  * default, and always the kernel of the masked form).  "attn_slots", "attn_force_split": load-balancing knobs of the tests.
  * "attn_fp8_variant": kernel of pe_flash_attn_fp8: 1 default (software-pipelined: the MFMAs of S(t+1) and P(t-1) V(t-1) ride between the
  * slices of the softmax of S(t); the softmax reference is raised lazily, by tiles whose maximum exceeds it by 2^8 -- oracle:
- * flash_attention_fp8(kv_tile=64, lazy_tau_log2=8)); 0 = the plain kernel (running maximum; oracle: kv_tile=64). */
+ * flash_attention_fp8(kv_tile=64, lazy_tau_log2=8)); 2 = 1 with a maximum-free fast path (a row keeps its reference while its 64 P of
+ * the tile sum to 448 at most, else the wave redoes the tile with the maximum; oracle: lazy_sum_limit=448; -5 % alone, -0.4 % per
+ * configs[2] image); 0 = the plain kernel (running maximum; oracle: kv_tile=64). */
 int pe_debug_set(const char* key, int value);
 /* Device buffer for a profiling variant's output ("gemm_stamps": long long [work-groups][8] s_memtime stamps of
  * gemm variant 15; "attn_stamps": long long [work-groups][10] of attention variants 3 - 6 built with -DPE_W4_STAMPS=1; "gemm_workspace": stream-K scratch for the granular pe_gemm_* calls);

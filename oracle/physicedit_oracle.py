@@ -230,7 +230,7 @@ def _heads(x: torch.Tensor, h: int = 24) -> torch.Tensor:
 
 
 def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dtype=torch.float8_e4m3fn, kv_tile: Optional[int] = None,
-                        lazy_tau_log2: float = 0.0) -> torch.Tensor:
+                        lazy_tau_log2: float = 0.0, lazy_sum_limit: Optional[float] = None) -> torch.Tensor:
     """qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35: q, k, v [B, H, S, D] bf16 are divided by their
     global standard deviations (torch.std: unbiased, over the whole tensor, a bf16 scalar), cast to float8_e4m3fn, handed to
     FlashAttention-3 with softmax_scale = q_std * k_std / sqrt(D), and the output (bf16) is multiplied by v_std.
@@ -244,6 +244,9 @@ def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dty
     64).  lazy_tau_log2 = T > 0 restates the LAZY online form (the library's default kernel; FlashAttention-4 publishes the same
     trick with T = 8): the reference value m is raised to a tile's maximum only when that exceeds m by more than a factor 2^T,
     so P = exp(s - m) may reach 2^T (256 for T = 8, below e4m3's 448) and the accumulator is rescaled on a few tiles only.
+    lazy_sum_limit = L restates the library's max-free fast path (attn_fp8_variant 2): a row keeps its reference m as long as its P of
+    the tile, exp(s - m), sum to L at most (L = 448, the largest e4m3: then no single P saturates); a row over the limit (always on
+    the first tile: m = -inf) moves m to the tile's maximum and recomputes its P.
     All these forms differ by e4m3 rounding noise of P only (same size, different rounding points).  Everything outside the kernel
     (the three std, the two casts, the scale, the output product and its roundings) is the reference's own arithmetic.
     -> [B, H, S, D] bf16."""
@@ -263,7 +266,11 @@ def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dty
             st = s[..., t0:t0 + kv_tile]
             m_tile = st.amax(dim=-1, keepdim=True)
             # T = 0: the running maximum.  (m = -inf on the first tile: always raised)
-            m_new = torch.where(m_tile - m > lazy_tau_log2 * math.log(2.0), m_tile, m)
+            if lazy_sum_limit is not None:
+                over = ~(torch.exp(st - m).sum(dim=-1, keepdim=True) <= lazy_sum_limit)          # NaN / inf (m = -inf) count as over
+                m_new = torch.where(over, m_tile, m)
+            else:
+                m_new = torch.where(m_tile - m > lazy_tau_log2 * math.log(2.0), m_tile, m)
             alpha = torch.exp(m - m_new)
             e = torch.exp(st - m_new)
             l = l * alpha + e.sum(dim=-1, keepdim=True)

@@ -42,7 +42,7 @@ int pe_debug_set(const char* key, int value) {
     PE_REQUIRE(key != nullptr, "pe_debug_set: null key");
     if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return PE_OK; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
-    if (!strcmp(key, "attn_fp8_variant")) { PE_REQUIRE(value == 0 || value == 1, "attn_fp8_variant: 0 or 1"); g_attn_fp8_variant = value; return PE_OK; }
+    if (!strcmp(key, "attn_fp8_variant")) { PE_REQUIRE(value >= 0 && value <= 2, "attn_fp8_variant: 0, 1 or 2"); g_attn_fp8_variant = value; return PE_OK; }
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return PE_OK; }
     if (!strcmp(key, "gemm_persist_min_rounds")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_persist_min_rounds out of range"); g_gemm_persist_min_rounds = value; return PE_OK; }
     if (!strcmp(key, "gemm_band")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_band out of range"); g_gemm_band = value; return PE_OK; }

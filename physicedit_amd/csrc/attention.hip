@@ -1218,9 +1218,10 @@ flash_attn_fp8_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict_
 // with -fno-slp-vectorize).
 int g_attn_fp8_variant = 1;
 constexpr float F8_TAU = 8.0f;
+constexpr float F8_SUM_LIMIT = 448.0f;     // variant 2: a row's 64 P of one tile may sum to the largest e4m3 at most
 #define F8_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int NW>
+template <int NW, bool SUM>
 __global__ void __launch_bounds__(NW * 64, 2)
 flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict__ K8, const uint8_t* __restrict__ Vt8,
                        bf16* __restrict__ out, int S, int S_pad, int ldo, const float* __restrict__ stats, AttnPlan plan,
@@ -1363,74 +1364,150 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
             }
             F8_FENCE();
         }
-        float mx0 = sc[0][0];
+        if constexpr (SUM) {
+            // Variant 2: no maximum on the fast path.  P = exp2(s c - m) against the reference m the row already has; a lane adds up its 32 P,
+            // the two lanes of a row exchange their sums, and as long as the row's 64 P sum to <= 448 (the largest e4m3: then no single P
+            // saturates) the tile is done -- 4 VALU per score, none of them waiting for a reduction.  Otherwise (always on a part's first
+            // tile: m = -inf gives inf or NaN sums) the WAVE redoes the tile the long way: rows over the limit move m to the tile's maximum,
+            // O and l are rescaled, every P is recomputed.  Per row the rule does not depend on which rows share a wave.
+            const float nm0 = -m_run;
+            float ps0 = 0.f, ps1 = 0.f;
+            auto group = [&](int g, float nm) {            // scores 4 a .. 4 a + 3 of accumulator s2 -> dword g = 4 s2 + a of this lane's k-slots
+                const int s2 = g >> 2, a = g & 3;
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a], scale_log2, nm));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 1], scale_log2, nm));
+                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 2], scale_log2, nm));
+                const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 3], scale_log2, nm));
+                ps0 += p0;
+                ps1 += p1;
+                ps0 += p2;
+                ps1 += p3;
+                int v = pc[g];                           // both halves are overwritten: no zero fill
+                v = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, v, false);
+                v = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, v, true);
+                pc[g] = v;
+                asm volatile("" : "+v"(pc[g]));          // computed HERE (not sunk to its reader in the next iteration)
+            };
+            F8_SLOT(0)
+            group(0, nm0);
+            F8_SLOT(1)
+            group(1, nm0);
+            F8_SLOT(2)
+            group(2, nm0);
+            F8_SLOT(3)
+            group(3, nm0);
+            F8_SLOT(4)
+            group(4, nm0);
+            F8_SLOT(5)
+            group(5, nm0);
+            F8_SLOT(6)
+            group(6, nm0);
+            F8_SLOT(7)
+            group(7, nm0);
+            float ps = ps0 + ps1;
+            const float row = sum_with_lane_xor32(ps);
+            const bool over = !(row <= F8_SUM_LIMIT);          // NaN (a masked key against m = -inf) counts as over
+            if (on(7)) {
+                F8_KEEP(f[3]);
+                F8_KEEP(pq);
+            } else if (on(3)) {
+                F8_KEEP(f[3]);                           // no MFMA behind slot 3 in the first iteration: fragment 3 lives to the tail
+            }
+            F8_FENCE();
+            if (__any(over)) {
+                float mx = sc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx0 = fmaxf(mx0, sc[0][r]);
-        asm volatile("" : "+v"(mx0));            // pins: pure arithmetic is otherwise placed wherever instruction selection likes
-        F8_SLOT(0)
-        float mx = sc[1][0];
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
-        mx = fmaxf(mx, mx0);
-        asm volatile("" : "+v"(mx));
-        F8_SLOT(1)
-        mx = max_with_lane_xor32(mx);
-        // lazily raised reference: m moves to the tile's maximum only when that exceeds it by more than 2^F8_TAU (the first tile always:
-        // m = -inf); otherwise P = exp2(s c - m) <= 2^8 = 256 < 448 = the largest e4m3 and O, l keep their scale: no pass over O
-        const float m_tile = mx * scale_log2;
-        const bool moved = m_tile - m_run > F8_TAU;
-        const float m_new = moved ? m_tile : m_run;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        const float nm = -m_new;
-        float ps0 = 0.f, ps1 = 0.f;
-        auto group = [&](int g) {            // scores 4 a .. 4 a + 3 of accumulator s2 -> dword g = 4 s2 + a of this lane's k-slots
-            const int s2 = g >> 2, a = g & 3;
-            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a], scale_log2, nm));
-            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 1], scale_log2, nm));
-            const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 2], scale_log2, nm));
-            const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 3], scale_log2, nm));
-            ps0 += p0;
-            ps1 += p1;
-            ps0 += p2;
-            ps1 += p3;
-            int v = pc[g];                           // both halves are overwritten: no zero fill
-            v = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, v, false);
-            v = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, v, true);
-            pc[g] = v;
-            asm volatile("" : "+v"(pc[g]));          // computed HERE (not sunk to its reader in the next iteration)
-        };
-        group(0);
-        F8_SLOT(2)
-        group(1);
-        F8_SLOT(3)
-        group(2);
-        F8_SLOT(4)
-        group(3);
-        F8_SLOT(5)
-        group(4);
-        F8_SLOT(6)
-        group(5);
-        F8_SLOT(7)
-        group(6);
-        group(7);
-        l_run = __builtin_fmaf(l_run, alpha, ps0 + ps1);
-        asm volatile("" : "+v"(l_run));
-        if (on(7)) {
-            F8_KEEP(f[3]);
-            F8_KEEP(pq);
-        } else if (on(3)) {
-            F8_KEEP(f[3]);                           // no MFMA behind slot 3 in the first iteration: fragment 3 lives to the tail
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[s2][r]);
+                mx = max_with_lane_xor32(mx);
+                const float m_new = over ? mx * scale_log2 : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // rows that stay: exp2(0) = 1
+                m_run = m_new;
+                if (on(7)) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the last P.V MFMA of this iteration -> the pass over O
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                l_run *= alpha;
+                ps0 = ps1 = 0.f;
+                const float nm1 = -m_new;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) group(g, nm1);
+                ps = ps0 + ps1;
+            }
+            l_run += ps;
+            asm volatile("" : "+v"(l_run));
+        } else {
+            float mx0 = sc[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx0 = fmaxf(mx0, sc[0][r]);
+            asm volatile("" : "+v"(mx0));            // pins: pure arithmetic is otherwise placed wherever instruction selection likes
+            F8_SLOT(0)
+            float mx = sc[1][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+            mx = fmaxf(mx, mx0);
+            asm volatile("" : "+v"(mx));
+            F8_SLOT(1)
+            mx = max_with_lane_xor32(mx);
+            // lazily raised reference: m moves to the tile's maximum only when that exceeds it by more than 2^F8_TAU (the first tile always:
+            // m = -inf); otherwise P = exp2(s c - m) <= 2^8 = 256 < 448 = the largest e4m3 and O, l keep their scale: no pass over O
+            const float m_tile = mx * scale_log2;
+            const bool moved = m_tile - m_run > F8_TAU;
+            const float m_new = moved ? m_tile : m_run;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            const float nm = -m_new;
+            float ps0 = 0.f, ps1 = 0.f;
+            auto group = [&](int g) {            // scores 4 a .. 4 a + 3 of accumulator s2 -> dword g = 4 s2 + a of this lane's k-slots
+                const int s2 = g >> 2, a = g & 3;
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a], scale_log2, nm));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 1], scale_log2, nm));
+                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 2], scale_log2, nm));
+                const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s2][4 * a + 3], scale_log2, nm));
+                ps0 += p0;
+                ps1 += p1;
+                ps0 += p2;
+                ps1 += p3;
+                int v = pc[g];                           // both halves are overwritten: no zero fill
+                v = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, v, false);
+                v = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, v, true);
+                pc[g] = v;
+                asm volatile("" : "+v"(pc[g]));          // computed HERE (not sunk to its reader in the next iteration)
+            };
+            group(0);
+            F8_SLOT(2)
+            group(1);
+            F8_SLOT(3)
+            group(2);
+            F8_SLOT(4)
+            group(3);
+            F8_SLOT(5)
+            group(4);
+            F8_SLOT(6)
+            group(5);
+            F8_SLOT(7)
+            group(6);
+            group(7);
+            l_run = __builtin_fmaf(l_run, alpha, ps0 + ps1);
+            asm volatile("" : "+v"(l_run));
+            if (on(7)) {
+                F8_KEEP(f[3]);
+                F8_KEEP(pq);
+            } else if (on(3)) {
+                F8_KEEP(f[3]);                           // no MFMA behind slot 3 in the first iteration: fragment 3 lives to the tail
+            }
+            F8_FENCE();
+            if (__any(moved)) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
         }
-        F8_FENCE();
 #undef F8_SLOT
 #undef F8_KEEP
-        if (__any(moved)) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        }
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -1537,7 +1614,8 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
     static std::atomic<bool> configured{false};
     if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fp8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_fp8p_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_fp8p_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_fp8p_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
@@ -1566,8 +1644,12 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
         hipLaunchKernelGGL((flash_attn_fp8_kernel<8>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
                            (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
                            part_o, part_ml);
+    else if (g_attn_fp8_variant == 1)
+        hipLaunchKernelGGL((flash_attn_fp8p_kernel<8, false>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
+                           (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
+                           part_o, part_ml);
     else
-        hipLaunchKernelGGL((flash_attn_fp8p_kernel<8>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
+        hipLaunchKernelGGL((flash_attn_fp8p_kernel<8, true>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
                            (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
                            part_o, part_ml);
     rc = check_launch("flash_attn_fp8_kernel");

@@ -549,14 +549,18 @@ def _fp8_attn(ops, q, k, v, S, workspace=True, want_stats=False):
 
 @pytest.fixture
 def fp8_variant(request):
-    """attn_fp8_variant knob for one test: 1 = the default (software-pipelined, lazily raised reference, 2^8), 0 = the plain kernel (running max)"""
+    """attn_fp8_variant knob for one test: 2 = software-pipelined with the max-free fast path (reference kept while a row's tile sum <= 448),
+    1 = software-pipelined, reference raised by tiles 2^8 above it, 0 = the plain kernel (running max)"""
     from physicedit_amd._lib import lib, check
     check(lib().pe_debug_set(b"attn_fp8_variant", request.param), "attn_fp8_variant")
     yield request.param
-    check(lib().pe_debug_set(b"attn_fp8_variant", 1), "attn_fp8_variant")
+    check(lib().pe_debug_set(b"attn_fp8_variant", FP8_ATTN_DEFAULT), "attn_fp8_variant")
 
 
-@pytest.mark.parametrize("fp8_variant", [1, 0], indirect=True)
+FP8_ATTN_DEFAULT = 1
+
+
+@pytest.mark.parametrize("fp8_variant", [2, 1, 0], indirect=True)
 @pytest.mark.parametrize("S,scales", [(64, (1.0, 1.0, 1.0)), (100, (1.0, 1.0, 1.0)), (700, (0.7, 1.9, 3.1)), (1093, (2.5, 0.4, 0.05)),
                                       (2208, (1.0, 1.3, 0.8))])
 def test_flash_attn_fp8(ops, S, scales, fp8_variant):
@@ -570,8 +574,9 @@ def test_flash_attn_fp8(ops, S, scales, fp8_variant):
     q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in scales)
     torch.set_num_threads(max(torch.get_num_threads(), 16))
     ref = O.flash_attention_fp8(q[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
-    tau = 8.0 if fp8_variant == 1 else 0.0      # the default kernel raises its reference lazily (oracle: lazy_tau_log2)
-    ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64, lazy_tau_log2=tau)[0].permute(1, 0, 2).reshape(S, H * 128)
+    tau = 8.0 if fp8_variant == 1 else 0.0      # the pipelined kernels raise their reference lazily (oracle: lazy_tau_log2 / lazy_sum_limit)
+    ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64, lazy_tau_log2=tau,
+                                  lazy_sum_limit=448.0 if fp8_variant == 2 else None)[0].permute(1, 0, 2).reshape(S, H * 128)
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
     out, stats = _fp8_attn(ops, q, k, v, S, workspace=False, want_stats=True)
     assert torch.isfinite(out.float()).all()
@@ -587,7 +592,7 @@ def test_flash_attn_fp8(ops, S, scales, fp8_variant):
     assert e_tile <= 0.05 * e_fp8 + 1e-6
     # against the form that knows the final max: the same size of P rounding noise at other rounding points
     # (the lazy form moves its rounding points further from the final-max form's than the running max does: 0.66 measured, 0.44 for variant 0)
-    noise = 0.8 if fp8_variant == 1 else 0.6
+    noise = 0.8 if fp8_variant >= 1 else 0.6
     assert e_glob <= noise * e_fp8 + 1e-6
     assert _rms(out, ref32) <= 1.1 * e_fp8 + 1e-6
     out1 = out
@@ -611,19 +616,22 @@ def test_flash_attn_fp8_every_peeled_path(ops, H, S):
     q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in (1.0, 1.2, 0.9))
     outs = []
     try:
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             check(lib().pe_debug_set(b"attn_fp8_variant", variant), "attn_fp8_variant")
             outs.append(_fp8_attn(ops, q, k, v, S))
     finally:
-        check(lib().pe_debug_set(b"attn_fp8_variant", 1), "attn_fp8_variant")
+        check(lib().pe_debug_set(b"attn_fp8_variant", FP8_ATTN_DEFAULT), "attn_fp8_variant")
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
-    e0, e1, d = _rms(outs[0], ref32), _rms(outs[1], ref32), _rms(outs[1], outs[0])
-    print(f"[parity] flash_attn_fp8 peeled paths H={H} S={S}: vs fp32 truth plain {e0:.3e} pipelined {e1:.3e}; pipelined vs plain {d:.3e}")
-    assert torch.isfinite(outs[1].float()).all()
-    assert e1 <= 1.1 * e0 + 1e-6 and d <= 0.9 * e0 + 1e-6
+    e0 = _rms(outs[0], ref32)
+    for variant in (1, 2):
+        e1, d = _rms(outs[variant], ref32), _rms(outs[variant], outs[0])
+        print(f"[parity] flash_attn_fp8 peeled paths H={H} S={S} variant {variant}: vs fp32 truth plain {e0:.3e} pipelined {e1:.3e}; pipelined vs plain {d:.3e}")
+        assert torch.isfinite(outs[variant].float()).all()
+        assert e1 <= 1.1 * e0 + 1e-6 and d <= 0.9 * e0 + 1e-6
     if H == 256 and S <= 192:       # no KV split (every part of a split item starts its own reference sequence), and seconds of CPU
-        ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64, lazy_tau_log2=8.0)[0].permute(1, 0, 2).reshape(S, H * 128)
-        assert _rms(outs[1], ref_t) <= 0.05 * e0 + 1e-6
+        for variant, kw in ((1, dict(lazy_tau_log2=8.0)), (2, dict(lazy_sum_limit=448.0))):
+            ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64, **kw)[0].permute(1, 0, 2).reshape(S, H * 128)
+            assert _rms(outs[variant], ref_t) <= 0.05 * e0 + 1e-6
 
 
 # ------------------------------------------------------------------------------------------------

@@ -30,11 +30,15 @@ def wait_states(ins: str) -> int:
     return 1
 
 
-def kernel_body(asm: str):
+def kernel_bodies(asm: str):
+    """-> {symbol: instruction list} for every instantiation of the kernel"""
     lines = asm.split("\n")
-    st = [i for i, l in enumerate(lines) if l.startswith(KERNEL) and l.rstrip().endswith(":") or (l.startswith(KERNEL) and ": " in l)][0]
-    en = [i for i in range(st, len(lines)) if ".amdhsa_kernel" in lines[i]][0]
-    return [l.strip() for l in lines[st + 1:en] if l.strip() and not l.strip().startswith((";", ".", "_Z"))]
+    out = {}
+    for st, l in enumerate(lines):
+        if l.startswith(KERNEL) and ":" in l and not l.startswith("\t"):
+            en = [i for i in range(st, len(lines)) if ".amdhsa_kernel" in lines[i] or lines[i].startswith(".Lfunc_end")][0]
+            out[l.split(":")[0]] = [x.strip() for x in lines[st + 1:en] if x.strip() and not x.strip().startswith((";", ".", "_Z"))]
+    return out
 
 
 def scan(body):
@@ -75,13 +79,19 @@ def main() -> int:
         if r.returncode != 0:
             print(r.stderr)
             return 2
-        body = kernel_body(open(out).read())
-    n = sum(1 for l in body if l.startswith("v_mfma_scale"))
-    found = scan(body)
-    print(f"flash_attn_fp8p_kernel: {len(body)} instructions, {n} MFMAs, {len(found)} hazard(s)")
-    for i, k, what, ins, nxt in found:
-        print(f"  +{k}: `{nxt[:70]}` {what} `{ins[:90]}` (instruction {i})")
-    return 1 if found else 0
+        bodies = kernel_bodies(open(out).read())
+    bad = 0
+    for sym, body in bodies.items():
+        n = sum(1 for l in body if l.startswith("v_mfma_scale"))
+        found = scan(body)
+        bad += len(found)
+        print(f"{sym}: {len(body)} instructions, {n} MFMAs, {len(found)} hazard(s)")
+        for i, k, what, ins, nxt in found:
+            print(f"  +{k}: `{nxt[:70]}` {what} `{ins[:90]}` (instruction {i})")
+    if not bodies:
+        print("kernel not found in the assembly")
+        return 2
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":

@@ -15,10 +15,11 @@ for H, S in ((4, 64), (256, 128), (256, 192), (256, 256), (256, 320), (4, 700), 
     scratch = torch.empty((n + 256,), dtype=torch.uint8, device="cuda"); base = (scratch.data_ptr() + 255) // 256 * 256
     nb = lib().pe_flash_attn_workspace_bytes(H, S); ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
     outs = []
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         check(lib().pe_debug_set(b"attn_fp8_variant", variant), "knob")
         out = torch.empty((S, H * 128), dtype=BF, device='cuda')
         check(lib().pe_flash_attn_fp8(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, base, n, ws.data_ptr(), nb, stream_ptr()), "fp8")
         torch.cuda.synchronize(); outs.append(out.float())
-    d = outs[1] - outs[0]
-    print(f"H={H} S={S}: max abs {float(d.abs().max()):.3e} rms rel {float((d.pow(2).mean() / outs[0].pow(2).mean()).sqrt()):.3e}", flush=True)
+    for variant in (1, 2):
+        d = outs[variant] - outs[0]
+        print(f"H={H} S={S} variant {variant} vs 0: max abs {float(d.abs().max()):.3e} rms rel {float((d.pow(2).mean() / outs[0].pow(2).mean()).sqrt()):.3e}", flush=True)

@@ -20,7 +20,7 @@ for S in (8704, 8464):
     def run():
         check(lib().pe_flash_attn_fp8(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, base, n, ws.data_ptr(), nb, stream_ptr()), "fp8")
     ref = None
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         check(lib().pe_debug_set(b"attn_fp8_variant", variant), "knob")
         run(); torch.cuda.synchronize()
         if variant == 0:
