@@ -80,12 +80,25 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const bf16* __restrict
         const float dv = scq + 1e-8f;
         if (lane == 0) q_scale[row] = scq;
         uint8_t* qrow = q_out + (size_t)row * dim;
+        if (dv == 1.0f) {
+            // scale 1 (every row whose largest magnitude is <= 447, i.e. all of them in practice): 1 + 1e-8f IS 1.0f, x / 1.0f IS x --
+            // the same bytes without 48 IEEE divisions per lane (they made this kernel compute-bound: 30 us against 21.7 us for the
+            // bf16-only form that moves more bytes)
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            u32x2 pk;
-            pk[0] = pack4_e4m3(v[i][0] / dv, v[i][1] / dv, v[i][2] / dv, v[i][3] / dv);
-            pk[1] = pack4_e4m3(v[i][4] / dv, v[i][5] / dv, v[i][6] / dv, v[i][7] / dv);
-            *(u32x2*)(qrow + (i * 64 + lane) * 8) = pk;
+            for (int i = 0; i < VPL; ++i) {
+                u32x2 pk;
+                pk[0] = pack4_e4m3(v[i][0], v[i][1], v[i][2], v[i][3]);
+                pk[1] = pack4_e4m3(v[i][4], v[i][5], v[i][6], v[i][7]);
+                *(u32x2*)(qrow + (i * 64 + lane) * 8) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                u32x2 pk;
+                pk[0] = pack4_e4m3(v[i][0] / dv, v[i][1] / dv, v[i][2] / dv, v[i][3] / dv);
+                pk[1] = pack4_e4m3(v[i][4] / dv, v[i][5] / dv, v[i][6] / dv, v[i][7] / dv);
+                *(u32x2*)(qrow + (i * 64 + lane) * 8) = pk;
+            }
         }
     }
 }
@@ -863,14 +876,27 @@ __global__ void __launch_bounds__(256) quantize_rows_e4m3_kernel(const bf16* __r
     const float dv = sc + 1e-8f;
     if (t == 0) scale[row] = sc;
     uint8_t* orow = out + (size_t)row * Kp;
+    if (dv == 1.0f) {          // scale 1: x / (1 + 1e-8f) is x / 1.0f is x (see ln_modulate_kernel): no divisions
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = i * 256 + t;
-        if (c < nch) {
-            u32x2 o;
-            o[0] = pack4_e4m3((float)v[i][0] / dv, (float)v[i][1] / dv, (float)v[i][2] / dv, (float)v[i][3] / dv);
-            o[1] = pack4_e4m3((float)v[i][4] / dv, (float)v[i][5] / dv, (float)v[i][6] / dv, (float)v[i][7] / dv);
-            *(u32x2*)(orow + c * 8) = o;
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = i * 256 + t;
+            if (c < nch) {
+                u32x2 o;
+                o[0] = pack4_e4m3((float)v[i][0], (float)v[i][1], (float)v[i][2], (float)v[i][3]);
+                o[1] = pack4_e4m3((float)v[i][4], (float)v[i][5], (float)v[i][6], (float)v[i][7]);
+                *(u32x2*)(orow + c * 8) = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = i * 256 + t;
+            if (c < nch) {
+                u32x2 o;
+                o[0] = pack4_e4m3((float)v[i][0] / dv, (float)v[i][1] / dv, (float)v[i][2] / dv, (float)v[i][3] / dv);
+                o[1] = pack4_e4m3((float)v[i][4] / dv, (float)v[i][5] / dv, (float)v[i][6] / dv, (float)v[i][7] / dv);
+                *(u32x2*)(orow + c * 8) = o;
+            }
         }
     }
     for (int c = nch + t; c < (Kp >> 3); c += 256) *(u32x2*)(orow + c * 8) = u32x2{0u, 0u};

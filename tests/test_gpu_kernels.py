@@ -560,9 +560,12 @@ def fp8_variant(request):
 FP8_ATTN_DEFAULT = 1
 
 
-@pytest.mark.parametrize("fp8_variant", [2, 1, 0], indirect=True)
-@pytest.mark.parametrize("S,scales", [(64, (1.0, 1.0, 1.0)), (100, (1.0, 1.0, 1.0)), (700, (0.7, 1.9, 3.1)), (1093, (2.5, 0.4, 0.05)),
-                                      (2208, (1.0, 1.3, 0.8))])
+# the default kernel at every size; the plain kernel and the opt-in fast path where tails, splits and unequal scales meet (suite time)
+@pytest.mark.parametrize("S,scales,fp8_variant", [(64, (1.0, 1.0, 1.0), 1), (100, (1.0, 1.0, 1.0), 1), (700, (0.7, 1.9, 3.1), 1),
+                                                  (1093, (2.5, 0.4, 0.05), 1), (2208, (1.0, 1.3, 0.8), 1),
+                                                  (100, (1.0, 1.0, 1.0), 0), (1093, (2.5, 0.4, 0.05), 0), (2208, (1.0, 1.3, 0.8), 0),
+                                                  (100, (1.0, 1.0, 1.0), 2), (700, (0.7, 1.9, 3.1), 2), (1093, (2.5, 0.4, 0.05), 2)],
+                         indirect=["fp8_variant"])
 def test_flash_attn_fp8(ops, S, scales, fp8_variant):
     """The e4m3 attention operator against the oracle's restatement of the reference branch (global std of q, k, v in bf16, e4m3 casts,
     softmax_scale = q_std k_std / sqrt(128), P cast to e4m3, output x v_std), on tensors whose three scales differ: what the kernel
