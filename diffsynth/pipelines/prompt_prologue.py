@@ -357,6 +357,21 @@ class GraphDecoder:
         self._static = {}           # capacity bucket -> static planes, tables, counters and the captured decode step
         self.captures = 0           # graphs captured so far (tests: calls of one bucket share one)
 
+    def _weights_fingerprint(self):
+        """Addresses (and versions) of every tensor the captured launches take by pointer.  A captured hipGraph bakes them in: after
+        .to() / offload + reload / a LoRA merge that re-allocates / a dtype change, a replay would read freed or stale memory without
+        any error, so generate() compares this with the fingerprint taken at capture time and re-captures on a mismatch."""
+        ts = [self.lm.embed_tokens.weight, self.lm.norm.weight, self.model.lm_head.weight, self.model.lm_head.bias]
+        for ly in self.layers:
+            at, mlp = ly.self_attn, ly.mlp
+            ts += [at.q_proj.weight, at.q_proj.bias, at.k_proj.weight, at.k_proj.bias, at.v_proj.weight, at.v_proj.bias, at.o_proj.weight,
+                   mlp.gate_proj.weight, mlp.up_proj.weight, mlp.down_proj.weight, ly.input_layernorm.weight, ly.post_attention_layernorm.weight]
+        return tuple((t.data_ptr(), t.dtype, tuple(t.shape)) if t is not None else None for t in ts)
+
+    def reset(self):
+        """Drop the captured graphs and their static planes (the pipeline calls this when it moves or reloads the text encoder)."""
+        self._static = {}
+
     def _step(self, st):
         """one decode step on the current stream (captured); st: dict of static device tensors"""
         ops = self.ops
@@ -405,11 +420,14 @@ class GraphDecoder:
         # first Lp rows, the table rows [Lp, Lp + max_new_tokens) and the counter, and replays
         bucket = min(self.MAX_CACHE_ROWS, (cap + 1023) // 1024 * 1024)
         st = self._static.get(bucket)
+        fp = self._weights_fingerprint()
+        if st is not None and st.get("weights") != fp:
+            st = None                                      # the weights moved since the capture: those launches point at the old ones
         if st is None:
             st = {"kc": torch.zeros((L, self.hkv, bucket, 128), dtype=torch.bfloat16, device=dev), "base": 0, "cap": bucket,
                   "cos": torch.zeros((bucket, 128), dtype=torch.bfloat16, device=dev),
                   "token": torch.zeros(1, dtype=torch.int32, device=dev), "step": torch.zeros(1, dtype=torch.int32, device=dev),
-                  "out_ids": torch.zeros(bucket, dtype=torch.int32, device=dev), "graph": None}
+                  "out_ids": torch.zeros(bucket, dtype=torch.int32, device=dev), "graph": None, "weights": fp}
             st["vc"] = torch.zeros_like(st["kc"])
             st["sin"] = torch.zeros_like(st["cos"])
             self._static = {bucket: st}                    # one bucket alive at a time (28 KiB per row of capacity and plane pair)

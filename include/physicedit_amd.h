@@ -158,8 +158,10 @@ int pe_flash_attn_prescaled(const void* q, const void* k, const void* vt, void* 
  * q, k, vt in pe_flash_attn's bf16 layouts with a PLAIN Q.  Computes the three global standard deviations (torch.std semantics, bf16),
  * e4m3(q / q_std), e4m3(k / k_std), e4m3(v / v_std), softmax(q8 k8^T q_std k_std / sqrt(128)) with P cast to e4m3 for the second
  * e4m3 matmul, and bf16(bf16(out) * v_std).  scratch: pe_flash_attn_fp8_scratch_bytes(H, S_pad) bytes, 256-byte aligned; workspace
- * as for pe_flash_attn (nullable).  What FlashAttention-3 does INSIDE its kernel is restated from its published design (oracle
- * flash_attention_fp8): parity of the P quantisation is unpinned. */
+ * as for pe_flash_attn (nullable).  Rows / positions of tokens >= S (the planes' padding up to S_pad) may hold anything FINITE: the
+ * statistics and the softmax skip them (Vt's token order inside a 16-group is undone for that), so one set of planes can serve
+ * sequences of different lengths without re-zeroing.  What FlashAttention-3 does INSIDE its kernel is restated from its published
+ * design (oracle flash_attention_fp8): parity of the P quantisation is unpinned. */
 size_t pe_flash_attn_fp8_scratch_bytes(int H, int S_pad);
 int pe_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
                       size_t scratch_bytes, void* workspace, size_t workspace_bytes, void* stream);

@@ -910,7 +910,7 @@ constexpr int F8_STAGE = 2 * KV_TILE * 128;       // K8 tile 8 KiB + Vt8 tile 8 
 constexpr int F8_LDS = 2 * F8_STAGE;
 constexpr int F8_STAT_WGS = 512;
 
-// grid (F8_STAT_WGS, 3): tensor z = Q (rows < S of every head), K (same), Vt (all S_pad columns: the pad columns are zero)
+// grid (F8_STAT_WGS, 3): tensor z = Q (rows < S of every head), K (same), Vt (the positions of tokens < S; what the pad columns hold is ignored)
 __global__ void __launch_bounds__(256) attn_fp8_stats_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                              const bf16* __restrict__ Vt, int H, int S, int S_pad,
                                                              double* __restrict__ part) {
@@ -923,15 +923,27 @@ __global__ void __launch_bounds__(256) attn_fp8_stats_kernel(const bf16* __restr
     float s1 = 0.f, s2 = 0.f;
     double d1 = 0.0, d2 = 0.0;
     int cnt = 0;
+    const int per_row8 = S_pad >> 3;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)F8_STAT_WGS * 256) {
+        int g0 = 0, hh = 0;       // Vt: first token of the chunk's 16-group, which 8-position half of the group the chunk is
         if (z < 2) {
             const size_t row = i >> 4;                      // 16 chunks of 8 per 128-wide row
             if ((int)(row % (size_t)S_pad) >= S) continue;
+        } else {
+            // Vt's columns [S, S_pad) belong to no token: a caller that re-uses one plane for sequences of different lengths (the CFG
+            // pair's two prompt lengths on one pe_dit handle) leaves another call's values there.  Position p of an aligned 16-group
+            // holds token perm16(p): positions 8 hh + j (j = 0..7) are tokens 4 hh + (j & 3) + 8 (j >> 2).
+            const int c0 = (int)(i % (size_t)per_row8) << 3;
+            g0 = c0 & ~15;
+            hh = (c0 >> 3) & 1;
         }
         const bf16x8 v = *(const bf16x8*)(base + i * 8);
+        const bool ragged = z == 2 && g0 + 16 > S;          // the group that straddles S and the all-pad groups behind it (counted as
+                                                            // zeros, not skipped: the fp32 partials keep the grouping they have on zeroed pads)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float x = (float)v[j];
+            float x = (float)v[j];
+            if (ragged && g0 + 4 * hh + (j & 3) + 8 * (j >> 2) >= S) x = 0.f;
             s1 += x;
             s2 = __builtin_fmaf(x, x, s2);
         }

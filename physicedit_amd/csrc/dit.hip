@@ -106,9 +106,12 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->attn_ws, h->attn_ws_bytes);
     h->attn_f8_bytes = flash_attn_fp8_scratch_bytes(HEADS, (int)S_pad);
     take(&h->attn_f8, h->attn_f8_bytes);
-    take(&h->gemm_ws, gemm_workspace_bytes());
-    h->gws.sync = h->gemm_ws;
-    h->gws.bytes = gemm_workspace_bytes();
+    // stream-K scratch (4 KiB + 256 KiB per CU = 64 MiB) only where the opt-in schedule is switched on when the workspace is sized AND
+    // bound (pe_debug_set "gemm_sk" / "gemm_variant" 19 before pe_dit_workspace_bytes); without it launch_gemm never takes schedule 19
+    const size_t sk_bytes = (g_gemm_sk != 0 || g_gemm_variant == 19) ? gemm_workspace_bytes() : 0;
+    take(&h->gemm_ws, sk_bytes);
+    h->gws.sync = sk_bytes ? h->gemm_ws : nullptr;
+    h->gws.bytes = sk_bytes;
     const size_t rows = S > (size_t)n_steps ? S : (size_t)n_steps;
     take(&h->lora_t, rows * 3 * 128 * 2);
     if (h->w.weights_e4m3) {
@@ -292,8 +295,10 @@ int pe_dit_bind_workspace(pe_dit_handle h, void* workspace, size_t bytes, int S_
     // Q/K pad rows only feed masked scores.  Zero all three once.
     hipError_t e = hipMemsetAsync(h->q, 0, (size_t)(h->attn - h->q), (hipStream_t)stream);
     if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
-    e = hipMemsetAsync(h->gemm_ws, 0, 4096, (hipStream_t)stream);       // ticket counter and flags; the kernels leave them zero
-    if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
+    if (h->gws.sync != nullptr) {
+        e = hipMemsetAsync(h->gemm_ws, 0, 4096, (hipStream_t)stream);       // ticket counter and flags; the kernels leave them zero
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_bind_workspace: memset: %s", hipGetErrorString(e));
+    }
     if (h->qflags != nullptr) {
         const size_t rows = (size_t)S_img_max + T_max > (size_t)n_steps ? (size_t)S_img_max + T_max : (size_t)n_steps;
         e = hipMemsetAsync(h->qflags, 0, rows * sizeof(unsigned), (hipStream_t)stream);

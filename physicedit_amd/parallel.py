@@ -131,10 +131,18 @@ class CfgPairExchange:
         """The two ranks of a pair must draw the SAME noise (and the same RandomCrop in training mode): a job without a seed would
         take it from each process's own global RNG.  The pair's even rank decides: its seed (a fresh random one when the job has
         none) is broadcast inside the pair."""
-        if self.role == 0 and seed is None:
+        if seed is not None:
+            return seed         # both ranks of the pair hold the same jobs list: nothing to agree on, no collective
+        if self.group is None:
+            # the default group is a pair only in a 2-rank world: anywhere else `src = 0` would take rank 0's seed for every pair
+            if dist.get_world_size() != 2:
+                raise ValueError("CfgPairExchange without a pair group is only valid in a 2-rank world (use make_pairs)")
+            src = 0
+        else:
+            src = dist.get_global_rank(self.group, 0)
+        if self.role == 0:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         box = [seed]
-        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         dist.broadcast_object_list(box, src=src, group=self.group)
         return box[0]
 

@@ -310,7 +310,8 @@ def make_state_dict_device(layout: Iterable[Tuple[str, Shape]], seed: int, devic
                            dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
     """Same distribution family, drawn directly with the DEVICE generator (used only for the
     full 60-layer benchmark model: 40.9 GB would take minutes through the CPU generator).
-    Values differ from `make_state_dict`; nothing at this size is compared with the oracle."""
+    Values differ from `make_state_dict` and from box to box only in the sense that no host can regenerate them: the 60-layer parity
+    tests use `make_state_dict_hashed` (same bits on host and device), bench.py keeps this one."""
     layout = list(layout)
     fan = {k[: -len(".weight")]: (math.prod(s[1:]) if len(s) >= 2 else None)
            for k, s in layout if k.endswith(".weight")}
@@ -330,6 +331,57 @@ def make_state_dict_device(layout: Iterable[Tuple[str, Shape]], seed: int, devic
             t = u * (1.0 / math.sqrt(fan_in))
         sd[key] = t.to(dtype)
         del u, t
+    return sd
+
+
+# --------------------------------------------------------------------------------------
+# counter-based values: the SAME bits on any device (fixture G21-G23: the reference runs the 60-layer model in the build container,
+# the GPU box regenerates the 41 GB there instead of shipping them)
+# --------------------------------------------------------------------------------------
+def hash_uniform(key32: int, numel: int, device, chunk: int = 1 << 20) -> torch.Tensor:
+    """fp32 U[-1, 1) on a 2^-23 grid: element i = murmur3's 32-bit finaliser of (i * 0x9E3779B1 + key32) mod 2^32, top 24 bits.
+    Integer arithmetic in int64 with explicit masks (no signed overflow is relied on, no device RNG): torch CPU and torch on the GPU
+    compute the same function bit for bit.  Chunks keep the temporaries cache-resident on the host (65 s for the 60-layer DiT on 8 cores)."""
+    out = torch.empty(numel, dtype=torch.float32, device=device)
+    n0 = min(numel, chunk)
+    h = torch.empty(n0, dtype=torch.int64, device=device)
+    t = torch.empty(n0, dtype=torch.int64, device=device)
+    for s in range(0, numel, chunk):
+        e = min(numel, s + chunk)
+        hh, tt = h[:e - s], t[:e - s]
+        torch.arange(s, e, dtype=torch.int64, device=device, out=hh)
+        hh.mul_(0x9E3779B1).add_(int(key32) & 0xFFFFFFFF).bitwise_and_(0xFFFFFFFF)
+        torch.bitwise_right_shift(hh, 16, out=tt); hh.bitwise_xor_(tt)
+        hh.mul_(0x85EBCA6B).bitwise_and_(0xFFFFFFFF)
+        torch.bitwise_right_shift(hh, 13, out=tt); hh.bitwise_xor_(tt)
+        hh.mul_(0xC2B2AE35).bitwise_and_(0xFFFFFFFF)
+        torch.bitwise_right_shift(hh, 16, out=tt); hh.bitwise_xor_(tt)
+        hh.bitwise_right_shift_(8)                       # 24 bits: exact in fp32
+        o = out[s:e]
+        o.copy_(hh)
+        o.mul_(2.0 ** -23).sub_(1.0)                     # both exact
+    return out
+
+
+def make_state_dict_hashed(layout: Iterable[Tuple[str, Shape]], seed: int, device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """`make_state_dict`'s distribution family (U(+-1/sqrt(fan_in)) weights and biases, 1 + 0.1 U norm gains) from `hash_uniform`:
+    identical tensors whether drawn on the host or on the GPU (tests/test_gpu_parity_configs.py regenerates on the device the model
+    whose REFERENCE outputs tests/golden/make_golden.py stored).  The scale is an fp32 value on both sides, each op rounds once."""
+    layout = list(layout)
+    fan = {k[: -len(".weight")]: (math.prod(s[1:]) if len(s) >= 2 else None)
+           for k, s in layout if k.endswith(".weight")}
+    sd: Dict[str, torch.Tensor] = {}
+    for key, shape in layout:
+        key32 = (seed * 1000003 + zlib.crc32(key.encode("utf-8"))) & 0xFFFFFFFF
+        u = hash_uniform(key32, math.prod(shape), device)
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf == "gamma" or (leaf == "weight" and len(shape) == 1):
+            u.mul_(float(torch.tensor(0.1, dtype=torch.float32))).add_(1.0)
+        else:
+            fan_in = math.prod(shape[1:]) if len(shape) >= 2 else (fan.get(key[: -len(".bias")]) or shape[0])
+            u.mul_(float(torch.tensor(1.0 / math.sqrt(fan_in), dtype=torch.float32)))
+        sd[key] = u.to(dtype).view(shape)
+        del u
     return sd
 
 

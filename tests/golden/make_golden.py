@@ -731,10 +731,156 @@ def G12_prologue():
     save("G12_prologue", outs, meta=meta)
 
 
+class _F32View:
+    """fp32 view of a bf16 state dict, widened per access (the 60-layer model is 41 GB in bf16: 82 GB of fp32 do not fit this container)"""
+
+    def __init__(self, sd):
+        self.sd = sd
+
+    def __contains__(self, k):
+        return k in self.sd
+
+    def __getitem__(self, k):
+        return self.sd[k].float()
+
+    def get(self, k, default=None):
+        return self.sd[k].float() if k in self.sd else default
+
+    def keys(self):
+        return self.sd.keys()
+
+
+def G21_60_layers():
+    """The FULL 60-layer DiT + adapter run by the REFERENCE's own `model_fn_qwen_image` (qwen_image_physical.py:1302-1403), weights from
+    `synth.make_state_dict_hashed` (counter-based: the GPU box regenerates the same 41 GB bit for bit).  Three files:
+      G21  BASELINE configs[1]'s geometry: 1024x1024 target + 1024x1024 edit image, T 512 with 64 special tokens (S = 8704), one call at the
+           first timestep of the 40-step schedule: latents and the special rows of prompt_emb after the call;
+      G22  512x512 + 512x512 edit, T 160 / 16 special (S = 2208): the same in bf16, plus an fp32 evaluation of the same graph (by the oracle
+           with weights widened per access -- the reference module cannot hold 82 GB here) for the fp32-distance criterion; the oracle's
+           bf16 run is checked bit for bit against the reference's at this depth (meta: oracle_bit_exact);
+      G23  TWO CFG-4 steps of the loop (:644-661) at 256x256 + 256x256 edit, T_pos 160 / T_neg 80, 16 special tokens each.
+    PE_G21_FP32=1 adds the fp32 evaluation at the headline geometry; PE_G21_PARTS=21,22,23,24 selects the files to write (24 = BASELINE
+    configs[4]'s per-GPU geometry, 1328x1328 + the 1024x1024 edit image, S = 11497)."""
+    import time
+    import oracle.physicedit_oracle as O
+    t0 = time.time()
+    with torch.device("meta"):
+        dit = QwenImageDiT(num_layers=60)
+    sd = synth.make_state_dict_hashed(synth.dit_layout(60), 1234)
+    dit.load_state_dict(sd, assign=True, strict=True)
+    dit.pos_embed = QwenEmbedRope(theta=10000, axes_dim=[16, 56, 56], scale_rope=True)
+    dit.eval()
+    ad, adsd, (t_min, t_max) = build_adapter(4321)
+    print(f"  60-layer model ready in {time.time() - t0:.0f} s", flush=True)
+
+    def first_timestep(hw):
+        sch = ref_scheduler()
+        sch.set_timesteps(40, denoising_strength=1.0, dynamic_shift_len=(hw // 16) * (hw // 16))
+        return sch.timesteps[0:1].to(BF)
+
+    def one_call(hw, ehw, T, nsp, seed):
+        noise = synth.make_noise(seed, hw, hw)
+        g = torch.Generator().manual_seed(seed + 100)
+        edit = torch.randn((1, 16, ehw // 8, ehw // 8), generator=g).to(BF)
+        pe = synth.make_prompt_emb(seed + 7, T)
+        mask = synth.make_special_token_mask(T, nsp)
+        t = first_timestep(hw)
+        pe_run = pe.clone()
+        t1 = time.time()
+        lat, _ = model_fn_qwen_image(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad, latents=noise, timestep=t,
+                                     prompt_emb=pe_run, prompt_emb_mask=torch.ones((1, T), dtype=torch.long), special_token_mask=mask,
+                                     height=hw, width=hw, edit_latents=edit, is_train=False)
+        print(f"  reference model_fn {hw}x{hw} + {ehw}x{ehw} edit, T {T}: {time.time() - t1:.0f} s", flush=True)
+        return dict(noise=noise, edit=edit, pe=pe, mask=mask, t=t, lat=lat, special_after=pe_run[mask].clone())
+
+    parts = set(os.environ.get("PE_G21_PARTS", "22,23,21").split(","))       # which files to (re)write; "24" = configs[4]'s geometry
+    ad32 = {k: v.float() for k, v in adsd.items()}
+    if "22" in parts:
+        _g22(O, sd, adsd, ad32, one_call, t_min, t_max)
+    if "23" in parts:
+        _g23(dit, ad)
+    if "24" in parts:
+        # BASELINE configs[4]'s per-GPU geometry: 1328x1328 target (83 x 83 noise tokens) + the 1024x1024 edit image, T 512: S = 11497
+        c = one_call(1328, 1024, 512, 64, 0)
+        save("G24_60_layers_configs4", {"latents": c["lat"], "special_after": c["special_after"]},
+             meta={"hw": 1328, "edit_hw": 1024, "T": 512, "n_special": 64, "seed": 0, "seed_weights": 1234, "seed_adapter": 4321, "layers": 60,
+                   "timestep": float(c["t"].float().item()), "weights": "synth.make_state_dict_hashed"})
+    if "21" in parts:       # last: its optional fp32 pass is the long one
+        _g21(O, sd, ad32, one_call, t_min, t_max)
+
+
+def _g22(O, sd, adsd, ad32, one_call, t_min, t_max):
+    import time
+    # ---- G22 (small): reference bf16, oracle bf16 (must be bit-identical), oracle fp32
+    c = one_call(512, 512, 160, 16, 0)
+    t1 = time.time()
+    pe_o = c["pe"].clone()
+    lat_o = O.model_fn(sd, adsd, c["noise"], c["t"], pe_o, c["mask"], 512, 512, c["edit"], t_min, t_max)
+    exact = bool(torch.equal(lat_o, c["lat"]) and torch.equal(pe_o[c["mask"]], c["special_after"]))
+    print(f"  oracle bf16 at 60 layers x S = 2208: bit-identical to the reference: {exact} ({time.time() - t1:.0f} s)", flush=True)
+    assert exact, "oracle and reference disagree at 60 layers"
+    t1 = time.time()
+    lat32 = O.model_fn(_F32View(sd), ad32, c["noise"].float(), c["t"].float(), c["pe"].clone().float(), c["mask"], 512, 512,
+                       c["edit"].float(), t_min, t_max)
+    print(f"  oracle fp32 at 60 layers x S = 2208: {time.time() - t1:.0f} s", flush=True)
+    save("G22_60_layers_s2208", {"latents": c["lat"], "special_after": c["special_after"], "latents_fp32": lat32.float()},
+         meta={"hw": 512, "edit_hw": 512, "T": 160, "n_special": 16, "seed": 0, "seed_weights": 1234, "seed_adapter": 4321, "layers": 60,
+               "timestep": float(c["t"].float().item()), "weights": "synth.make_state_dict_hashed", "oracle_bit_exact": exact,
+               "latents_fp32": "oracle, fp32 weights widened per access"})
+
+
+def _g23(dit, ad):
+    import time
+    # ---- G23: two CFG-4 steps of the reference's loop
+    h = w = 256
+    noise = synth.make_noise(3, h, w)
+    g = torch.Generator().manual_seed(3 + 100)
+    edit = torch.randn((1, 16, h // 8, w // 8), generator=g).to(BF)
+    pe_p, mask_p = synth.make_prompt_emb(3 + 7, 160), synth.make_special_token_mask(160, 16)
+    pe_n, mask_n = synth.make_prompt_emb(11, 80), synth.make_special_token_mask(80, 16)
+    sch = ref_scheduler()
+    sch.set_timesteps(2, denoising_strength=1.0, dynamic_shift_len=(h // 16) * (w // 16))
+    latents = noise.clone()
+    pp, pn = pe_p.clone(), pe_n.clone()
+    outs = {}
+    t1 = time.time()
+    for progress_id, timestep in enumerate(sch.timesteps):  # :648-661
+        timestep = timestep.unsqueeze(0).to(dtype=BF)
+        kw = dict(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad, latents=latents, height=h, width=w, edit_latents=edit,
+                  is_train=False, timestep=timestep, progress_id=progress_id)
+        posi, _ = model_fn_qwen_image(prompt_emb=pp, prompt_emb_mask=torch.ones((1, 160), dtype=torch.long), special_token_mask=mask_p, **kw)
+        nega, _ = model_fn_qwen_image(prompt_emb=pn, prompt_emb_mask=torch.ones((1, 80), dtype=torch.long), special_token_mask=mask_n, **kw)
+        pred = nega + 4.0 * (posi - nega)
+        latents = sch.step(pred, sch.timesteps[progress_id], latents)
+        outs[f"latents_step{progress_id}"] = latents.clone()
+    outs["special_posi_after"], outs["special_nega_after"] = pp[mask_p].clone(), pn[mask_n].clone()
+    print(f"  reference loop, two CFG-4 steps at 256x256: {time.time() - t1:.0f} s", flush=True)
+    save("G23_60_layers_two_cfg_steps", outs, meta={"hw": 256, "T_pos": 160, "T_neg": 80, "n_special": 16, "seed": 3, "seed_nega": 11,
+                                                    "steps": 2, "cfg_scale": 4.0, "layers": 60, "weights": "synth.make_state_dict_hashed"})
+
+
+def _g21(O, sd, ad32, one_call, t_min, t_max):
+    import time
+    # ---- G21: the headline geometry
+    c = one_call(1024, 1024, 512, 64, 0)
+    tensors = {"latents": c["lat"], "special_after": c["special_after"]}
+    meta = {"hw": 1024, "edit_hw": 1024, "T": 512, "n_special": 64, "seed": 0, "seed_weights": 1234, "seed_adapter": 4321, "layers": 60,
+            "timestep": float(c["t"].float().item()), "weights": "synth.make_state_dict_hashed"}
+    if os.environ.get("PE_G21_FP32") == "1":
+        t1 = time.time()
+        lat32 = O.model_fn(_F32View(sd), ad32, c["noise"].float(), c["t"].float(), c["pe"].clone().float(), c["mask"], 1024, 1024,
+                           c["edit"].float(), t_min, t_max)
+        print(f"  oracle fp32 at 60 layers x S = 8704: {time.time() - t1:.0f} s", flush=True)
+        tensors["latents_fp32"] = lat32.float()
+        meta["latents_fp32"] = "oracle, fp32 weights widened per access"
+    save("G21_60_layers_headline", tensors, meta=meta)
+
+
 GROUPS = {k: v for k, v in list(globals().items()) if k[0] == "G" and k[1].isdigit()}
 
 if __name__ == "__main__":
-    want = sys.argv[1:] or sorted(GROUPS, key=lambda s: int(s[1:].split("_")[0]))
+    # G21 (the 60-layer model: 41 GB, tens of minutes) only when named
+    want = sys.argv[1:] or [g for g in sorted(GROUPS, key=lambda s: int(s[1:].split("_")[0])) if not g.startswith("G21")]
     for name in want:
         fn = [v for k, v in GROUPS.items() if k.split("_")[0] == name.split("_")[0]][0]
         print("==", fn.__name__)

@@ -526,11 +526,16 @@ def test_flash_attn_plain_q_takes_exact_form(ops, attn_variant):
 
 
 # --- e4m3 attention (qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35) ---
-def _fp8_attn(ops, q, k, v, S, workspace=True, want_stats=False):
+def _fp8_attn(ops, q, k, v, S, workspace=True, want_stats=False, stale_pad=None):
     from physicedit_amd._lib import check, lib, stream_ptr
     H = q.shape[0]
     qd, kd, vt = _dev_qkv(ops, q, k, v, S, nan_pad=False)
     sp = qd.shape[1]
+    if stale_pad is not None:       # what another call of a different length left in the positions of tokens >= S (finite values)
+        pos = ops.vt_positions(sp, vt.device)[S:]
+        vt[:, :, pos] = stale_pad[:, :, :pos.numel()].to(vt.device)
+        qd[:, S:] = 3.0
+        kd[:, S:] = -2.0
     n = lib().pe_flash_attn_fp8_scratch_bytes(H, sp)
     scratch = torch.empty((n + 256,), dtype=torch.uint8, device="cuda")
     base = (scratch.data_ptr() + 255) // 256 * 256
@@ -606,6 +611,23 @@ def test_flash_attn_fp8(ops, S, scales, fp8_variant):
     assert _rms(out, out1) <= noise * e_fp8 + 1e-6 and _rms(out, ref32) <= 1.1 * e_fp8 + 1e-6
     for _ in range(5):
         assert torch.equal(_fp8_attn(ops, q, k, v, S), out)
+
+
+@pytest.mark.parametrize("S", [65, 100, 1093, 2192])
+def test_flash_attn_fp8_ignores_stale_pad_columns(ops, S):
+    """One pe_dit handle serves both prompt lengths of a CFG pair, so the planes' positions [S, S_pad) hold whatever the other branch
+    wrote there: the three standard deviations (v_std sums Vt, whose token order is permuted inside 16-groups) and the output must
+    not see them.  Bit for bit against zeroed pads."""
+    H = 3
+    g = torch.Generator().manual_seed(4100 + S)
+    q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in (1.1, 0.8, 1.7))
+    stale = (torch.randn((H, 128, 64), generator=g) * 9.0).to(BF)
+    out0, st0 = _fp8_attn(ops, q, k, v, S, want_stats=True)
+    out1, st1 = _fp8_attn(ops, q, k, v, S, want_stats=True, stale_pad=stale)
+    assert torch.equal(st0, st1), (st0, st1)
+    assert torch.equal(out0, out1)
+    want = torch.stack([t.float().std() for t in (q, k, v)]).to(BF).float()
+    assert torch.equal(st1[:3], want)
 
 
 @pytest.mark.parametrize("H,S", [(256, 64), (256, 128), (256, 192), (256, 256), (256, 320), (256, 384), (4, 700), (3, 1093)])

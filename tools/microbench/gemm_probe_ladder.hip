@@ -1,0 +1,269 @@
+// Attainable-ceiling ladder of the bf16 GEMM main loop for TWO wave tilings, on N(0,1) and on all-zero operands (round 5).
+//
+//   8 waves x (64 x 128) per 256 x 256 x 64 block tile  (gemm_bf16_kernel's tiling: 0.75 ds_read_b128 per MFMA, two waves per SIMD)
+//   4 waves x (128 x 128)                                (0.5 ds_read_b128 per MFMA, one wave per SIMD, 256 accumulator registers)
+//
+// Per tiling: MFMA only / + LDS fragment reads / + the LDS-DMA operand stream (64 KiB per K tile and work-group, L2 resident),
+// free-running: no barriers, nothing waits for arriving data, no epilogue (the 8-wave modes are pe_gemm_mix_probe's).  The
+// zero-operand column separates what is ENERGY (the chip's power limit lowers the clock on random data; on zeros it holds 2.4 GHz,
+// so a mode that only costs energy shows no drop there) from what is ISSUE / latency (drops on zeros too).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench/gemm_probe_ladder.hip -o /tmp/gemm_probe_ladder && /tmp/gemm_probe_ladder
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define DEV __device__ __forceinline__
+DEV void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+// ---------------------------------------------------------------- 8 waves x 64 x 128 (the library probe's modes 0 / 1 / 2)
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) probe8(const char* __restrict__ src, unsigned window_bytes, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int sw = (l31 >> 1) & 7;
+    const char* win = src + (size_t)(blockIdx.x & 7) * window_bytes;
+    const unsigned wmask = window_bytes - 1u;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    for (int i = 0; i < 20; ++i) {
+        const unsigned piece = (unsigned)(w * 20 + i);
+        glds16(win + ((piece * 1024u + lane_off) & wmask), smem + piece * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc[2][4];
+    for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 4; ++ni)
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int a_off = (wm * 64 + l31) * 128;
+    const int w_off = (wn * 128 + l31) * 128;
+    char* const a_base = smem;
+    char* const w_base = smem + 2 * 32768;
+    bf16x8 fa[4], fw[4][4];
+    for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = *(const bf16x8*)(a_base + a_off + (((ks * 2 + h) ^ sw) << 4));
+        for (int ni = 0; ni < 4; ++ni) fw[ni][ks] = *(const bf16x8*)(w_base + w_off + ni * 4096 + (((ks * 2 + h) ^ sw) << 4));
+    }
+    unsigned stream_off = (unsigned)blockIdx.x * 65536u + (unsigned)w * 8192u;
+    int ab = 0, ws = 0;
+    for (int it = 0; it < iters; ++it) {
+        const char* Sa = a_base + ab * 32768;
+        const char* Sw = w_base + ws * 32768;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            if constexpr (MODE >= 1) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[ks] = *(const bf16x8*)(Sa + a_off + mi * 4096 + (((ks * 2 + h) ^ sw) << 4));
+                if (mi == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) fw[ni][ks] = *(const bf16x8*)(Sw + w_off + ni * 4096 + (((ks * 2 + h) ^ sw) << 4));
+                }
+            }
+            if constexpr (MODE >= 2) {
+                char* dst = mi == 0 ? a_base + (ab ^ 1) * 32768 + w * 4096 : w_base + ((ws + 2) % 3) * 32768 + w * 4096;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    glds16(win + ((stream_off + lane_off) & wmask), dst + j * 1024);
+                    stream_off += 1024u;
+                }
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
+        }
+        stream_off += 65536u - 8192u;
+        ab ^= 1;
+        ws = ws == 2 ? 0 : ws + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+    for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 4; ++ni)
+            for (int r = 0; r < 16; ++r) s += acc[mi][ni][r];
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+// ---------------------------------------------------------------- 4 waves x 128 x 128, one wave per SIMD
+// Per K tile and wave: 64 MFMAs (4 x 4 blocks x 4 k-steps), 32 ds_read_b128 (4 activation + 4 weight fragments per k-step, read one
+// k-step ahead into the other register set), 16 LDS-DMA pieces.  The interleave inside a k-step is pinned: 8 x (MFMA, read),
+// 4 x (MFMA, DMA piece), 4 MFMAs.
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) probe4(const char* __restrict__ src, unsigned window_bytes, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int sw = (l31 >> 1) & 7;
+    const char* win = src + (size_t)(blockIdx.x & 7) * window_bytes;
+    const unsigned wmask = window_bytes - 1u;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    for (int i = 0; i < 40; ++i) {
+        const unsigned piece = (unsigned)(w * 40 + i);
+        glds16(win + ((piece * 1024u + lane_off) & wmask), smem + piece * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc[4][4];
+    for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 4; ++ni)
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int a_off = (wm * 128 + l31) * 128;
+    const int w_off = (wn * 128 + l31) * 128;
+    char* const a_base = smem;
+    char* const w_base = smem + 2 * 32768;
+    bf16x8 fa[2][4], fw[2][4];
+    auto rd = [&](const char* Sa, const char* Sw, int ks, int set) __attribute__((always_inline)) {
+        const int c = ((ks * 2 + h) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[set][i] = *(const bf16x8*)(Sa + a_off + i * 4096 + c);
+            fw[set][i] = *(const bf16x8*)(Sw + w_off + i * 4096 + c);
+        }
+    };
+    rd(a_base, w_base, 0, 0);
+    rd(a_base, w_base, 1, 1);     // MODE 0 never reads again
+    unsigned stream_off = (unsigned)blockIdx.x * 65536u + (unsigned)w * 16384u;
+    int ab = 0, ws = 0;
+    for (int it = 0; it < iters; ++it) {
+        const char* Sa = a_base + ab * 32768;
+        const char* Sw = w_base + ws * 32768;
+        const char* San = a_base + (ab ^ 1) * 32768;
+        const char* Swn = w_base + (ws == 2 ? 0 : ws + 1) * 32768;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1;
+            if constexpr (MODE >= 1) {
+                if (ks < 3) rd(Sa, Sw, ks + 1, cur ^ 1);
+                else rd(San, Swn, 0, cur ^ 1);
+            }
+            if constexpr (MODE >= 2) {
+                // 4 pieces per k-step: k-steps 0, 1 fill this wave's quarter of the other A buffer, 2, 3 of the W slot two ahead
+                char* dst = ks < 2 ? a_base + (ab ^ 1) * 32768 + w * 8192 + ks * 4096 : w_base + ((ws + 2) % 3) * 32768 + w * 8192 + (ks - 2) * 4096;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    glds16(win + ((stream_off + lane_off) & wmask), dst + j * 1024);
+                    stream_off += 1024u;
+                }
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cur][ni], fa[cur][mi], acc[mi][ni], 0, 0, 0);
+            if constexpr (MODE >= 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { SGB(0x008, 1); SGB(0x100, 1); }
+                if constexpr (MODE >= 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { SGB(0x008, 1); SGB(0x020, 1); }
+                    SGB(0x008, 4);
+                } else {
+                    SGB(0x008, 8);
+                }
+            }
+        }
+        stream_off += 65536u - 16384u;
+        ab ^= 1;
+        ws = ws == 2 ? 0 : ws + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+    for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 4; ++ni)
+            for (int r = 0; r < 16; ++r) s += acc[mi][ni][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+
+static uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <typename K>
+static double run(K kernel, int threads, const char* src, unsigned window, float* out, int iters, double flops_per_iter_block) {
+    const int blocks = 256, lds = 160 * 1024;
+    CK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    double best = 0.0;
+    for (int rep = 0; rep < 3; ++rep) {
+        const int n = rep == 0 ? 2000 : iters;
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, 0, src, window, out, n);
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (rep > 0) {
+            const double tf = flops_per_iter_block * blocks * (double)n / (ms * 1e-3) / 1e12;
+            if (tf > best) best = tf;
+        }
+    }
+    return best;
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 100000;
+    const size_t n = (size_t)8 << 20;      // 16 MiB of bf16 = 8 windows of 2 MiB
+    std::vector<uint16_t> hrand(n);
+    uint64_t s = 88172645463325252ull;
+    for (size_t i = 0; i < n; i += 2) {     // Box-Muller on a xorshift stream: N(0,1)
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u1 = ((s >> 11) + 1.0) / 9007199254740993.0;
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u2 = (s >> 11) / 9007199254740992.0;
+        const double r = sqrt(-2.0 * log(u1));
+        hrand[i] = f2bf((float)(r * cos(6.283185307179586 * u2)));
+        hrand[i + 1] = f2bf((float)(r * sin(6.283185307179586 * u2)));
+    }
+    char *drand, *dzero;
+    float* out;
+    CK(hipMalloc(&drand, n * 2));
+    CK(hipMalloc(&dzero, n * 2));
+    CK(hipMalloc(&out, 256 * 512 * 4));
+    CK(hipMemcpy(drand, hrand.data(), n * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(dzero, 0, n * 2));
+    const unsigned window = (unsigned)(n * 2 / 8);
+    const double f8 = 8.0 * 32.0 * (2.0 * 32 * 32 * 16), f4 = 4.0 * 64.0 * (2.0 * 32 * 32 * 16);   // per K tile and work-group: the same 256 MFMAs
+    printf("mode                                         N(0,1) TF/s   zeros TF/s\n");
+    struct Row { const char* name; double r, z; };
+    Row rows[6];
+    rows[0] = {"8 waves x 64x128: MFMA only", run(probe8<0>, 512, drand, window, out, iters, f8), run(probe8<0>, 512, dzero, window, out, iters, f8)};
+    rows[1] = {"8 waves x 64x128: + 0.75 ds_read_b128 / MFMA", run(probe8<1>, 512, drand, window, out, iters, f8), run(probe8<1>, 512, dzero, window, out, iters, f8)};
+    rows[2] = {"8 waves x 64x128: + LDS-DMA stream", run(probe8<2>, 512, drand, window, out, iters, f8), run(probe8<2>, 512, dzero, window, out, iters, f8)};
+    rows[3] = {"4 waves x 128x128: MFMA only", run(probe4<0>, 256, drand, window, out, iters, f4), run(probe4<0>, 256, dzero, window, out, iters, f4)};
+    rows[4] = {"4 waves x 128x128: + 0.5 ds_read_b128 / MFMA", run(probe4<1>, 256, drand, window, out, iters, f4), run(probe4<1>, 256, dzero, window, out, iters, f4)};
+    rows[5] = {"4 waves x 128x128: + LDS-DMA stream", run(probe4<2>, 256, drand, window, out, iters, f4), run(probe4<2>, 256, dzero, window, out, iters, f4)};
+    for (const Row& r : rows) printf("%-46s %8.0f %12.0f\n", r.name, r.r, r.z);
+    return 0;
+}
