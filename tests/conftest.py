@@ -8,19 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-import time
-
-SESSION_START = time.time()
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-def suite_seconds() -> float:
-    """wall-clock seconds since this pytest session started: the long host-oracle tests look at it before they begin (the GPU box's
-    host is shared by several jobs; its speed varies by 2x) so that the `-m gpu` suite stays inside the driver's time limit"""
-    return time.time() - SESSION_START
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -184,3 +184,20 @@ def test_asm_mfma_hazards_of_the_e4m3_attention_kernel():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main() == 0
+
+
+def test_hashed_weights_checksum():
+    """`synth.make_state_dict_hashed` is what ties the 60-layer fixtures G21-G24 (written by the reference in the build container) to the
+    model the GPU box regenerates: pure integer arithmetic, so its bits are a constant of the repository.  One block + the embeds."""
+    import hashlib
+    import torch
+    from physicedit_amd import synth
+    sd = synth.make_state_dict_hashed(synth.dit_layout(1), 1234)
+    hh = hashlib.sha256()
+    for k in sorted(sd):
+        hh.update(sd[k].view(torch.int16).numpy().tobytes())
+    assert hh.hexdigest()[:16] == "ea475a4c871df204"
+    w = sd["transformer_blocks.0.img_mlp.net.0.proj.weight"].float()
+    assert abs(w.std().item() * (3 * 3072) ** 0.5 - 1.0) < 1e-2 and abs(w.mean().item()) < 1e-5      # U(+-1/sqrt(fan_in))
+    u = synth.hash_uniform(7, 1 << 16, "cpu", chunk=1000)           # chunking does not change the stream
+    assert torch.equal(u, synth.hash_uniform(7, 1 << 16, "cpu"))

@@ -1,16 +1,19 @@
-"""`-m gpu` end-to-end parity at the depth and geometry of the BASELINE configs (VERDICT r01 item 1):
+"""`-m gpu` end-to-end parity at the depth and geometry of the BASELINE configs:
 
-  * configs[1]/[3]: the FULL 60-layer DiT (+ adapter, 16 special tokens) at 512x512 + 512x512 (S = 2208: depth AND length), one
-    `model_fn` call, against the oracle in bf16 and in fp32 (`qwen_image_physical.py:644-661`, `:1302-1403`), for both attention
-    variants; VAE decode at 1024 x 1024 against the oracle;
-  * configs[4]: one layer at the 1328x1328 geometry (83x83 noise tokens + 64x64 edit tokens, T = 512).
+  * configs[1]/[3]: the FULL 60-layer DiT (+ adapter) against fixtures written by the REFERENCE ITSELF in the build container
+    (tests/golden/make_golden.py G21: `model_fn_qwen_image`, `qwen_image_physical.py:1302-1403`, on the same counter-based weights
+    `synth.make_state_dict_hashed` regenerates on the GPU bit for bit): G21 = the headline geometry (1024x1024 + 1024x1024 edit, S = 8704),
+    G22 = 512x512 + 512x512 (S = 2208) with an fp32 evaluation of the same graph for the fp32-distance criterion, G23 = two CFG-4 steps
+    of the loop (`:644-661`), G24 = configs[4]'s per-GPU geometry (S = 11497).  No host oracle pass runs for them: nothing to skip
+    when the host is slow.  VAE decode at 1024 x 1024 against the oracle;
+  * configs[4]: one layer at the 1328x1328 geometry (83x83 noise tokens + 64x64 edit tokens, T = 512) against the oracle.
 
 Each test records frac(|d| <= 1e-3), max |d| and the fp32-distance ratio (tests/parity_record.py)."""
 import pytest
 import torch
 
 import oracle.physicedit_oracle as O
-from parity_record import record
+from parity_record import parity_stats, record
 from physicedit_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -65,46 +68,81 @@ def _release_model60():
 
 
 def model60():
-    """the 60-layer DiT (+ adapter) of this module's tests: generated on the device and wrapped in an engine ONCE (41 GB), with one host
-    cache for the oracle's views"""
+    """the 60-layer DiT (+ adapter) of this module's tests: generated on the device and wrapped in an engine ONCE (41 GB), from the
+    counter-based generator -- the same bits the build container drew on its host for the reference's fixtures (checked against it in
+    tests/test_cabi_host.py::test_hashed_weights_checksum and test_hashed_weights_same_on_device below); `host`: a host cache for the
+    opt-in oracle passes"""
     if not _MODEL60:
         from physicedit_amd.dit import QwenImageDiTEngine
         dev = torch.device("cuda")
-        sd_dev = synth.make_state_dict_device(synth.dit_layout(60), 1234, dev)
+        sd_dev = synth.make_state_dict_hashed(synth.dit_layout(60), 1234, dev)
         ad = synth.make_state_dict(synth.adapter_layout(), 4321)
         _MODEL60.update(sd=sd_dev, ad=ad, eng=QwenImageDiTEngine(sd_dev, ad, device=dev), host={})
     return _MODEL60["sd"], _MODEL60["ad"], _MODEL60["eng"], _MODEL60["host"]
 
 
-def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]", fp32=True):
-    """60-layer DiT + adapter, one `model_fn` call at the first timestep of the 40-step schedule, against the oracle in bf16 and (fp32=True)
-    in fp32, for the default attention kernel (5: folded scale and max) and the two it is judged against (4: the same schedule with
-    the exact per-score form, round 3's default; 0: textbook).  fp32=False: the default kernel against the bf16 oracle only (the fp32
-    pass is what costs host time), held to the element-wise numbers the full form measured.  Returns the parity records by variant."""
-    import os
+def test_hashed_weights_same_on_device():
+    """the premise of the G21-G24 fixtures: `synth.make_state_dict_hashed` draws the same bits on the GPU as on a host"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    lay = [kv for kv in synth.dit_layout(1) if "img_mlp.net.0" in kv[0] or "norm_q" in kv[0] or "to_q" in kv[0] or kv[0].startswith("proj_out")]
+    a = synth.make_state_dict_hashed(lay, 1234, "cpu")
+    b = synth.make_state_dict_hashed(lay, 1234, torch.device("cuda"))
+    assert len(a) >= 7
+    for k in a:
+        assert torch.equal(a[k], b[k].cpu()), k
+
+
+def _forward60(HW, EH, T, nsp, variants, fp8=False):
+    """one `model_fn` call of the 60-layer engine at the first timestep of the 40-step schedule per attention variant"""
     from physicedit_amd._lib import lib
     from physicedit_amd.dit import special_indices
     from physicedit_amd.scheduler import qwen_image_scheduler
     dev = torch.device("cuda")
     sd_dev, ad, eng, host = model60()
-    EH = HW if edit_hw is None else edit_hw
     noise, edit, pe, mask = _inputs(HW, HW, EH, EH, T, nsp, 0)
     sch = qwen_image_scheduler()
     sch.set_timesteps(40, dynamic_shift_len=(HW // 16) * (HW // 16))
     t = sch.timesteps[0:1].to(BF)
-    t_min, t_max = O.adapter_t_range()
-    variants = (5, 4, 0) if fp32 else (5,)
-    got = {}
+    got, special = {}, {}
     try:
         for variant in variants:
             assert lib().pe_debug_set(b"attn_variant", variant) == 0
-            got[variant] = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, dev), edit.cuda()).clone()
-        if fp32:      # the e4m3 attention branch at depth: reported next to the bf16 kernels' distance to fp32 (no oracle pass of its own)
+            pe_d = pe.cuda().clone()
+            got[variant] = eng.forward(noise.cuda(), t, pe_d, special_indices(mask, dev), edit.cuda()).clone()
+            special[variant] = pe_d[mask.cuda()].cpu()
+        if fp8:      # the e4m3 attention branch at depth: reported next to the bf16 kernels' distance to fp32
             got["fp8"] = eng.forward(noise.cuda(), t, pe.cuda().clone(), special_indices(mask, dev), edit.cuda(),
                                      enable_fp8_attention=True).clone()
         torch.cuda.synchronize()
     finally:
         lib().pe_debug_set(b"attn_variant", 5)
+    return got, special, (noise, edit, pe, mask, t)
+
+
+_NAMES = {5: "attention variant 5 = default", 4: "attention variant 4", 0: "attention variant 0"}
+
+
+def _check_vs_fp32(st):
+    # as close to the fp32 evaluation of the same graph as the reference's own bf16 run is
+    for s_ in st.values():
+        assert s_["fp32_distance_ratio"] <= 1.25, s_
+        assert s_["max_to_fp32_hip"] <= 1.5 * s_["max_to_fp32_reference_bf16"] + 1e-3, s_
+    # the decision rule for the default attention kernel: not measurably further from fp32 than the textbook update
+    if 0 in st:
+        for v in st:
+            assert st[v]["fp32_distance_ratio"] <= st[0]["fp32_distance_ratio"] * 1.02 + 1e-3, (st[v], st[0])
+
+
+def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]", fp32=True):
+    """OPT-IN form (PE_PARITY_FULL=1): the same comparison against host ORACLE passes in bf16 and fp32 (minutes of CPU), for geometries
+    without an fp32 fixture.  Returns the parity records by variant."""
+    import os
+    sd_dev, ad, eng, host = model60()
+    EH = HW if edit_hw is None else edit_hw
+    variants = (5, 4, 0) if fp32 else (5,)
+    got, _, (noise, edit, pe, mask, t) = _forward60(HW, EH, T, nsp, variants, fp8=fp32)
+    t_min, t_max = O.adapter_t_range()
     threads = torch.get_num_threads()
     ref32 = None
     try:
@@ -118,75 +156,81 @@ def _depth_meets_length(HW, T, nsp, case, edit_hw=None, config="configs[1]", fp3
                                edit.float(), t_min, t_max)
     finally:
         torch.set_num_threads(threads)
-    names = {5: "attention variant 5 = default", 4: "attention variant 4", 0: "attention variant 0"}
-    st = {v: record(config, f"{case} [{names[v]}]" + ("" if fp32 else " [bf16 oracle only]"), got[v], ref, ref32) for v in variants}
+    st = {v: record(config, f"{case} [{_NAMES[v]}] [host oracle]", got[v], ref, ref32) for v in variants}
     assert torch.isfinite(ref.float()).all() and all(torch.isfinite(g.float()).all() for g in got.values())
     if "fp8" in got:
-        # enable_fp8_attention=True against the SAME references (the bf16-attention oracle and its fp32 run): what e4m3 attention
-        # operands cost at 60 layers, as a multiple of the bf16 path's own distance to fp32
-        st8 = record(config, f"{case} [enable_fp8_attention: e4m3 attention vs the bf16-attention references]", got["fp8"], ref, ref32)
+        st8 = record(config, f"{case} [enable_fp8_attention: e4m3 attention vs the bf16-attention references] [host oracle]", got["fp8"], ref, ref32)
         assert st8["fp32_distance_ratio"] <= 6.0, st8
     if not fp32:
-        # the numbers of the full form (profiles/r03_parity.json: mean |d| 1.63e-3, 5 ulp at this depth for every variant) with headroom
         assert st[5]["mean_abs_diff"] <= 2e-3 and st[5]["max_ulp"] <= 6.0, st[5]
         return st
-    # as close to the fp32 evaluation of the same graph as the reference's own bf16 run is
-    for s_ in st.values():
-        assert s_["fp32_distance_ratio"] <= 1.25, s_
-        assert s_["max_to_fp32_hip"] <= 1.5 * s_["max_to_fp32_reference_bf16"] + 1e-3, s_
-    # the decision rule for the default attention kernel: not measurably further from fp32 than the textbook update
-    assert st[5]["fp32_distance_ratio"] <= st[0]["fp32_distance_ratio"] * 1.02 + 1e-3, (st[5], st[0])
-    assert st[4]["fp32_distance_ratio"] <= st[0]["fp32_distance_ratio"] * 1.02 + 1e-3, (st[4], st[0])
+    _check_vs_fp32(st)
     return st
 
 
-def test_60_layers_depth_meets_length():
-    """Depth AND sequence length together: the FULL 60-layer DiT + adapter on a 512x512 target with a 512x512
-    edit image (S_img = 2048) and T = 160 with 16 special tokens: S = 2208 -> 9 query blocks and 35 KV tiles per head in the flash
-    kernel (multi-tile, split-KV leftovers), 9 M tiles per GEMM (432 / 324 tiles for MLP-up / QKV: several rounds of work-groups,
-    the persistent schedule 17 walks tiles).  One `model_fn` call at the first timestep of the 40-step schedule (t ~ 1000: the
-    adapter's in-place update of the special rows included) against the oracle in bf16 and in fp32
-    (`qwen_image_physical.py:1302-1403`).  The fp32 evaluation is what costs time on the host (its element-wise passes over
-    [S, 12288] fp32 tensors), which is why this is one forward and not a CFG step: the CFG combine / Euler kernel is pinned on the
-    reference's own tensors elsewhere (G6, G15) and at this depth in test_60_layers_two_cfg_steps.  Run for THREE attention variants:
-    the default (5: lazy max, scale and max folded out of the softmax stream, Q rounded once with the scale applied) and round 3's (4)
-    must be as close to the fp32 evaluation as the reference's own bf16 run, and no further from it than the textbook kernel (0) --
-    the repo's criterion for choosing a default (profiles/r03_attention_notes.md, r04_attention_notes.md)."""
+def test_60_layers_depth_meets_length(golden):
+    """Depth AND sequence length together: the FULL 60-layer DiT + adapter on a 512x512 target with a 512x512 edit image (S_img = 2048)
+    and T = 160 with 16 special tokens: S = 2208 -> 9 query blocks and 35 KV tiles per head in the flash kernel (multi-tile, split-KV
+    leftovers), 9 M tiles per GEMM (several rounds of work-groups: the persistent schedule walks tiles).  One `model_fn` call at the first
+    timestep of the 40-step schedule (t = 1000: the adapter's in-place update of the special rows included) against fixture G22: the
+    REFERENCE's own bf16 output (`qwen_image_physical.py:1302-1403`; the oracle was bit-identical to it at this depth when the fixture
+    was written) and an fp32 evaluation of the same graph.  THREE attention variants: the default (5: lazy max, scale and max folded
+    out of the softmax stream) and round 3's (4) must be as close to the fp32 evaluation as the reference's own bf16 run, and no further
+    from it than the textbook kernel (0) -- the repo's criterion for choosing a default (profiles/r03_attention_notes.md,
+    r04_attention_notes.md).  The e4m3 attention branch is reported against the same pair."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    _depth_meets_length(512, 160, 16, "60 layers, 512x512 + 512x512 edit (S = 2208), T 160, one model_fn call (first of 40 steps)")
+    fx = golden("G22_60_layers_s2208")
+    ref, ref32 = fx["latents"], fx["latents_fp32"]
+    got, special, _ = _forward60(512, 512, 160, 16, (5, 4, 0), fp8=True)
+    case = "60 layers, 512x512 + 512x512 edit (S = 2208), T 160, one model_fn call (first of 40 steps) vs the REFERENCE (G22)"
+    st = {v: record("configs[1]", f"{case} [{_NAMES[v]}]", got[v], ref, ref32) for v in (5, 4, 0)}
+    assert all(torch.isfinite(g.float()).all() for g in got.values())
+    _check_vs_fp32(st)
+    st8 = record("configs[1]", f"{case} [enable_fp8_attention: e4m3 attention vs the bf16-attention references]", got["fp8"], ref, ref32)
+    assert st8["fp32_distance_ratio"] <= 6.0, st8
+    # the adapter's in-place update of the special rows (adapter GEMMs only: shallow), against the reference's
+    sp = parity_stats(special[5], fx["special_after"])
+    assert sp["max_ulp"] <= 4.0 and sp["frac_bit_identical"] >= 0.9, sp
 
 
-def test_60_layers_headline_geometry():
+def test_60_layers_headline_geometry(golden):
     """The same at BASELINE configs[1]'s own geometry: 1024x1024 target + 1024x1024 edit image, T = 512 with 64 special tokens,
-    S = 8704 (34 query blocks x 136 KV tiles per head; 1632 / 1224 / 408-tile GEMM launches).  By default against the bf16 oracle
-    only (60 layers at S = 8704 on >= 32 host threads: a couple of minutes), held to the element-wise numbers the full form measured
-    (mean |d| <= 2e-3, <= 6 ulp); PE_PARITY_FULL=1 adds the fp32 oracle pass and the other attention variants (~10 minutes; numbers
-    in profiles/r03_parity.json, r04_parity.json)."""
+    S = 8704 (34 query blocks x 136 KV tiles per head; 1632 / 1224 / 408-tile GEMM launches), against fixture G21: the output of the
+    REFERENCE's `model_fn_qwen_image` itself on the same 60-layer weights (176 s of the build container's CPU; no host pass here, so
+    the test never skips).  Element-wise it is held to what 60 layers of bf16 allow (mean |d| <= 2e-3, <= 6 ulp: two bf16 runs of the
+    graph that sum in different orders differ by that -- the reference's own run is 2e-2 rms from an fp32 evaluation); when the fixture
+    carries the fp32 evaluation (PE_G21_FP32=1 at generation) the fp32-distance criterion is applied too.  PE_PARITY_FULL=1 adds the
+    host-oracle form with all attention variants."""
     import os
-    from conftest import suite_seconds
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    full = os.environ.get("PE_PARITY_FULL") == "1"
-    if not full and suite_seconds() > float(os.environ.get("PE_SUITE_BUDGET_S", "820")):
-        pytest.skip(f"suite time budget: {suite_seconds():.0f} s gone when this ~190 s host-oracle test came up (slow / shared host); "
-                    "its numbers of the last full run are in profiles/r04_parity.json")
-    _depth_meets_length(1024, 512, 64, "60 layers, 1024x1024 + 1024x1024 edit (S = 8704), T 512, one model_fn call (first of 40 steps)",
-                        fp32=full)
+    fx = golden("G21_60_layers_headline")
+    ref, ref32 = fx["latents"], fx.get("latents_fp32")
+    got, special, _ = _forward60(1024, 1024, 512, 64, (5,))
+    case = "60 layers, 1024x1024 + 1024x1024 edit (S = 8704), T 512, one model_fn call (first of 40 steps) vs the REFERENCE (G21)"
+    st = record("configs[1]", f"{case} [{_NAMES[5]}]", got[5], ref, ref32)
+    assert torch.isfinite(got[5].float()).all()
+    assert st["mean_abs_diff"] <= 2e-3 and st["max_ulp"] <= 6.0, st
+    if ref32 is not None:
+        _check_vs_fp32({5: st})
+    sp = parity_stats(special[5], fx["special_after"])
+    assert sp["max_ulp"] <= 4.0 and sp["frac_bit_identical"] >= 0.9, sp
+    if os.environ.get("PE_PARITY_FULL") == "1":
+        _depth_meets_length(1024, 512, 64, "60 layers, 1024x1024 + 1024x1024 edit (S = 8704), T 512, one model_fn call (first of 40 steps)")
 
 
-def test_60_layers_two_cfg_steps():
+def test_60_layers_two_cfg_steps(golden):
     """Multi-step at depth: TWO CFG-4 steps of the 60-layer loop at S = 672 / 592 (256x256 target + 256x256 edit image, T_pos = 160
-    and T_neg = 80, 16 special tokens each: four 60-layer oracle forwards have to fit the suite's budget -- at 512x512 they took 238 s
-    of host time; depth x LENGTH is the test above) through DenoiseLoop's default form (two streams), against the oracle's loop in bf16
-    (`qwen_image_physical.py:644-661`): the adapter's in-place accumulation on the special rows across steps (the second step's
-    prompt embeddings are the first step's outputs), the CFG combine and the Euler update, at the depth where only single forwards
-    were compared.  Bound: a 2-step schedule moves the latents by 0.5 pred per step and CFG 4 weighs the two forwards' errors by
-    4 and 3, so the single-call mean |d| of 1.65e-3 (test above) becomes ~1e-2 at the end; twice that is the limit."""
-    import os
+    and T_neg = 80, 16 special tokens each) through DenoiseLoop's default form (two streams), against fixture G23: the REFERENCE's own
+    loop (`qwen_image_physical.py:644-661`, four `model_fn_qwen_image` forwards + `step`) on the same weights: the adapter's in-place
+    accumulation on the special rows across steps (the second step's prompt embeddings are the first step's outputs), the CFG combine
+    and the Euler update, at full depth.  Bound: a 2-step schedule moves the latents by 0.5 pred per step and CFG 4 weighs the two
+    forwards' errors by 4 and 3, so the single-call mean |d| of 1.65e-3 becomes ~1e-2 at the end; twice that is the limit."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from physicedit_amd.pipeline import DenoiseLoop
+    fx = golden("G23_60_layers_two_cfg_steps")
     sd_dev, ad, eng, host = model60()
     noise, edit, pe_p, mask_p = _inputs(256, 256, 256, 256, 160, 16, 3)
     pe_n = synth.make_prompt_emb(11, 80)
@@ -195,33 +239,41 @@ def test_60_layers_two_cfg_steps():
     pp, pn = pe_p.cuda().clone(), pe_n.cuda().clone()
     got = loop(noise.cuda(), pp, pn, mask_p, mask_n, 256, 256, num_inference_steps=2, cfg_scale=4.0, edit_latents=edit.cuda())
     torch.cuda.synchronize()
-    threads = torch.get_num_threads()
-    try:
-        torch.set_num_threads(max(threads, min(32, os.cpu_count() or 16)))
-        ref = O.denoise_loop(HostView(sd_dev, cache=host), ad, noise, pe_p, pe_n, mask_p, mask_n, 256, 256, 2, cfg_scale=4.0, edit_latents=edit)
-    finally:
-        torch.set_num_threads(threads)
-    st = record("configs[1]", "60 layers, 256x256 + 256x256 edit, TWO CFG-4 steps of the loop (two streams) vs the oracle's loop [bf16 oracle only]",
+    ref = fx["latents_step1"]
+    st = record("configs[1]", "60 layers, 256x256 + 256x256 edit, TWO CFG-4 steps of the loop (two streams) vs the REFERENCE's loop (G23)",
                 got, ref)
-    assert torch.isfinite(got.float()).all() and torch.isfinite(ref.float()).all()
+    assert torch.isfinite(got.float()).all()
     assert st["mean_abs_diff"] <= 2e-2 and st["max_abs_diff"] <= 0.25, st
     # the loop owns its prompt embeddings like the reference's `inputs_posi` / `inputs_nega` entries: the adapter rewrote the special
-    # rows (twice), nothing else
+    # rows (twice), nothing else -- and to the reference's values
     mp, mn = mask_p[0].bool(), mask_n[0].bool()
     assert torch.equal(pp[0].cpu()[~mp], pe_p[0][~mp]) and torch.equal(pn[0].cpu()[~mn], pe_n[0][~mn])
     assert not torch.equal(pp[0].cpu()[mp], pe_p[0][mp]) and not torch.equal(pn[0].cpu()[mn], pe_n[0][mn])
+    for name, rows, want in (("posi", pp[0].cpu()[mp], fx["special_posi_after"]), ("nega", pn[0].cpu()[mn], fx["special_nega_after"])):
+        sp = parity_stats(rows, want)
+        assert sp["max_ulp"] <= 6.0 and sp["frac_bit_identical"] >= 0.7, (name, sp)
 
 
-def test_60_layers_configs4_geometry():
+def test_60_layers_configs4_geometry(golden):
     """And at BASELINE configs[4]'s per-GPU geometry: 1328x1328 target (83 x 83 = 6889 noise tokens, odd) + the 1024x1024 edit image,
-    T = 512: S = 11497, 60 layers.  ~15 minutes of host oracle time: PE_PARITY_FULL=1 only; numbers in profiles/r03_parity.json."""
+    T = 512: S = 11497, 60 layers, against fixture G24 (the REFERENCE's `model_fn_qwen_image` on the same weights).  PE_PARITY_FULL=1
+    adds the host-oracle form with the fp32 pass (~15 minutes of CPU; numbers in profiles/r03_parity.json)."""
     import os
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    if os.environ.get("PE_PARITY_FULL") != "1":
-        pytest.skip("set PE_PARITY_FULL=1 (about 15 minutes of CPU oracle time)")
-    _depth_meets_length(1328, 512, 64, "60 layers, 1328x1328 + 1024x1024 edit (S = 11497), T 512, one model_fn call (first of 40 steps)",
-                        edit_hw=1024, config="configs[4]")
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G24_60_layers_configs4.safetensors")):
+        pytest.skip("fixture G24 not generated (tests/golden/make_golden.py G21 with PE_G21_PARTS=24)")
+    fx = golden("G24_60_layers_configs4")
+    got, special, _ = _forward60(1328, 1024, 512, 64, (5,))
+    case = "60 layers, 1328x1328 + 1024x1024 edit (S = 11497), T 512, one model_fn call (first of 40 steps) vs the REFERENCE (G24)"
+    st = record("configs[4]", f"{case} [{_NAMES[5]}]", got[5], fx["latents"])
+    assert torch.isfinite(got[5].float()).all()
+    assert st["mean_abs_diff"] <= 2e-3 and st["max_ulp"] <= 6.0, st
+    sp = parity_stats(special[5], fx["special_after"])
+    assert sp["max_ulp"] <= 4.0 and sp["frac_bit_identical"] >= 0.9, sp
+    if os.environ.get("PE_PARITY_FULL") == "1":
+        _depth_meets_length(1328, 512, 64, "60 layers, 1328x1328 + 1024x1024 edit (S = 11497), T 512, one model_fn call (first of 40 steps)",
+                            edit_hw=1024, config="configs[4]")
 
 
 def test_vae_decode_1024_vs_oracle():
