@@ -159,11 +159,11 @@ def time_shape(M, N, K, epi, configs, rounds=5, reps=12):
                 res[c].append(e0.elapsed_time(e1) / reps)
         print(f"{M}x{N}x{K} {epi} cold={cold}: " + "  ".join(
             f"v{c[0]}/b{c[1]}: {sorted(t)[len(t)//2]*1e3:.0f}us {fl/sorted(t)[len(t)//2]/1e9:.0f} TF (best {fl/min(t)/1e9:.0f})" for c, t in res.items()), flush=True)
-    knob("gemm_band", 8)
+    knob("gemm_band", 4)
 
 
 for (M, N, K, epi) in shapes:
-    time_shape(M, N, K, epi, [(v, 8) for v in variants])
+    time_shape(M, N, K, epi, [(v, 4) for v in variants])
 if bands:
     for (M, N, K, epi) in shapes:
         time_shape(M, N, K, epi, [(variants[-1], b) for b in bands], rounds=3)
