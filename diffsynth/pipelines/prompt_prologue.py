@@ -354,6 +354,7 @@ class GraphDecoder:
         for ly in self.layers:
             if ly.self_attn.o_proj.bias is not None or ly.mlp.down_proj.bias is not None or ly.mlp.gate_proj.bias is not None:
                 raise ValueError("GraphDecoder: unexpected biases in o_proj / the MLP")
+        self.split_attention = True  # pe_decode_step_attention_split (448 work-groups per launch) instead of the 28-work-group launch; same bits
         self._static = {}           # capacity bucket -> static planes, tables, counters and the captured decode step
         self.captures = 0           # graphs captured so far (tests: calls of one bucket share one)
 
@@ -382,7 +383,7 @@ class GraphDecoder:
             q = ops.decode_step_qkv(x, at.q_proj.weight, at.q_proj.bias, at.k_proj.weight, at.k_proj.bias, at.v_proj.weight,
                                     at.v_proj.bias, st["cos"], st["sin"], st["kc"][l], st["vc"][l], st["step"], st["base"],
                                     norm_w=ly.input_layernorm.weight, eps=float(ly.input_layernorm.variance_epsilon))
-            a = ops.decode_step_attention(q, st["kc"][l], st["vc"][l], st["step"], st["base"], float(at.scaling))
+            a = ops.decode_step_attention(q, st["kc"][l], st["vc"][l], st["step"], st["base"], float(at.scaling), workspace=st.get("attn_ws"))
             h1 = ops.gemv(a, at.o_proj.weight, None, res=x)
             hid = ops.gemv_swiglu_norm(h1, ly.post_attention_layernorm.weight, float(ly.post_attention_layernorm.variance_epsilon),
                                        mlp.gate_proj.weight, mlp.up_proj.weight)
@@ -429,6 +430,8 @@ class GraphDecoder:
                   "token": torch.zeros(1, dtype=torch.int32, device=dev), "step": torch.zeros(1, dtype=torch.int32, device=dev),
                   "out_ids": torch.zeros(bucket, dtype=torch.int32, device=dev), "graph": None, "weights": fp}
             st["vc"] = torch.zeros_like(st["kc"])
+            if self.split_attention:     # scratch of the three-launch single-query attention (layers run one after the other: one buffer)
+                st["attn_ws"] = self.ops.decode_attention_workspace(len(self.layers[0].self_attn.q_proj.weight) // 128, bucket, dev)
             st["sin"] = torch.zeros_like(st["cos"])
             self._static = {bucket: st}                    # one bucket alive at a time (28 KiB per row of capacity and plane pair)
         kc, vc = st["kc"], st["vc"]

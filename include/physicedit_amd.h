@@ -46,7 +46,9 @@ const char* pe_build_id(void);
  * "gemm_variant": 17 default (persistent work-groups with cross-tile prefetch; launches of at most one round of tiles run 15 --
  * "gemm_persist_min_rounds", default 1); 15 = one tile per work-group (the round-2 default; writes s_memtime stamps when "gemm_stamps"
  * is attached); 10 = the round-1 schedule (A/B reference); 19 = stream-K (bit-identical, needs a workspace: pe_gemm_workspace_bytes;
- * "gemm_sk" = 1 lets 17 take it where tiles do not fill whole rounds; measured slower, default off).  "gemm_band": M tiles per band of
+ * "gemm_sk" = 1 lets 17 take it where tiles do not fill whole rounds; measured slower, default off); 21 = 17 with one hand-off per K
+ * tile (32-MFMA slots; a tie); 22 = four waves x 128 x 128, one wave per SIMD, one tile per work-group (gemm4.hip; +2.5 % on the bare
+ * main loop, a tie to -6 % on the block's Linears: profiles/r05_gemm_notes.md).  All bit-identical.  "gemm_band": M tiles per band of
  * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of schedule 17's grid (0 = one per CU).
  * "attn_variant": 5 default (4 waves x 64 query rows, one wave per SIMD, lazy running max, the softmax scale folded into Q and the max
  * fed through the MFMA C operand: pe_attn_q_prescale / pe_flash_attn_prescaled; same distance to an fp32 result as the reference's own
@@ -239,6 +241,13 @@ int pe_gemv_swiglu_norm_bf16(const void* x, const void* norm_w, float eps, const
                              void* stream);
 int pe_decode_step_attention(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads,
                              const int* step, int base_len, int cache_len, float scale, void* stream);
+/* pe_decode_step_attention as three small launches over 16 x as many work-groups (scores + block maxima, softmax sums + P.V per wave of
+ * the one-launch form, combine): every sum keeps its grouping, the output is bit-identical.  workspace: fp32 scratch of
+ * pe_decode_attention_workspace_bytes(n_q_heads, cache_len) bytes, 16-byte aligned, private to the stream. */
+size_t pe_decode_attention_workspace_bytes(int n_q_heads, int cache_len);
+int pe_decode_step_attention_split(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads,
+                                   const int* step, int base_len, int cache_len, float scale, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 int pe_decode_embed(const void* table, const int* token, void* x, int dim, int vocab, void* stream);
 int pe_decode_argmax(const void* logits, int vocab, int* token, int* out_ids, int* step, int max_steps, void* stream);
 /* BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18): out = bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of

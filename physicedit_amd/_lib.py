@@ -141,6 +141,9 @@ SIGNATURES = {
     "pe_gemv_norm_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_gemv_swiglu_norm_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_decode_step_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "pe_decode_attention_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pe_decode_step_attention_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p,
+                                               c_size_t, c_void_p]),
     "pe_decode_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_decode_argmax": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pe_gemv_res_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

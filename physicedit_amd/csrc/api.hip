@@ -44,6 +44,8 @@ int pe_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
     if (!strcmp(key, "attn_fp8_variant")) { PE_REQUIRE(value >= 0 && value <= 2, "attn_fp8_variant: 0, 1 or 2"); g_attn_fp8_variant = value; return PE_OK; }
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return PE_OK; }
+    if (!strcmp(key, "gemm4_x")) { g_gemm4_x = value; return PE_OK; }
+    if (!strcmp(key, "gemm_skip_ragged")) { g_gemm_skip_ragged = value; return PE_OK; }
     if (!strcmp(key, "gemm_persist_min_rounds")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_persist_min_rounds out of range"); g_gemm_persist_min_rounds = value; return PE_OK; }
     if (!strcmp(key, "gemm_band")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_band out of range"); g_gemm_band = value; return PE_OK; }
     if (!strcmp(key, "gemm_persist_wgs")) { PE_REQUIRE(value >= 0 && value <= 1024, "gemm_persist_wgs out of range"); g_gemm_persist_wgs = value; return PE_OK; }
@@ -270,6 +272,15 @@ int pe_decode_step_attention(const void* q, const void* k_cache, const void* v_c
                              const int* step, int base_len, int cache_len, float scale, void* stream) {
     PE_REQUIRE(step, "pe_decode_step_attention: null step counter");
     return launch_attn_decode(q, k_cache, v_cache, out, n_q_heads, n_kv_heads, cache_len, scale, (hipStream_t)stream, step, base_len);
+}
+
+size_t pe_decode_attention_workspace_bytes(int n_q_heads, int cache_len) { return attn_decode_workspace_bytes(n_q_heads, cache_len); }
+
+int pe_decode_step_attention_split(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads,
+                                   const int* step, int base_len, int cache_len, float scale, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    return launch_attn_decode_split(q, k_cache, v_cache, out, n_q_heads, n_kv_heads, cache_len, scale, (hipStream_t)stream, step, base_len,
+                                    workspace, workspace_bytes);
 }
 
 int pe_decode_embed(const void* table, const int* token, void* x, int dim, int vocab, void* stream) {

@@ -703,6 +703,126 @@ int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out,
     return check_launch("attn_decode_kernel");
 }
 
+// ---- the same operator as THREE small launches over 448 + 448 + 28 work-groups instead of one over 28 (round 5; captured decode step).
+// The one-launch form is latency bound: 28 work-groups on 256 CUs, 17 us of a 110 us layer.  The split keeps every sum's grouping --
+// the output is bit-identical, so the greedy tokens are too:
+//   scores   (head, block b of 16): keys j = 64 b + g .. step 1024, the same 4-lane dot product per key; scores and the block's maximum
+//            go to the workspace (a maximum does not depend on its grouping)
+//   softmax + P.V (head, w of 16): ONE wave = wave w of the 16-wave work-group: its 64 lanes sum exp(s - m) over keys lane + 64 w + 1024 i
+//            exactly as slots t = 64 w + lane did, then the same butterfly; its four 16-lane groups accumulate P.V over keys
+//            4 w + (lane >> 4) + 64 i in the same order (P = bf16(exp(s - m)) recomputed per lane: same bits), the same two shuffles
+//   combine  (head): the 16 wave sums and the 16 x 128 partial outputs added in wave order, o / sum
+constexpr int DEC_SB = 16;      // score blocks per head = waves of the one-launch form
+__global__ void __launch_bounds__(256) attn_decode_scores_kernel(const bf16* __restrict__ q, const bf16* __restrict__ Kc, float* __restrict__ sc_g,
+                                                                 float* __restrict__ mx_g, int n_q, int n_kv, float scale,
+                                                                 const int* __restrict__ step, int base, int ld) {
+    __shared__ float red[4];
+    const int h = (int)blockIdx.x, b = (int)blockIdx.y, t = (int)threadIdx.x;
+    const int kvh = h / (n_q / n_kv);
+    const int L = min(base + *step + 1, ld);
+    const bf16* kb = Kc + (size_t)kvh * ld * 128;
+    float* sc = sc_g + (size_t)h * ld;
+    const int s4 = t & 3, g4 = t >> 2;
+    float qf[32];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bf16x8 t8 = *(const bf16x8*)(q + (size_t)h * 128 + s4 * 32 + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[c * 8 + j] = (float)t8[j];
+    }
+    float mx = -INFINITY;
+#pragma unroll 2
+    for (int j = b * 64 + g4; j < L; j += 64 * DEC_SB) {
+        const bf16* kr = kb + (size_t)j * 128 + s4 * 32;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bf16x8 k8 = *(const bf16x8*)(kr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qf[c * 8 + e], (float)k8[e], acc);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc *= scale;
+        if (s4 == 0) sc[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) mx_g[h * DEC_SB + b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ void __launch_bounds__(64) attn_decode_pv_kernel(const float* __restrict__ sc_g, const float* __restrict__ mx_g,
+                                                            const bf16* __restrict__ Vc, float* __restrict__ red_g, float* __restrict__ part_g,
+                                                            int n_q, int n_kv, const int* __restrict__ step, int base, int ld) {
+    const int h = (int)blockIdx.x, w = (int)blockIdx.y, lane = (int)threadIdx.x;
+    const int kvh = h / (n_q / n_kv);
+    const int L = min(base + *step + 1, ld);
+    const bf16* vb = Vc + (size_t)kvh * ld * 128;
+    const float* sc = sc_g + (size_t)h * ld;
+    float mx = mx_g[h * DEC_SB];
+#pragma unroll
+    for (int b = 1; b < DEC_SB; ++b) mx = fmaxf(mx, mx_g[h * DEC_SB + b]);
+    float sum = 0.f;
+    for (int j = w * 64 + lane; j < L; j += 64 * DEC_SB) sum += __expf(sc[j] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red_g[h * DEC_SB + w] = sum;
+    const int sub = lane & 15, grp = 4 * w + (lane >> 4);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int j = grp; j < L; j += 64) {
+        const bf16x8 v8 = *(const bf16x8*)(vb + (size_t)j * 128 + sub * 8);
+        const float p = bf16r(__expf(sc[j] - mx));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)v8[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part_g[((size_t)h * DEC_SB + w) * 128 + sub * 8 + e] = acc[e];
+    }
+}
+
+__global__ void __launch_bounds__(128) attn_decode_combine_kernel(const float* __restrict__ red_g, const float* __restrict__ part_g,
+                                                                 bf16* __restrict__ out) {
+    const int h = (int)blockIdx.x, t = (int)threadIdx.x;
+    float sum = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < DEC_SB; ++w) sum += red_g[h * DEC_SB + w];
+#pragma unroll
+    for (int w = 0; w < DEC_SB; ++w) o += part_g[((size_t)h * DEC_SB + w) * 128 + t];
+    out[(size_t)h * 128 + t] = (bf16)(o / sum);
+}
+
+size_t attn_decode_workspace_bytes(int n_q_heads, int cache_len) {
+    return ((size_t)n_q_heads * cache_len + (size_t)n_q_heads * DEC_SB * (2 + 128)) * sizeof(float);
+}
+
+int launch_attn_decode_split(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int cache_len,
+                             float scale, hipStream_t stream, const int* step, int base, void* workspace, size_t workspace_bytes) {
+    PE_REQUIRE(q && Kc && Vc && out && step && workspace, "attn_decode_split: null pointer");
+    PE_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && cache_len > 0 && cache_len <= 15360,
+               "attn_decode_split: bad shape (cache_len=%d)", cache_len);
+    PE_REQUIRE(base >= 0 && base < cache_len, "attn_decode_split: base=%d outside the cache of %d rows", base, cache_len);
+    PE_REQUIRE(workspace_bytes >= attn_decode_workspace_bytes(n_q_heads, cache_len) && ((uintptr_t)workspace & 15) == 0,
+               "attn_decode_split: workspace of %zu bytes, 16-byte aligned, needed", attn_decode_workspace_bytes(n_q_heads, cache_len));
+    float* sc_g = (float*)workspace;
+    float* mx_g = sc_g + (size_t)n_q_heads * cache_len;
+    float* red_g = mx_g + (size_t)n_q_heads * DEC_SB;
+    float* part_g = red_g + (size_t)n_q_heads * DEC_SB;
+    hipLaunchKernelGGL(attn_decode_scores_kernel, dim3(n_q_heads, DEC_SB), dim3(256), 0, stream, (const bf16*)q, (const bf16*)Kc, sc_g, mx_g,
+                       n_q_heads, n_kv_heads, scale, step, base, cache_len);
+    hipLaunchKernelGGL(attn_decode_pv_kernel, dim3(n_q_heads, DEC_SB), dim3(64), 0, stream, (const float*)sc_g, (const float*)mx_g,
+                       (const bf16*)Vc, red_g, part_g, n_q_heads, n_kv_heads, step, base, cache_len);
+    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(n_q_heads), dim3(128), 0, stream, (const float*)red_g, (const float*)part_g, (bf16*)out);
+    return check_launch("attn_decode_split");
+}
+
 // Training-loss head of the visual-thinking adapter (VisualThinkingDualAdapter.get_loss, pipelines/helpers.py:166-183), the part that
 // touches tensors: F.mse_loss(pred, gt, reduction='none').mean(dim=[1, 2]) for the two heads -- (pred - gt) rounded to bf16, its
 // square rounded to bf16, fp32 mean.  One work-group per head; out[head] = fp32 mean (the caller rounds it to bf16 as .mean() does).

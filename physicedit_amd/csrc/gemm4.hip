@@ -1,0 +1,241 @@
+// bf16 GEMM, schedule 22: four waves (one per SIMD) x 128 x 128 of a 256 x 256 x 64 block tile.  Shares launch arguments, tile order and the
+// fused epilogue with gemm.hip (gemm_tile.h); reached through launch_gemm() with pe_debug_set("gemm_variant", 22).
+#include "gemm_tile.h"
+
+namespace pe {
+
+// ------------------------------------------------------------------------------------------
+// Schedule 22 (round 5): FOUR waves, one per SIMD, each owning 128 x 128 of the 256 x 256 tile (4 x 4 MFMA blocks, 256 accumulator
+// registers in the AGPR half, fragments double buffered in the VGPR half).  Why: tools/microbench/gemm_probe_ladder.hip -- with two waves
+// per SIMD the fragment reads and LDS-DMA requests of one wave take issue slots from the other's MFMAs (free-running mix on zero
+// operands: 2486 -> 2083 TF/s), a single wave hides them inside its own MFMA shadows (2470 -> 2409), and a 128 x 128 wave tile needs
+// 0.5 instead of 0.75 ds_read_b128 per MFMA (N(0,1) operands, power-limited: ceiling 1531 vs 1429 TF/s).  The wave is its own
+// software pipeline: k-step ks of K tile kt issues 16 MFMAs on fragment set ks & 1 while the 8 fragments of the next k-step load
+// into the other set and 4 LDS-DMA pieces are requested; ONE barrier per K tile, between k-steps 2 and 3:
+//     ks0  MFMA set0 | read k-step 1        | W(kt+3) pieces 0-3 -> W[kt % 3] ... see below
+//     ks1  MFMA set1 | read k-step 2        | W(kt+2) pieces 4-7
+//     ks2  MFMA set0 | read k-step 3        | -
+//     vmcnt: this wave's pieces of A(kt+1), W(kt+1) landed; lgkmcnt(0): its reads of A(kt), W(kt) done;  s_barrier
+//     ks3  MFMA set1 | read k-step 0 of kt+1| A(kt+2) pieces 0-7 -> A[kt & 1] (free: every wave is past its reads of K tile kt)
+// and W(kt+2) pieces 0-3 ride in ks0, 4-7 in ks1 of tile kt (slot (kt+2) % 3 held K tile kt-1, dead since barrier kt-1).
+// Same K order per output element as every other schedule: bit-identical.
+// ------------------------------------------------------------------------------------------
+template <int EPI, bool FP8, int X = 0>      // X: timing experiments only (1 no barrier, 2 no vmcnt wait: racy)
+__device__ __forceinline__ void gemm4_tile(const KARG GemmArgs& args, char* smem, int bid) {
+    constexpr int ES = FP8 ? 1 : 2;
+    constexpr int KT_BYTES = 128;
+    constexpr int KS = FP8 ? 2 : 4;            // MFMA k-steps per K tile (e4m3: 64 elements = 64 B of a row per k-step)
+    constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
+    using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const TileCoord tc0 = decode_tile(args, bid);
+    const KARG GemmProblem& P = args.p[tc0.pi];
+    const int M = P.M, N = P.N, K = P.K;
+    const int m0 = tc0.m0, n0 = tc0.n0;
+    const int nk = K * ES / KT_BYTES;
+    // staging: wave w moves pieces 8w .. 8w + 7 (1 KiB = 8 rows x 128 B) of A and of W
+    const char* a_src[8];
+    const char* w_src[8];
+    {
+        const int rin = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (w * 8 + i) * 8 + rin;
+            const int gr = min(m0 + row, M - 1), gn = min(n0 + row, N - 1);
+            a_src[i] = (const char*)P.A + (size_t)gr * P.lda * ES + (slot ^ ((row >> 1) & 7)) * 16;
+            w_src[i] = (const char*)P.W + (size_t)gn * K * ES + (slot ^ ((row >> 1) & 7)) * 16;
+        }
+    }
+    char* const a_base = smem;
+    char* const w_base = smem + 2 * A_BYTES;
+    auto st_a = [&](int t, int first, int count) __attribute__((always_inline)) {
+        const long long off = (long long)min(t, nk - 1) * KT_BYTES;
+        char* base = a_base + (t & 1) * A_BYTES + w * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i >= first && i < first + count) glds16(a_src[i] + off, base + i * 1024);
+    };
+    auto st_w = [&](int t, int slot, int first, int count) __attribute__((always_inline)) {
+        const long long off = (long long)min(t, nk - 1) * KT_BYTES;
+        char* base = w_base + slot * W_BYTES + w * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i >= first && i < first + count) glds16(w_src[i] + off, base + i * 1024);
+    };
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int sw = (l31 >> 1) & 7;
+    const int a_off = (wm * 128 + l31) * 128, w_off = (wn * 128 + l31) * 128;
+    FragT fa[2][4], fw[2][4];
+    auto frag = [&](const char* rowp, int ks) __attribute__((always_inline)) -> FragT {
+        if constexpr (FP8) {
+            const int c0 = 4 * ks + 2 * h;
+            const i32x4 lo = *(const i32x4*)(rowp + ((c0 ^ sw) << 4));
+            const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            return *(const bf16x8*)(rowp + (((ks * 2 + h) ^ sw) << 4));
+        }
+    };
+    auto rd = [&](const char* Sa, const char* Sw, int ks, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[set][i] = frag(Sa + a_off + i * 4096, ks);
+            fw[set][i] = frag(Sw + w_off + i * 4096, ks);
+        }
+    };
+    auto mma = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                if constexpr (FP8)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[set][ni], fa[set][mi], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                else
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][ni], fa[set][mi], acc[mi][ni], 0, 0, 0);
+            }
+    };
+#define PE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    // interleave of one k-step of 16 MFMAs: ND ds_read_b128 per MFMA for the first 8 (bf16: 1, e4m3: 2), then NV x (MFMA, LDS-DMA piece),
+    // then the remaining MFMAs
+#define PE_KSTEP_SCHED(NV)                                                                 \
+    do {                                                                                   \
+        for (int i_ = 0; i_ < 8; ++i_) { PE_SGB(0x008, 1); PE_SGB(0x100, FP8 ? 2 : 1); }  \
+        for (int i_ = 0; i_ < (NV); ++i_) { PE_SGB(0x008, 1); PE_SGB(0x020, 1); }          \
+        PE_SGB(0x008, 8 - (NV));                                                           \
+    } while (0)
+#define PE_TILE_BARRIER()                                                                                                  \
+    do {                                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if constexpr (X & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); /* all but W(kt+2): A(kt+1), W(kt+1) landed */   \
+        if constexpr (!(X & 1)) __builtin_amdgcn_s_barrier();                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+    // prologue: A(0), W(0) | A(1), W(1) | (W(2) rides in tile 0)
+    st_a(0, 0, 8); st_w(0, 0, 0, 8);
+    st_a(1, 0, 8); st_w(1, 1, 0, 8);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // A(0), W(0) landed
+    __syncthreads();
+    rd(a_base, w_base, 0, 0);
+    int ws = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* Sa = a_base + (kt & 1) * A_BYTES;
+        const char* San = a_base + ((kt + 1) & 1) * A_BYTES;
+        const int ws1 = ws == 2 ? 0 : ws + 1, ws2 = ws1 == 2 ? 0 : ws1 + 1;
+        const char* Sw = w_base + ws * W_BYTES;
+        const char* Swn = w_base + ws1 * W_BYTES;
+        if constexpr (FP8) {
+            // ks0
+            rd(Sa, Sw, 1, 1);
+            st_w(kt + 2, ws2, 0, 8);
+            mma(0);
+            PE_KSTEP_SCHED(8);
+            PE_TILE_BARRIER();
+            // ks1
+            rd(San, Swn, 0, 0);
+            st_a(kt + 2, 0, 8);
+            mma(1);
+            PE_KSTEP_SCHED(8);
+        } else {
+            // ks0
+            rd(Sa, Sw, 1, 1);
+            st_w(kt + 2, ws2, 0, 4);
+            mma(0);
+            PE_KSTEP_SCHED(4);
+            // ks1
+            rd(Sa, Sw, 2, 0);
+            st_w(kt + 2, ws2, 4, 4);
+            mma(1);
+            PE_KSTEP_SCHED(4);
+            // ks2
+            rd(Sa, Sw, 3, 1);
+            mma(0);
+            PE_KSTEP_SCHED(0);
+            PE_TILE_BARRIER();
+            // ks3
+            rd(San, Swn, 0, 0);
+            st_a(kt + 2, 0, 8);
+            mma(1);
+            PE_KSTEP_SCHED(8);
+        }
+        ws = ws1;
+    }
+#undef PE_TILE_BARRIER
+#undef PE_KSTEP_SCHED
+#undef PE_SGB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // epilogue: the wave's 128 x 128 block as two 64 x 128 blocks of "virtual" waves (2 wm + half) * 2 + wn of the 8-wave layout
+    char* E = smem + w * 32768;
+    gemm_epilogue<EPI, FP8, false, 4, 0>(P, M, N, acc, m0, n0, E, E + 8192, lane, (wm * 2 + 0) * 2 + wn, nullptr);
+    gemm_epilogue<EPI, FP8, false, 4, 2>(P, M, N, acc, m0, n0, E + 16384, E + 24576, lane, (wm * 2 + 1) * 2 + wn, nullptr);
+}
+
+template <int EPI, bool FP8, int X = 0>
+__global__ void __launch_bounds__(256, 1) gemm4_kernel(const GemmArgs args_by_value) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KARG GemmArgs& args = *(const KARG GemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    gemm4_tile<EPI, FP8, X>(args, smem, xcd_remap((int)blockIdx.x, (int)gridDim.x));
+}
+int g_gemm4_x = 0;
+
+template <int EPI, bool FP8>
+static int launch4(const GemmArgs& args, int grid, hipStream_t stream) {
+    static std::atomic<bool> configured{false};
+    if (!configured.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm4_kernel<EPI, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured.store(true, std::memory_order_release);
+    }
+    if constexpr (EPI == EPI_BIAS && !FP8) {
+        if (g_gemm4_x != 0) {
+            static bool cfgx = false;
+            if (!cfgx) {
+                (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI, FP8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI, FP8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI, FP8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                cfgx = true;
+            }
+            if (g_gemm4_x == 1) hipLaunchKernelGGL((gemm4_kernel<EPI, FP8, 1>), dim3(grid), dim3(256), GEMM_LDS, stream, args);
+            else if (g_gemm4_x == 2) hipLaunchKernelGGL((gemm4_kernel<EPI, FP8, 2>), dim3(grid), dim3(256), GEMM_LDS, stream, args);
+            else hipLaunchKernelGGL((gemm4_kernel<EPI, FP8, 3>), dim3(grid), dim3(256), GEMM_LDS, stream, args);
+            return check_launch("gemm4_kernel");
+        }
+    }
+    hipLaunchKernelGGL((gemm4_kernel<EPI, FP8>), dim3(grid), dim3(256), GEMM_LDS, stream, args);
+    return check_launch("gemm4_kernel");
+}
+
+int launch_gemm4(int epilogue, bool fp8, const GemmArgs& args, int grid, hipStream_t stream) {
+    if (fp8) {
+        switch (epilogue) {
+            case EPI_BIAS: return launch4<EPI_BIAS, true>(args, grid, stream);
+            case EPI_GELU_SIG: return launch4<EPI_GELU_SIG, true>(args, grid, stream);
+            case EPI_GELU_ERF: return launch4<EPI_GELU_ERF, true>(args, grid, stream);
+            case EPI_GATE_RES: return launch4<EPI_GATE_RES, true>(args, grid, stream);
+            case EPI_QKV: return launch4<EPI_QKV, true>(args, grid, stream);
+            case EPI_SILU: return launch4<EPI_SILU, true>(args, grid, stream);
+        }
+        return set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
+    }
+    switch (epilogue) {
+        case EPI_BIAS: return launch4<EPI_BIAS, false>(args, grid, stream);
+        case EPI_GELU_SIG: return launch4<EPI_GELU_SIG, false>(args, grid, stream);
+        case EPI_GELU_ERF: return launch4<EPI_GELU_ERF, false>(args, grid, stream);
+        case EPI_GATE_RES: return launch4<EPI_GATE_RES, false>(args, grid, stream);
+        case EPI_QKV: return launch4<EPI_QKV, false>(args, grid, stream);
+        case EPI_SILU: return launch4<EPI_SILU, false>(args, grid, stream);
+    }
+    return set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
+}
+
+}  // namespace pe

@@ -1,0 +1,482 @@
+// Shared pieces of the bf16 / e4m3 GEMM kernels (gemm.hip: the 8-wave schedules, gemm4.hip: the 4-wave schedule 22): launch arguments,
+// tile order, and the fused epilogue of one 64 x 128 wave block.  Device code only; included by those two translation units.
+#pragma once
+#include <stdlib.h>
+
+#include <atomic>
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace pe {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int GEMM_THREADS = 512;
+constexpr int GEMM_LDS = 5 * 32768;   // A x2 + W x3 = 160 KiB (all of a CU's LDS)
+constexpr int GEMM_DEFAULT_BAND = 4;      // M tiles per band: 8 until round 4; in the two-stream pipeline 4 is 0.45 - 0.6 % faster per image (profiles/r04_gemm_notes.md section 5)
+constexpr int GEMM_DEFAULT_VARIANT = 17;  // see the VAR list below
+
+struct GemmArgs {
+    GemmProblem p[2];
+    int tiles0;       // tiles of problem 0 (tile ids >= tiles0 belong to problem 1)
+    int ntiles;       // all tiles of the launch (schedule 17: the grid is smaller)
+    int band;         // M tiles per band of the tile order
+    int skip_ragged;  // 1: row blocks beyond M skip their MFMAs (A/B knob "gemm_skip_ragged", default 1)
+    long long* dbg;   // per work-group s_memtime stamps [grid][8] of schedule 15 (pe_debug_set_ptr("gemm_stamps", p)), or null
+    unsigned* sk_sync;   // schedule 19: [0] arrivals, [1 + c] position counter of chunk c, [SK_FLAG0 + pos] flag of the seam behind position pos; zero at rest
+    char* sk_part;       // schedule 19: fp32 accumulator images, SK_PART_BYTES per seam
+};
+constexpr int SK_FLAG0 = 32;                          // flags start on their own 128-byte line
+constexpr size_t SK_PART_BYTES = (size_t)BM * BN * 4;   // one 256 x 256 fp32 accumulator tile
+extern long long* g_gemm_dbg;
+struct GemmArgs;
+int launch_gemm4(int epilogue, bool fp8, const GemmArgs& args, int grid, hipStream_t stream);      // gemm4.hip
+// Device code reads the launch arguments where the dispatcher put them: the kernarg segment (constant address space, scalar
+// loads at a wave-uniform problem index).  Through a by-value copy `args.p[pi]` with a run-time pi is an indexed private array:
+// the compiler parks fields in scratch.
+#define KARG __attribute__((address_space(4)))
+
+#define PE_STAMP(k)                                                                                     \
+    do {                                                                                                \
+        if constexpr (VAR == 15) {                                                                      \
+            if (args.dbg != nullptr && threadIdx.x == 0) args.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); \
+        }                                                                                               \
+    } while (0)
+
+PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+// VAR selects the main-loop schedule (A/B-tested in one process through pe_debug_set("gemm_variant"); the studies,
+// incl. the variants that no longer live here, are profiles/r01_gemm_ablation.md, r02_gemm_notes.md, r03_gemm_notes.md):
+//   10  (round-1 default, kept as the A/B reference) pipelined clusters: fragments double buffered in registers, tile barrier
+//       before the LAST cluster, staging spread over the clusters, MFMA / ds_read / LDS-DMA interleave pinned with
+//       sched_group_barrier, three-deep W ring and counted vmcnt
+//   15  (round-2 default) "ping-pong": the two wave groups run the same stream one barrier apart, 2 phases x 16 MFMAs per
+//       K tile, A half tiles staged by the group that reads them; one tile per work-group
+//   17  (default) 15's main loop in persistent work-groups with cross-tile prefetch (gemm_persistent below); launches of
+//       fewer than three rounds of tiles run 15
+//
+// FP8 = true: operands are OCP e4m3 bytes (activation rows quantised by quantize_rows_e4m3, weights stored in e4m3),
+// the K tile is 128 elements (the SAME 128-B LDS rows, staging and swizzle), the MFMA is the CDNA4 block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the bf16 rate), and the epilogue starts with
+// y = bf16(acc * scale_a[m] + bias[n])  (AutoWrappedLinear.fp8_linear, vram_management/layers.py:115-151).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+struct TileCoord {
+    int pi, m0, n0;
+};
+// tile id in the banded order -> problem and tile origin.  Band = `band` M tiles x all N tiles, N-major inside a band, so a
+// run of consecutive ids (what one XCD's 32 CUs work on at a time) covers band x (32 / band) tiles.
+PE_DEV TileCoord decode_tile(const KARG GemmArgs& args, int bid) {
+    TileCoord c;
+    c.pi = bid >= args.tiles0 ? 1 : 0;
+    const KARG GemmProblem& P = args.p[c.pi];
+    bid -= c.pi ? args.tiles0 : 0;
+    const int tilesM = P.tilesM, tilesN = P.tilesN;
+    const int per_band = args.band * tilesN;
+    const int band = bid / per_band;
+    const int rem = bid - band * per_band;
+    const int gm = min(args.band, tilesM - band * args.band);
+    const int tn = rem / gm;
+    const int tm = band * args.band + (rem - tn * gm);
+    c.m0 = tm * BM;
+    c.n0 = tn * BN;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// epilogue of one 256x256 tile.  acc[mi][ni][4q+r] = C[m0 + wm*64 + mi*32 + l31][n0 + wn*128 + ni*32 + 8q + 4h + r]
+// The wave's 64 x 128 bf16 block goes through LDS as two 32-row halves (mi = 0, 1) of 8 KiB at E0 / E1: 16-B chunk c of row
+// r sits at chunk c ^ (r & 15), and its two 8-B halves are swapped when r & 8 (rows r and r ^ 8 would otherwise land on the
+// same banks in one ds_write_b64 lane group).  A wave reads back only what it wrote, and one wave's LDS accesses execute in
+// order: no barrier.  TWO_PASS (schedule 17, E0 == E1): stage half 0, emit it, stage half 1, emit it.
+//
+// FAST (the tile lies inside M x N and the problem has no hot-LoRA `pre` operand: every tile of the DiT's Linears but the ragged
+// text-stream one): no bounds checks, no per-chunk branches.  The general form costs ~100 exec-mask branches and their scalar
+// chains per wave and tile -- the epilogue is VALU / issue bound (profiles/r03_gemm_notes.md section 6).
+// ------------------------------------------------------------------------------------------
+PE_DEV f32x2 up2(uint32_t p) { return f32x2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)}; }   // two packed bf16 -> fp32
+PE_DEV uint32_t pk2(f32x2 v) {                                                                                // v_cvt_pk_bf16_f32
+    const bf16x2 b = {(bf16)v.x, (bf16)v.y};
+    return __builtin_bit_cast(uint32_t, b);
+}
+PE_DEV f32x2 rnd2(f32x2 v) { return up2(pk2(v)); }      // bf16r of a pair: one convert for two values
+// sum over the 16 lanes of a DPP row, result in every lane; the xor-butterfly order (1, 2, 4, 8) with DPP operands instead of
+// ds_bpermute: after the two quad steps a quad's lanes agree, so the half-mirror (lane 7 - l) and mirror (15 - l) partners hold
+// what lanes l ^ 4 and l ^ 8 hold -- same bits as the __shfl_xor form, no LDS round trips, no lane-id register
+PE_DEV float row16_sum(float v) {
+    const auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
+template <int EPI, bool FP8, bool TWO_PASS, bool FAST, int NMI = 2, int MI0 = 0>
+__device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, const int M, const int N, const f32x16 (&acc)[NMI][4], int m0, int n0,
+                                                   char* E0, char* E1, int lane, int w, long long* stamp4) {
+    // NMI / MI0: the accumulator array holds NMI 32-row blocks, this call emits blocks MI0, MI0 + 1 as the 64 x 128 block of (virtual)
+    // wave `w` (the 4-wave kernel's 128 x 128 wave tile is two such calls)
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    auto unswap = [](bf16x8 v, int row) -> bf16x8 {
+        return (row & 8) ? __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3) : v;
+    };
+    const int nw0 = n0 + wn * 128;
+    const int mw0 = m0 + wm * 64;
+    bf16x8 rv16[EPI == EPI_GATE_RES ? 16 : 1];   // residual rows of the gated-residual epilogue, prefetched
+    const bf16* bias = (const bf16*)P.bias;
+    const bf16* pre = (const bf16*)P.pre;   // hot LoRA: `out + x @ A.T @ B.T` (vram_management/layers.py:179-180)
+    float sa[2] = {1.f, 1.f};               // FP8: per-row activation scale (fp8_linear's scale_a)
+    if constexpr (FP8) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[FAST ? mw0 + mi * 32 + l31 : min(mw0 + mi * 32 + l31, M - 1)];
+    }
+    // bias first, then (EPI_GATE_RES) all 16 residual rows of this lane: 16-B loads that stay in flight under the LDS
+    // staging below (issued 4 at a time inside the store loop they cost 15-21k cycles of exposed latency)
+    bf16x4 bvs[16];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bvs[i] = bf16x4{0, 0, 0, 0};
+        if (bias != nullptr) {      // one wave-uniform branch for the 16 loads
+            const bf16* bl = bias + nw0 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bvs[i] = *(const bf16x4*)(bl + (i >> 2) * 32 + 8 * (i & 3));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = nw0 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h;
+            bvs[i] = bf16x4{0, 0, 0, 0};
+            if (bias != nullptr && n < N) bvs[i] = *(const bf16x4*)(bias + n);
+        }
+    }
+    if constexpr (EPI == EPI_GATE_RES) {
+        const int n = nw0 + (lane & 15) * 8;
+        if constexpr (FAST) {
+            const bf16* rl = (const bf16*)P.res + (size_t)(mw0 + (lane >> 4)) * P.ldr + n;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) rv16[it] = *(const bf16x8*)(rl + (size_t)(it * 4) * P.ldr);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int m = mw0 + it * 4 + (lane >> 4);
+                rv16[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < M && n < N) rv16[it] = *(const bf16x8*)((const bf16*)P.res + (size_t)m * P.ldr + n);
+            }
+        }
+    }
+    // gate vector / q-k norm weight of this lane's 8 columns: loaded BEFORE any store (vmcnt retires in order: a load issued
+    // behind the first half's stores could only be consumed after they have drained)
+    bf16x8 gate_v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EPI == EPI_GATE_RES) {
+        const int n = nw0 + (lane & 15) * 8;
+        if (P.gate != nullptr && (FAST || n < N)) gate_v = *(const bf16x8*)((const bf16*)P.gate + n);
+    }
+    // y = bf16(acc + bias) (+ pre) of the lane's four columns 8q + 4h .. + 3 of block ni, row half mi
+    auto y_chunk = [&](int mi, int ni, int q) __attribute__((always_inline)) -> bf16x4 {
+        const int n = nw0 + ni * 32 + 8 * q + 4 * h;
+        float b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = (float)bvs[ni * 4 + q][r];
+        bf16x4 y;
+        if constexpr (FP8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[MI0 + mi][ni][4 * q + r] * sa[mi] + b[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[MI0 + mi][ni][4 * q + r] + b[r]);
+        }
+        const int row = mi * 32 + l31;
+        if (!FAST && pre != nullptr && n < N && mw0 + row < M) {
+            // y = pre + y : the linear's own (already rounded) output plus this low-rank product
+            const bf16x4 pv = *(const bf16x4*)(pre + (size_t)(mw0 + row) * P.ldp + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (bf16)((float)pv[r] + (float)y[r]);
+        }
+        return y;
+    };
+    // PACK_FIRST (schedule 17's two-pass form on full tiles): both halves are rounded and packed before anything is staged --
+    // 64 registers of bf16 pairs instead of 128 accumulators + 32 of bias live while the first half is emitted, which is what
+    // lets the second half's operands (RoPE tables, residual rows) be requested BEFORE the first half's stores
+    constexpr bool PACK_FIRST = TWO_PASS && FAST;
+    bf16x4 ypk[PACK_FIRST ? 2 : 1][PACK_FIRST ? 16 : 1];
+    if constexpr (PACK_FIRST) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) ypk[mi][ni * 4 + q] = y_chunk(mi, ni, q);
+    }
+    // the row halves [mi_lo, mi_hi) -> LDS
+    auto stage_rows = [&](int mi_lo, int mi_hi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    if (mi < mi_lo || mi >= mi_hi) continue;
+                    const int c = ni * 4 + q;
+                    bf16x4 y;
+                    if constexpr (PACK_FIRST) y = ypk[mi][c];
+                    else y = y_chunk(mi, ni, q);
+                    char* Eb = mi == 0 ? E0 : E1;
+                    *(bf16x4*)(Eb + l31 * 256 + ((c ^ (l31 & 15)) << 4) + ((h ^ ((l31 >> 3) & 1)) << 3)) = y;
+                }
+            }
+    };
+
+    // the lane's 8 rows of the staged half `mi` (one 16-B chunk = 8 consecutive columns of each)
+    auto load_rows = [&](int mi, bf16x8 (&rows)[8]) __attribute__((always_inline)) {
+        const char* Eb = mi == 0 ? E0 : E1;
+        const int c = lane & 15;
+#pragma unroll
+        for (int j8 = 0; j8 < 8; ++j8) {
+            const int lrow = j8 * 4 + (lane >> 4);
+            rows[j8] = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
+        }
+    };
+    // read the staged half `mi` back row-wise (held_tag false) or take the rows load_rows fetched earlier (true), apply the
+    // epilogue proper, store
+    auto emit_rows = [&](int mi, auto held_tag, const bf16x8 (&held)[8]) __attribute__((always_inline)) {
+        constexpr bool HELD = decltype(held_tag)::value;
+        const char* Eb = mi == 0 ? E0 : E1;
+        if constexpr (EPI == EPI_QKV) {
+            const int HD = N / 3;
+            const int section = nw0 / HD;  // wave-uniform: the wave's 128 columns are exactly one head
+            const int head = (nw0 - section * HD) >> 7;
+            const int S_pad = P.S_pad;
+            if (section < 2) {
+                const bf16* nw = (const bf16*)(section == 0 ? P.norm_q_w : P.norm_k_w);
+                bf16* dst = (bf16*)(section == 0 ? P.q_out : P.k_out);
+                const int c = lane & 15;
+                const bf16x8 wv = *(const bf16x8*)(nw + c * 8);
+                // Q may carry the attention's scale . log2(e) (attention variants 5 / 6): multiplied in fp32 before the one rounding
+                const float qs1 = (section == 0 && P.q_scale != 0.f) ? P.q_scale : 1.0f;
+                const f32x2 qs = f32x2{qs1, qs1};
+                // RoPE operands of the lane's 8 rows, loaded UNCONDITIONALLY (row clamped) and before the first store of this half:
+                // vmcnt retires in order, so a load issued behind a store is only usable once that store has drained -- with the
+                // loads inside the per-row `if (m < M)` every group of rows paid a store round trip (s_memtime stamps: 17k ticks
+                // for this epilogue in steady state against 9.5k for the GELU one)
+                f32x4 cs8[8], sn8[8];
+#pragma unroll
+                for (int j8 = 0; j8 < 8; ++j8) {
+                    const int mr = mw0 + mi * 32 + j8 * 4 + (lane >> 4);
+                    const int mc = FAST ? mr : min(mr, M - 1);
+                    cs8[j8] = *(const f32x4*)(P.rope_cos + (size_t)mc * 64 + c * 4);
+                    sn8[j8] = *(const f32x4*)(P.rope_sin + (size_t)mc * 64 + c * 4);
+                }
+#pragma unroll
+                for (int j8 = 0; j8 < 8; ++j8) {
+                    const int lrow = j8 * 4 + (lane >> 4);
+                    const int m = mw0 + mi * 32 + lrow;
+                    bf16x8 v;
+                    if constexpr (HELD) v = held[j8];
+                    else v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
+                    // pairs of columns as f32x2 (packed fp32 maths, one bf16 convert per pair); the operations and their order are
+                    // those of the scalar form this replaces: squares summed left to right, every op rounded where the reference rounds
+                    const u32x4 vp = __builtin_bit_cast(u32x4, v);
+                    const u32x4 wp = __builtin_bit_cast(u32x4, wv);
+                    f32x2 y2[4];
+                    float ss = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        y2[jj] = up2(vp[jj]);
+                        const f32x2 sq = y2[jj] * y2[jj];
+                        ss += sq.x;
+                        ss += sq.y;
+                    }
+                    ss = row16_sum(ss);
+                    // RMSNorm(128, eps 1e-6): models/utils.py:250-257
+                    const float rs = __builtin_amdgcn_rsqf(ss * (1.0f / 128.0f) + 1e-6f);   // v_rsq_f32: the argument is a normal number >= 1e-6
+                    if (FAST || m < M) {
+                        const f32x4 cs = cs8[j8], sn = sn8[j8];
+                        u32x4 o;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const f32x2 x = rnd2(rnd2(y2[jj] * f32x2{rs, rs}) * up2(wp[jj]));
+                            // apply_rotary_emb_qwen: fp32 complex multiply (qwen_image_dit.py:51-57)
+                            const f32x2 a = x * f32x2{cs[jj], cs[jj]};
+                            const f32x2 b = f32x2{x.y, x.x} * f32x2{sn[jj], sn[jj]};
+                            o[jj] = pk2(f32x2{a.x - b.x, a.y + b.y} * qs);
+                        }
+                        *(u32x4*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
+                    }
+                }
+            } else {
+                // V: written TRANSPOSED, Vt[head][d][pos(token)], tokens permuted inside aligned 16-groups
+                // (pos = perm16) so the attention kernel's P.V MFMA needs no cross-lane shuffle.
+                bf16* vt = (bf16*)P.vt_out + (size_t)head * 128 * S_pad;
+                const int seq0 = P.seq_off + mw0;
+                const int valid = FAST ? 64 : min(64, M - mw0);
+                if ((seq0 & 15) == 0) {
+                    // this half holds the 16-token groups 2 mi and 2 mi + 1 of the wave's 64 tokens: 128 d x 2 groups x 2 halves
+#pragma unroll 2
+                    for (int it = 0; it < 8; ++it) {
+                        const int id = it * 64 + lane;
+                        const int d = id >> 2, tg = id & 3;
+                        const int gl = tg >> 1, hh = tg & 1;       // group inside this half, 8-token half of the group
+                        const int gi = mi * 2 + gl;
+                        unsigned short e[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int lrow = gl * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
+                            e[j] = *(const unsigned short*)(Eb + lrow * 256 + (((d >> 3) ^ (lrow & 15)) << 4) + ((((d & 7) * 2) ^ (lrow & 8))));
+                        }
+                        bf16* dstp = vt + (size_t)d * S_pad + seq0 + gi * 16 + hh * 8;
+                        if (FAST || gi * 16 + 16 <= valid) {
+                            u32x4 pk;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pk[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+                            *(u32x4*)dstp = pk;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int tok = gi * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
+                                if (tok < valid) ((unsigned short*)dstp)[j] = e[j];
+                            }
+                        }
+                    }
+                } else {
+                    // unaligned joint offset (text stream behind an odd-sized image stream): element-wise, lane = token
+                    const int s = seq0 + lane;
+                    const int pos = (s & ~15) | perm16(s & 15);
+                    const int lrow = lane & 31;
+                    if (lane < valid && (lane >> 5) == mi) {
+                        for (int d = 0; d < 128; ++d) {
+                            const unsigned short e =
+                                *(const unsigned short*)(Eb + lrow * 256 + (((d >> 3) ^ (lrow & 15)) << 4) + (((d & 7) * 2) ^ (lrow & 8)));
+                            ((unsigned short*)vt)[(size_t)d * S_pad + pos] = e;
+                        }
+                    }
+                }
+            }
+        } else {
+            const int c = lane & 15;
+            const int n = nw0 + c * 8;
+            bf16* out = (bf16*)P.out;
+            float g[8];
+            if constexpr (EPI == EPI_GATE_RES) {
+                const float gs = P.has_gate_scalar ? P.gate_scalar : 1.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = gs;
+                if (P.gate != nullptr && n < N) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = (float)gate_v[j];
+                }
+            }
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) {
+                const int lrow = j8 * 4 + (lane >> 4);
+                const int m = mw0 + mi * 32 + lrow;
+                if (!FAST && (m >= M || n >= N)) continue;
+                bf16x8 v;
+                if constexpr (HELD) v = held[j8];
+                else v = unswap(*(const bf16x8*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4)), j8 << 2);   // lrow & 8 == (j8 << 2) & 8
+                bf16x8 o;
+                if constexpr (EPI == EPI_BIAS) {
+                    o = v;
+                } else if constexpr (EPI == EPI_GELU_SIG) {
+                    // x * sigmoid(1.702 x) with the reference's three bf16 roundings (qwen_image_dit.py:44-49), two columns at a time:
+                    // packed fp32 multiplies / adds, one bf16 convert per pair and rounding; exp(-t) = v_exp_f32(-t log2 e) as
+                    // __expf evaluates it, v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide
+                    const u32x4 vp = __builtin_bit_cast(u32x4, v);
+                    u32x4 op;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x2 y = up2(vp[jj]);
+                        const f32x2 t = rnd2(f32x2{1.702f, 1.702f} * y);
+                        const f32x2 a = t * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + f32x2{1.0f, 1.0f};
+                        const f32x2 sg = rnd2(f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)});
+                        op[jj] = pk2(y * sg);
+                    }
+                    o = __builtin_bit_cast(bf16x8, op);
+                    if constexpr (FP8) {
+                        if (P.q8_out != nullptr) {
+                            // the next Linear's e4m3 operand (fp8_linear's row quantisation with scale 1, GemmProblem.q8_out)
+                            float f[8];
+                            float amax = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                f[j] = (float)o[j];
+                                amax = fmaxf(amax, fabsf(f[j]));
+                            }
+                            u32x2 pk;
+                            pk[0] = pack4_e4m3(f[0], f[1], f[2], f[3]);
+                            pk[1] = pack4_e4m3(f[4], f[5], f[6], f[7]);
+                            *(u32x2*)((uint8_t*)P.q8_out + (size_t)m * P.ldq8 + n) = pk;
+                            if (amax > 447.0f) atomicOr(P.q8_flags + m, 1u);      // rare: the row needs a scale above 1
+                        }
+                    }
+                } else if constexpr (EPI == EPI_GELU_ERF) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = (float)v[j];
+                        o[j] = (bf16)(0.5f * y * (1.0f + erff(y * 0.70710678118654752440f)));
+                    }
+                } else if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = (float)v[j];
+                        o[j] = (bf16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
+                    }
+                } else if constexpr (EPI == EPI_GATE_RES) {
+                    const u32x4 rp = __builtin_bit_cast(u32x4, rv16[mi * 8 + j8]);
+                    const u32x4 vp = __builtin_bit_cast(u32x4, v);
+                    u32x4 op;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) op[jj] = pk2(up2(rp[jj]) + rnd2(f32x2{g[2 * jj], g[2 * jj + 1]} * up2(vp[jj])));
+                    o = __builtin_bit_cast(bf16x8, op);
+                }
+                *(bf16x8*)(out + (size_t)m * P.ldo + n) = o;
+            }
+        }
+    };
+
+    bf16x8 rows[8];
+    if constexpr (TWO_PASS) {
+        // One 8 KiB region for both halves.  A wave's LDS operations execute in order, so half 1 may be staged as soon as the
+        // READS of half 0 have been issued: its 32 ds_write_b64 then run under the epilogue maths and stores of half 0 instead of
+        // behind them.
+        // Not for the gated-residual and QKV epilogues: with their 16 prefetched residual rows / RoPE operands the held rows
+        // push the kernel over the 256-register budget (19-31 spilled registers measured).
+        constexpr bool EARLY_STAGE = EPI != EPI_GATE_RES && EPI != EPI_QKV;
+        if constexpr (EARLY_STAGE) {
+            stage_rows(0, 1);
+            load_rows(0, rows);
+            stage_rows(1, 2);
+            emit_rows(0, std::true_type{}, rows);
+            load_rows(1, rows);
+            emit_rows(1, std::true_type{}, rows);
+        } else {
+            stage_rows(0, 1);
+            emit_rows(0, std::false_type{}, rows);
+            stage_rows(1, 2);
+            emit_rows(1, std::false_type{}, rows);
+        }
+    } else {
+        stage_rows(0, 2);
+        if (stamp4 != nullptr && threadIdx.x == 0) *stamp4 = (long long)__builtin_readcyclecounter();
+        emit_rows(0, std::false_type{}, rows);
+        emit_rows(1, std::false_type{}, rows);
+    }
+}
+
+template <int EPI, bool FP8, bool TWO_PASS, int NMI = 2, int MI0 = 0>
+__device__ __forceinline__ void gemm_epilogue(const KARG GemmProblem& P, const int M, const int N, const f32x16 (&acc)[NMI][4], int m0, int n0,
+                                              char* E0, char* E1, int lane, int w, long long* stamp4) {
+    if (m0 + BM <= M && n0 + BN <= N && P.pre == nullptr)      // wave-uniform
+        gemm_epilogue_body<EPI, FP8, TWO_PASS, true, NMI, MI0>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
+    else
+        gemm_epilogue_body<EPI, FP8, TWO_PASS, false, NMI, MI0>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
+}
+
+
+}  // namespace pe

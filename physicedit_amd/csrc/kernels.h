@@ -68,7 +68,7 @@ struct GemmWorkspace {
 };
 size_t gemm_workspace_bytes();
 extern GemmWorkspace g_gemm_ws;
-extern int g_gemm_sk, g_gemm_persist_min_rounds;
+extern int g_gemm_sk, g_gemm_persist_min_rounds, g_gemm4_x, g_gemm_skip_ragged;
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace = nullptr);
 extern int g_gemm_band;          // M tiles per band of the tile order (default 4)
 extern int g_gemm_persist_wgs;   // schedule 17: work-groups of the persistent grid (0 = one per CU)
@@ -126,6 +126,9 @@ int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void*
                       const void* bv, const void* cos_sel, const void* sin_sel, void* q, void* k, void* v, int n_q_heads,
                       int n_kv_heads, int K, hipStream_t stream, const int* step = nullptr, int base = 0, int ld = 0,
                       const void* norm_w = nullptr, float eps = 0.f);
+size_t attn_decode_workspace_bytes(int n_q_heads, int cache_len);
+int launch_attn_decode_split(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int cache_len,
+                             float scale, hipStream_t stream, const int* step, int base, void* workspace, size_t workspace_bytes);
 int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int L, float scale,
                        hipStream_t stream, const int* step = nullptr, int base = 0);
 int launch_adapter_mse(const void* pred_dino, const void* gt_dino, const void* pred_vae, const void* gt_vae, size_t n, float* out,

@@ -363,10 +363,21 @@ def decode_step_qkv(x, wq, bq, wk, bk, wv, bv, cos_table, sin_table, k_cache, v_
     return q
 
 
-def decode_step_attention(q, k_cache, v_cache, step, base_len: int, scale: float) -> torch.Tensor:
+def decode_attention_workspace(hq: int, cache_len: int, device) -> torch.Tensor:
+    """fp32 scratch of the split single-query attention (pe_decode_step_attention_split): one per decode stream"""
+    return torch.empty((lib().pe_decode_attention_workspace_bytes(hq, cache_len) // 4,), dtype=torch.float32, device=device)
+
+
+def decode_step_attention(q, k_cache, v_cache, step, base_len: int, scale: float, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """workspace (decode_attention_workspace): the three-launch form over 16 x as many work-groups, bit-identical to the one-launch form"""
     _chk(q, "q"), _chk(k_cache, "k_cache"), _chk(v_cache, "v_cache"), _chk_i32(step, "step")
     hq, hkv, cache_len = q.numel() // 128, k_cache.shape[0], k_cache.shape[1]
     out = torch.empty((hq * 128,), dtype=BF, device=q.device)
+    if workspace is not None:
+        check(lib().pe_decode_step_attention_split(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(), hq, hkv,
+                                                   step.data_ptr(), int(base_len), cache_len, float(scale), workspace.data_ptr(),
+                                                   workspace.numel() * 4, stream_ptr()), "pe_decode_step_attention_split")
+        return out
     check(lib().pe_decode_step_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(), hq, hkv,
                                          step.data_ptr(), int(base_len), cache_len, float(scale), stream_ptr()),
           "pe_decode_step_attention")

@@ -119,6 +119,48 @@ def test_gemm_persistent_schedule_bit_identical(ops, M, N, K):
         lib().pe_debug_set(b"gemm_persist_wgs", 0)
 
 
+@pytest.mark.parametrize("var", [21, 22])
+def test_gemm_round5_schedules_bit_identical(ops, var):
+    """Round 5's two opt-in main loops against schedule 15: 21 = the persistent ping-pong with ONE hand-off per K tile (32-MFMA slots),
+    22 = four waves, one per SIMD, 128 x 128 per wave (gemm4.hip: the tiling whose attainable ceiling the probe ladder puts 7 % higher).
+    Same K order per output element, so bit-identical: every epilogue incl. QKV (RMSNorm + RoPE + transposed V) and e4m3 operands,
+    ragged / tiny / multi-round shapes, a short race screen."""
+    from physicedit_amd._lib import lib
+    try:
+        for (M, N, K) in ((300, 3072, 3072), (257, 264, 64), (272, 3072, 12288), (1, 3072, 256), (8704, 3072, 3072), (2100, 12288, 3072)):
+            x, w, b = rnd((M, K), 1).cuda(), rnd((N, K), 2, K ** -0.5).cuda(), rnd((N,), 3, 0.1).cuda()
+            gate, res = rnd((N,), 7, 0.5).cuda(), rnd((M, N), 8).cuda()
+            for epi in ("bias", "gelu_sigmoid", "gelu_erf", "silu", "gate_res"):
+                kw = dict(gate=gate, res=res) if epi == "gate_res" else {}
+                assert lib().pe_debug_set(b"gemm_variant", 15) == 0
+                a = ops.gemm(x, w, b, epi, **kw)
+                assert lib().pe_debug_set(b"gemm_variant", var) == 0
+                for _ in range(3):
+                    assert torch.equal(a, ops.gemm(x, w, b, epi, **kw)), (M, N, K, epi)
+        for (M, seq_off) in ((300, 0), (2300, 0), (37, 135)):
+            x, w, b = rnd((M, 3072), 11).cuda(), rnd((9216, 3072), 12, 3072 ** -0.5).cuda(), rnd((9216,), 13, 0.1).cuda()
+            nq, nk = synth.make_tensor(5, "norm_q.weight", (128,)).cuda(), synth.make_tensor(5, "norm_k.weight", (128,)).cuda()
+            _, txt = O.rope_tables([(1, 8, 8)], M)
+            cos, sin = txt.real.contiguous().cuda(), txt.imag.contiguous().cuda()
+            outs = {}
+            for v in (15, var):
+                assert lib().pe_debug_set(b"gemm_variant", v) == 0
+                q, k, vt = ops.alloc_qkv(24, seq_off + M, "cuda")
+                ops.qkv_rmsnorm_rope(x, w, b, nq, nk, cos, sin, q, k, vt, seq_off, q_scale=0.1275)
+                outs[v] = (q, k, vt)
+            assert all(torch.equal(u, v) for u, v in zip(outs[15], outs[var])), (M, seq_off)
+        for (M, N, K) in ((300, 3072, 3072), (2300, 3072, 12288), (272, 256, 128)):
+            x, w8, b = rnd((M, K), 21).cuda(), rnd((N, K), 22, K ** -0.5).cuda().to(torch.float8_e4m3fn), rnd((N,), 23, 0.1).cuda()
+            xq, sc = ops.quantize_rows_e4m3(x)
+            for epi in ("bias", "gelu_sigmoid"):
+                assert lib().pe_debug_set(b"gemm_variant", 15) == 0
+                a = ops.gemm_e4m3(xq, sc, w8, b, epi)
+                assert lib().pe_debug_set(b"gemm_variant", var) == 0
+                assert torch.equal(a, ops.gemm_e4m3(xq, sc, w8, b, epi)), (M, N, K, epi)
+    finally:
+        lib().pe_debug_set(b"gemm_variant", 17)
+
+
 @pytest.fixture
 def gemm_workspace():
     """a zeroed stream-K workspace installed for the granular pe_gemm_* calls of one test (pe_debug_set_ptr), removed afterwards"""
@@ -907,6 +949,24 @@ def test_decode_step_kernels(ops):
     ops.decode_argmax(logits, tok, out_ids, st)
     torch.cuda.synchronize()
     assert tok.item() == 77 == int(logits.float().argmax()) and out_ids[3].item() == 77 and st.item() == 4
+
+
+@pytest.mark.parametrize("cap,base,stepv", [(96, 40, 5), (2048, 1390, 9), (3072, 2047, 1000), (1024, 0, 0), (15360, 9000, 3)])
+def test_decode_attention_split_bit_identical(ops, cap, base, stepv):
+    """pe_decode_step_attention_split (scores / softmax sums + P.V per wave / combine over 16 x as many work-groups) keeps every sum's
+    grouping: bit-identical to the one-launch form on caches of 1 ... 9004 valid rows, stale values in its workspace included (the
+    captured decode step reuses one workspace for 28 layers and every token)."""
+    hq, hkv = 28, 4
+    q = rnd((hq * 128,), 201 + cap).cuda()
+    kc, vc = rnd((hkv, cap, 128), 202 + cap).cuda(), rnd((hkv, cap, 128), 203 + cap, 2.0).cuda()
+    step = torch.tensor([stepv], dtype=torch.int32, device="cuda")
+    ws = ops.decode_attention_workspace(hq, cap, "cuda")
+    ws.fill_(float("nan"))
+    ref = ops.decode_step_attention(q, kc, vc, step, base, 128 ** -0.5)
+    for _ in range(3):
+        out = ops.decode_step_attention(q, kc, vc, step, base, 128 ** -0.5, workspace=ws)
+        assert torch.equal(out, ref)
+    assert torch.isfinite(out.float()).all()
 
 
 def test_fused_rmsnorm_single_row_forms(ops):
