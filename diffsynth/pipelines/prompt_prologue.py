@@ -354,7 +354,7 @@ class GraphDecoder:
         for ly in self.layers:
             if ly.self_attn.o_proj.bias is not None or ly.mlp.down_proj.bias is not None or ly.mlp.gate_proj.bias is not None:
                 raise ValueError("GraphDecoder: unexpected biases in o_proj / the MLP")
-        self.split_attention = True  # pe_decode_step_attention_split (448 work-groups per launch) instead of the 28-work-group launch; same bits
+        self.split_attention = os.environ.get("PE_DECODE_SPLIT_ATTENTION", "1") != "0"  # pe_decode_step_attention_split (448 work-groups per launch) instead of the 28-work-group launch; same bits
         self._static = {}           # capacity bucket -> static planes, tables, counters and the captured decode step
         self.captures = 0           # graphs captured so far (tests: calls of one bucket share one)
 

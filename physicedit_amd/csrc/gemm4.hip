@@ -174,6 +174,15 @@ __device__ __forceinline__ void gemm4_tile(const KARG GemmArgs& args, char* smem
 #undef PE_SGB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (X & 4) {      // no epilogue: one value per lane keeps the accumulators alive
+        float sacc = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) sacc += acc[mi][ni][(mi * 4 + ni) & 15];
+        if (sacc == 12345.678f) ((bf16*)P.out)[lane] = (bf16)sacc;
+        return;
+    }
     // epilogue: the wave's 128 x 128 block as two 64 x 128 blocks of "virtual" waves (2 wm + half) * 2 + wn of the 8-wave layout
     char* E = smem + w * 32768;
     gemm_epilogue<EPI, FP8, false, 4, 0>(P, M, N, acc, m0, n0, E, E + 8192, lane, (wm * 2 + 0) * 2 + wn, nullptr);
@@ -196,18 +205,14 @@ static int launch4(const GemmArgs& args, int grid, hipStream_t stream) {
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
-    if constexpr (EPI == EPI_BIAS && !FP8) {
-        if (g_gemm4_x != 0) {
+    if constexpr ((EPI == EPI_BIAS || EPI == EPI_GELU_SIG || EPI == EPI_GATE_RES) && !FP8) {
+        if (g_gemm4_x == 4) {       // timing experiment: the tile without its epilogue (what a fully hidden epilogue would cost); output garbage
             static bool cfgx = false;
             if (!cfgx) {
-                (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI, FP8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI, FP8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI, FP8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI, FP8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
                 cfgx = true;
             }
-            if (g_gemm4_x == 1) hipLaunchKernelGGL((gemm4_kernel<EPI, FP8, 1>), dim3(grid), dim3(256), GEMM_LDS, stream, args);
-            else if (g_gemm4_x == 2) hipLaunchKernelGGL((gemm4_kernel<EPI, FP8, 2>), dim3(grid), dim3(256), GEMM_LDS, stream, args);
-            else hipLaunchKernelGGL((gemm4_kernel<EPI, FP8, 3>), dim3(grid), dim3(256), GEMM_LDS, stream, args);
+            hipLaunchKernelGGL((gemm4_kernel<EPI, FP8, 4>), dim3(grid), dim3(256), GEMM_LDS, stream, args);
             return check_launch("gemm4_kernel");
         }
     }
