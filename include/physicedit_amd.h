@@ -48,7 +48,8 @@ const char* pe_build_id(void);
  * is attached); 10 = the round-1 schedule (A/B reference); 19 = stream-K (bit-identical, needs a workspace: pe_gemm_workspace_bytes;
  * "gemm_sk" = 1 lets 17 take it where tiles do not fill whole rounds; measured slower, default off); 21 = 17 with one hand-off per K
  * tile (32-MFMA slots; a tie); 22 = four waves x 128 x 128, one wave per SIMD, one tile per work-group (gemm4.hip; +2.5 % on the bare
- * main loop, a tie to -6 % on the block's Linears: profiles/r05_gemm_notes.md).  All bit-identical.  "gemm_band": M tiles per band of
+ * main loop, a tie to -6 % on the block's Linears: profiles/r05_gemm_notes.md).  All bit-identical.  "gemm_skip_ragged" (default 1): 32-row blocks beyond M skip their MFMAs;
+ * "gemm_direct_epilogue" (default 1): complete tiles of the GELU / gate + residual epilogues skip the LDS round trip.  "gemm_band": M tiles per band of
  * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of schedule 17's grid (0 = one per CU).
  * "attn_variant": 5 default (4 waves x 64 query rows, one wave per SIMD, lazy running max, the softmax scale folded into Q and the max
  * fed through the MFMA C operand: pe_attn_q_prescale / pe_flash_attn_prescaled; same distance to an fp32 result as the reference's own

@@ -395,7 +395,7 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
     char* E = smem + w * 16384;
     long long* stamp4 = nullptr;
     if constexpr (VAR == 15) stamp4 = args.dbg != nullptr ? args.dbg + (size_t)blockIdx.x * 8 + 4 : nullptr;
-    gemm_epilogue<EPI, FP8, false>(P, M, N, acc, m0, n0, E, E + 8192, lane, w, stamp4);
+    gemm_epilogue<EPI, FP8, false>(P, M, N, acc, m0, n0, E, E + 8192, lane, w, stamp4, args.direct_epi);
     PE_STAMP(5);
 }
 
@@ -766,7 +766,7 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(args.sk_sync + SK_FLAG0 + sk_pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            gemm_epilogue<EPI, FP8, true>(P, M, N, acc, m0, n0, E, E, lane, w, nullptr);
+            gemm_epilogue<EPI, FP8, true>(P, M, N, acc, m0, n0, E, E, lane, w, nullptr, args.direct_epi);
         }
         ab = abk;
         ws = wsk;
@@ -793,6 +793,7 @@ static int env_int(const char* name, int dflt) {
 int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_skip_ragged = env_int("PE_GEMM_SKIP_RAGGED", 1);
+int g_gemm_direct_epi = env_int("PE_GEMM_DIRECT_EPILOGUE", 1);
 int g_gemm_persist_wgs = 0;    // 0 = one work-group per CU of the current device
 int g_gemm_sk = env_int("PE_GEMM_SK", 0);     // schedule 19 where it applies (A/B knob "gemm_sk"; measured slower: profiles/r04_gemm_notes.md)
 // schedule 17 from this many rounds of tiles on (knob "gemm_persist_min_rounds"; G + 1 tiles at least).  Round 3 used 3: in isolation
@@ -914,6 +915,7 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     args.ntiles = tiles[0] + tiles[1];
     args.band = g_gemm_band;
     args.skip_ragged = g_gemm_skip_ragged;
+    args.direct_epi = g_gemm_direct_epi;
     args.dbg = g_gemm_dbg;
     args.sk_sync = nullptr;
     args.sk_part = nullptr;

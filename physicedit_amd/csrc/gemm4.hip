@@ -185,8 +185,8 @@ __device__ __forceinline__ void gemm4_tile(const KARG GemmArgs& args, char* smem
     }
     // epilogue: the wave's 128 x 128 block as two 64 x 128 blocks of "virtual" waves (2 wm + half) * 2 + wn of the 8-wave layout
     char* E = smem + w * 32768;
-    gemm_epilogue<EPI, FP8, false, 4, 0>(P, M, N, acc, m0, n0, E, E + 8192, lane, (wm * 2 + 0) * 2 + wn, nullptr);
-    gemm_epilogue<EPI, FP8, false, 4, 2>(P, M, N, acc, m0, n0, E + 16384, E + 24576, lane, (wm * 2 + 1) * 2 + wn, nullptr);
+    gemm_epilogue<EPI, FP8, false, 4, 0>(P, M, N, acc, m0, n0, E, E + 8192, lane, (wm * 2 + 0) * 2 + wn, nullptr, args.direct_epi);
+    gemm_epilogue<EPI, FP8, false, 4, 2>(P, M, N, acc, m0, n0, E + 16384, E + 24576, lane, (wm * 2 + 1) * 2 + wn, nullptr, args.direct_epi);
 }
 
 template <int EPI, bool FP8, int X = 0>

@@ -22,6 +22,7 @@ struct GemmArgs {
     int tiles0;       // tiles of problem 0 (tile ids >= tiles0 belong to problem 1)
     int ntiles;       // all tiles of the launch (schedule 17: the grid is smaller)
     int band;         // M tiles per band of the tile order
+    int direct_epi;   // 1: complete tiles of the element-wise epilogues skip the LDS round trip (A/B knob "gemm_direct_epilogue", default 1)
     int skip_ragged;  // 1: row blocks beyond M skip their MFMAs (A/B knob "gemm_skip_ragged", default 1)
     long long* dbg;   // per work-group s_memtime stamps [grid][8] of schedule 15 (pe_debug_set_ptr("gemm_stamps", p)), or null
     unsigned* sk_sync;   // schedule 19: [0] arrivals, [1 + c] position counter of chunk c, [SK_FLAG0 + pos] flag of the seam behind position pos; zero at rest
@@ -469,9 +470,142 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same epilogue WITHOUT the LDS round trip, for complete tiles of the element-wise epilogues (round 5; bias, GELU, gate x y + residual).
+// The accumulator layout already has 4 consecutive columns of a row per lane and quad, and its partner lane (l ^ 32) holds the next 4:
+// one v_permlane32_swap per dword on the quad pairs (q, q + 1) leaves 16 contiguous bytes of the row in every lane (lower lanes: quad
+// q, upper lanes: quad q + 1), i.e. 16-byte residual loads and 16-byte stores straight from registers -- no staging writes, no read-back,
+// no swizzle arithmetic (3.3k of the 4.8k - 11k cycles an LDS epilogue takes per tile: profiles/r03_gemm_notes.md section 5).  A store
+// instruction covers 32 rows x 32 bytes instead of 4 rows x 256 bytes.  The arithmetic per output element is the LDS form's, rounding
+// for rounding: bit-identical.  Knob "gemm_direct_epilogue" (default 1) for the A/B.
+// ------------------------------------------------------------------------------------------
+template <int EPI>
+constexpr bool kDirectEpi = EPI == EPI_GELU_SIG || EPI == EPI_GATE_RES;      // (bias only: measured 1 % slower bf16, 4.6 % slower e4m3 than the LDS form)
+
+template <int EPI, bool FP8, int NMI = 2, int MI0 = 0>
+__device__ __forceinline__ void gemm_epilogue_direct(const KARG GemmProblem& P, const f32x16 (&acc)[NMI][4], int m0, int n0, int lane, int w) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int nw0 = n0 + wn * 128, mw0 = m0 + wm * 64;
+    const bf16* bias = (const bf16*)P.bias;
+    float sa[2] = {1.f, 1.f};
+    if constexpr (FP8) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[mw0 + mi * 32 + l31];
+    }
+    bf16x4 bvs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bvs[i] = bf16x4{0, 0, 0, 0};
+    if (bias != nullptr) {
+        const bf16* bl = bias + nw0 + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bvs[i] = *(const bf16x4*)(bl + (i >> 2) * 32 + 8 * (i & 3));
+    }
+    // residual rows of the gated epilogue in the STORE layout: row mi * 32 + l31, columns ni * 32 + 16 j + 8 h .. + 7.  Row block 0 is
+    // requested here (its latency rides under the packing of the accumulators), row block 1 once the accumulators are dead: with all 16
+    // rows in flight next to 128 accumulators the allocator spills 125 registers
+    u32x4 rv[EPI == EPI_GATE_RES ? 16 : 1];
+    const bf16* rl = nullptr;
+    if constexpr (EPI == EPI_GATE_RES) {
+        rl = (const bf16*)P.res + (size_t)(mw0 + l31) * P.ldr + nw0 + 8 * h;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rv[ni * 2 + j] = *(const u32x4*)(rl + ni * 32 + 16 * j);
+    }
+    // y = bf16(acc + bias) as pairs, every quad of the wave's block (64 registers; the accumulators are dead behind this)
+    uint32_t yp[2][4][8];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x4 b4 = bvs[ni * 4 + q];
+                f32x2 y0, y1;
+                if constexpr (FP8) {
+                    y0 = f32x2{acc[MI0 + mi][ni][4 * q] * sa[mi] + (float)b4[0], acc[MI0 + mi][ni][4 * q + 1] * sa[mi] + (float)b4[1]};
+                    y1 = f32x2{acc[MI0 + mi][ni][4 * q + 2] * sa[mi] + (float)b4[2], acc[MI0 + mi][ni][4 * q + 3] * sa[mi] + (float)b4[3]};
+                } else {
+                    y0 = f32x2{acc[MI0 + mi][ni][4 * q] + (float)b4[0], acc[MI0 + mi][ni][4 * q + 1] + (float)b4[1]};
+                    y1 = f32x2{acc[MI0 + mi][ni][4 * q + 2] + (float)b4[2], acc[MI0 + mi][ni][4 * q + 3] + (float)b4[3]};
+                }
+                yp[mi][ni][2 * q] = pk2(y0);
+                yp[mi][ni][2 * q + 1] = pk2(y1);
+            }
+    if constexpr (EPI == EPI_GATE_RES) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rv[8 + ni * 2 + j] = *(const u32x4*)(rl + (size_t)32 * P.ldr + ni * 32 + 16 * j);
+    }
+    bf16* out = (bf16*)P.out;
+    const float gs = (EPI == EPI_GATE_RES && P.has_gate_scalar) ? P.gate_scalar : 1.0f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = nw0 + ni * 32 + 16 * j + 8 * h;
+                const int m = mw0 + mi * 32 + l31;
+                const auto sx = __builtin_amdgcn_permlane32_swap(yp[mi][ni][4 * j], yp[mi][ni][4 * j + 2], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(yp[mi][ni][4 * j + 1], yp[mi][ni][4 * j + 3], false, false);
+                const u32x4 vp = {sx[0], sy[0], sx[1], sy[1]};
+                u32x4 op;
+                if constexpr (EPI == EPI_BIAS) {
+                    op = vp;
+                } else if constexpr (EPI == EPI_GELU_SIG) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x2 y = up2(vp[jj]);
+                        const f32x2 t = rnd2(f32x2{1.702f, 1.702f} * y);
+                        const f32x2 a = t * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + f32x2{1.0f, 1.0f};
+                        const f32x2 sg = rnd2(f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)});
+                        op[jj] = pk2(y * sg);
+                    }
+                    if constexpr (FP8) {
+                        if (P.q8_out != nullptr) {
+                            const bf16x8 o = __builtin_bit_cast(bf16x8, op);
+                            float f[8];
+                            float amax = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                f[e] = (float)o[e];
+                                amax = fmaxf(amax, fabsf(f[e]));
+                            }
+                            u32x2 pk;
+                            pk[0] = pack4_e4m3(f[0], f[1], f[2], f[3]);
+                            pk[1] = pack4_e4m3(f[4], f[5], f[6], f[7]);
+                            *(u32x2*)((uint8_t*)P.q8_out + (size_t)m * P.ldq8 + n) = pk;
+                            if (amax > 447.0f) atomicOr(P.q8_flags + m, 1u);
+                        }
+                    }
+                } else {
+                    f32x2 g2[4] = {f32x2{gs, gs}, f32x2{gs, gs}, f32x2{gs, gs}, f32x2{gs, gs}};
+                    if (P.gate != nullptr) {
+                        const u32x4 gv = *(const u32x4*)((const bf16*)P.gate + n);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) g2[jj] = up2(gv[jj]);
+                    }
+                    const u32x4 rp = rv[(mi * 4 + ni) * 2 + j];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) op[jj] = pk2(up2(rp[jj]) + rnd2(g2[jj] * up2(vp[jj])));
+                }
+                *(u32x4*)(out + (size_t)m * P.ldo + n) = op;
+            }
+}
+
 template <int EPI, bool FP8, bool TWO_PASS, int NMI = 2, int MI0 = 0>
 __device__ __forceinline__ void gemm_epilogue(const KARG GemmProblem& P, const int M, const int N, const f32x16 (&acc)[NMI][4], int m0, int n0,
-                                              char* E0, char* E1, int lane, int w, long long* stamp4) {
+                                              char* E0, char* E1, int lane, int w, long long* stamp4, int direct = 0) {
+    if constexpr (kDirectEpi<EPI>) {
+        if (direct && m0 + BM <= M && n0 + BN <= N && P.pre == nullptr) {      // wave-uniform
+            gemm_epilogue_direct<EPI, FP8, NMI, MI0>(P, acc, m0, n0, lane, w);
+            return;
+        }
+    }
     if (m0 + BM <= M && n0 + BN <= N && P.pre == nullptr)      // wave-uniform
         gemm_epilogue_body<EPI, FP8, TWO_PASS, true, NMI, MI0>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
     else

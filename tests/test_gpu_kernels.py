@@ -161,6 +161,37 @@ def test_gemm_round5_schedules_bit_identical(ops, var):
         lib().pe_debug_set(b"gemm_variant", 17)
 
 
+@pytest.mark.parametrize("var", [15, 17, 22])
+def test_gemm_direct_epilogue_bit_identical(ops, var):
+    """Round 5: complete tiles of the GELU and gate x y + residual epilogues go accumulators -> v_permlane32_swap -> 16-byte stores without
+    the LDS round trip (gemm_tile.h gemm_epilogue_direct; knob gemm_direct_epilogue, default 1).  Same operations and roundings per element
+    as the LDS form: bit-identical, with and without bias, vector and scalar gate, in place (residual aliases the output), ragged shapes
+    (whose ragged tiles keep the LDS form) and e4m3 operands incl. the fused quantisation of the GELU output."""
+    from physicedit_amd._lib import lib
+    try:
+        assert lib().pe_debug_set(b"gemm_variant", var) == 0
+        for (M, N, K) in ((2100, 3072, 3072), (600, 12288, 3072), (8464, 3072, 3072)):
+            x, w, b = rnd((M, K), 31).cuda(), rnd((N, K), 32, K ** -0.5).cuda(), rnd((N,), 33, 0.1).cuda()
+            gate, res = rnd((N,), 37, 0.5).cuda(), rnd((M, N), 38).cuda()
+            xq, sc = ops.quantize_rows_e4m3(x)
+            w8 = w.to(torch.float8_e4m3fn)
+            outs = []
+            for d in (0, 1):
+                assert lib().pe_debug_set(b"gemm_direct_epilogue", d) == 0
+                r1 = res.clone()
+                ops.gemm(x, w, b, "gate_res", gate=gate, res=r1, out=r1)
+                o = [ops.gemm(x, w, b, "gelu_sigmoid"), ops.gemm(x, w, None, "gelu_sigmoid"), ops.gemm(x, w, b, "gate_res", gate=gate, res=res),
+                     ops.gemm(x, w, b, "gate_res", gate=None, res=res), r1, ops.gemm_e4m3(xq, sc, w8, b, "gelu_sigmoid"),
+                     ops.gemm_e4m3(xq, sc, w8, b, "gate_res", gate=gate, res=res)]
+                o += list(ops.gemm_e4m3_gelu_q8(xq, sc, w8, b))
+                outs.append(o)
+            for i, (p_, q_) in enumerate(zip(*outs)):
+                assert torch.equal(p_, q_), (var, M, N, K, i)
+    finally:
+        lib().pe_debug_set(b"gemm_direct_epilogue", 1)
+        lib().pe_debug_set(b"gemm_variant", 17)
+
+
 @pytest.fixture
 def gemm_workspace():
     """a zeroed stream-K workspace installed for the granular pe_gemm_* calls of one test (pe_debug_set_ptr), removed afterwards"""
