@@ -644,8 +644,7 @@ def cpu_baseline(args):
       1. one full-width DiT block at the full configs[1] sequence (S_img = 8192, T = T_pos; T_neg scaled by tokens), timed once per
          torch thread count in {8, 16, 32, 64, 128} (stopping past the knee: 256 threads oversubscribe oneDNN, round 1 measured
          3-4x slower than 8 vCPUs that way); the best count's time is the sample, and that count is used for everything below;
-      3. VAE encode + decode TIMED at 256 x 256 and scaled by the pixel count (convolutions are linear in pixels; the
-         mid-block attention, 0.41 of 7.6 TFLOP at 1024^2, is scaled the same way, which under-prices it slightly);
+      3. VAE encode + decode TIMED at the real image size (one pass each, ~10 s apiece at 1024^2 on 32 threads);
       4. configs[0] (c1) end to end: 2-layer DiT, 512 x 512, 4 steps, CFG off, T = 128, edit image NOT auto-resized
          (S_img = 2048): reported as its own number, not part of the extrapolation."""
     import torch
@@ -685,14 +684,18 @@ def cpu_baseline(args):
     S = S_img + args.t_pos
     blk_flops = 226_492_416 * S + 12_288 * S * S + 226_492_416
     cpu_rate = blk_flops / t_blk[args.t_pos]
-    # VAE: timed at 256^2, scaled by pixels
+    # VAE: timed ONCE at the real size (round 5; rounds 1-4 scaled a 256^2 run by pixels, which under-prices the mid-block attention:
+    # its work grows with the square of the pixel count), in the oracle's 2-D form of the causal convolutions (one frame: the last
+    # temporal tap; pinned to the literal conv3d within 2 ulp by tests/test_oracle_golden.py)
     vs = synth.make_state_dict(synth.vae_layout(), 77)
-    x = O.preprocess_image(synth.make_edit_image_u8(256, 256, 0))
-    with torch.no_grad():
-        t0 = time.perf_counter(); z = O.vae_encode(vs, x); t_enc256 = time.perf_counter() - t0
-        t0 = time.perf_counter(); O.vae_decode(vs, z); t_dec256 = time.perf_counter() - t0
-    t_enc = t_enc256 * (1024 * 1024) / (256 * 256)
-    t_dec = t_dec256 * (args.height * args.width) / (256 * 256)
+    x = O.preprocess_image(synth.make_edit_image_u8(args.height, args.width, 0))
+    O.VAE_CONV_MODE = "2d"
+    try:
+        with torch.no_grad():
+            t0 = time.perf_counter(); z = O.vae_encode(vs, x); t_enc = time.perf_counter() - t0
+            t0 = time.perf_counter(); O.vae_decode(vs, z); t_dec = time.perf_counter() - t0
+    finally:
+        O.VAE_CONV_MODE = "3d"
     # c1 end to end (loop only, as SURVEY 8d defines the timed region; the VAE is priced above)
     sd2 = synth.make_state_dict(synth.dit_layout(2), 1234)
     noise = synth.make_noise(0, 512, 512)
@@ -707,7 +710,7 @@ def cpu_baseline(args):
             "sample": f"1 DiT block fwd at full shape S_img={S_img}, T={args.t_pos}, torch threads swept at that shape "
                       f"{{{', '.join(f'{k}: {v:.2f}s' for k, v in sweep.items())}}} -> {best} threads: {t_blk[args.t_pos]:.2f}s "
                       f"(T={args.t_neg} scaled by tokens: {t_blk[args.t_neg]:.2f}s) = {cpu_rate/1e12:.3f} TFLOP/s; "
-                      f"VAE timed at 256x256 (enc {t_enc256:.2f}s, dec {t_dec256:.2f}s) and scaled by pixels -> enc {t_enc:.1f}s dec {t_dec:.1f}s; "
+                      f"VAE timed at {args.height}x{args.width} (2-D form of the causal convolutions): enc {t_enc:.1f}s dec {t_dec:.1f}s; "
                       f"extrapolated x{args.inference_steps} steps x{args.layers} layers",
             "c1_end_to_end_seconds": t_c1,
             "c1_config": "configs[0]: 2-layer DiT, 512x512 + 512x512 edit latents (S_img 2048), T=128, 4 steps, CFG off (loop only)",
