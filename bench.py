@@ -607,12 +607,12 @@ def attention_ceiling(dev, S):
 def pmc_traffic(args):
     """HBM-side (L2-miss) bytes per launch and matrix-pipe utilisation of the block GEMMs, launch-weighted over QKV / out-proj /
     MLP-up / MLP-down.  PMC counters cannot be collected from inside this process: they come from the committed rocprofv3 --pmc
-    passes of tools/pmc_collect.sh (profiles/r02_pmc.json, which records its own command line).  They are per-launch properties
+    passes of tools/pmc_collect.sh (profiles/r05_pmc.json, which records its own command line).  They are per-launch properties
     of (kernel, shape), so they are reported ONLY when this run launches the same kernels on the same shapes -- same layer count,
     geometry, prompt lengths, operand dtype and stream count as the recorded command -- and are null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r04_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r05_pmc.json")
     if not os.path.exists(path) and not args.fp8:
-        path = os.path.join(ROOT, "profiles", "r03_pmc.json")
+        path = os.path.join(ROOT, "profiles", "r04_pmc.json")
     if not os.path.exists(path):
         return None, None, None
     rec = json.load(open(path))
@@ -624,7 +624,9 @@ def pmc_traffic(args):
         return None, None, f"profiles/{os.path.basename(path)} was collected for another configuration ({rec.get('command')}): not reported"
     # the block GEMMs only (QKV 1224, MLP-up 1632, out-proj / MLP-down 408 work-groups at this geometry): the hoisted modulation
     # GEMMs of pe_dit_prepare (M = steps) share the kernel name but are not what `roofline` is about
-    rows = [r for r in rec["kernels"] if "gemm_bf16_kernel" in r["kernel"] and r.get("algorithmic_gflop_per_launch")]
+    # (since round 4 all four run the persistent schedule on one work-group per CU; the gate + residual instantiation serves out-proj AND
+    # MLP-down, so its row has no single algorithmic size: the block GEMMs are recognised by their launch count instead)
+    rows = [r for r in rec["kernels"] if "gemm_bf16_kernel" in r["kernel"] and (r.get("algorithmic_gflop_per_launch") or (r.get("launches", 0) >= 300 and r.get("workgroups", 0) >= 256))]
     n = sum(r["launches"] for r in rows)
     if not n:
         return None, None, None

