@@ -20,7 +20,7 @@ namespace pe {
 // and W(kt+2) pieces 0-3 ride in ks0, 4-7 in ks1 of tile kt (slot (kt+2) % 3 held K tile kt-1, dead since barrier kt-1).
 // Same K order per output element as every other schedule: bit-identical.
 // ------------------------------------------------------------------------------------------
-template <int EPI, bool FP8, int X = 0>      // X: timing experiments only (1 no barrier, 2 no vmcnt wait: racy)
+template <int EPI, bool FP8, int X = 0>      // X = 4: timing build that stops after the main loop (pe_debug_set("gemm4_x", 4); output garbage)
 __device__ __forceinline__ void gemm4_tile(const KARG GemmArgs& args, char* smem, int bid) {
     constexpr int ES = FP8 ? 1 : 2;
     constexpr int KT_BYTES = 128;
@@ -115,9 +115,8 @@ __device__ __forceinline__ void gemm4_tile(const KARG GemmArgs& args, char* smem
 #define PE_TILE_BARRIER()                                                                                                  \
     do {                                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        if constexpr (X & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); /* all but W(kt+2): A(kt+1), W(kt+1) landed */   \
-        if constexpr (!(X & 1)) __builtin_amdgcn_s_barrier();                                                              \
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); /* all but W(kt+2): A(kt+1), W(kt+1) landed */        \
+        __builtin_amdgcn_s_barrier();                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
     } while (0)
     // prologue: A(0), W(0) | A(1), W(1) | (W(2) rides in tile 0)
