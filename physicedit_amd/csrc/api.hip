@@ -47,6 +47,7 @@ int pe_debug_set(const char* key, int value) {
     if (!strcmp(key, "gemm4_x")) { g_gemm4_x = value; return PE_OK; }
     if (!strcmp(key, "gemm_skip_ragged")) { g_gemm_skip_ragged = value; return PE_OK; }
     if (!strcmp(key, "gemm_direct_epilogue")) { g_gemm_direct_epi = value; return PE_OK; }
+    if (!strcmp(key, "gemm_mfma16")) { g_gemm_mfma16 = value; return PE_OK; }
     if (!strcmp(key, "gemm_persist_min_rounds")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_persist_min_rounds out of range"); g_gemm_persist_min_rounds = value; return PE_OK; }
     if (!strcmp(key, "gemm_band")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_band out of range"); g_gemm_band = value; return PE_OK; }
     if (!strcmp(key, "gemm_persist_wgs")) { PE_REQUIRE(value >= 0 && value <= 1024, "gemm_persist_wgs out of range"); g_gemm_persist_wgs = value; return PE_OK; }

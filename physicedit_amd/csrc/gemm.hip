@@ -9,7 +9,10 @@
 //
 // Structure (MI355X-first, not a CUDA tiling):
 //   * 256x256x64 block tile, 512 threads = 8 waves as 4(M) x 2(N); each wave owns 64x128 of C as
-//     2x4 v_mfma_f32_32x32x16_bf16 tiles (128 fp32 accumulators / lane).
+//     4x8 v_mfma_f32_16x16x32_bf16 blocks (128 fp32 accumulators / lane; round 5: the 4-pass shape moves half the
+//     accumulator bytes per FLOP of the 8-pass 32x32x16 and sustains 12-16 % more FLOP/s under the chip's power limit --
+//     profiles/r05_gemm_notes.md section 7; the 32x32 form is kept behind the knob "gemm_mfma16" = 0; e4m3 uses the
+//     block-scaled 32x32x64).
 //   * A and W tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip): A double
 //     buffered, W in a three-deep ring (2 x 32 KiB + 3 x 32 KiB = all of the CU's 160 KiB).
 //   * LDS image is [row][64 k] bf16 = 128 B rows; the 16-B chunk index is XORed with (row>>1)&7 so
@@ -31,14 +34,35 @@ namespace pe {
 
 long long* g_gemm_dbg = nullptr;
 
-// One output tile per work-group (schedules 10 and 15): `bid` = tile id in the banded order.
-template <int EPI, int VAR, bool FP8>
+// Accumulators of a wave's 64 x 128 block in the two MFMA shapes (S16: 4 x 8 blocks of 16 x 16, else 2 x 4 blocks of 32 x 32): 32 quads either way
+template <bool S16>
+struct AccTile {
+    typename std::conditional<S16, f32x4[4][8], f32x16[2][4]>::type v;
+    PE_DEV f32x4 quad(int j) const {
+        if constexpr (S16) return v[j >> 3][j & 7];
+        else return f32x4{v[j >> 4][(j >> 2) & 3][4 * (j & 3)], v[j >> 4][(j >> 2) & 3][4 * (j & 3) + 1], v[j >> 4][(j >> 2) & 3][4 * (j & 3) + 2],
+                          v[j >> 4][(j >> 2) & 3][4 * (j & 3) + 3]};
+    }
+    PE_DEV void set_quad(int j, f32x4 q) {
+        if constexpr (S16) v[j >> 3][j & 7] = q;
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j >> 4][(j >> 2) & 3][4 * (j & 3) + r] = q[r];
+        }
+    }
+};
+
+// One output tile per work-group (schedule 15): `bid` = tile id in the banded order.
+template <int EPI, int VAR, bool FP8, bool S16>
 __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem, int bid) {
+    static_assert(VAR == 15, "unknown GEMM schedule");
+    static_assert(!(FP8 && S16), "the 16 x 16 x 32 shape is the bf16 kernels'");
     constexpr int ES = FP8 ? 1 : 2;        // bytes per operand element
     constexpr int KT_BYTES = 128;          // one K tile of a row, in bytes (64 bf16 / 128 e4m3)
     const int lane = lane_id();
     const int w = wave_id();
-    const int l31 = lane & 31, h = lane >> 5;
+    // fragment row of the lane inside an MFMA block and its k group: 32 rows x 2 groups of 8 (32 x 32 x 16), 16 rows x 4 groups of 8 (16 x 16 x 32)
+    const int lrow = S16 ? (lane & 15) : (lane & 31), h = S16 ? (lane >> 4) : (lane >> 5);
     const int wm = w >> 1, wn = w & 1;
 
     PE_STAMP(0);
@@ -56,9 +80,9 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
         const int rin = lane >> 3, slot = lane & 7;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // piece (1 KiB = 8 rows) i of this wave.  VAR 10: whole tiles, piece 4w + i.  VAR 15: A pieces come from the wave
-            // group's OWN half (the only one it reads), piece = grp*16 + 4(w&3) + i; W pieces 4w + i.
-            const int piece_a = VAR >= 15 ? (w >> 2) * 16 + (w & 3) * 4 + i : w * 4 + i;
+            // piece (1 KiB = 8 rows) i of this wave.  A pieces come from the wave group's OWN half (the only one it reads),
+            // piece = grp*16 + 4(w&3) + i; W pieces 4w + i.
+            const int piece_a = (w >> 2) * 16 + (w & 3) * 4 + i;
             const int piece_w = w * 4 + i;
             const int row_a = piece_a * 8 + rin, row_w = piece_w * 8 + rin;
             const int gr = min(m0 + row_a, M - 1);
@@ -68,19 +92,16 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
         }
     }
 
-    f32x16 acc[2][4];
+    AccTile<S16> accT;
+    auto& acc = accT.v;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int j = 0; j < 32; ++j) accT.set_quad(j, f32x4{0.f, 0.f, 0.f, 0.f});
 
-    // per-lane fragment addressing: row = tile_row + l31, chunk = kk*2 + h, swizzle (row>>1)&7
-    const int sw = (l31 >> 1) & 7;
+    // per-lane fragment addressing: row = tile_row + lrow, chunk = the lane's 8 k of the k-step, swizzle (row>>1)&7
+    const int sw = (lrow >> 1) & 7;
 
     const int nk = K * ES / KT_BYTES;
-    if constexpr (VAR >= 15) {
+    {
         // "Ping-pong" schedule: the two wave groups (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; waves w and w+4
         // share a SIMD) run the SAME instruction stream one barrier apart, so at any time every SIMD has one wave in its MFMA
         // part and one in its load part: LDS latency, the DMA issue and the barrier skew of one group hide under the other
@@ -94,13 +115,13 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
         // p0 of tile kt-1, i.e. >= 4 barriers earlier.  RAW: vmcnt(4) in p1 retires A(kt+1), W(kt+1); both groups
         // pass a barrier between that wait and the first read of tile kt+1.
         using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
-        constexpr int KS = FP8 ? 2 : 4;            // MFMA k-steps per K tile
+        constexpr int KS = FP8 || S16 ? 2 : 4;     // MFMA k-steps per K tile
         constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
         char* const a_base = smem;
         char* const w_base = smem + 2 * A_BYTES;
         const int grp = w >> 2;
-        const int a_off = (wm * 64 + l31) * 128;
-        const int w_off = (wn * 128 + l31) * 128;
+        const int a_off = (wm * 64 + lrow) * 128;
+        const int w_off = (wn * 128 + lrow) * 128;
         auto rd = [&](const char* rowp, int ks) -> FragT {
             if constexpr (FP8) {
                 const int c0 = 4 * ks + 2 * h;
@@ -108,7 +129,7 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
                 const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
                 return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             } else {
-                return *(const bf16x8*)(rowp + (((ks * 2 + h) ^ sw) << 4));
+                return *(const bf16x8*)(rowp + (((ks * (S16 ? 4 : 2) + h) ^ sw) << 4));
             }
         };
 #define PE_BAR()                                   \
@@ -117,28 +138,47 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
         __builtin_amdgcn_s_barrier();              \
         __builtin_amdgcn_sched_barrier(0);         \
     } while (0)
-        FragT fa[KS], fw4[4][KS];
+        // fragments of one phase (32 rows of the wave's block x its 128 columns x the K tile): 4 of A and 16 of W in either bf16 shape
+        // (32 x 32: fa[ks], fw[ni][ks]; 16 x 16: fa[mb * 2 + ks], fw[nb][ks])
+        constexpr int NB = S16 ? 8 : 4;            // column blocks of the wave
+        FragT fa[S16 ? 4 : KS], fw4[NB][KS];
         auto rd_a1 = [&](const char* Sa, int mi) {
+            if constexpr (S16) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) fa[mb * 2 + ks] = rd(Sa + a_off + mi * 4096 + mb * 2048, ks);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
+            }
         };
         auto rd_w4 = [&](const char* Sw) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) fw4[ni][ks] = rd(Sw + w_off + ni * 4096, ks);
+                for (int ks = 0; ks < KS; ++ks) fw4[ni][ks] = rd(Sw + w_off + ni * (S16 ? 2048 : 4096), ks);
         };
         auto mma16 = [&](int mi) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks) {
+                if constexpr (S16) {
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    if constexpr (FP8)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                            fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                    else
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 8; ++nb)
+                            acc[mi * 2 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw4[nb][ks], fa[mb * 2 + ks], acc[mi * 2 + mb][nb], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        if constexpr (FP8)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                                fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                        else
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
+                    }
                 }
+            }
         };
         auto st_a4 = [&](int i) {
             const int tc = min(i, nk - 1);
@@ -194,199 +234,6 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
         PE_STAMP(2);
 #undef PE_MMA16
 #undef PE_BAR
-    } else if constexpr (FP8) {
-        // v10's structure (A 2 x 32 KiB + W 3 x 32 KiB ring, tile barrier with vmcnt(4)) on 64-cycle MFMAs:
-        // four clusters of 4 MFMAs per K tile.  Cluster c covers k-half c>>1 and output column pair c&1:
-        //   c0: A(k0) x W(k0, ni 0,1)   c1: A(k0) x W(k0, ni 2,3)   c2: A(k1) x W(k1, ni 0,1)   c3: A(k1) x W(k1, ni 2,3)
-        // Fragment of one 32-row tile for one MFMA = 32 bytes of k per lane (k = 32*h .. +31) = two 16-B chunks.
-        constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
-        char* const a_base = smem;
-        char* const w_base = smem + 2 * A_BYTES;
-        auto frag = [&](const char* rowp, int k2) -> i32x8 {
-            const int c0 = 4 * k2 + 2 * h;
-            const i32x4 lo = *(const i32x4*)(rowp + ((c0 ^ sw) << 4));
-            const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
-            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        };
-        auto frag_a = [&](const char* Sa, int k2, i32x8 (&af)[2]) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = frag(Sa + (wm * 64 + mi * 32 + l31) * 128, k2);
-        };
-        auto frag_w = [&](const char* Sw, int k2, int pair, i32x8 (&wf)[2]) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) wf[j] = frag(Sw + (wn * 128 + (pair * 2 + j) * 32 + l31) * 128, k2);
-        };
-        const int unit = 0x7f7f7f7f;   // E8M0 block scales = 2^0
-        auto mma = [&](i32x8 (&af)[2], i32x8 (&wf)[2], int pair) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[mi][pair * 2 + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                        wf[j], af[mi], acc[mi][pair * 2 + j], 0, 0, 0, unit, 0, unit);
-        };
-        auto stage_a = [&](int t, int first, int count) {
-            const int tc = min(t, nk - 1);
-            char* base = a_base + (t & 1) * A_BYTES + w * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i >= first && i < first + count) glds16(a_src[i] + tc * KT_BYTES, base + i * 1024);
-        };
-        auto stage_w = [&](int t, int slot, int first, int count) {
-            const int tc = min(t, nk - 1);
-            char* base = w_base + slot * W_BYTES + w * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i >= first && i < first + count) glds16(w_src[i] + tc * KT_BYTES, base + i * 1024);
-        };
-#define PE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define PE_CLUSTER8(NDS)                                          \
-    do {                                                          \
-        PE_SGB(0x008, 1); PE_SGB(0x100, (NDS) / 2);               \
-        PE_SGB(0x008, 1); PE_SGB(0x100, (NDS) / 2);               \
-        PE_SGB(0x008, 1); PE_SGB(0x020, 1);                       \
-        PE_SGB(0x008, 1); PE_SGB(0x020, 1);                       \
-    } while (0)
-        stage_a(0, 0, 4);
-        stage_w(0, 0, 0, 4);
-        stage_w(1, 1, 0, 4);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
-        __syncthreads();
-        i32x8 fa0[2], fa1[2], fwp[2], fwq[2];
-        frag_a(a_base, 0, fa0);
-        frag_w(w_base, 0, 0, fwp);
-        stage_a(1, 0, 2);
-        int ws_cur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* Sa = a_base + (kt & 1) * A_BYTES;
-            const char* San = a_base + ((kt + 1) & 1) * A_BYTES;
-            const int ws_n1 = ws_cur == 2 ? 0 : ws_cur + 1;
-            const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;
-            const char* Sw = w_base + ws_cur * W_BYTES;
-            const char* Swn = w_base + ws_n1 * W_BYTES;
-            // cluster 0
-            frag_w(Sw, 0, 1, fwq); frag_a(Sa, 1, fa1);
-            stage_a(kt + 1, 2, 2);
-            mma(fa0, fwp, 0);
-            PE_CLUSTER8(8);
-            // cluster 1
-            frag_w(Sw, 1, 0, fwp);
-            stage_w(kt + 2, ws_n2, 0, 2);
-            mma(fa0, fwq, 1);
-            PE_CLUSTER8(4);
-            // cluster 2
-            frag_w(Sw, 1, 1, fwq);
-            stage_w(kt + 2, ws_n2, 2, 2);
-            mma(fa1, fwp, 0);
-            PE_CLUSTER8(4);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // all but the 4 newest (= W(kt+2))
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // cluster 3
-            frag_a(San, 0, fa0); frag_w(Swn, 0, 0, fwp);
-            stage_a(kt + 2, 0, 2);
-            mma(fa1, fwq, 1);
-            PE_CLUSTER8(8);
-            ws_cur = ws_n1;
-        }
-#undef PE_CLUSTER8
-#undef PE_SGB
-    } else {
-        static_assert(VAR == 10, "unknown GEMM schedule");
-        // v8 + a THREE-deep W ring: the weight matrix is the cold operand of every block GEMM (each of
-        // the 40 GB of weights is touched once per forward), the activation tile is cache resident.  LDS:
-        // A 2 x 32 KiB + W 3 x 32 KiB = the CU's whole 160 KiB.  W(kt+2) is issued during tile kt, AFTER
-        // A(kt+1) in program order, so the tile barrier can wait with vmcnt(4): everything but the four
-        // newest W pieces (HBM latency then spans ~1.5 K tiles instead of ~0.75).
-        constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
-        char* const a_base = smem;
-        char* const w_base = smem + 2 * A_BYTES;
-        auto frag_a = [&](const char* Sa, int kk, bf16x8 (&af)[2]) {
-            const int coff = ((kk * 2 + h) ^ sw) << 4;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(Sa + (wm * 64 + l31) * 128 + mi * 32 * 128 + coff);
-        };
-        auto frag_w = [&](const char* Sw, int kk, bf16x8 (&wf)[4]) {
-            const int coff = ((kk * 2 + h) ^ sw) << 4;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const bf16x8*)(Sw + (wn * 128 + l31) * 128 + ni * 32 * 128 + coff);
-        };
-        auto mma = [&](bf16x8 (&af)[2], bf16x8 (&wf)[4]) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-        };
-        auto stage_a = [&](int t, int first, int count) {
-            const int tc = min(t, nk - 1);
-            char* base = a_base + (t & 1) * A_BYTES + w * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i >= first && i < first + count) glds16(a_src[i] + tc * KT_BYTES, base + i * 1024);
-        };
-        auto stage_w = [&](int t, int slot, int first, int count) {
-            const int tc = min(t, nk - 1);
-            char* base = w_base + slot * W_BYTES + w * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i >= first && i < first + count) glds16(w_src[i] + tc * KT_BYTES, base + i * 1024);
-        };
-#define PE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define PE_CLUSTER_SCHED(NVMEM)                                    \
-    do {                                                          \
-        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
-        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
-        PE_SGB(0x008, 1); PE_SGB(0x100, 2);                       \
-        for (int v_ = 0; v_ < (NVMEM); ++v_) { PE_SGB(0x008, 1); PE_SGB(0x020, 1); } \
-        PE_SGB(0x008, 5 - (NVMEM));                               \
-    } while (0)
-        stage_a(0, 0, 4);
-        stage_w(0, 0, 0, 4);
-        stage_w(1, 1, 0, 4);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
-        __syncthreads();
-        bf16x8 fa0[2], fw0[4], fa1[2], fw1[4];
-        frag_a(a_base, 0, fa0);
-        frag_w(w_base, 0, fw0);
-        stage_a(1, 0, 2);
-        int ws_cur = 0;                       // W ring slot of tile kt
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* Sa = a_base + (kt & 1) * A_BYTES;
-            const char* San = a_base + ((kt + 1) & 1) * A_BYTES;
-            const int ws_n1 = ws_cur == 2 ? 0 : ws_cur + 1;   // slot of tile kt+1
-            const int ws_n2 = ws_n1 == 2 ? 0 : ws_n1 + 1;     // slot of tile kt+2 (held tile kt-1: dead)
-            const char* Sw = w_base + ws_cur * W_BYTES;
-            const char* Swn = w_base + ws_n1 * W_BYTES;
-            // cluster 0
-            frag_a(Sa, 1, fa1); frag_w(Sw, 1, fw1);
-            stage_a(kt + 1, 2, 2);
-            mma(fa0, fw0);
-            PE_CLUSTER_SCHED(2);
-            // cluster 1
-            frag_a(Sa, 2, fa0); frag_w(Sw, 2, fw0);
-            stage_w(kt + 2, ws_n2, 0, 2);
-            mma(fa1, fw1);
-            PE_CLUSTER_SCHED(2);
-            // cluster 2
-            frag_a(Sa, 3, fa1); frag_w(Sw, 3, fw1);
-            stage_w(kt + 2, ws_n2, 2, 2);
-            mma(fa0, fw0);
-            PE_CLUSTER_SCHED(2);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // all but the 4 newest (= W(kt+2))
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // cluster 3
-            frag_a(San, 0, fa0); frag_w(Swn, 0, fw0);
-            stage_a(kt + 2, 0, 2);
-            mma(fa1, fw1);
-            PE_CLUSTER_SCHED(2);
-            ws_cur = ws_n1;
-        }
-#undef PE_CLUSTER_SCHED
-#undef PE_SGB
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain every LDS-DMA (incl. the clamped tail tiles) before LDS is reused
@@ -395,7 +242,7 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
     char* E = smem + w * 16384;
     long long* stamp4 = nullptr;
     if constexpr (VAR == 15) stamp4 = args.dbg != nullptr ? args.dbg + (size_t)blockIdx.x * 8 + 4 : nullptr;
-    gemm_epilogue<EPI, FP8, false>(P, M, N, acc, m0, n0, E, E + 8192, lane, w, stamp4, args.direct_epi);
+    gemm_epilogue<EPI, FP8, false, 2, 0, S16 ? 1 : 0>(P, M, N, acc, m0, n0, E, E + 8192, lane, w, stamp4, args.direct_epi);
     PE_STAMP(5);
 }
 
@@ -444,12 +291,14 @@ __device__ __attribute__((noinline)) unsigned sk_take_position(unsigned* sync, u
     return chunk | (idx << 3);
 }
 
-template <int EPI, bool FP8, bool SK, int PH = 2>
+template <int EPI, bool FP8, bool SK, int PH, bool S16>
 __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char* smem) {
+    static_assert(!(FP8 && S16), "the 16 x 16 x 32 shape is the bf16 kernels'");
     constexpr int ES = FP8 ? 1 : 2;
     constexpr int KT_BYTES = 128;
     using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
-    constexpr int KS = FP8 ? 2 : 4;
+    constexpr int KS = FP8 || S16 ? 2 : 4;
+    constexpr int NB = S16 ? 8 : 4;
     constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
     const int w = wave_id();
     const int wm = w >> 1, wn = w & 1;
@@ -523,10 +372,10 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
         int lane_;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
         const int lane = lane_;
-        const int l31 = lane & 31, h = lane >> 5;
-        const int sw = (l31 >> 1) & 7;
-        const int a_off = (wm * 64 + l31) * 128;
-        const int w_off = (wn * 128 + l31) * 128;
+        const int lrow = S16 ? (lane & 15) : (lane & 31), h = S16 ? (lane >> 4) : (lane >> 5);
+        const int sw = (lrow >> 1) & 7;
+        const int a_off = (wm * 64 + lrow) * 128;
+        const int w_off = (wn * 128 + lrow) * 128;
         const TileCoord tc0 = decode_tile(args, cur.tile);
         const KARG GemmProblem& P = args.p[tc0.pi];
         const int M = P.M, N = P.N, K = P.K;
@@ -592,12 +441,13 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
                 const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
                 return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             } else {
-                return *(const bf16x8*)(rowp + (((ks * 2 + h) ^ sw) << 4));
+                return *(const bf16x8*)(rowp + (((ks * (S16 ? 4 : 2) + h) ^ sw) << 4));
             }
         };
 
-        f32x16 acc[2][4];
-        // image of a tile's accumulators in the stream-K workspace: quad j = (mi * 4 + ni) * 4 + q of thread tid at ((j * 512 + tid) * 16
+        AccTile<S16> accT;
+        auto& acc = accT.v;
+        // image of a tile's accumulators in the stream-K workspace: quad j (AccTile::quad) of thread tid at ((j * 512 + tid) * 16
         // bytes: every store / load instruction of a wave covers 1 KiB contiguous
         auto sk_image = [&](int seam) -> char* { return args.sk_part + (size_t)seam * SK_PART_BYTES + (size_t)(w * 64 + lane) * 16; };
         if (sk_consume) {
@@ -611,39 +461,40 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
             __syncthreads();
             const char* img = sk_image(sk_pos - 1);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 v = *(const f32x4*)(img + (size_t)((mi * 4 + ni) * 4 + q4) * (GEMM_THREADS * 16));
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[mi][ni][4 * q4 + r] = v[r];
-                    }
+            for (int j = 0; j < 32; ++j) accT.set_quad(j, *(const f32x4*)(img + (size_t)j * (GEMM_THREADS * 16)));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the main loop counts its own LDS-DMA requests only
         } else {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            for (int j = 0; j < 32; ++j) accT.set_quad(j, f32x4{0.f, 0.f, 0.f, 0.f});
         }
 
-        FragT fa[KS], fw4[4][KS];
+        FragT fa[S16 ? 4 : KS], fw4[NB][KS];
         auto rd_a1 = [&](const char* Sa, int mi) {
+            if constexpr (S16) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) fa[mb * 2 + ks] = rd(Sa + a_off + mi * 4096 + mb * 2048, ks);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
+            }
         };
         auto rd_w4 = [&](const char* Sw) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) fw4[ni][ks] = rd(Sw + w_off + ni * 4096, ks);
+                for (int ks = 0; ks < KS; ++ks) fw4[ni][ks] = rd(Sw + w_off + ni * (S16 ? 2048 : 4096), ks);
         };
-        auto mma16 = [&](int mi) {
+        // the MFMAs of k-step ks of row half mi
+        auto mma_ks = [&](int mi, int ks) __attribute__((always_inline)) {
+            if constexpr (S16) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 8; ++nb)
+                        acc[mi * 2 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw4[nb][ks], fa[mb * 2 + ks], acc[mi * 2 + mb][nb], 0, 0, 0);
+            } else {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     if constexpr (FP8)
@@ -652,6 +503,11 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
                     else
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
                 }
+            }
+        };
+        auto mma16 = [&](int mi) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mma_ks(mi, ks);
         };
 #define PE_MMA16(mi, active)                       \
     do {                                           \
@@ -702,15 +558,15 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        if constexpr (FP8)
-                            acc[0][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw4[ni][ks], fa[ks], acc[0][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                        else
-                            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw4[ni][ks], fa[ks], acc[0][ni], 0, 0, 0);
-                    }
+                    mma_ks(0, ks);
                     __builtin_amdgcn_sched_barrier(0);
-                    fa[ks] = rd(Sa + a_off + 4096, ks);      // row block 1's fragment of this k-step, into the registers just consumed
+                    // row block 1's fragments of this k-step, into the registers just consumed
+                    if constexpr (S16) {
+                        fa[ks] = rd(Sa + a_off + 4096, ks);
+                        fa[2 + ks] = rd(Sa + a_off + 4096 + 2048, ks);
+                    } else {
+                        fa[ks] = rd(Sa + a_off + 4096, ks);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 mma16(1);
@@ -753,20 +609,15 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
             // handoff-flag); the tail's holder acquires and reads them with plain loads
             char* img = sk_image(sk_pos);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 v = {acc[mi][ni][4 * q4], acc[mi][ni][4 * q4 + 1], acc[mi][ni][4 * q4 + 2], acc[mi][ni][4 * q4 + 3]};
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(img + (size_t)((mi * 4 + ni) * 4 + q4) * (GEMM_THREADS * 16)), "v"(v)
-                                     : "memory");
-                    }
+            for (int j = 0; j < 32; ++j) {
+                const f32x4 v = accT.quad(j);
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(img + (size_t)j * (GEMM_THREADS * 16)), "v"(v) : "memory");
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(args.sk_sync + SK_FLAG0 + sk_pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            gemm_epilogue<EPI, FP8, true>(P, M, N, acc, m0, n0, E, E, lane, w, nullptr, args.direct_epi);
+            gemm_epilogue<EPI, FP8, true, 2, 0, S16 ? 1 : 0>(P, M, N, acc, m0, n0, E, E, lane, w, nullptr, args.direct_epi);
         }
         ab = abk;
         ws = wsk;
@@ -775,15 +626,15 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
 #undef PE_BAR
 }
 
-template <int EPI, int VAR, bool FP8>
+template <int EPI, int VAR, bool FP8, bool S16>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_bf16_kernel(const GemmArgs args_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the only kernel argument sits at offset 0 of the kernarg segment
     const KARG GemmArgs& args = *(const KARG GemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (VAR == 17 || VAR == 19 || VAR == 21)
-        gemm_persistent<EPI, FP8, VAR == 19, VAR == 21 ? 1 : 2>(args, smem);
+        gemm_persistent<EPI, FP8, VAR == 19, VAR == 21 ? 1 : 2, S16>(args, smem);
     else
-        gemm_tile<EPI, VAR, FP8>(args, smem, xcd_remap((int)blockIdx.x, (int)gridDim.x));
+        gemm_tile<EPI, VAR, FP8, S16>(args, smem, xcd_remap((int)blockIdx.x, (int)gridDim.x));
 }
 
 static int env_int(const char* name, int dflt) {
@@ -794,6 +645,8 @@ int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_skip_ragged = env_int("PE_GEMM_SKIP_RAGGED", 1);
 int g_gemm_direct_epi = env_int("PE_GEMM_DIRECT_EPILOGUE", 1);
+// bf16 MFMA shape of the 8-wave schedules: 1 = v_mfma_f32_16x16x32_bf16 (default since round 5), 0 = 32x32x16 (schedules 15 / 17 only: the A/B)
+int g_gemm_mfma16 = env_int("PE_GEMM_MFMA16", 1);
 int g_gemm_persist_wgs = 0;    // 0 = one work-group per CU of the current device
 int g_gemm_sk = env_int("PE_GEMM_SK", 0);     // schedule 19 where it applies (A/B knob "gemm_sk"; measured slower: profiles/r04_gemm_notes.md)
 // schedule 17 from this many rounds of tiles on (knob "gemm_persist_min_rounds"; G + 1 tiles at least).  Round 3 used 3: in isolation
@@ -821,24 +674,24 @@ static int persistent_grid() {
 
 size_t gemm_workspace_bytes() { return SK_SYNC_BYTES + (size_t)persistent_grid() * SK_PART_BYTES; }
 
-template <int EPI, int VAR, bool FP8 = false>
+template <int EPI, int VAR, bool FP8 = false, bool S16 = !FP8>
 static int launch_v(const GemmArgs& args, int grid, hipStream_t stream) {
     static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
     if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, VAR, FP8>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, VAR, FP8, S16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR, FP8>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, stream, args);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, VAR, FP8, S16>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, stream, args);
     return check_launch(FP8 ? "gemm_fp8_kernel" : "gemm_bf16_kernel");
 }
 
 template <int EPI>
 static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     // instantiated schedules: 17 (default: persistent work-groups; needs more than one round of tiles), 15 (one tile per
-    // work-group: the round-2 default, what 17 falls back to, and the one that can write s_memtime stamps), 10 (the round-1
-    // schedule, kept as the A/B reference).  Everything else that was tried is in profiles/r0*_gemm_*.md.
+    // work-group: the round-2 default, what 17 falls back to, and the one that can write s_memtime stamps).  (10, the round-1
+    // schedule, left the library in round 5.)  Everything else that was tried is in profiles/r0*_gemm_*.md.
     const int ntiles = args.ntiles;
     int var = g_gemm_variant;
     const int G = persistent_grid();
@@ -859,12 +712,14 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     // in the two-stream pipeline it also pays at 1.6 rounds: g_gemm_persist_min_rounds above); "gemm_persist_wgs" > 0 forces it
     if ((var == 17 || var == 21) && ntiles < (g_gemm_persist_wgs > 0 || g_gemm_persist_min_rounds <= 1 ? G + 1 : g_gemm_persist_min_rounds * G)) var = 15;
     if (fp8) {
-        if (var == 10) return launch_v<EPI, 10, true>(args, ntiles, stream);
         if (var == 17) return launch_v<EPI, 17, true>(args, G, stream);
         if (var == 21) return launch_v<EPI, 21, true>(args, G, stream);
         return launch_v<EPI, 15, true>(args, ntiles, stream);
     }
-    if (var == 10) return launch_v<EPI, 10>(args, ntiles, stream);
+    if (g_gemm_mfma16 == 0) {      // the round-4 shape, schedules 15 / 17 (A/B reference)
+        if (var == 17 || var == 21) return launch_v<EPI, 17, false, false>(args, G, stream);
+        return launch_v<EPI, 15, false, false>(args, ntiles, stream);
+    }
     if (var == 17) return launch_v<EPI, 17>(args, G, stream);
     if (var == 21) return launch_v<EPI, 21>(args, G, stream);
     return launch_v<EPI, 15>(args, ntiles, stream);
@@ -872,7 +727,7 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
 
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace) {
     PE_REQUIRE(nproblems >= 1 && nproblems <= 2, "gemm: 1 or 2 problems per launch, got %d", nproblems);
-    PE_REQUIRE(g_gemm_variant == 10 || g_gemm_variant == 15 || g_gemm_variant == 17 || g_gemm_variant == 19 || g_gemm_variant == 21 || g_gemm_variant == 22,
+    PE_REQUIRE(g_gemm_variant == 15 || g_gemm_variant == 17 || g_gemm_variant == 19 || g_gemm_variant == 21 || g_gemm_variant == 22,
                "gemm: gemm_variant %d does not exist",
                g_gemm_variant);
     PE_REQUIRE(g_gemm_band >= 1 && g_gemm_band <= 64, "gemm: gemm_band %d out of range", g_gemm_band);

@@ -117,12 +117,18 @@ PE_DEV float row16_sum(float v) {
     return v;
 }
 
-template <int EPI, bool FP8, bool TWO_PASS, bool FAST, int NMI = 2, int MI0 = 0>
-__device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, const int M, const int N, const f32x16 (&acc)[NMI][4], int m0, int n0,
+// LAY: the accumulator layout.  0: 2 x 4 blocks of v_mfma 32 x 32 (e4m3, and the four-wave schedule): acc[mi][ni][4 q + r] as above.
+// 1 (bf16 since round 5): 4 x 8 blocks of v_mfma_f32_16x16x32_bf16: acc[mb][nb][r] = C[m0 + wm*64 + mb*16 + (lane & 15)][n0 + wn*128 + nb*16 +
+// 4 (lane >> 4) + r].  Both are 16 chunks of 4 columns per lane and 32-row half (k = 4 ni + q, resp. 8 (mb & 1) + nb); only where a chunk
+// comes from and where it lands in the staged image differs.
+template <int EPI, bool FP8, bool TWO_PASS, bool FAST, int NMI = 2, int MI0 = 0, int LAY = 0, typename ACC>
+__device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, const int M, const int N, const ACC& acc, int m0, int n0,
                                                    char* E0, char* E1, int lane, int w, long long* stamp4) {
     // NMI / MI0: the accumulator array holds NMI 32-row blocks, this call emits blocks MI0, MI0 + 1 as the 64 x 128 block of (virtual)
     // wave `w` (the 4-wave kernel's 128 x 128 wave tile is two such calls)
+    static_assert(LAY == 0 || (!FP8 && NMI == 2 && MI0 == 0), "layout 1 is the 8-wave bf16 kernels'");
     const int l31 = lane & 31, h = lane >> 5;
+    const int l15 = lane & 15, g4 = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
     auto unswap = [](bf16x8 v, int row) -> bf16x8 {
         return (row & 8) ? __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3) : v;
@@ -140,7 +146,16 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
     // bias first, then (EPI_GATE_RES) all 16 residual rows of this lane: 16-B loads that stay in flight under the LDS
     // staging below (issued 4 at a time inside the store loop they cost 15-21k cycles of exposed latency)
     bf16x4 bvs[16];
-    if constexpr (FAST) {
+    if constexpr (LAY == 1) {
+        // the lane's 4 columns of each of the 8 column blocks
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bvs[i] = bf16x4{0, 0, 0, 0};
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const int n = nw0 + nb * 16 + 4 * g4;
+            if (bias != nullptr && (FAST || n < N)) bvs[nb] = *(const bf16x4*)(bias + n);
+        }
+    } else if constexpr (FAST) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) bvs[i] = bf16x4{0, 0, 0, 0};
         if (bias != nullptr) {      // one wave-uniform branch for the 16 loads
@@ -178,21 +193,34 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
         const int n = nw0 + (lane & 15) * 8;
         if (P.gate != nullptr && (FAST || n < N)) gate_v = *(const bf16x8*)((const bf16*)P.gate + n);
     }
-    // y = bf16(acc + bias) (+ pre) of the lane's four columns 8q + 4h .. + 3 of block ni, row half mi
-    auto y_chunk = [&](int mi, int ni, int q) __attribute__((always_inline)) -> bf16x4 {
-        const int n = nw0 + ni * 32 + 8 * q + 4 * h;
+    // y = bf16(acc + bias) (+ pre) of chunk k (0 .. 15) of row half mi: the lane's four columns 8q + 4h .. + 3 of block ni (k = 4 ni + q),
+    // resp. 4 g4 .. + 3 of column block nb in row block 2 mi + mb (k = 8 mb + nb)
+    auto y_chunk = [&](int mi, int k) __attribute__((always_inline)) -> bf16x4 {
+        int n, row;
         float b[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = (float)bvs[ni * 4 + q][r];
         bf16x4 y;
-        if constexpr (FP8) {
+        if constexpr (LAY == 1) {
+            const int mb = k >> 3, nb = k & 7;
+            n = nw0 + nb * 16 + 4 * g4;
+            row = mi * 32 + mb * 16 + l15;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[MI0 + mi][ni][4 * q + r] * sa[mi] + b[r]);
+            for (int r = 0; r < 4; ++r) b[r] = (float)bvs[nb][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi * 2 + mb][nb][r] + b[r]);
         } else {
+            const int ni = k >> 2, q = k & 3;
+            n = nw0 + ni * 32 + 8 * q + 4 * h;
+            row = mi * 32 + l31;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[MI0 + mi][ni][4 * q + r] + b[r]);
+            for (int r = 0; r < 4; ++r) b[r] = (float)bvs[k][r];
+            if constexpr (FP8) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[MI0 + mi][ni][4 * q + r] * sa[mi] + b[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[MI0 + mi][ni][4 * q + r] + b[r]);
+            }
         }
-        const int row = mi * 32 + l31;
         if (!FAST && pre != nullptr && n < N && mw0 + row < M) {
             // y = pre + y : the linear's own (already rounded) output plus this low-rank product
             const bf16x4 pv = *(const bf16x4*)(pre + (size_t)(mw0 + row) * P.ldp + n);
@@ -208,29 +236,27 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
     bf16x4 ypk[PACK_FIRST ? 2 : 1][PACK_FIRST ? 16 : 1];
     if constexpr (PACK_FIRST) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int k = 0; k < 16; ++k)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) ypk[mi][ni * 4 + q] = y_chunk(mi, ni, q);
+            for (int mi = 0; mi < 2; ++mi) ypk[mi][k] = y_chunk(mi, k);
     }
-    // the row halves [mi_lo, mi_hi) -> LDS
+    // the row halves [mi_lo, mi_hi) -> LDS: chunk k of local row lrow = columns 8 c + 4 hs .. + 3 of the staged image
     auto stage_rows = [&](int mi_lo, int mi_hi) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int k = 0; k < 16; ++k) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    if (mi < mi_lo || mi >= mi_hi) continue;
-                    const int c = ni * 4 + q;
-                    bf16x4 y;
-                    if constexpr (PACK_FIRST) y = ypk[mi][c];
-                    else y = y_chunk(mi, ni, q);
-                    char* Eb = mi == 0 ? E0 : E1;
-                    *(bf16x4*)(Eb + l31 * 256 + ((c ^ (l31 & 15)) << 4) + ((h ^ ((l31 >> 3) & 1)) << 3)) = y;
-                }
+            for (int mi = 0; mi < 2; ++mi) {
+                if (mi < mi_lo || mi >= mi_hi) continue;
+                bf16x4 y;
+                if constexpr (PACK_FIRST) y = ypk[mi][k];
+                else y = y_chunk(mi, k);
+                char* Eb = mi == 0 ? E0 : E1;
+                const int lrow = LAY == 1 ? (k >> 3) * 16 + l15 : l31;
+                const int c = LAY == 1 ? (k & 7) * 2 + (g4 >> 1) : k;
+                const int hs = LAY == 1 ? (g4 & 1) : h;
+                *(bf16x4*)(Eb + lrow * 256 + ((c ^ (lrow & 15)) << 4) + ((hs ^ ((lrow >> 3) & 1)) << 3)) = y;
             }
+        }
     };
 
     // the lane's 8 rows of the staged half `mi` (one 16-B chunk = 8 consecutive columns of each)
@@ -482,8 +508,130 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
 template <int EPI>
 constexpr bool kDirectEpi = EPI == EPI_GELU_SIG || EPI == EPI_GATE_RES;      // (bias only: measured 1 % slower bf16, 4.6 % slower e4m3 than the LDS form)
 
-template <int EPI, bool FP8, int NMI = 2, int MI0 = 0>
-__device__ __forceinline__ void gemm_epilogue_direct(const KARG GemmProblem& P, const f32x16 (&acc)[NMI][4], int m0, int n0, int lane, int w) {
+// the epilogue proper of 8 consecutive columns of one row (bf16 pairs vp -> op), shared by both layouts of the direct form
+template <int EPI, bool FP8>
+__device__ __forceinline__ u32x4 direct_epi_math(const KARG GemmProblem& P, u32x4 vp, u32x4 rp, const f32x2 (&g2)[4], int m, int n) {
+    u32x4 op;
+    if constexpr (EPI == EPI_BIAS) {
+        op = vp;
+    } else if constexpr (EPI == EPI_GELU_SIG) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x2 y = up2(vp[jj]);
+            const f32x2 t = rnd2(f32x2{1.702f, 1.702f} * y);
+            const f32x2 a = t * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+            const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + f32x2{1.0f, 1.0f};
+            const f32x2 sg = rnd2(f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)});
+            op[jj] = pk2(y * sg);
+        }
+        if constexpr (FP8) {
+            if (P.q8_out != nullptr) {
+                const bf16x8 o = __builtin_bit_cast(bf16x8, op);
+                float f[8];
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[e] = (float)o[e];
+                    amax = fmaxf(amax, fabsf(f[e]));
+                }
+                u32x2 pk;
+                pk[0] = pack4_e4m3(f[0], f[1], f[2], f[3]);
+                pk[1] = pack4_e4m3(f[4], f[5], f[6], f[7]);
+                *(u32x2*)((uint8_t*)P.q8_out + (size_t)m * P.ldq8 + n) = pk;
+                if (amax > 447.0f) atomicOr(P.q8_flags + m, 1u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) op[jj] = pk2(up2(rp[jj]) + rnd2(g2[jj] * up2(vp[jj])));
+    }
+    return op;
+}
+
+// Layout 1 (16 x 16 blocks): a row's 16 columns of a block sit in FOUR lanes (l, l + 16, l + 32, l + 48), 4 columns each.  One
+// v_permlane16_swap per dword on the column-block pairs (nb, nb + 1) -- odd 16-lane rows of block nb <-> even rows of block nb + 1 -- leaves
+// 8 consecutive columns in every lane: lane group g holds columns 8 (g >> 1) .. + 7 of block nb + (g & 1); a store instruction covers
+// 16 rows x 64 contiguous bytes.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_direct16(const KARG GemmProblem& P, const f32x4 (&acc)[4][8], int m0, int n0, int lane, int w) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int nw0 = n0 + wn * 128, mw0 = m0 + wm * 64;
+    const bf16* bias = (const bf16*)P.bias;
+    bf16x4 bvs[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) bvs[nb] = bf16x4{0, 0, 0, 0};
+    if (bias != nullptr) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) bvs[nb] = *(const bf16x4*)(bias + nw0 + nb * 16 + 4 * g4);
+    }
+    // the lane's store position inside a (row block mb, column-block pair p): row mb * 16 + l15, columns (2 p + (g4 & 1)) * 16 + 8 (g4 >> 1)
+    const int ncol = (g4 & 1) * 16 + 8 * (g4 >> 1);
+    // residual rows in the STORE layout; row blocks 0, 1 are requested here, 2, 3 once the accumulators are dead (register budget)
+    u32x4 rv[EPI == EPI_GATE_RES ? 16 : 1];
+    const bf16* rl = nullptr;
+    if constexpr (EPI == EPI_GATE_RES) {
+        rl = (const bf16*)P.res + (size_t)(mw0 + l15) * P.ldr + nw0 + ncol;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) rv[mb * 4 + p_] = *(const u32x4*)(rl + (size_t)(mb * 16) * P.ldr + p_ * 32);
+    }
+    uint32_t yp[4][8][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const bf16x4 b4 = bvs[nb];
+            yp[mb][nb][0] = pk2(f32x2{acc[mb][nb][0] + (float)b4[0], acc[mb][nb][1] + (float)b4[1]});
+            yp[mb][nb][1] = pk2(f32x2{acc[mb][nb][2] + (float)b4[2], acc[mb][nb][3] + (float)b4[3]});
+        }
+    if constexpr (EPI == EPI_GATE_RES) {
+#pragma unroll
+        for (int mb = 2; mb < 4; ++mb)
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) rv[mb * 4 + p_] = *(const u32x4*)(rl + (size_t)(mb * 16) * P.ldr + p_ * 32);
+    }
+    bf16* out = (bf16*)P.out;
+    const float gs = (EPI == EPI_GATE_RES && P.has_gate_scalar) ? P.gate_scalar : 1.0f;
+    // the gate vector of the lane's 4 x 8 columns (same for every row block)
+    u32x4 gv[EPI == EPI_GATE_RES ? 4 : 1];
+    bool has_gate = false;
+    if constexpr (EPI == EPI_GATE_RES) {
+        has_gate = P.gate != nullptr;
+        if (has_gate) {
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) gv[p_] = *(const u32x4*)((const bf16*)P.gate + nw0 + p_ * 32 + ncol);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            const int n = nw0 + p_ * 32 + ncol;
+            const int m = mw0 + mb * 16 + l15;
+            const auto s0 = __builtin_amdgcn_permlane16_swap(yp[mb][2 * p_][0], yp[mb][2 * p_ + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(yp[mb][2 * p_][1], yp[mb][2 * p_ + 1][1], false, false);
+            const u32x4 vp = {s0[0], s1[0], s0[1], s1[1]};
+            f32x2 g2[4] = {f32x2{gs, gs}, f32x2{gs, gs}, f32x2{gs, gs}, f32x2{gs, gs}};
+            u32x4 rp = {0, 0, 0, 0};
+            if constexpr (EPI == EPI_GATE_RES) {
+                if (has_gate) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) g2[jj] = up2(gv[p_][jj]);
+                }
+                rp = rv[mb * 4 + p_];
+            }
+            *(u32x4*)(out + (size_t)m * P.ldo + n) = direct_epi_math<EPI, false>(P, vp, rp, g2, m, n);
+        }
+}
+
+template <int EPI, bool FP8, int NMI = 2, int MI0 = 0, int LAY = 0, typename ACC>
+__device__ __forceinline__ void gemm_epilogue_direct(const KARG GemmProblem& P, const ACC& acc, int m0, int n0, int lane, int w) {
+    if constexpr (LAY == 1) {
+        gemm_epilogue_direct16<EPI>(P, acc, m0, n0, lane, w);
+        return;
+    } else {
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
     const int nw0 = n0 + wn * 128, mw0 = m0 + wm * 64;
@@ -595,22 +743,22 @@ __device__ __forceinline__ void gemm_epilogue_direct(const KARG GemmProblem& P, 
                 }
                 *(u32x4*)(out + (size_t)m * P.ldo + n) = op;
             }
+    }
 }
 
-template <int EPI, bool FP8, bool TWO_PASS, int NMI = 2, int MI0 = 0>
-__device__ __forceinline__ void gemm_epilogue(const KARG GemmProblem& P, const int M, const int N, const f32x16 (&acc)[NMI][4], int m0, int n0,
+template <int EPI, bool FP8, bool TWO_PASS, int NMI = 2, int MI0 = 0, int LAY = 0, typename ACC>
+__device__ __forceinline__ void gemm_epilogue(const KARG GemmProblem& P, const int M, const int N, const ACC& acc, int m0, int n0,
                                               char* E0, char* E1, int lane, int w, long long* stamp4, int direct = 0) {
     if constexpr (kDirectEpi<EPI>) {
         if (direct && m0 + BM <= M && n0 + BN <= N && P.pre == nullptr) {      // wave-uniform
-            gemm_epilogue_direct<EPI, FP8, NMI, MI0>(P, acc, m0, n0, lane, w);
+            gemm_epilogue_direct<EPI, FP8, NMI, MI0, LAY>(P, acc, m0, n0, lane, w);
             return;
         }
     }
     if (m0 + BM <= M && n0 + BN <= N && P.pre == nullptr)      // wave-uniform
-        gemm_epilogue_body<EPI, FP8, TWO_PASS, true, NMI, MI0>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
+        gemm_epilogue_body<EPI, FP8, TWO_PASS, true, NMI, MI0, LAY>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
     else
-        gemm_epilogue_body<EPI, FP8, TWO_PASS, false, NMI, MI0>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
+        gemm_epilogue_body<EPI, FP8, TWO_PASS, false, NMI, MI0, LAY>(P, M, N, acc, m0, n0, E0, E1, lane, w, stamp4);
 }
-
 
 }  // namespace pe

@@ -68,7 +68,7 @@ struct GemmWorkspace {
 };
 size_t gemm_workspace_bytes();
 extern GemmWorkspace g_gemm_ws;
-extern int g_gemm_sk, g_gemm_persist_min_rounds, g_gemm4_x, g_gemm_skip_ragged, g_gemm_direct_epi;
+extern int g_gemm_sk, g_gemm_persist_min_rounds, g_gemm4_x, g_gemm_skip_ragged, g_gemm_direct_epi, g_gemm_mfma16;
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace = nullptr);
 extern int g_gemm_band;          // M tiles per band of the tile order (default 4)
 extern int g_gemm_persist_wgs;   // schedule 17: work-groups of the persistent grid (0 = one per CU)

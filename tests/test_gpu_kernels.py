@@ -127,6 +127,9 @@ def test_gemm_round5_schedules_bit_identical(ops, var):
     ragged / tiny / multi-round shapes, a short race screen."""
     from physicedit_amd._lib import lib
     try:
+        # the four-wave kernel keeps the 32 x 32 x 16 MFMA (another summation order inside a K tile than the 16 x 16 x 32 the eight-wave
+        # schedules use since round 5): its reference is schedule 15 in that shape
+        assert lib().pe_debug_set(b"gemm_mfma16", 0 if var == 22 else 1) == 0
         for (M, N, K) in ((300, 3072, 3072), (257, 264, 64), (272, 3072, 12288), (1, 3072, 256), (8704, 3072, 3072), (2100, 12288, 3072)):
             x, w, b = rnd((M, K), 1).cuda(), rnd((N, K), 2, K ** -0.5).cuda(), rnd((N,), 3, 0.1).cuda()
             gate, res = rnd((N,), 7, 0.5).cuda(), rnd((M, N), 8).cuda()
@@ -159,6 +162,42 @@ def test_gemm_round5_schedules_bit_identical(ops, var):
                 assert torch.equal(a, ops.gemm_e4m3(xq, sc, w8, b, epi)), (M, N, K, epi)
     finally:
         lib().pe_debug_set(b"gemm_variant", 17)
+        lib().pe_debug_set(b"gemm_mfma16", 1)
+
+
+def test_gemm_mfma_shapes_agree(ops):
+    """The bf16 GEMM's two MFMA shapes (round 5: v_mfma_f32_16x16x32_bf16 by default, 32x32x16 behind "gemm_mfma16" = 0) accumulate a K tile's
+    products in different orders: not bit-identical, but the same distance from the fp64 result -- and for each shape schedules 15 and 17 are
+    bit-identical with each other, LDS and direct epilogue alike."""
+    from physicedit_amd._lib import lib
+    try:
+        for (M, N, K) in ((2300, 3072, 3072), (300, 3072, 12288), (257, 264, 64)):
+            x, w, b = rnd((M, K), 1).cuda(), rnd((N, K), 2, K ** -0.5).cuda(), rnd((N,), 3, 0.1).cuda()
+            gate, res = rnd((N,), 7, 0.5).cuda(), rnd((M, N), 8).cuda()
+            ref = (x.double() @ w.double().T + b.double())
+            for epi in ("bias", "gate_res", "gelu_sigmoid"):
+                kw = dict(gate=gate, res=res) if epi == "gate_res" else {}
+                outs = {}
+                for shape in (1, 0):
+                    assert lib().pe_debug_set(b"gemm_mfma16", shape) == 0
+                    for var in (15, 17):
+                        assert lib().pe_debug_set(b"gemm_variant", var) == 0
+                        for direct in (1, 0):
+                            assert lib().pe_debug_set(b"gemm_direct_epilogue", direct) == 0
+                            o = ops.gemm(x, w, b, epi, **kw)
+                            assert torch.equal(outs.setdefault(shape, o), o), (M, N, K, epi, shape, var, direct)
+                if epi == "bias":
+                    e16 = (outs[1].double() - ref).abs().mean().item()
+                    e32 = (outs[0].double() - ref).abs().mean().item()
+                    assert abs(e16 - e32) <= 0.02 * e32, (e16, e32)          # both are the bf16 rounding of the same fp32-accurate sum
+                d = (outs[1].float() - outs[0].float()).abs()
+                frac = (d == 0).float().mean().item()
+                assert frac >= 0.97, (M, N, K, epi, frac)                     # they differ where the fp32 sums straddle a bf16 rounding boundary
+                assert d.max().item() <= 2.0 ** -6 * max(1.0, outs[0].float().abs().max().item()), (M, N, K, epi)
+    finally:
+        lib().pe_debug_set(b"gemm_variant", 17)
+        lib().pe_debug_set(b"gemm_mfma16", 1)
+        lib().pe_debug_set(b"gemm_direct_epilogue", 1)
 
 
 @pytest.mark.parametrize("var", [15, 17, 22])

@@ -99,6 +99,87 @@ __global__ void __launch_bounds__(512, 2) probe8(const char* __restrict__ src, u
     out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// ---------------------------------------------------------------- 8 waves x 64 x 128 on v_mfma_f32_16x16x32_bf16 (4 x 8 blocks of 16 x 16, two
+// k-steps of 32 per K tile: the same 24 fragment reads and 8 LDS-DMA pieces per K tile and wave, 64 MFMAs of 4 passes instead of 32 of 8)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) probe8s(const char* __restrict__ src, unsigned window_bytes, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int sw = (l15 >> 1) & 7;
+    const char* win = src + (size_t)(blockIdx.x & 7) * window_bytes;
+    const unsigned wmask = window_bytes - 1u;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    for (int i = 0; i < 20; ++i) {
+        const unsigned piece = (unsigned)(w * 20 + i);
+        glds16(win + ((piece * 1024u + lane_off) & wmask), smem + piece * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 acc[4][8];
+    for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 8; ++ni)
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+    const int a_off = (wm * 64 + l15) * 128;
+    const int w_off = (wn * 128 + l15) * 128;
+    char* const a_base = smem;
+    char* const w_base = smem + 2 * 32768;
+    bf16x8 fa[2][2], fw[8][2];       // one 32-row phase: 2 activation blocks x 2 k-steps, 8 weight blocks x 2 k-steps
+    for (int ks = 0; ks < 2; ++ks) {
+        for (int mi = 0; mi < 2; ++mi) fa[mi][ks] = *(const bf16x8*)(a_base + a_off + mi * 2048 + (((ks * 4 + g) ^ sw) << 4));
+        for (int ni = 0; ni < 8; ++ni) fw[ni][ks] = *(const bf16x8*)(w_base + w_off + ni * 2048 + (((ks * 4 + g) ^ sw) << 4));
+    }
+    unsigned stream_off = (unsigned)blockIdx.x * 65536u + (unsigned)w * 8192u;
+    int ab = 0, ws = 0;
+    for (int it = 0; it < iters; ++it) {
+        const char* Sa = a_base + ab * 32768;
+        const char* Sw = w_base + ws * 32768;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if constexpr (MODE >= 1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) fa[mi][ks] = *(const bf16x8*)(Sa + a_off + (ph * 2 + mi) * 2048 + (((ks * 4 + g) ^ sw) << 4));
+                if (ph == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) fw[ni][ks] = *(const bf16x8*)(Sw + w_off + ni * 2048 + (((ks * 4 + g) ^ sw) << 4));
+                }
+            }
+            if constexpr (MODE >= 2) {
+                char* dst = ph == 0 ? a_base + (ab ^ 1) * 32768 + w * 4096 : w_base + ((ws + 2) % 3) * 32768 + w * 4096;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    glds16(win + ((stream_off + lane_off) & wmask), dst + j * 1024);
+                    stream_off += 1024u;
+                }
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 8; ++ni)
+                        acc[ph * 2 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni][ks], fa[mi][ks], acc[ph * 2 + mi][ni], 0, 0, 0);
+        }
+        stream_off += 65536u - 8192u;
+        ab ^= 1;
+        ws = ws == 2 ? 0 : ws + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+    for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 8; ++ni)
+            for (int r = 0; r < 4; ++r) s += acc[mi][ni][r];
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 // ---------------------------------------------------------------- 4 waves x 128 x 128, one wave per SIMD
 // Per K tile and wave: 64 MFMAs (4 x 4 blocks x 4 k-steps), 32 ds_read_b128 (4 activation + 4 weight fragments per k-step, read one
 // k-step ahead into the other register set), 16 LDS-DMA pieces.  The interleave inside a k-step is pinned: 8 x (MFMA, read),
@@ -257,13 +338,16 @@ int main(int argc, char** argv) {
     const double f8 = 8.0 * 32.0 * (2.0 * 32 * 32 * 16), f4 = 4.0 * 64.0 * (2.0 * 32 * 32 * 16);   // per K tile and work-group: the same 256 MFMAs
     printf("mode                                         N(0,1) TF/s   zeros TF/s\n");
     struct Row { const char* name; double r, z; };
-    Row rows[6];
+    Row rows[9];
     rows[0] = {"8 waves x 64x128: MFMA only", run(probe8<0>, 512, drand, window, out, iters, f8), run(probe8<0>, 512, dzero, window, out, iters, f8)};
     rows[1] = {"8 waves x 64x128: + 0.75 ds_read_b128 / MFMA", run(probe8<1>, 512, drand, window, out, iters, f8), run(probe8<1>, 512, dzero, window, out, iters, f8)};
     rows[2] = {"8 waves x 64x128: + LDS-DMA stream", run(probe8<2>, 512, drand, window, out, iters, f8), run(probe8<2>, 512, dzero, window, out, iters, f8)};
     rows[3] = {"4 waves x 128x128: MFMA only", run(probe4<0>, 256, drand, window, out, iters, f4), run(probe4<0>, 256, dzero, window, out, iters, f4)};
     rows[4] = {"4 waves x 128x128: + 0.5 ds_read_b128 / MFMA", run(probe4<1>, 256, drand, window, out, iters, f4), run(probe4<1>, 256, dzero, window, out, iters, f4)};
     rows[5] = {"4 waves x 128x128: + LDS-DMA stream", run(probe4<2>, 256, drand, window, out, iters, f4), run(probe4<2>, 256, dzero, window, out, iters, f4)};
+    rows[6] = {"8 waves, 16x16x32 MFMA: MFMA only", run(probe8s<0>, 512, drand, window, out, iters, f8), run(probe8s<0>, 512, dzero, window, out, iters, f8)};
+    rows[7] = {"8 waves, 16x16x32 MFMA: + 0.375 ds_read_b128 / MFMA", run(probe8s<1>, 512, drand, window, out, iters, f8), run(probe8s<1>, 512, dzero, window, out, iters, f8)};
+    rows[8] = {"8 waves, 16x16x32 MFMA: + LDS-DMA stream", run(probe8s<2>, 512, drand, window, out, iters, f8), run(probe8s<2>, 512, dzero, window, out, iters, f8)};
     for (const Row& r : rows) printf("%-46s %8.0f %12.0f\n", r.name, r.r, r.z);
     return 0;
 }
