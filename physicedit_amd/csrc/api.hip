@@ -40,7 +40,7 @@ const char* pe_build_id(void) { return PE_SRC_HASH; }
 
 int pe_debug_set(const char* key, int value) {
     PE_REQUIRE(key != nullptr, "pe_debug_set: null key");
-    if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return PE_OK; }
+    if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value == 0 ? GEMM_DEFAULT_VARIANT : value; return PE_OK; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
     if (!strcmp(key, "attn_fp8_variant")) { PE_REQUIRE(value >= 0 && value <= 2, "attn_fp8_variant: 0, 1 or 2"); g_attn_fp8_variant = value; return PE_OK; }
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return PE_OK; }

@@ -56,7 +56,6 @@ struct AccTile {
 template <int EPI, int VAR, bool FP8, bool S16>
 __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem, int bid) {
     static_assert(VAR == 15, "unknown GEMM schedule");
-    static_assert(!(FP8 && S16), "the 16 x 16 x 32 shape is the bf16 kernels'");
     constexpr int ES = FP8 ? 1 : 2;        // bytes per operand element
     constexpr int KT_BYTES = 128;          // one K tile of a row, in bytes (64 bf16 / 128 e4m3)
     const int lane = lane_id();
@@ -115,7 +114,7 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
         // p0 of tile kt-1, i.e. >= 4 barriers earlier.  RAW: vmcnt(4) in p1 retires A(kt+1), W(kt+1); both groups
         // pass a barrier between that wait and the first read of tile kt+1.
         using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
-        constexpr int KS = FP8 || S16 ? 2 : 4;     // MFMA k-steps per K tile
+        constexpr int KS = (FP8 ? 2 : 4) / (S16 ? 2 : 1);     // MFMA k-steps per K tile
         constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
         char* const a_base = smem;
         char* const w_base = smem + 2 * A_BYTES;
@@ -124,7 +123,7 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
         const int w_off = (wn * 128 + lrow) * 128;
         auto rd = [&](const char* rowp, int ks) -> FragT {
             if constexpr (FP8) {
-                const int c0 = 4 * ks + 2 * h;
+                const int c0 = (S16 ? 8 : 4) * ks + 2 * h;
                 const i32x4 lo = *(const i32x4*)(rowp + ((c0 ^ sw) << 4));
                 const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
                 return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -141,13 +140,13 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
         // fragments of one phase (32 rows of the wave's block x its 128 columns x the K tile): 4 of A and 16 of W in either bf16 shape
         // (32 x 32: fa[ks], fw[ni][ks]; 16 x 16: fa[mb * 2 + ks], fw[nb][ks])
         constexpr int NB = S16 ? 8 : 4;            // column blocks of the wave
-        FragT fa[S16 ? 4 : KS], fw4[NB][KS];
+        FragT fa[S16 ? 2 * KS : KS], fw4[NB][KS];
         auto rd_a1 = [&](const char* Sa, int mi) {
             if constexpr (S16) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) fa[mb * 2 + ks] = rd(Sa + a_off + mi * 4096 + mb * 2048, ks);
+                    for (int ks = 0; ks < KS; ++ks) fa[mb * KS + ks] = rd(Sa + a_off + mi * 4096 + mb * 2048, ks);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
@@ -166,8 +165,13 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < 8; ++nb)
-                            acc[mi * 2 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw4[nb][ks], fa[mb * 2 + ks], acc[mi * 2 + mb][nb], 0, 0, 0);
+                        for (int nb = 0; nb < 8; ++nb) {
+                            if constexpr (FP8)
+                                acc[mi * 2 + mb][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                                    fw4[nb][ks], fa[mb * KS + ks], acc[mi * 2 + mb][nb], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                            else
+                                acc[mi * 2 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw4[nb][ks], fa[mb * KS + ks], acc[mi * 2 + mb][nb], 0, 0, 0);
+                        }
                 } else {
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
@@ -293,11 +297,10 @@ __device__ __attribute__((noinline)) unsigned sk_take_position(unsigned* sync, u
 
 template <int EPI, bool FP8, bool SK, int PH, bool S16>
 __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char* smem) {
-    static_assert(!(FP8 && S16), "the 16 x 16 x 32 shape is the bf16 kernels'");
     constexpr int ES = FP8 ? 1 : 2;
     constexpr int KT_BYTES = 128;
     using FragT = typename std::conditional<FP8, i32x8, bf16x8>::type;
-    constexpr int KS = FP8 || S16 ? 2 : 4;
+    constexpr int KS = (FP8 ? 2 : 4) / (S16 ? 2 : 1);
     constexpr int NB = S16 ? 8 : 4;
     constexpr int A_BYTES = BM * KT_BYTES, W_BYTES = BN * KT_BYTES;
     const int w = wave_id();
@@ -436,7 +439,7 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
         };
         auto rd = [&](const char* rowp, int ks) -> FragT {
             if constexpr (FP8) {
-                const int c0 = 4 * ks + 2 * h;
+                const int c0 = (S16 ? 8 : 4) * ks + 2 * h;
                 const i32x4 lo = *(const i32x4*)(rowp + ((c0 ^ sw) << 4));
                 const i32x4 hi = *(const i32x4*)(rowp + (((c0 + 1) ^ sw) << 4));
                 return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -468,13 +471,13 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
             for (int j = 0; j < 32; ++j) accT.set_quad(j, f32x4{0.f, 0.f, 0.f, 0.f});
         }
 
-        FragT fa[S16 ? 4 : KS], fw4[NB][KS];
+        FragT fa[S16 ? 2 * KS : KS], fw4[NB][KS];
         auto rd_a1 = [&](const char* Sa, int mi) {
             if constexpr (S16) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) fa[mb * 2 + ks] = rd(Sa + a_off + mi * 4096 + mb * 2048, ks);
+                    for (int ks = 0; ks < KS; ++ks) fa[mb * KS + ks] = rd(Sa + a_off + mi * 4096 + mb * 2048, ks);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) fa[ks] = rd(Sa + a_off + mi * 4096, ks);
@@ -492,8 +495,13 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < 8; ++nb)
-                        acc[mi * 2 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw4[nb][ks], fa[mb * 2 + ks], acc[mi * 2 + mb][nb], 0, 0, 0);
+                    for (int nb = 0; nb < 8; ++nb) {
+                        if constexpr (FP8)
+                            acc[mi * 2 + mb][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                                fw4[nb][ks], fa[mb * KS + ks], acc[mi * 2 + mb][nb], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                        else
+                            acc[mi * 2 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw4[nb][ks], fa[mb * KS + ks], acc[mi * 2 + mb][nb], 0, 0, 0);
+                    }
             } else {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
@@ -563,7 +571,7 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
                     // row block 1's fragments of this k-step, into the registers just consumed
                     if constexpr (S16) {
                         fa[ks] = rd(Sa + a_off + 4096, ks);
-                        fa[2 + ks] = rd(Sa + a_off + 4096 + 2048, ks);
+                        fa[KS + ks] = rd(Sa + a_off + 4096 + 2048, ks);
                     } else {
                         fa[ks] = rd(Sa + a_off + 4096, ks);
                     }
@@ -645,7 +653,8 @@ int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_skip_ragged = env_int("PE_GEMM_SKIP_RAGGED", 1);
 int g_gemm_direct_epi = env_int("PE_GEMM_DIRECT_EPILOGUE", 1);
-// bf16 MFMA shape of the 8-wave schedules: 1 = v_mfma_f32_16x16x32_bf16 (default since round 5), 0 = 32x32x16 (schedules 15 / 17 only: the A/B)
+// MFMA shape of the 8-wave schedules, a bit mask: bit 0 = bf16 on v_mfma_f32_16x16x32_bf16 (default since round 5; clear: 32x32x16, schedules 15 / 17 only),
+// bit 1 = e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (schedules 15 / 17 only; default clear: 32x32x64)
 int g_gemm_mfma16 = env_int("PE_GEMM_MFMA16", 1);
 int g_gemm_persist_wgs = 0;    // 0 = one work-group per CU of the current device
 int g_gemm_sk = env_int("PE_GEMM_SK", 0);     // schedule 19 where it applies (A/B knob "gemm_sk"; measured slower: profiles/r04_gemm_notes.md)
@@ -674,7 +683,7 @@ static int persistent_grid() {
 
 size_t gemm_workspace_bytes() { return SK_SYNC_BYTES + (size_t)persistent_grid() * SK_PART_BYTES; }
 
-template <int EPI, int VAR, bool FP8 = false, bool S16 = !FP8>
+template <int EPI, int VAR, bool FP8, bool S16>
 static int launch_v(const GemmArgs& args, int grid, hipStream_t stream) {
     static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
     if (!configured.load(std::memory_order_acquire)) {
@@ -702,27 +711,30 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     const int nk = args.p[0].K / (fp8 ? 128 : BK);
     const bool sk_can = SK_EPI && args.sk_sync != nullptr && args.sk_part != nullptr && ntiles >= G && nk >= 2 && args.p[0].K == args.p[1].K &&
                         g_gemm_persist_wgs == 0;
-    const bool sk_want = var == 19 || (var == 17 && g_gemm_sk != 0 && ntiles % G != 0);
-    if (sk_can && sk_want) {
-        if constexpr (SK_EPI) return fp8 ? launch_v<EPI, 19, true>(args, G, stream) : launch_v<EPI, 19>(args, G, stream);
+    const bool sk_want = var == 19 || ((var == 17 || var == 21) && g_gemm_sk != 0 && ntiles % G != 0);
+    // MFMA shape: the 16 x 16 blocks for bf16 (bit 0 of "gemm_mfma16", default set), the 32 x 32 blocks for e4m3 (bit 1, default clear: measured
+    // 2 - 10 % SLOWER in the 16 x 16 x 128 form, profiles/r05_gemm_notes.md section 7).  The non-default shape of either dtype exists in schedules 15 / 17.
+    const bool s16 = fp8 ? (g_gemm_mfma16 & 2) != 0 : (g_gemm_mfma16 & 1) != 0;
+    const bool dflt_shape = fp8 ? !s16 : s16;
+    if (sk_can && sk_want && dflt_shape) {
+        if constexpr (SK_EPI) return fp8 ? launch_v<EPI, 19, true, false>(args, G, stream) : launch_v<EPI, 19, false, true>(args, G, stream);
     }
     if (var == 19) var = 17;
     if (var == 22) return launch_gemm4(EPI, fp8, args, ntiles, stream);
     // 17 needs more than one round of tiles (profiles/r03_gemm_notes.md: +1.2 ... +1.5 % at 4.8 / 6.4 rounds, a tie at 1.6 rounds in isolation;
     // in the two-stream pipeline it also pays at 1.6 rounds: g_gemm_persist_min_rounds above); "gemm_persist_wgs" > 0 forces it
     if ((var == 17 || var == 21) && ntiles < (g_gemm_persist_wgs > 0 || g_gemm_persist_min_rounds <= 1 ? G + 1 : g_gemm_persist_min_rounds * G)) var = 15;
+    if (var == 21 && !dflt_shape) var = 17;
     if (fp8) {
-        if (var == 17) return launch_v<EPI, 17, true>(args, G, stream);
-        if (var == 21) return launch_v<EPI, 21, true>(args, G, stream);
-        return launch_v<EPI, 15, true>(args, ntiles, stream);
+        if (s16) return var == 17 ? launch_v<EPI, 17, true, true>(args, G, stream) : launch_v<EPI, 15, true, true>(args, ntiles, stream);
+        if (var == 17) return launch_v<EPI, 17, true, false>(args, G, stream);
+        if (var == 21) return launch_v<EPI, 21, true, false>(args, G, stream);
+        return launch_v<EPI, 15, true, false>(args, ntiles, stream);
     }
-    if (g_gemm_mfma16 == 0) {      // the round-4 shape, schedules 15 / 17 (A/B reference)
-        if (var == 17 || var == 21) return launch_v<EPI, 17, false, false>(args, G, stream);
-        return launch_v<EPI, 15, false, false>(args, ntiles, stream);
-    }
-    if (var == 17) return launch_v<EPI, 17>(args, G, stream);
-    if (var == 21) return launch_v<EPI, 21>(args, G, stream);
-    return launch_v<EPI, 15>(args, ntiles, stream);
+    if (!s16) return var == 17 ? launch_v<EPI, 17, false, false>(args, G, stream) : launch_v<EPI, 15, false, false>(args, ntiles, stream);
+    if (var == 17) return launch_v<EPI, 17, false, true>(args, G, stream);
+    if (var == 21) return launch_v<EPI, 21, false, true>(args, G, stream);
+    return launch_v<EPI, 15, false, true>(args, ntiles, stream);
 }
 
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace) {

@@ -15,7 +15,6 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;
 constexpr int GEMM_LDS = 5 * 32768;   // A x2 + W x3 = 160 KiB (all of a CU's LDS)
 constexpr int GEMM_DEFAULT_BAND = 4;      // M tiles per band: 8 until round 4; in the two-stream pipeline 4 is 0.45 - 0.6 % faster per image (profiles/r04_gemm_notes.md section 5)
-constexpr int GEMM_DEFAULT_VARIANT = 17;  // see the VAR list below
 
 struct GemmArgs {
     GemmProblem p[2];
@@ -126,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
                                                    char* E0, char* E1, int lane, int w, long long* stamp4) {
     // NMI / MI0: the accumulator array holds NMI 32-row blocks, this call emits blocks MI0, MI0 + 1 as the 64 x 128 block of (virtual)
     // wave `w` (the 4-wave kernel's 128 x 128 wave tile is two such calls)
-    static_assert(LAY == 0 || (!FP8 && NMI == 2 && MI0 == 0), "layout 1 is the 8-wave bf16 kernels'");
+    static_assert(LAY == 0 || (NMI == 2 && MI0 == 0), "layout 1 is the 8-wave kernels'");
     const int l31 = lane & 31, h = lane >> 5;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
@@ -138,8 +137,11 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
     bf16x8 rv16[EPI == EPI_GATE_RES ? 16 : 1];   // residual rows of the gated-residual epilogue, prefetched
     const bf16* bias = (const bf16*)P.bias;
     const bf16* pre = (const bf16*)P.pre;   // hot LoRA: `out + x @ A.T @ B.T` (vram_management/layers.py:179-180)
-    float sa[2] = {1.f, 1.f};               // FP8: per-row activation scale (fp8_linear's scale_a)
-    if constexpr (FP8) {
+    float sa[LAY == 1 ? 4 : 2] = {1.f, 1.f};      // FP8: per-row activation scale (fp8_linear's scale_a) of the lane's rows (layout 0: 2, layout 1: 4)
+    if constexpr (FP8 && LAY == 1) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) sa[mb] = P.scale_a[FAST ? mw0 + mb * 16 + l15 : min(mw0 + mb * 16 + l15, M - 1)];
+    } else if constexpr (FP8) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) sa[mi] = P.scale_a[FAST ? mw0 + mi * 32 + l31 : min(mw0 + mi * 32 + l31, M - 1)];
     }
@@ -205,8 +207,13 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
             row = mi * 32 + mb * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) b[r] = (float)bvs[nb][r];
+            if constexpr (FP8) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi * 2 + mb][nb][r] + b[r]);
+                for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi * 2 + mb][nb][r] * sa[mi * 2 + mb] + b[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = (bf16)(acc[mi * 2 + mb][nb][r] + b[r]);
+            }
         } else {
             const int ni = k >> 2, q = k & 3;
             n = nw0 + ni * 32 + 8 * q + 4 * h;
@@ -552,12 +559,17 @@ __device__ __forceinline__ u32x4 direct_epi_math(const KARG GemmProblem& P, u32x
 // v_permlane16_swap per dword on the column-block pairs (nb, nb + 1) -- odd 16-lane rows of block nb <-> even rows of block nb + 1 -- leaves
 // 8 consecutive columns in every lane: lane group g holds columns 8 (g >> 1) .. + 7 of block nb + (g & 1); a store instruction covers
 // 16 rows x 64 contiguous bytes.
-template <int EPI>
+template <int EPI, bool FP8>
 __device__ __forceinline__ void gemm_epilogue_direct16(const KARG GemmProblem& P, const f32x4 (&acc)[4][8], int m0, int n0, int lane, int w) {
     const int l15 = lane & 15, g4 = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
     const int nw0 = n0 + wn * 128, mw0 = m0 + wm * 64;
     const bf16* bias = (const bf16*)P.bias;
+    float sa[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (FP8) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) sa[mb] = P.scale_a[mw0 + mb * 16 + l15];
+    }
     bf16x4 bvs[8];
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) bvs[nb] = bf16x4{0, 0, 0, 0};
@@ -583,8 +595,13 @@ __device__ __forceinline__ void gemm_epilogue_direct16(const KARG GemmProblem& P
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
             const bf16x4 b4 = bvs[nb];
-            yp[mb][nb][0] = pk2(f32x2{acc[mb][nb][0] + (float)b4[0], acc[mb][nb][1] + (float)b4[1]});
-            yp[mb][nb][1] = pk2(f32x2{acc[mb][nb][2] + (float)b4[2], acc[mb][nb][3] + (float)b4[3]});
+            if constexpr (FP8) {
+                yp[mb][nb][0] = pk2(f32x2{acc[mb][nb][0] * sa[mb] + (float)b4[0], acc[mb][nb][1] * sa[mb] + (float)b4[1]});
+                yp[mb][nb][1] = pk2(f32x2{acc[mb][nb][2] * sa[mb] + (float)b4[2], acc[mb][nb][3] * sa[mb] + (float)b4[3]});
+            } else {
+                yp[mb][nb][0] = pk2(f32x2{acc[mb][nb][0] + (float)b4[0], acc[mb][nb][1] + (float)b4[1]});
+                yp[mb][nb][1] = pk2(f32x2{acc[mb][nb][2] + (float)b4[2], acc[mb][nb][3] + (float)b4[3]});
+            }
         }
     if constexpr (EPI == EPI_GATE_RES) {
 #pragma unroll
@@ -622,14 +639,14 @@ __device__ __forceinline__ void gemm_epilogue_direct16(const KARG GemmProblem& P
                 }
                 rp = rv[mb * 4 + p_];
             }
-            *(u32x4*)(out + (size_t)m * P.ldo + n) = direct_epi_math<EPI, false>(P, vp, rp, g2, m, n);
+            *(u32x4*)(out + (size_t)m * P.ldo + n) = direct_epi_math<EPI, FP8>(P, vp, rp, g2, m, n);
         }
 }
 
 template <int EPI, bool FP8, int NMI = 2, int MI0 = 0, int LAY = 0, typename ACC>
 __device__ __forceinline__ void gemm_epilogue_direct(const KARG GemmProblem& P, const ACC& acc, int m0, int n0, int lane, int w) {
     if constexpr (LAY == 1) {
-        gemm_epilogue_direct16<EPI>(P, acc, m0, n0, lane, w);
+        gemm_epilogue_direct16<EPI, FP8>(P, acc, m0, n0, lane, w);
         return;
     } else {
     const int l31 = lane & 31, h = lane >> 5;

@@ -68,6 +68,9 @@ struct GemmWorkspace {
 };
 size_t gemm_workspace_bytes();
 extern GemmWorkspace g_gemm_ws;
+// the GEMM schedule production runs (pe_debug_set("gemm_variant", 0) returns to it): 21 since round 5 (17 with one hand-off per K tile; with the
+// 16 x 16 MFMA shapes it is 2 - 4 % faster per block Linear and 0.7 - 1.2 % per image than 17: profiles/r05_gemm_notes.md section 7)
+constexpr int GEMM_DEFAULT_VARIANT = 21;
 extern int g_gemm_sk, g_gemm_persist_min_rounds, g_gemm4_x, g_gemm_skip_ragged, g_gemm_direct_epi, g_gemm_mfma16;
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace = nullptr);
 extern int g_gemm_band;          // M tiles per band of the tile order (default 4)

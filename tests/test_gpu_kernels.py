@@ -115,7 +115,7 @@ def test_gemm_persistent_schedule_bit_identical(ops, M, N, K):
                     c = ops.gemm(x, w, b, epi, **kw)
                     assert torch.equal(a, c), (wgs, epi)
     finally:
-        lib().pe_debug_set(b"gemm_variant", 17)
+        lib().pe_debug_set(b"gemm_variant", 0)
         lib().pe_debug_set(b"gemm_persist_wgs", 0)
 
 
@@ -161,7 +161,7 @@ def test_gemm_round5_schedules_bit_identical(ops, var):
                 assert lib().pe_debug_set(b"gemm_variant", var) == 0
                 assert torch.equal(a, ops.gemm_e4m3(xq, sc, w8, b, epi)), (M, N, K, epi)
     finally:
-        lib().pe_debug_set(b"gemm_variant", 17)
+        lib().pe_debug_set(b"gemm_variant", 0)
         lib().pe_debug_set(b"gemm_mfma16", 1)
 
 
@@ -194,8 +194,25 @@ def test_gemm_mfma_shapes_agree(ops):
                 frac = (d == 0).float().mean().item()
                 assert frac >= 0.97, (M, N, K, epi, frac)                     # they differ where the fp32 sums straddle a bf16 rounding boundary
                 assert d.max().item() <= 2.0 ** -6 * max(1.0, outs[0].float().abs().max().item()), (M, N, K, epi)
+        # e4m3 operands: v_mfma_scale_f32_16x16x128_f8f6f4 against 32x32x64
+        for (M, N, K) in ((2300, 3072, 3072), (300, 3072, 12288), (272, 256, 128)):
+            x, w8, b = rnd((M, K), 21).cuda(), rnd((N, K), 22, K ** -0.5).cuda().to(torch.float8_e4m3fn), rnd((N,), 23, 0.1).cuda()
+            xq, sc = ops.quantize_rows_e4m3(x)
+            for epi in ("bias", "gelu_sigmoid"):
+                outs = {}
+                for shape in (3, 1):      # bit 1: e4m3 on the 16 x 16 x 128 MFMA (the production default keeps 32 x 32 x 64 for e4m3)
+                    assert lib().pe_debug_set(b"gemm_mfma16", shape) == 0
+                    for var in (15, 17):
+                        assert lib().pe_debug_set(b"gemm_variant", var) == 0
+                        for direct in (1, 0):
+                            assert lib().pe_debug_set(b"gemm_direct_epilogue", direct) == 0
+                            o = ops.gemm_e4m3(xq, sc, w8, b, epi)
+                            assert torch.equal(outs.setdefault(shape, o), o), (M, N, K, epi, shape, var, direct)
+                d = (outs[3].float() - outs[1].float()).abs()
+                assert (d == 0).float().mean().item() >= 0.97, (M, N, K, epi)
+                assert d.max().item() <= 2.0 ** -6 * max(1.0, outs[1].float().abs().max().item()), (M, N, K, epi)
     finally:
-        lib().pe_debug_set(b"gemm_variant", 17)
+        lib().pe_debug_set(b"gemm_variant", 0)
         lib().pe_debug_set(b"gemm_mfma16", 1)
         lib().pe_debug_set(b"gemm_direct_epilogue", 1)
 
@@ -228,7 +245,7 @@ def test_gemm_direct_epilogue_bit_identical(ops, var):
                 assert torch.equal(p_, q_), (var, M, N, K, i)
     finally:
         lib().pe_debug_set(b"gemm_direct_epilogue", 1)
-        lib().pe_debug_set(b"gemm_variant", 17)
+        lib().pe_debug_set(b"gemm_variant", 0)
 
 
 @pytest.fixture
@@ -242,7 +259,7 @@ def gemm_workspace():
     assert lib().pe_debug_set_ptr(b"gemm_workspace", ws.data_ptr()) == 0
     yield ws
     lib().pe_debug_set_ptr(b"gemm_workspace", None)
-    lib().pe_debug_set(b"gemm_variant", 17)
+    lib().pe_debug_set(b"gemm_variant", 0)
 
 
 @pytest.mark.parametrize("M,N,K", [(8704, 3072, 3072), (8464, 3072, 12288), (8704, 9216, 3072), (8704, 12288, 3072), (8200, 2048, 128),

@@ -167,4 +167,4 @@ for (M, N, K, epi) in shapes:
 if bands:
     for (M, N, K, epi) in shapes:
         time_shape(M, N, K, epi, [(variants[-1], b) for b in bands], rounds=3)
-setv(17)
+setv(0)

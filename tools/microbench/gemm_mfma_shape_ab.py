@@ -1,7 +1,7 @@
 """Interleaved A/B of the bf16 GEMM's two MFMA shapes (knob "gemm_mfma16": 1 = v_mfma_f32_16x16x32_bf16, 0 = 32x32x16) on the four Linear shapes
 of a DiT block and the text stream's ragged shape, schedule 17, hot and cold weights (run on the GPU box from the repo root):
 
-    python tools/microbench/gemm_mfma_shape_ab.py [--fp32ref]
+    python tools/microbench/gemm_mfma_shape_ab.py [--fp8]      (--fp8: e4m3 operands, v_mfma_scale_f32_16x16x128_f8f6f4 against 32x32x64)
 """
 import sys
 
@@ -12,10 +12,13 @@ from physicedit_amd import ops
 from physicedit_amd._lib import lib
 
 BF = torch.bfloat16
+FP8 = "--fp8" in sys.argv
 g = torch.Generator(device='cuda').manual_seed(0)
 
 
 def knob(k, v):
+    if k == "gemm_mfma16" and FP8:
+        v = 3 if v else 1        # bit 1 = the e4m3 kernels' shape
     assert lib().pe_debug_set(k.encode(), v) == 0
 
 
@@ -31,9 +34,13 @@ knob("gemm_variant", 17)
 for (M, N, K) in ((2048, 3072, 3072), (1024, 3072, 12288)):
     x, w, b = rnd((M, K)), rnd((N, K), K ** -0.5), rnd((N,), 0.1)
     ref = x.double() @ w.double().T + b.double()
+    if FP8:
+        xq, sc = ops.quantize_rows_e4m3(x)
+        w8 = w.to(torch.float8_e4m3fn)
+        ref = (xq.float() * sc[:, None]).double() @ w8.double().T + b.double()
     for s in (1, 0):
         knob("gemm_mfma16", s)
-        o = ops.gemm(x, w, b, "bias")
+        o = ops.gemm_e4m3(xq, sc, w8, b, "bias") if FP8 else ops.gemm(x, w, b, "bias")
         e = (o.double() - ref).abs()
         print(f"accuracy {M}x{N}x{K} mfma16={s}: mean |err| {e.mean().item():.3e} max {e.max().item():.3e}", flush=True)
 
@@ -41,6 +48,9 @@ for (M, N, K) in ((2048, 3072, 3072), (1024, 3072, 12288)):
 def time_shape(M, N, K, epi, rounds=5, reps=12):
     xs = [rnd((M, K)) for _ in range(3)]
     ws = [rnd((N, K), K ** -0.5) for _ in range(NW)]
+    if FP8:
+        xqs = [ops.quantize_rows_e4m3(x) for x in xs]
+        ws = [w.to(torch.float8_e4m3fn) for w in ws]
     b = rnd((N,)); gate = rnd((N,), 0.5)
     outs = [rnd((M, N)) for _ in range(3)]
     fl = 2.0 * M * N * K
@@ -53,10 +63,11 @@ def time_shape(M, N, K, epi, rounds=5, reps=12):
                 def run(i):
                     j = i % NW if cold else 0
                     k = i % 3 if cold else 0
-                    if epi == "gate_res":
-                        ops.gemm(xs[k], ws[j], b, epi, gate=gate, res=outs[k], out=outs[k])
+                    kw = dict(gate=gate, res=outs[k]) if epi == "gate_res" else {}
+                    if FP8:
+                        ops.gemm_e4m3(xqs[k][0], xqs[k][1], ws[j], b, epi, out=outs[k], **kw)
                     else:
-                        ops.gemm(xs[k], ws[j], b, epi, out=outs[k])
+                        ops.gemm(xs[k], ws[j], b, epi, out=outs[k], **kw)
                 run(0)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -21,6 +21,19 @@ __global__ void k(const uint8_t* A /*[32][64]*/, const uint8_t* B /*[32 n][64 k]
     }
 }
 
+// v_mfma_scale_f32_16x16x128_f8f6f4: guess lane l: row l & 15, k = 32 (l >> 4) .. + 31 contiguous bytes; D: lane l holds i = 4 (l >> 4) + r, j = l & 15
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__global__ void k16(const uint8_t* A /*[16][128]*/, const uint8_t* B /*[16 n][128 k]*/, float* C /*[16][16]*/) {
+    const int l = threadIdx.x, l15 = l & 15, g = l >> 4;
+    i32x8 a, b;
+    const int* ap = (const int*)(A + l15 * 128 + g * 32);
+    const int* bp = (const int*)(B + l15 * 128 + g * 32);
+    for (int i = 0; i < 8; ++i) { a[i] = ap[i]; b[i] = bp[i]; }
+    f32x4 c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    for (int r = 0; r < 4; ++r) C[(4 * g + r) * 16 + l15] = c[r];
+}
+
 static float e4m3_to_float(uint8_t v) {
     const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
     float f;
@@ -51,5 +64,16 @@ int main() {
     printf("layout guess (lane l: row l&31, k = 32*(l>>5)..+31 contiguous bytes): max err %.6g (max |ref| %.4g) -> %s\n", maxerr, maxref,
            maxerr < 1e-3 * maxref ? "MATCH" : "MISMATCH");
     printf("C[0][0..3] = %g %g %g %g\n", hC[0], hC[1], hC[2], hC[3]);
+    // 16 x 16 x 128: the same 2048 bytes read as [16][128]
+    hipLaunchKernelGGL(k16, dim3(1), dim3(64), 0, 0, dA, dB, dC);
+    hipMemcpy(hC, dC, 16 * 16 * 4, hipMemcpyDeviceToHost);
+    maxerr = 0; maxref = 0;
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) {
+        double ref = 0;
+        for (int kk = 0; kk < 128; ++kk) ref += (double)e4m3_to_float(hA[i * 128 + kk]) * e4m3_to_float(hB[j * 128 + kk]);
+        maxerr = fmax(maxerr, fabs(ref - hC[i * 16 + j])); maxref = fmax(maxref, fabs(ref));
+    }
+    printf("16x16x128 layout guess (lane l: row l&15, k = 32*(l>>4)..+31; D[4(l>>4)+r][l&15]): max err %.6g (max |ref| %.4g) -> %s\n", maxerr, maxref,
+           maxerr < 1e-3 * maxref ? "MATCH" : "MISMATCH");
     return 0;
 }
