@@ -48,11 +48,11 @@ const char* pe_build_id(void);
  * hand-offs per K tile (the round-3/4 default); 15 = one tile per work-group (the round-2 default; writes s_memtime stamps when "gemm_stamps"
  * is attached); 19 = stream-K (bit-identical, needs a workspace: pe_gemm_workspace_bytes; "gemm_sk" = 1 lets 17 / 21 take it where tiles
  * do not fill whole rounds; measured slower, default off); 22 = four waves x 128 x 128, one wave per SIMD, one tile per work-group (gemm4.hip,
- * 32 x 32 MFMA blocks).  15 / 17 / 19 / 21 are bit-identical with each other.  "gemm_mfma16" (bit mask, default 1): bit 0 = the bf16 8-wave schedules
+ * 32 x 32 MFMA blocks).  15 / 17 / 19 / 21 are bit-identical with each other.  "gemm_mfma16" (bit mask, default 3): bit 0 = the bf16 8-wave schedules
  * use v_mfma_f32_16x16x32_bf16 (12 - 16 % more FLOP/s under the power limit than 32x32x16, -10 .. -13 % per block Linear: profiles/r05_gemm_notes.md
- * section 7; clear = the 32 x 32 blocks of rounds 1 - 4 in schedules 15 / 17: another summation order inside a K tile, same accuracy, not
- * bit-identical with the default, bit-identical with 22); bit 1 = the e4m3 schedules 15 / 17 use v_mfma_scale_f32_16x16x128_f8f6f4 (default clear:
- * measured 2 - 10 % slower than 32x32x64).  "gemm_skip_ragged" (default 1): 32-row blocks beyond M skip their MFMAs;
+ * section 7), bit 1 = the e4m3 ones v_mfma_scale_f32_16x16x128_f8f6f4 (slower per Linear in isolation, 1 % faster per image); a clear bit = that
+ * dtype on the 32 x 32 blocks of rounds 1 - 4, schedules 15 / 17 (another summation order inside a K tile: same accuracy, not bit-identical with
+ * the default, bit-identical with 22).  "gemm_skip_ragged" (default 1): 32-row blocks beyond M skip their MFMAs;
  * "gemm_direct_epilogue" (default 1): complete tiles of the GELU / gate + residual epilogues skip the LDS round trip.  "gemm_band": M tiles per band of
  * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of schedule 17's grid (0 = one per CU).
  * "attn_variant": 5 default (4 waves x 64 query rows, one wave per SIMD, lazy running max, the softmax scale folded into Q and the max

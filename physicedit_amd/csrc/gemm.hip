@@ -653,9 +653,11 @@ int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_skip_ragged = env_int("PE_GEMM_SKIP_RAGGED", 1);
 int g_gemm_direct_epi = env_int("PE_GEMM_DIRECT_EPILOGUE", 1);
-// MFMA shape of the 8-wave schedules, a bit mask: bit 0 = bf16 on v_mfma_f32_16x16x32_bf16 (default since round 5; clear: 32x32x16, schedules 15 / 17 only),
-// bit 1 = e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (schedules 15 / 17 only; default clear: 32x32x64)
-int g_gemm_mfma16 = env_int("PE_GEMM_MFMA16", 1);
+// MFMA shape of the 8-wave schedules, a bit mask: bit 0 = bf16 on v_mfma_f32_16x16x32_bf16, bit 1 = e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (both
+// default since round 5); a clear bit = that dtype on the 32 x 32 blocks of rounds 1 - 4 (schedules 15 / 17 only: the A/B reference).  e4m3: the
+// 16 x 16 x 128 form is 2 - 10 % slower per Linear in isolation and 1 % FASTER per image in the two-stream pipeline (less energy per FLOP: the
+// other stream's kernels run faster) -- profiles/r05_gemm_notes.md section 7.
+int g_gemm_mfma16 = env_int("PE_GEMM_MFMA16", 3);
 int g_gemm_persist_wgs = 0;    // 0 = one work-group per CU of the current device
 int g_gemm_sk = env_int("PE_GEMM_SK", 0);     // schedule 19 where it applies (A/B knob "gemm_sk"; measured slower: profiles/r04_gemm_notes.md)
 // schedule 17 from this many rounds of tiles on (knob "gemm_persist_min_rounds"; G + 1 tiles at least).  Round 3 used 3: in isolation
@@ -712,29 +714,23 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     const bool sk_can = SK_EPI && args.sk_sync != nullptr && args.sk_part != nullptr && ntiles >= G && nk >= 2 && args.p[0].K == args.p[1].K &&
                         g_gemm_persist_wgs == 0;
     const bool sk_want = var == 19 || ((var == 17 || var == 21) && g_gemm_sk != 0 && ntiles % G != 0);
-    // MFMA shape: the 16 x 16 blocks for bf16 (bit 0 of "gemm_mfma16", default set), the 32 x 32 blocks for e4m3 (bit 1, default clear: measured
-    // 2 - 10 % SLOWER in the 16 x 16 x 128 form, profiles/r05_gemm_notes.md section 7).  The non-default shape of either dtype exists in schedules 15 / 17.
+    // MFMA shape: bit 0 of "gemm_mfma16" = bf16, bit 1 = e4m3, both set by default (16 x 16 blocks).  The 32 x 32 shapes exist in schedules 15 / 17.
     const bool s16 = fp8 ? (g_gemm_mfma16 & 2) != 0 : (g_gemm_mfma16 & 1) != 0;
-    const bool dflt_shape = fp8 ? !s16 : s16;
-    if (sk_can && sk_want && dflt_shape) {
-        if constexpr (SK_EPI) return fp8 ? launch_v<EPI, 19, true, false>(args, G, stream) : launch_v<EPI, 19, false, true>(args, G, stream);
+    if (sk_can && sk_want && s16) {
+        if constexpr (SK_EPI) return fp8 ? launch_v<EPI, 19, true, true>(args, G, stream) : launch_v<EPI, 19, false, true>(args, G, stream);
     }
     if (var == 19) var = 17;
     if (var == 22) return launch_gemm4(EPI, fp8, args, ntiles, stream);
     // 17 needs more than one round of tiles (profiles/r03_gemm_notes.md: +1.2 ... +1.5 % at 4.8 / 6.4 rounds, a tie at 1.6 rounds in isolation;
     // in the two-stream pipeline it also pays at 1.6 rounds: g_gemm_persist_min_rounds above); "gemm_persist_wgs" > 0 forces it
     if ((var == 17 || var == 21) && ntiles < (g_gemm_persist_wgs > 0 || g_gemm_persist_min_rounds <= 1 ? G + 1 : g_gemm_persist_min_rounds * G)) var = 15;
-    if (var == 21 && !dflt_shape) var = 17;
-    if (fp8) {
-        if (s16) return var == 17 ? launch_v<EPI, 17, true, true>(args, G, stream) : launch_v<EPI, 15, true, true>(args, ntiles, stream);
-        if (var == 17) return launch_v<EPI, 17, true, false>(args, G, stream);
-        if (var == 21) return launch_v<EPI, 21, true, false>(args, G, stream);
-        return launch_v<EPI, 15, true, false>(args, ntiles, stream);
+    if (!s16) {
+        if (var != 15) return fp8 ? launch_v<EPI, 17, true, false>(args, G, stream) : launch_v<EPI, 17, false, false>(args, G, stream);
+        return fp8 ? launch_v<EPI, 15, true, false>(args, ntiles, stream) : launch_v<EPI, 15, false, false>(args, ntiles, stream);
     }
-    if (!s16) return var == 17 ? launch_v<EPI, 17, false, false>(args, G, stream) : launch_v<EPI, 15, false, false>(args, ntiles, stream);
-    if (var == 17) return launch_v<EPI, 17, false, true>(args, G, stream);
-    if (var == 21) return launch_v<EPI, 21, false, true>(args, G, stream);
-    return launch_v<EPI, 15, false, true>(args, ntiles, stream);
+    if (var == 17) return fp8 ? launch_v<EPI, 17, true, true>(args, G, stream) : launch_v<EPI, 17, false, true>(args, G, stream);
+    if (var == 21) return fp8 ? launch_v<EPI, 21, true, true>(args, G, stream) : launch_v<EPI, 21, false, true>(args, G, stream);
+    return fp8 ? launch_v<EPI, 15, true, true>(args, ntiles, stream) : launch_v<EPI, 15, false, true>(args, ntiles, stream);
 }
 
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace) {

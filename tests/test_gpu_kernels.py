@@ -129,7 +129,7 @@ def test_gemm_round5_schedules_bit_identical(ops, var):
     try:
         # the four-wave kernel keeps the 32 x 32 x 16 MFMA (another summation order inside a K tile than the 16 x 16 x 32 the eight-wave
         # schedules use since round 5): its reference is schedule 15 in that shape
-        assert lib().pe_debug_set(b"gemm_mfma16", 0 if var == 22 else 1) == 0
+        assert lib().pe_debug_set(b"gemm_mfma16", 0 if var == 22 else 3) == 0
         for (M, N, K) in ((300, 3072, 3072), (257, 264, 64), (272, 3072, 12288), (1, 3072, 256), (8704, 3072, 3072), (2100, 12288, 3072)):
             x, w, b = rnd((M, K), 1).cuda(), rnd((N, K), 2, K ** -0.5).cuda(), rnd((N,), 3, 0.1).cuda()
             gate, res = rnd((N,), 7, 0.5).cuda(), rnd((M, N), 8).cuda()
@@ -162,7 +162,7 @@ def test_gemm_round5_schedules_bit_identical(ops, var):
                 assert torch.equal(a, ops.gemm_e4m3(xq, sc, w8, b, epi)), (M, N, K, epi)
     finally:
         lib().pe_debug_set(b"gemm_variant", 0)
-        lib().pe_debug_set(b"gemm_mfma16", 1)
+        lib().pe_debug_set(b"gemm_mfma16", 3)
 
 
 def test_gemm_mfma_shapes_agree(ops):
@@ -180,7 +180,7 @@ def test_gemm_mfma_shapes_agree(ops):
                 outs = {}
                 for shape in (1, 0):
                     assert lib().pe_debug_set(b"gemm_mfma16", shape) == 0
-                    for var in (15, 17):
+                    for var in (15, 17) + ((21,) if shape else ()):
                         assert lib().pe_debug_set(b"gemm_variant", var) == 0
                         for direct in (1, 0):
                             assert lib().pe_debug_set(b"gemm_direct_epilogue", direct) == 0
@@ -200,9 +200,9 @@ def test_gemm_mfma_shapes_agree(ops):
             xq, sc = ops.quantize_rows_e4m3(x)
             for epi in ("bias", "gelu_sigmoid"):
                 outs = {}
-                for shape in (3, 1):      # bit 1: e4m3 on the 16 x 16 x 128 MFMA (the production default keeps 32 x 32 x 64 for e4m3)
+                for shape in (3, 1):      # bit 1: e4m3 on the 16 x 16 x 128 MFMA (default), clear: 32 x 32 x 64
                     assert lib().pe_debug_set(b"gemm_mfma16", shape) == 0
-                    for var in (15, 17):
+                    for var in (15, 17) + ((21,) if shape == 3 else ()):
                         assert lib().pe_debug_set(b"gemm_variant", var) == 0
                         for direct in (1, 0):
                             assert lib().pe_debug_set(b"gemm_direct_epilogue", direct) == 0
@@ -213,7 +213,7 @@ def test_gemm_mfma_shapes_agree(ops):
                 assert d.max().item() <= 2.0 ** -6 * max(1.0, outs[1].float().abs().max().item()), (M, N, K, epi)
     finally:
         lib().pe_debug_set(b"gemm_variant", 0)
-        lib().pe_debug_set(b"gemm_mfma16", 1)
+        lib().pe_debug_set(b"gemm_mfma16", 3)
         lib().pe_debug_set(b"gemm_direct_epilogue", 1)
 
 

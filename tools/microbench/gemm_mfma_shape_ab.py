@@ -83,3 +83,4 @@ def time_shape(M, N, K, epi, rounds=5, reps=12):
 for (M, N, K, epi) in shapes:
     time_shape(M, N, K, epi)
 knob("gemm_mfma16", 1)
+lib().pe_debug_set(b"gemm_mfma16", 3)

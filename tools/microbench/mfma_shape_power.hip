@@ -47,6 +47,34 @@ __global__ void __launch_bounds__(512) probe(const uint4* __restrict__ frags, fl
     }
     out[tid] = s;
 }
+// Does the ORDER in which a wave's MFMAs walk its operand fragments change the power (= the sustained rate)?  16 x 16 x 32 bf16, 16 accumulators,
+// 4 A and 4 B fragments: MODE 0 = A changes with every MFMA, B every 4th (the GEMM's loop order); 1 = B every MFMA, A every 4th;
+// 2 = both change with every MFMA; 3 = both change every 4th MFMA only (not a GEMM: the same product four times)
+template <int MODE>
+__global__ void __launch_bounds__(512) probe_order(const uint4* __restrict__ frags, float* __restrict__ out, int iters) {
+    const int tid = threadIdx.x + blockIdx.x * 512;
+    bf16x8 av[4], bv[4];
+    for (int i = 0; i < 4; ++i) {
+        av[i] = __builtin_bit_cast(bf16x8, frags[(tid * 8 + i) & 0xfffff]);
+        bv[i] = __builtin_bit_cast(bf16x8, frags[(tid * 8 + 4 + i) & 0xfffff]);
+    }
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ia = MODE == 0 ? (i & 3) : MODE == 1 ? (i >> 2) : MODE == 2 ? (i & 3) : (i >> 2);
+                const int ib = MODE == 0 ? (i >> 2) : MODE == 1 ? (i & 3) : MODE == 2 ? ((i + (i >> 2)) & 3) : (i >> 2);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[(ia + k) & 3], bv[ib], acc[i], 0, 0, 0);
+            }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j];
+    out[tid] = s;
+}
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 // the e4m3 pair: v_mfma_scale_f32_32x32x64_f8f6f4 (16 passes, 128 KiFLOP) against v_mfma_scale_f32_16x16x128_f8f6f4 (8 passes, 64 KiFLOP), unit scales
 template <int SHAPE>
@@ -119,6 +147,10 @@ int main() {
     printf("shape                       N(0,1) TF/s   zeros TF/s\n");
     printf("v_mfma_f32_32x32x16_bf16  %10.0f %12.0f\n", run(probe<32>, dr, out, 100000, f32), run(probe<32>, dz, out, 100000, f32));
     printf("v_mfma_f32_16x16x32_bf16  %10.0f %12.0f\n", run(probe<16>, dr, out, 100000, f16), run(probe<16>, dz, out, 100000, f16));
+    printf("16x16x32 bf16, A changes every MFMA, B every 4th   %10.0f\n", run(probe_order<0>, dr, out, 100000, f16));
+    printf("16x16x32 bf16, B changes every MFMA, A every 4th   %10.0f\n", run(probe_order<1>, dr, out, 100000, f16));
+    printf("16x16x32 bf16, both change every MFMA              %10.0f\n", run(probe_order<2>, dr, out, 100000, f16));
+    printf("16x16x32 bf16, both change every 4th MFMA          %10.0f\n", run(probe_order<3>, dr, out, 100000, f16));
     // e4m3 operands: N(0,1) values rounded to e4m3 (sign, 4-bit exponent bias 7, 3-bit mantissa)
     std::vector<uint8_t> h8(n * 2);
     for (size_t i = 0; i < n * 2; ++i) {

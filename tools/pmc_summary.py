@@ -44,7 +44,7 @@ def mean(v):
 # algorithmic FLOPs of the block GEMMs at the bench geometry, by (epilogue, work-groups): mean over T_pos = 512 / T_neg = 272
 def gemm_flops(epi, wgs, sched=15):
     S = 8192 + (512 + 272) / 2
-    if sched == 17 and wgs == 256:        # persistent grid (one work-group per CU): the shape is told by the epilogue
+    if sched in (17, 21) and wgs == 256:        # persistent grid (one work-group per CU): the shape is told by the epilogue
         return {1: 2 * S * 12288 * 3072, 4: 2 * S * 9216 * 3072}.get(epi)
     return {(1, 1632): 2 * S * 12288 * 3072, (4, 1224): 2 * S * 9216 * 3072, (3, 408): 2 * S * 3072 * (3072 + 12288) / 2}.get((epi, wgs))
 
@@ -77,7 +77,7 @@ def main(root, out):
             fl = gemm_flops(epi, wgs, sched)
             if fl and busy:
                 row["algorithmic_gflop_per_launch"] = fl / 1e9
-                row["mfma_busy_counter_over_algorithmic_mfma_cycles"] = busy / (fl / (2 * 32 * 32 * 16) * 32)
+                row["mfma_busy_counter_over_algorithmic_mfma_cycles"] = busy / (fl / (2 * 32 * 32 * 16) * 32)      # pipe cycles: 32 per 32 KiFLOP in either MFMA shape
         rows.append(row)
     json.dump({"command": cmd, "config": {"layers": 60, "height": 1024, "width": 1024, "t_pos": 512, "t_neg": 272, "fp8": "--fp8" in cmd,
                                            "dual_stream": "--dual-stream" in cmd},

@@ -30,7 +30,7 @@ def main(dbpath, outpath):
                 "| kernel | work-groups | calls | avg us |\n|---|---|---|---|\n")
         for name, wg, n, avg in g:
             ep = name.split("<")[1].split(">")[0] if "<" in name else (name.split("ILi")[1].split("E")[0] if "ILi" in name else "?")
-            f.write(f"| gemm_bf16_kernel<{ep}> (EPI, schedule, e4m3) | {wg} | {n} | {avg/1e3:.1f} |\n")
+            f.write(f"| gemm_bf16_kernel<{ep}> (EPI, schedule, e4m3, 16 x 16 MFMA shape) | {wg} | {n} | {avg/1e3:.1f} |\n")
     print(open(outpath).read())
 
 
