@@ -734,6 +734,265 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
     }
 }
 
+// ================================================================================================================
+// Variant 7 (round 5): the folded one-wave-per-SIMD schedule of variants 5 / 6 on v_mfma_f32_16x16x32_bf16 -- the 4-pass MFMA shape spends less
+// energy per FLOP (half the accumulator traffic), and on this power-limited chip energy is time (profiles/r05_gemm_notes.md section 7).
+// Same work item, ring, staging, split-KV plan and arithmetic (Q pre-scaled, -m through the C operand, lazy max with tau); what changes is
+// the tiling of a wave's 64 x 64 score tile into 16 x 16 blocks and everything that follows from the accumulator layout:
+//   * lane l: l15 = l & 15 is the query row of a 16-row block qb (0..3), g = l >> 4 its k group; an MFMA block's 4 registers are rows 4g..4g+3
+//   * MFMA key block m (0..3) does NOT take 16 consecutive keys: its row i is key 32 (m >> 1) + 16 (i >> 3) + 8 (m & 1) + (i & 7) of the tile,
+//     i.e. lane group g holds keys 32c + 16 (g >> 1) + 8e + 4 (g & 1) + r (m = 2c + e).  The 8 k-slots a lane group feeds the P.V MFMA of the
+//     32-key chunk c -- its 4 registers of block 2c, then of block 2c + 1 -- are then positions 8u .. 8u + 7 of a 16-group of Vt's perm16 layout
+//     (u = g & 1, group 2c + (g >> 1)): ONE ds_read_b128 per Vt fragment, Vt's layout in memory unchanged.
+//   * K tile in LDS: chunk ^ key(row), key = (row & 7) | ((row >> 1) & 8) (not row & 15): the 16 rows an MFMA block's fragment read touches
+//     ((l & 7) + 16 (l >> 3) + const) get 16 distinct keys = the lane's l15: conflict-free ds_read_b128.
+//   * -m of the lane's row as the C operand is 4 registers (written by one exact v_mfma_f32_16x16x4_f32), row max / row sum reductions cross
+//     the 4 lane groups (v_permlane32_swap + v_permlane16_swap), the epilogue pairs d blocks with v_permlane16_swap for 16-byte stores.
+// Not bit-identical with variants 3 - 6 (another summation order inside the MFMAs); same distance to an fp32 result.
+// The instruction schedule (two MFMAs per 32-cycle gap) is generated: tools/gen_attn_w7.py -> attention_w7_body.inc.
+// ================================================================================================================
+PE_DEV float max_with_lane_xor16(float x) {      // v_permlane16_swap: odd 16-lane rows of the first <-> even rows of the second operand
+    float y;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(x), "=&v"(y));
+    return x;
+}
+PE_DEV float sum_with_lane_xor16(float x) {
+    float y;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_add_f32 %0, %0, %1" : "+v"(x), "=&v"(y));
+    return x;
+}
+
+__global__ void __launch_bounds__(256, 1)
+flash_attn_w7_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
+                     bf16* __restrict__ out, int S, int S_pad, int ldo, AttnPlan plan,
+                     float* __restrict__ part_o, float* __restrict__ part_ml, float tau) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Q_BLOCK = 256;
+    constexpr int KT_BYTES = KV_TILE * 256;        // 16 KiB
+    constexpr int V_BASE = PP_STAGES * KT_BYTES;   // K ring [0, 64 KiB), Vt ring [64 KiB, 128 KiB); tile t sits in slot t & 3
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    const int nqb = plan.nqb;
+    const int nt_all = (S + KV_TILE - 1) / KV_TILE;
+    int item, t_begin = 0, t_end = nt_all, part_slot = -1;
+    if ((int)blockIdx.x < plan.n_full) {
+        item = xcd_remap((int)blockIdx.x, plan.n_full);
+    } else {
+        const int j = (int)blockIdx.x - plan.n_full;
+        item = plan.n_full + j / plan.split;
+        const int part = j - (j / plan.split) * plan.split;
+        if (plan.split > 1) {
+            t_begin = (int)((long long)nt_all * part / plan.split);
+            t_end = (int)((long long)nt_all * (part + 1) / plan.split);
+            part_slot = j;
+        }
+    }
+    const int head = item / nqb;
+    const int qblk = item - head * nqb;
+    const int q0 = qblk * Q_BLOCK + w * 64;
+    const bf16* Qh = Q + (size_t)head * S_pad * 128;
+    const bf16* Kh = K + (size_t)head * S_pad * 128;
+    const bf16* Vh = Vt + (size_t)head * 128 * S_pad;
+
+    // Q fragments [query block][k-step of 32], accumulator half.  ONE asm statement defines all 16 tuples (global loads straight into the
+    // accumulator half, one wait): tuples assembled from per-register v_accvgpr_write statements are 64 separate live ranges to the allocator,
+    // which then parks most of them in VGPRs and copies them in front of every QK^T statement (with no wait states before the MFMA)
+    u32x4 qf[4][4];
+    {
+        const bf16* qp[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) qp[b] = Qh + (size_t)min(q0 + b * 16 + l15, S - 1) * 128 + g4 * 8;
+        asm volatile(
+            "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:64\n\t"
+            "global_load_dwordx4 %2, %16, off offset:128\n\tglobal_load_dwordx4 %3, %16, off offset:192\n\t"
+            "global_load_dwordx4 %4, %17, off\n\tglobal_load_dwordx4 %5, %17, off offset:64\n\t"
+            "global_load_dwordx4 %6, %17, off offset:128\n\tglobal_load_dwordx4 %7, %17, off offset:192\n\t"
+            "global_load_dwordx4 %8, %18, off\n\tglobal_load_dwordx4 %9, %18, off offset:64\n\t"
+            "global_load_dwordx4 %10, %18, off offset:128\n\tglobal_load_dwordx4 %11, %18, off offset:192\n\t"
+            "global_load_dwordx4 %12, %19, off\n\tglobal_load_dwordx4 %13, %19, off offset:64\n\t"
+            "global_load_dwordx4 %14, %19, off offset:128\n\tglobal_load_dwordx4 %15, %19, off offset:192\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&a"(qf[0][0]), "=&a"(qf[0][1]), "=&a"(qf[0][2]), "=&a"(qf[0][3]), "=&a"(qf[1][0]), "=&a"(qf[1][1]), "=&a"(qf[1][2]), "=&a"(qf[1][3]),
+              "=&a"(qf[2][0]), "=&a"(qf[2][1]), "=&a"(qf[2][2]), "=&a"(qf[2][3]), "=&a"(qf[3][0]), "=&a"(qf[3][1]), "=&a"(qf[3][2]), "=&a"(qf[3][3])
+            : "v"(qp[0]), "v"(qp[1]), "v"(qp[2]), "v"(qp[3])
+            : "memory");
+    }
+    // staging as in flash_attn_w4_kernel, with this kernel's K swizzle key
+    uint32_t k_off[4], v_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int krow = piece * 4 + (lane >> 4);
+        const int kkey = (krow & 7) | ((krow >> 1) & 8);
+        k_off[i] = (uint32_t)(krow * 128 + ((lane & 15) ^ kkey) * 8) * 2u;
+        const int vrow = piece * 8 + (lane >> 3);
+        v_off[i] = (uint32_t)(vrow * S_pad + ((lane & 7) ^ ((vrow >> 1) & 7)) * 8) * 2u;
+    }
+    const int n = t_end - t_begin;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, 0x7fffffff, 0x00020000);
+    auto stage_k = [&](int st, int i, int j) {      // i: tile index relative to t_begin, clamped (a tile past the end re-reads the last)
+        const int t = __builtin_amdgcn_readfirstlane(t_begin + min(i, n - 1));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(smem + st * KT_BYTES + w * 4096 + j * 1024),
+                                                 16, (int)k_off[j], t * (KV_TILE * 256), 0, 0);
+    };
+    auto stage_v = [&](int st, int i, int j) {
+        const int t = __builtin_amdgcn_readfirstlane(t_begin + min(i, n - 1));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(smem + V_BASE + st * KT_BYTES + w * 4096 + j * 1024),
+                                                 16, (int)v_off[j], t * (KV_TILE * 2), 0, 0);
+    };
+    auto stage = [&](int st, int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { stage_k(st, i, j); stage_v(st, i, j); }
+    };
+
+    f32x4 o[4][8];           // O^T [query block][d block], accumulator half (whole tuples: see rescale)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            o[b][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+a"(o[b][db]));
+        }
+    float m_run[4] = {0.f, 0.f, 0.f, 0.f};
+    // softmax denominators, accumulated by the matrix pipe: lacc[b] += ones . P per 32-key chunk (every register of the tuple holds the row sum of
+    // the lane's query over all keys so far -- of the bf16 P the numerator uses); `ones` = a fragment of bf16 1.0
+    f32x4 lacc[4];
+    u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+a"(ones));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        lacc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+a"(lacc[b]));
+    }
+    int kaddr[4], vaddr[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = ((l15 & 7) + 16 * (l15 >> 3)) * 256 + (((kk * 4 + g4) ^ l15) << 4);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) vaddr[c] = V_BASE + l15 * 128 + (((c * 4 + g4) ^ ((l15 >> 1) & 7)) << 4);
+
+    f32x4 sc[2][4][4];       // [tile parity][query block][MFMA key block]
+    u32x4 pk[4][2];          // P, bf16 pairs: [query block][32-key chunk]
+    f32x4 negm[4];           // -m of the lane's row of block b, 4 copies = the C operand of the tile's first MFMAs
+    u32x4 kf[16], vf[16];    // K / Vt fragments, accumulator half: ~8 / ~5 live at a time
+    float sm_mx[4], sm_alpha[4];
+    bool sm_moved[4];
+
+    // sm_state_f of flash_attn_w4_kernel for the scores sc[P][b][*] = s . c - m of one tile
+    auto sm_state_f = [&](auto p_tag, int b, auto first_tag) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const float mx = max_with_lane_xor16(max_with_lane_xor32(sm_mx[b]));
+        const bool fix = FIRST || __any(mx > tau);
+        sm_moved[b] = !FIRST && fix;
+        float alpha = 1.0f;
+        if (fix) {
+            const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+            if constexpr (!FIRST) alpha = __builtin_amdgcn_exp2f(-delta);
+            m_run[b] += delta;
+            const float nm = -m_run[b];
+            // the 4 copies by ONE instruction that defines the tuple: the exact-fp32 MFMA D = A . B, A[i][k] = (k == 0), B[k][j] = -m of query
+            // row j (the four k groups hold the same m): 1 x nm + 3 x (0 x nm)
+            asm volatile("s_nop 3\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(negm[b]) : "v"(lane_id_fresh() < 16 ? 1.0f : 0.0f), "v"(nm));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[P][b][m][r] -= delta;
+        }
+        sm_alpha[b] = alpha;
+        asm volatile("" : "+v"(sm_alpha[b]), "+v"(m_run[b]));
+    };
+    // keys at or past s_lim -> -inf (the ragged last tile; every tile past the end of the sequence or of a split-KV part: s_lim = 0)
+    auto mask_scores = [&](auto p_tag, int t, int s_lim) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_tag)::value;
+        const int gf = lane_id_fresh() >> 4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * KV_TILE + 32 * (m >> 1) + 16 * (gf >> 1) + 8 * (m & 1) + 4 * (gf & 1) + r;
+                    if (key >= s_lim) sc[P][b][m][r] = -INFINITY;
+                }
+    };
+    // O(block b) *= alpha, after the P.V of the tile before is done.  Plain vector arithmetic on the whole 4-register tuples (the compiler reads /
+    // writes the accumulator half around the multiply): with the per-element asm operands of flash_attn_w4_kernel's rescale the merge behind this
+    // rarely taken branch splits 32 tuples into 128 single-register live ranges, and the allocator then gathers and scatters the O tuples around
+    // every P.V statement (300 v_accvgpr_mov per iteration)
+    // The empty asm re-defines every tuple HERE: without it the register allocator may place the accumulator -> VGPR copies of the multiply
+    // anywhere behind the tuple's last P.V statement -- right behind an MFMA it cannot see inside the asm, with no wait states (measured: the
+    // raise path of one block read stale accumulators).  Behind gap 2 the P.V MFMAs of the tile before are > 100 cycles old.
+    auto rescale = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int db = 0; db < 8; ++db) asm volatile("" : "+a"(o[b][db]));
+        asm volatile("" : "+a"(lacc[b]));
+        if (sm_moved[b]) {
+            const float alpha = sm_alpha[b];
+#pragma unroll
+            for (int db = 0; db < 8; ++db) o[b][db] *= alpha;
+            lacc[b] *= alpha;
+        }
+    };
+
+#ifndef W4_FENCE
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) negm[b][r] = 0.f;
+#include "attention_w7_body.inc"
+    for (int i = 0; i < n; i += 4) {
+        iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // stray DMA / K reads; last P.V -> reads of O
+
+    const int lane_e = lane_id_fresh();      // nothing lane-derived lives across the loop for the epilogue's sake
+    const int l15e = lane_e & 15, ge = lane_e >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float l_tot = lacc[b][0];      // every register of every lane group holds the whole row's sum
+        if (part_slot >= 0) {
+            float* po = part_o + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 16 + l15e) * 128 + 4 * ge;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = o[b][db][r];
+                *(f32x4*)(po + db * 16) = v;
+            }
+            if (ge == 0) {
+                float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + w * 64 + b * 16 + l15e) * 2;
+                pm[0] = m_run[b];
+                pm[1] = l_tot;
+            }
+            continue;
+        }
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + b * 16 + l15e;
+        // a row's 16 columns of a d block sit in four lanes (4 columns each); one v_permlane16_swap per dword on the block pairs (db, db + 1)
+        // leaves 8 consecutive columns in every lane: lane group g holds columns 8 (g >> 1) .. + 7 of block db + (g & 1)
+        bf16* op = out + (size_t)min(q, S - 1) * ldo + head * 128 + (ge & 1) * 16 + 8 * (ge >> 1);
+#pragma unroll
+        for (int db = 0; db < 8; db += 2) {
+            bf16x4 v0, v1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v0[r] = (bf16)(o[b][db][r] * inv);
+                v1[r] = (bf16)(o[b][db + 1][r] * inv);
+            }
+            const u32x2 w0 = __builtin_bit_cast(u32x2, v0), w1 = __builtin_bit_cast(u32x2, v1);
+            const auto sx = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
+            const u32x4 pkd = {sx[0], sy[0], sx[1], sy[1]};
+            if (q < S) *(u32x4*)(op + db * 16) = pkd;
+        }
+    }
+}
+
 // merge the `split` partials of each leftover (head, q-block): O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M)
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o,
                                                            const float* __restrict__ part_ml, bf16* __restrict__ out,
@@ -833,10 +1092,10 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
                S_pad, KV_TILE, S);
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
-    PE_REQUIRE(g_attn_variant == 0 || (g_attn_variant >= 3 && g_attn_variant <= 6), "flash_attn: attn_variant %d does not exist", g_attn_variant);
+    PE_REQUIRE(g_attn_variant == 0 || (g_attn_variant >= 3 && g_attn_variant <= 8), "flash_attn: attn_variant %d does not exist", g_attn_variant);
     // variants 5 / 6 need Q = q . scale . log2(e) (attn_q_prescale()); a caller with a plain Q gets the same schedule's exact form
     int variant = g_attn_variant;
-    if (variant >= 5 && !q_prescaled) variant = variant == 5 ? 4 : 3;
+    if (variant >= 5 && !q_prescaled) variant = (variant == 6 || variant == 8) ? 3 : 4;      // (7 -> 4, 8 -> 3: the 32 x 32 schedule's exact forms)
     // the one-wave-per-SIMD kernels store 16-byte vectors: rows must be 16-byte aligned (the 8-wave kernel needs 8)
     if (variant >= 3 && (ldo % 8 != 0 || ((uintptr_t)out & 15) != 0)) variant = 0;
     static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
@@ -848,6 +1107,8 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
             e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)flash_attn_w7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
@@ -867,6 +1128,9 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     if (words != nullptr)
         hipLaunchKernelGGL((flash_attn_kernel<8, true>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
                            (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)words, n_img);
+    else if (variant >= 7)      // 8 = 7 with the textbook max update (tests: the raise path on nearly every tile)
+        hipLaunchKernelGGL(flash_attn_w7_kernel, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                           (bf16*)out, S, S_pad, ldo, plan, part_o, part_ml, variant == 7 ? 8.0f : 0.0f);
     else if (variant >= 5)
         hipLaunchKernelGGL(flash_attn_w4_kernel<true>, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                            (bf16*)out, S, S_pad, ldo, 1.0f, plan, part_o, part_ml, variant == 5 ? 8.0f : 0.0f, g_attn_dbg);

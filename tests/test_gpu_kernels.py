@@ -554,7 +554,8 @@ def _rms(a, b):
     return (a.float().cpu() - b.float().cpu()).pow(2).mean().sqrt().item()
 
 
-@pytest.mark.parametrize("S,variant", [(64, 5), (100, 5), (257, 5), (700, 5), (1093, 5), (2208, 5), (100, 6), (1093, 6)])
+@pytest.mark.parametrize("S,variant", [(64, 5), (100, 5), (257, 5), (700, 5), (1093, 5), (2208, 5), (100, 6), (1093, 6),
+                                       (64, 7), (100, 7), (257, 7), (700, 7), (1093, 7), (2208, 7)])
 def test_flash_attn_fold(ops, attn_variant, S, variant):
     """Same criterion as test_flash_attn: the rms distance to the fp32 result must be the bf16 reference's own.  The folded kernel
     sees bf16(q . c) where the reference sees bf16(q) -- one rounding each of the same fp32 q, at different bits -- so element-wise
@@ -576,7 +577,7 @@ def test_flash_attn_fold(ops, attn_variant, S, variant):
         assert torch.equal(ops.flash_attn(qd, kd, vt, S, q_prescaled=True), out)
 
 
-@pytest.mark.parametrize("S,force,variant", [(700, 3, 5), (1093, 5, 5), (300, 8, 5), (1093, 5, 6)])
+@pytest.mark.parametrize("S,force,variant", [(700, 3, 5), (1093, 5, 5), (300, 8, 5), (1093, 5, 6), (700, 3, 7), (1093, 5, 7), (300, 8, 7)])
 def test_flash_attn_fold_split_kv(ops, attn_variant, S, force, variant):
     """split-KV partials of the folded kernel: every part starts from its own first tile (m = that tile's row max) and ends on up to
     three fully masked dummy tiles; the merged result must agree with the unsplit kernel to rounding."""
@@ -606,7 +607,7 @@ def test_flash_attn_fold_forced_raise(ops, attn_variant):
     qd, kd, vt = _dev_qkv(ops, qc, k, v, S)
     qp, _, _ = _dev_qkv(ops, qb, k, v, S)
     outs = {}
-    for variant in (5, 6):
+    for variant in (5, 6, 7):
         attn_variant(variant)
         outs[variant] = ops.flash_attn(qd, kd, vt, S, q_prescaled=True).clone()
     attn_variant(4)
@@ -620,21 +621,23 @@ def test_flash_attn_fold_forced_raise(ops, attn_variant):
         assert e_max <= 2.0 * ec_max + 1e-3
         assert _rms(out, ref32) <= 1.25 * ec_rms + 1e-6
     assert _rms(outs[5], outs[6]) <= 1.5 * ec_rms
+    assert _rms(outs[5], outs[7]) <= 1.5 * ec_rms
     assert _rms(outs[5], outs[4]) <= 1.5 * ec_rms
 
 
-def test_flash_attn_fold_full_size(ops, attn_variant):
+@pytest.mark.parametrize("variant", [5, 7])
+def test_flash_attn_fold_full_size(ops, attn_variant, variant):
     """BASELINE cfg 2 geometry with the folded kernel (816 items -> 768 whole + 48 x 5 split)."""
     H, S = 24, 8704
     qb, qc, k, v, ref, ref32 = _fold_case(S, 6)
-    attn_variant(5)
+    attn_variant(variant)
     vt = ops.pack_vt(v.cuda(), S)
     out = ops.flash_attn(qc.cuda(), k.cuda(), vt, S, q_prescaled=True)
     out1 = ops.flash_attn(qc.cuda(), k.cuda(), vt, S, workspace=False, q_prescaled=True)
     e_gpu, e_cpu = _rms(out, ref32), _rms(ref, ref32)
-    print(f"[parity] flash_attn v5 full size: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
+    print(f"[parity] flash_attn v{variant} full size: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")
     assert e_gpu <= 1.1 * e_cpu + 1e-6
-    report("flash_attn v5 full size: balanced vs single-kernel", out, out1, max_ulp=3.01, max_frac=0.05)
+    report(f"flash_attn v{variant} full size: balanced vs single-kernel", out, out1, max_ulp=3.01, max_frac=0.05)
 
 
 def test_flash_attn_plain_q_takes_exact_form(ops, attn_variant):

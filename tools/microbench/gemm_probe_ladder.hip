@@ -273,6 +273,96 @@ __global__ void __launch_bounds__(256, 1) probe4(const char* __restrict__ src, u
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---------------------------------------------------------------- 4 waves x 128 x 128 on v_mfma_f32_16x16x32_bf16 (8 x 8 blocks of 16 x 16): per K tile
+// and wave 128 MFMAs of 4 passes (2 k-steps of 32), 32 ds_read_b128 (8 + 8 fragments per k-step, read one k-step ahead), 16 LDS-DMA pieces
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) probe4s(const char* __restrict__ src, unsigned window_bytes, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int sw = (l15 >> 1) & 7;
+    const char* win = src + (size_t)(blockIdx.x & 7) * window_bytes;
+    const unsigned wmask = window_bytes - 1u;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    for (int i = 0; i < 40; ++i) {
+        const unsigned piece = (unsigned)(w * 40 + i);
+        glds16(win + ((piece * 1024u + lane_off) & wmask), smem + piece * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 acc[8][8];
+    for (int mi = 0; mi < 8; ++mi)
+        for (int ni = 0; ni < 8; ++ni)
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+    const int a_off = (wm * 128 + l15) * 128;
+    const int w_off = (wn * 128 + l15) * 128;
+    char* const a_base = smem;
+    char* const w_base = smem + 2 * 32768;
+    bf16x8 fa[2][8], fw[2][8];
+    auto rd = [&](const char* Sa, const char* Sw, int ks, int set) __attribute__((always_inline)) {
+        const int c = ((ks * 4 + g) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fa[set][i] = *(const bf16x8*)(Sa + a_off + i * 2048 + c);
+            fw[set][i] = *(const bf16x8*)(Sw + w_off + i * 2048 + c);
+        }
+    };
+    rd(a_base, w_base, 0, 0);
+    rd(a_base, w_base, 1, 1);     // MODE 0 never reads again
+    unsigned stream_off = (unsigned)blockIdx.x * 65536u + (unsigned)w * 16384u;
+    int ab = 0, ws = 0;
+    for (int it = 0; it < iters; ++it) {
+        const char* Sa = a_base + ab * 32768;
+        const char* Sw = w_base + ws * 32768;
+        const char* San = a_base + (ab ^ 1) * 32768;
+        const char* Swn = w_base + (ws == 2 ? 0 : ws + 1) * 32768;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int cur = ks & 1;
+            if constexpr (MODE >= 1) {
+                if (ks < 1) rd(Sa, Sw, ks + 1, cur ^ 1);
+                else rd(San, Swn, 0, cur ^ 1);
+            }
+            if constexpr (MODE >= 2) {
+                char* dst = ks == 0 ? a_base + (ab ^ 1) * 32768 + w * 8192 : w_base + ((ws + 2) % 3) * 32768 + w * 8192;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    glds16(win + ((stream_off + lane_off) & wmask), dst + j * 1024);
+                    stream_off += 1024u;
+                }
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 8; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[cur][ni], fa[cur][mi], acc[mi][ni], 0, 0, 0);
+            if constexpr (MODE >= 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { SGB(0x008, 2); SGB(0x100, 1); }
+                if constexpr (MODE >= 2) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { SGB(0x008, 2); SGB(0x020, 1); }
+                    SGB(0x008, 16);
+                } else {
+                    SGB(0x008, 32);
+                }
+            }
+        }
+        stream_off += 65536u - 16384u;
+        ab ^= 1;
+        ws = ws == 2 ? 0 : ws + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+    for (int mi = 0; mi < 8; ++mi)
+        for (int ni = 0; ni < 8; ++ni)
+            for (int r = 0; r < 4; ++r) s += acc[mi][ni][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 #define CK(x)                                                                          \
     do {                                                                               \
         hipError_t e_ = (x);                                                           \
@@ -338,7 +428,7 @@ int main(int argc, char** argv) {
     const double f8 = 8.0 * 32.0 * (2.0 * 32 * 32 * 16), f4 = 4.0 * 64.0 * (2.0 * 32 * 32 * 16);   // per K tile and work-group: the same 256 MFMAs
     printf("mode                                         N(0,1) TF/s   zeros TF/s\n");
     struct Row { const char* name; double r, z; };
-    Row rows[9];
+    Row rows[12];
     rows[0] = {"8 waves x 64x128: MFMA only", run(probe8<0>, 512, drand, window, out, iters, f8), run(probe8<0>, 512, dzero, window, out, iters, f8)};
     rows[1] = {"8 waves x 64x128: + 0.75 ds_read_b128 / MFMA", run(probe8<1>, 512, drand, window, out, iters, f8), run(probe8<1>, 512, dzero, window, out, iters, f8)};
     rows[2] = {"8 waves x 64x128: + LDS-DMA stream", run(probe8<2>, 512, drand, window, out, iters, f8), run(probe8<2>, 512, dzero, window, out, iters, f8)};
@@ -348,6 +438,9 @@ int main(int argc, char** argv) {
     rows[6] = {"8 waves, 16x16x32 MFMA: MFMA only", run(probe8s<0>, 512, drand, window, out, iters, f8), run(probe8s<0>, 512, dzero, window, out, iters, f8)};
     rows[7] = {"8 waves, 16x16x32 MFMA: + 0.375 ds_read_b128 / MFMA", run(probe8s<1>, 512, drand, window, out, iters, f8), run(probe8s<1>, 512, dzero, window, out, iters, f8)};
     rows[8] = {"8 waves, 16x16x32 MFMA: + LDS-DMA stream", run(probe8s<2>, 512, drand, window, out, iters, f8), run(probe8s<2>, 512, dzero, window, out, iters, f8)};
-    for (const Row& r : rows) printf("%-46s %8.0f %12.0f\n", r.name, r.r, r.z);
+    rows[9] = {"4 waves x 128x128, 16x16x32: MFMA only", run(probe4s<0>, 256, drand, window, out, iters, f4), run(probe4s<0>, 256, dzero, window, out, iters, f4)};
+    rows[10] = {"4 waves x 128x128, 16x16x32: + 0.25 ds_read_b128 / MFMA", run(probe4s<1>, 256, drand, window, out, iters, f4), run(probe4s<1>, 256, dzero, window, out, iters, f4)};
+    rows[11] = {"4 waves x 128x128, 16x16x32: + LDS-DMA stream", run(probe4s<2>, 256, drand, window, out, iters, f4), run(probe4s<2>, 256, dzero, window, out, iters, f4)};
+    for (const Row& r : rows) printf("%-56s %8.0f %12.0f\n", r.name, r.r, r.z);
     return 0;
 }
