@@ -518,7 +518,7 @@ def mfma_power_ceiling(dev):
             if iters > 2000:
                 best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
         res[name] = best
-    return {"what": "pe_mfma_probe: v_mfma_f32_32x32x16_bf16 only, 8 waves/CU, operands in registers, measured in this process "
+    return {"what": "pe_mfma_probe: v_mfma_f32_16x16x32_bf16 only (the shape the GEMM runs on since round 5; 32x32x16 sustains 14 - 16 % less), 8 waves/CU, operands in registers, measured in this process "
                     "after the timed region", "unit": "TFLOP/s", "random_normal_operands": res["random_normal"],
             "zero_operands": res["zeros"]}
 

@@ -42,42 +42,43 @@ void prof_end(int slot, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Matrix-pipe probe: nothing but v_mfma_f32_32x32x16_bf16 (8 independent accumulators per wave, 8 waves per work-group, operands
-// read once from `frags`, no LDS / memory access inside the loop).  On all-zero fragments it runs at the nominal dense peak
-// (2.4 GHz); on random fragments the chip's power limit lowers the clock, and the rate it reports is the ceiling any bf16 MFMA
-// kernel has on such data before a byte is moved (profiles/r02_gemm_notes.md section 5).
+// Matrix-pipe probe: nothing but v_mfma_f32_16x16x32_bf16 -- the shape the GEMM runs on since round 5 (16 independent accumulators per wave,
+// 8 waves per work-group, operands read once from `frags`, no LDS / memory access inside the loop).  On all-zero fragments it runs at the
+// nominal dense peak (2.4 GHz); on random fragments the chip's power limit lowers the clock, and the rate it reports is the ceiling any bf16
+// MFMA kernel has on such data before a byte is moved (profiles/r02_gemm_notes.md section 5; the 32x32x16 shape of rounds 1 - 4 sustains
+// 14 - 16 % less: profiles/r05_gemm_notes.md section 7, tools/microbench/mfma_shape_power.hip measures both).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512) mfma_probe_kernel(const uint4* __restrict__ frags, float* __restrict__ out, int iters) {
     typedef __attribute__((ext_vector_type(8))) __bf16 probe_bf16x8;
-    typedef __attribute__((ext_vector_type(16))) float probe_f32x16;
+    typedef __attribute__((ext_vector_type(4))) float probe_f32x4;
     const int tid = threadIdx.x + blockIdx.x * 512;
     uint4 av[4], bv[4];
     for (int i = 0; i < 4; ++i) {
         av[i] = frags[(tid * 8 + i) & 0xfffff];
         bv[i] = frags[(tid * 8 + 4 + i) & 0xfffff];
     }
-    probe_f32x16 acc[8];
-    for (int i = 0; i < 8; ++i)
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    probe_f32x4 acc[16];
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k) {      // 64 MFMAs x 16 KiFLOP = the 32 x 32 KiFLOP an iteration had in the 32x32x16 form
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(probe_bf16x8, av[(i + k) & 3]),
-                                                                 __builtin_bit_cast(probe_bf16x8, bv[(i >> 1) & 3]), acc[i], 0, 0, 0);
+            for (int i = 0; i < 16; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(probe_bf16x8, av[(i + k) & 3]),
+                                                                 __builtin_bit_cast(probe_bf16x8, bv[(i >> 2) & 3]), acc[i], 0, 0, 0);
         }
     }
     float s = 0.f;
-    for (int i = 0; i < 8; ++i)
-        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j];
     out[tid] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
 // "Attainable" probe: the GEMM main loop's per-MFMA resource mix without its barriers, its dependencies on arriving data and
-// its epilogue.  8 waves per work-group (two per SIMD), all 160 KiB of LDS, per "K tile" and wave 32 MFMAs fed by
-//   MODE 1: + 24 ds_read_b128 fragment reads (0.75 per MFMA, the 64 x 128 wave tile's ratio) from the swizzled LDS image
+// its epilogue.  8 waves per work-group (two per SIMD), all 160 KiB of LDS, per "K tile" and wave 64 MFMAs (v_mfma_f32_16x16x32_bf16) fed by
+//   MODE 1: + 24 ds_read_b128 fragment reads (0.375 per 4-pass MFMA: the 64 x 128 wave tile's ratio) from the swizzled LDS image
 //   MODE 2: + 8 LDS-DMA pieces of 1 KiB (global_load_lds_dwordx4) streamed from an L2-resident window into the ring
 // -- the instructions gemm_bf16_kernel<.., 15 / 17> issues per K tile, free-running (the waves drift, nothing waits for a
 // barrier, counted vmcnt only bounds the DMA queue).  On N(0,1) data the rates of MODE 0 (pe_mfma_probe) / 1 / 2 price the
@@ -88,14 +89,16 @@ __global__ void __launch_bounds__(512) mfma_probe_kernel(const uint4* __restrict
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) gemm_mix_probe_kernel(const char* __restrict__ src, unsigned window_bytes /* power of two */,
                                                                float* __restrict__ out, int iters) {
+    // (round 5: on v_mfma_f32_16x16x32_bf16, 4 x 8 blocks of 16 x 16 per wave, as the GEMM: per K tile and wave 64 MFMAs of 4 passes, the same
+    // 24 fragment reads and 8 LDS-DMA pieces)
     extern __shared__ __attribute__((aligned(16))) char probe_smem[];
     typedef __attribute__((ext_vector_type(8))) __bf16 probe_bf16x8;
-    typedef __attribute__((ext_vector_type(16))) float probe_f32x16;
+    typedef __attribute__((ext_vector_type(4))) float probe_f32x4;
     const int lane = (int)(threadIdx.x & 63);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int l31 = lane & 31, h = lane >> 5;
+    const int l15 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
-    const int sw = (l31 >> 1) & 7;
+    const int sw = (l15 >> 1) & 7;
     // every work-group of an XCD (block b runs on XCD b % 8) streams the same window: the stream is L2 resident
     const char* win = src + (size_t)(blockIdx.x & 7) * window_bytes;
     const unsigned wmask = window_bytes - 1u;
@@ -107,19 +110,19 @@ __global__ void __launch_bounds__(512, 2) gemm_mix_probe_kernel(const char* __re
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    probe_f32x16 acc[2][4];
-    for (int mi = 0; mi < 2; ++mi)
-        for (int ni = 0; ni < 4; ++ni)
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    const int a_off = (wm * 64 + l31) * 128;
-    const int w_off = (wn * 128 + l31) * 128;
+    probe_f32x4 acc[4][8];
+    for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 8; ++ni)
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+    const int a_off = (wm * 64 + l15) * 128;
+    const int w_off = (wn * 128 + l15) * 128;
     char* const a_base = probe_smem;
     char* const w_base = probe_smem + 2 * 32768;
-    probe_bf16x8 fa[4], fw[4][4];
+    probe_bf16x8 fa[2][2], fw[8][2];       // one 32-row phase: 2 activation blocks x 2 k-steps, 8 weight blocks x 2 k-steps
     // MODE 0 never touches LDS again: fragments are read once
-    for (int ks = 0; ks < 4; ++ks) {
-        fa[ks] = *(const probe_bf16x8*)(a_base + a_off + (((ks * 2 + h) ^ sw) << 4));
-        for (int ni = 0; ni < 4; ++ni) fw[ni][ks] = *(const probe_bf16x8*)(w_base + w_off + ni * 4096 + (((ks * 2 + h) ^ sw) << 4));
+    for (int ks = 0; ks < 2; ++ks) {
+        for (int mi = 0; mi < 2; ++mi) fa[mi][ks] = *(const probe_bf16x8*)(a_base + a_off + mi * 2048 + (((ks * 4 + g) ^ sw) << 4));
+        for (int ni = 0; ni < 8; ++ni) fw[ni][ks] = *(const probe_bf16x8*)(w_base + w_off + ni * 2048 + (((ks * 4 + g) ^ sw) << 4));
     }
     unsigned stream_off = (unsigned)blockIdx.x * 65536u + (unsigned)w * 8192u;
     int ab = 0, ws = 0;
@@ -127,21 +130,22 @@ __global__ void __launch_bounds__(512, 2) gemm_mix_probe_kernel(const char* __re
         const char* Sa = a_base + ab * 32768;
         const char* Sw = w_base + ws * 32768;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int ph = 0; ph < 2; ++ph) {
             if constexpr (MODE >= 1) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) fa[ks] = *(const probe_bf16x8*)(Sa + a_off + mi * 4096 + (((ks * 2 + h) ^ sw) << 4));
-                if (mi == 0) {
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int mi = 0; mi < 2; ++mi) fa[mi][ks] = *(const probe_bf16x8*)(Sa + a_off + (ph * 2 + mi) * 2048 + (((ks * 4 + g) ^ sw) << 4));
+                if (ph == 0) {
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
-                            fw[ni][ks] = *(const probe_bf16x8*)(Sw + w_off + ni * 4096 + (((ks * 2 + h) ^ sw) << 4));
+                    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) fw[ni][ks] = *(const probe_bf16x8*)(Sw + w_off + ni * 2048 + (((ks * 4 + g) ^ sw) << 4));
                 }
             }
             if constexpr (MODE >= 2) {
                 // 4 pieces per half K tile: A pieces into the other A buffer, W pieces into the ring slot two ahead
-                char* dst = mi == 0 ? a_base + (ab ^ 1) * 32768 + w * 4096 : w_base + ((ws + 2) % 3) * 32768 + w * 4096;
+                char* dst = ph == 0 ? a_base + (ab ^ 1) * 32768 + w * 4096 : w_base + ((ws + 2) % 3) * 32768 + w * 4096;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     glds16(win + ((stream_off + lane_off) & wmask), dst + j * 1024);
@@ -150,10 +154,12 @@ __global__ void __launch_bounds__(512, 2) gemm_mix_probe_kernel(const char* __re
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ni][ks], fa[ks], acc[mi][ni], 0, 0, 0);
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 8; ++ni)
+                        acc[ph * 2 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni][ks], fa[mi][ks], acc[ph * 2 + mi][ni], 0, 0, 0);
         }
         stream_off += 65536u - 8192u;
         ab ^= 1;
@@ -161,9 +167,9 @@ __global__ void __launch_bounds__(512, 2) gemm_mix_probe_kernel(const char* __re
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float s = 0.f;
-    for (int mi = 0; mi < 2; ++mi)
-        for (int ni = 0; ni < 4; ++ni)
-            for (int r = 0; r < 16; ++r) s += acc[mi][ni][r];
+    for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 8; ++ni)
+            for (int r = 0; r < 4; ++r) s += acc[mi][ni][r];
     out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
 }
 

@@ -6,6 +6,7 @@ Variants 5 / 6 (folded scale and max) are timed on the pre-scaled Q they take (p
 
 H = 24, D = 128, N(0,1) operands, S = 8704 / 8464 (the two CFG branches of the headline geometry) and 11497 (configs[4]);
 median of 7 interleaved rounds x 10 launches per variant.  Also checks variant 3 == variant 0 bit for bit."""
+import os
 import sys
 
 sys.path.insert(0, '.')
@@ -21,7 +22,7 @@ H = 24
 for S in (8704, 8464, 11497):
     sp = ops.s_pad_of(S)
     q = torch.zeros((H, sp, 128), dtype=BF, device='cuda'); q[:, :S] = torch.randn((H, S, 128), generator=g, device='cuda').to(BF)
-    k = torch.zeros((H, sp, 128), dtype=BF, device='cuda'); k[:, :S] = torch.randn((H, S, 128), generator=g, device='cuda').to(BF)
+    k = torch.zeros((H, sp, 128), dtype=BF, device='cuda'); k[:, :S] = (torch.randn((H, S, 128), generator=g, device='cuda') * float(os.environ.get('AB_KSCALE', '1'))).to(BF)      # AB_KSCALE > 1: wider scores, the lazy-max raise path runs on many tiles
     c = 0.08838834764831845 * 1.4426950408889634
     qc = (q.float() * c).to(BF)
     vt = ops.pack_vt(torch.randn((H, S, 128), generator=g, device='cuda').to(BF), sp)
