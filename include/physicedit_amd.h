@@ -54,12 +54,14 @@ const char* pe_build_id(void);
  * dtype on the 32 x 32 blocks of rounds 1 - 4, schedules 15 / 17 (another summation order inside a K tile: same accuracy, not bit-identical with
  * the default, bit-identical with 22).  "gemm_skip_ragged" (default 1): 32-row blocks beyond M skip their MFMAs;
  * "gemm_direct_epilogue" (default 1): complete tiles of the GELU / gate + residual epilogues skip the LDS round trip.  "gemm_band": M tiles per band of
- * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of schedule 17's grid (0 = one per CU).
+ * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of the persistent schedules' grid (0 = one per CU).
  * "attn_variant": 5 default (4 waves x 64 query rows, one wave per SIMD, lazy running max, the softmax scale folded into Q and the max
  * fed through the MFMA C operand: pe_attn_q_prescale / pe_flash_attn_prescaled; same distance to an fp32 result as the reference's own
  * bf16 SDPA, profiles/r04_attention_notes.md); 6 = 5 with the textbook max update; 4 / 3 = the same schedule with scale and max applied
- * per score (round 3's default / its textbook form, bit-identical to 0); 0 = 8 waves x 32 query rows, textbook update (the round-1/2
- * default, and always the kernel of the masked form).  "attn_slots", "attn_force_split": load-balancing knobs of the tests.
+ * per score (round 3's default / its textbook form, bit-identical to 0); 7 = the schedule of 5 on v_mfma_f32_16x16x32_bf16 (round 5: 16 x 16
+ * blocks, softmax denominators through the matrix pipe; 2 % faster alone, 5 % slower per image: opt-in, profiles/r05_attention_notes.md),
+ * 8 = 7 with the textbook max update; 0 = 8 waves x 32 query rows, textbook update (the round-1/2 default, and always the kernel of the
+ * masked form).  "attn_slots", "attn_force_split": load-balancing knobs of the tests.
  * "attn_fp8_variant": kernel of pe_flash_attn_fp8: 1 default (software-pipelined: the MFMAs of S(t+1) and P(t-1) V(t-1) ride between the
  * slices of the softmax of S(t); the softmax reference is raised lazily, by tiles whose maximum exceeds it by 2^8 -- oracle:
  * flash_attention_fp8(kv_tile=64, lazy_tau_log2=8)); 2 = 1 with a maximum-free fast path (a row keeps its reference while its 64 P of
