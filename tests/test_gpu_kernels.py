@@ -3,6 +3,7 @@ same seeded inputs.  Tolerances are in bf16 ulps of the reference value and are 
 assert; the only legitimate source of difference is fp32 summation order (and device exp/rsqrt
 rounding), which flips a small fraction of bf16 roundings by one ulp.
 """
+import functools
 import math
 
 import pytest
@@ -526,6 +527,7 @@ def test_flash_attn_lazy_max_forced_rescale(ops, attn_variant):
 
 
 # --- the folded form (variants 5 / 6): Q arrives multiplied by scale . log2(e), the running max goes through the MFMA C operand ---
+@functools.lru_cache(maxsize=16)     # variants 5 / 7 of a case share its CPU references (the fp32 SDPA at S = 8704 is seconds of host time)
 def _fold_case(S, seed, H=24, spikes=()):
     """fp32 q0 (what the QKV epilogue holds before its one rounding), its two roundings -- bf16(q0) for the reference form and
     bf16(q0 . c) for the folded kernel -- and the references: torch-CPU bf16 SDPA on bf16(q0), fp32 SDPA on q0."""
