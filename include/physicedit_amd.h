@@ -53,7 +53,8 @@ const char* pe_build_id(void);
  * section 7), bit 1 = the e4m3 ones v_mfma_scale_f32_16x16x128_f8f6f4 (slower per Linear in isolation, 1 % faster per image); a clear bit = that
  * dtype on the 32 x 32 blocks of rounds 1 - 4, schedules 15 / 17 (another summation order inside a K tile: same accuracy, not bit-identical with
  * the default, bit-identical with 22).  "gemm_skip_ragged" (default 1): 32-row blocks beyond M skip their MFMAs;
- * "gemm_direct_epilogue" (default 1): complete tiles of the GELU / gate + residual epilogues skip the LDS round trip.  "gemm_band": M tiles per band of
+ * "gemm_direct_epilogue" (bit mask, default 1): bit 0 = complete tiles of the GELU / gate + residual epilogues skip the LDS round trip; bit 1 = so do
+ * the q / k sections of the QKV epilogue (bit-identical, 1.2 % slower: off).  "gemm_band": M tiles per band of
  * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of the persistent schedules' grid (0 = one per CU).
  * "attn_variant": 5 default (4 waves x 64 query rows, one wave per SIMD, lazy running max, the softmax scale folded into Q and the max
  * fed through the MFMA C operand: pe_attn_q_prescale / pe_flash_attn_prescaled; same distance to an fp32 result as the reference's own

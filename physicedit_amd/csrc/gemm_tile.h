@@ -643,6 +643,110 @@ __device__ __forceinline__ void gemm_epilogue_direct16(const KARG GemmProblem& P
         }
 }
 
+// The QKV epilogue's q and k sections without the LDS round trip, 16 x 16 accumulator layout (the v section is written TRANSPOSED and keeps
+// the LDS form).  The wave's 128 columns are one head.  After the pair swap of gemm_epilogue_direct16 a lane holds, per row, the four
+// 8-column chunks c = 4 p + 2 (g & 1) + (g >> 1), p = 0 .. 3.  Per-head RMSNorm: the LDS form sums a row's squares as 16 chunk sums (8
+// columns each, left to right) joined by an xor butterfly over the chunk index (1, 2, 4, 8).  Here level 1 (c ^ 1) is the lane 32 away,
+// level 2 (c ^ 2) the lane 16 away (one swap each: the two results of swapping a value with itself are the two partners' values, and their
+// sum is the level's sum on both sides), levels 4 and 8 run inside the lane over p: the same additions, so the same bits.
+template <bool FP8>
+__device__ __forceinline__ void gemm_epilogue_direct16_qk(const KARG GemmProblem& P, const f32x4 (&acc)[4][8], int m0, int n0, int lane, int w,
+                                                          int section, int head) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int nw0 = n0 + wn * 128, mw0 = m0 + wm * 64;
+    const bf16* bias = (const bf16*)P.bias;
+    float sa[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (FP8) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) sa[mb] = P.scale_a[mw0 + mb * 16 + l15];
+    }
+    bf16x4 bvs[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) bvs[nb] = bf16x4{0, 0, 0, 0};
+    if (bias != nullptr) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) bvs[nb] = *(const bf16x4*)(bias + nw0 + nb * 16 + 4 * g4);
+    }
+    uint32_t yp[4][8][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const bf16x4 b4 = bvs[nb];
+            if constexpr (FP8) {
+                yp[mb][nb][0] = pk2(f32x2{acc[mb][nb][0] * sa[mb] + (float)b4[0], acc[mb][nb][1] * sa[mb] + (float)b4[1]});
+                yp[mb][nb][1] = pk2(f32x2{acc[mb][nb][2] * sa[mb] + (float)b4[2], acc[mb][nb][3] * sa[mb] + (float)b4[3]});
+            } else {
+                yp[mb][nb][0] = pk2(f32x2{acc[mb][nb][0] + (float)b4[0], acc[mb][nb][1] + (float)b4[1]});
+                yp[mb][nb][1] = pk2(f32x2{acc[mb][nb][2] + (float)b4[2], acc[mb][nb][3] + (float)b4[3]});
+            }
+        }
+    const bf16* nw = (const bf16*)(section == 0 ? P.norm_q_w : P.norm_k_w);
+    bf16* dst = (bf16*)(section == 0 ? P.q_out : P.k_out);
+    const float qs1 = (section == 0 && P.q_scale != 0.f) ? P.q_scale : 1.0f;
+    const f32x2 qs = f32x2{qs1, qs1};
+    const int S_pad = P.S_pad;
+    const int cg = 2 * (g4 & 1) + (g4 >> 1);
+    // the norm weights of the lane's four chunks (the same for every row)
+    u32x4 wpv[4];
+#pragma unroll
+    for (int p_ = 0; p_ < 4; ++p_) wpv[p_] = *(const u32x4*)(nw + (4 * p_ + cg) * 8);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int m = mw0 + mb * 16 + l15;
+        // RoPE operands of the row's four chunks: requested before the swaps and sums
+        f32x4 cs[4], sn[4];
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            cs[p_] = *(const f32x4*)(P.rope_cos + (size_t)m * 64 + (4 * p_ + cg) * 4);
+            sn[p_] = *(const f32x4*)(P.rope_sin + (size_t)m * 64 + (4 * p_ + cg) * 4);
+        }
+        u32x4 vp[4];
+        float ss[4];
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(yp[mb][2 * p_][0], yp[mb][2 * p_ + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(yp[mb][2 * p_][1], yp[mb][2 * p_ + 1][1], false, false);
+            vp[p_] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            float s_ = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x2 y2 = up2(vp[p_][jj]);
+                const f32x2 sq = y2 * y2;
+                s_ += sq.x;
+                s_ += sq.y;
+            }
+            ss[p_] = s_;
+        }
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {      // levels 1 and 2 of the butterfly: chunk c ^ 1 (lane ^ 32), then c ^ 2 (lane ^ 16)
+            const auto e1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss[p_]), __float_as_uint(ss[p_]), false, false);
+            ss[p_] = __uint_as_float(e1[0]) + __uint_as_float(e1[1]);
+            const auto e2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ss[p_]), __float_as_uint(ss[p_]), false, false);
+            ss[p_] = __uint_as_float(e2[0]) + __uint_as_float(e2[1]);
+        }
+        const float t0 = ss[0] + ss[1], t2 = ss[2] + ss[3];      // level 4 (p ^ 1), level 8 (p ^ 2)
+        const float tot = t0 + t2;
+        // RMSNorm(128, eps 1e-6): models/utils.py:250-257
+        const float rs = __builtin_amdgcn_rsqf(tot * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            const int c = 4 * p_ + cg;
+            u32x4 o;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x2 x = rnd2(rnd2(up2(vp[p_][jj]) * f32x2{rs, rs}) * up2(wpv[p_][jj]));
+                // apply_rotary_emb_qwen: fp32 complex multiply (qwen_image_dit.py:51-57)
+                const f32x2 a = x * f32x2{cs[p_][jj], cs[p_][jj]};
+                const f32x2 b = f32x2{x.y, x.x} * f32x2{sn[p_][jj], sn[p_][jj]};
+                o[jj] = pk2(f32x2{a.x - b.x, a.y + b.y} * qs);
+            }
+            *(u32x4*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
+        }
+    }
+}
+
 template <int EPI, bool FP8, int NMI = 2, int MI0 = 0, int LAY = 0, typename ACC>
 __device__ __forceinline__ void gemm_epilogue_direct(const KARG GemmProblem& P, const ACC& acc, int m0, int n0, int lane, int w) {
     if constexpr (LAY == 1) {
@@ -767,9 +871,21 @@ template <int EPI, bool FP8, bool TWO_PASS, int NMI = 2, int MI0 = 0, int LAY = 
 __device__ __forceinline__ void gemm_epilogue(const KARG GemmProblem& P, const int M, const int N, const ACC& acc, int m0, int n0,
                                               char* E0, char* E1, int lane, int w, long long* stamp4, int direct = 0) {
     if constexpr (kDirectEpi<EPI>) {
-        if (direct && m0 + BM <= M && n0 + BN <= N && P.pre == nullptr) {      // wave-uniform
+        if ((direct & 1) && m0 + BM <= M && n0 + BN <= N && P.pre == nullptr) {      // wave-uniform
             gemm_epilogue_direct<EPI, FP8, NMI, MI0, LAY>(P, acc, m0, n0, lane, w);
             return;
+        }
+    }
+    if constexpr (EPI == EPI_QKV && LAY == 1) {
+        // bit 1 of "gemm_direct_epilogue": the q / k sections of complete tiles (wave-uniform: a wave's 128 columns are one head of one section)
+        if ((direct & 2) && m0 + BM <= M && n0 + BN <= N && P.pre == nullptr) {
+            const int HD = N / 3;
+            const int nw0 = n0 + (w & 1) * 128;
+            const int section = nw0 / HD;
+            if (section < 2) {
+                gemm_epilogue_direct16_qk<FP8>(P, acc, m0, n0, lane, w, section, (nw0 - section * HD) >> 7);
+                return;
+            }
         }
     }
     if (m0 + BM <= M && n0 + BN <= N && P.pre == nullptr)      // wave-uniform

@@ -249,6 +249,31 @@ def test_gemm_direct_epilogue_bit_identical(ops, var):
         lib().pe_debug_set(b"gemm_variant", 0)
 
 
+@pytest.mark.parametrize("var", [15, 17, 21])
+def test_gemm_direct_qk_epilogue_bit_identical(ops, var):
+    """Bit 1 of gemm_direct_epilogue: the q / k sections of the QKV epilogue (per-head RMSNorm + RoPE + the attention's pre-scale) without the
+    LDS round trip in the 16 x 16 accumulator layout (gemm_epilogue_direct16_qk: the butterfly of the row's chunk sums runs over two lane
+    swaps and two in-lane levels).  Bit-identical with the LDS form: complete and ragged tiles, a joint offset, bf16 and e4m3 operands."""
+    from physicedit_amd._lib import lib
+    try:
+        assert lib().pe_debug_set(b"gemm_variant", var) == 0
+        for (M, seq_off) in ((2300, 0), (8704, 0), (300, 0), (37, 135)):
+            x, w, b = rnd((M, 3072), 11).cuda(), rnd((9216, 3072), 12, 3072 ** -0.5).cuda(), rnd((9216,), 13, 0.1).cuda()
+            nq, nk = synth.make_tensor(5, "norm_q.weight", (128,)).cuda(), synth.make_tensor(5, "norm_k.weight", (128,)).cuda()
+            _, txt = O.rope_tables([(1, 8, 8)], M)
+            cos, sin = txt.real.contiguous().cuda(), txt.imag.contiguous().cuda()
+            outs = {}
+            for d in (1, 3):
+                assert lib().pe_debug_set(b"gemm_direct_epilogue", d) == 0
+                q, k, vt = ops.alloc_qkv(24, seq_off + M, "cuda")
+                ops.qkv_rmsnorm_rope(x, w, b, nq, nk, cos, sin, q, k, vt, seq_off, q_scale=0.1275)
+                outs[d] = (q, k, vt)
+            assert all(torch.equal(u, v) for u, v in zip(outs[1], outs[3])), (var, M, seq_off)
+    finally:
+        lib().pe_debug_set(b"gemm_direct_epilogue", 1)
+        lib().pe_debug_set(b"gemm_variant", 0)
+
+
 @pytest.fixture
 def gemm_workspace():
     """a zeroed stream-K workspace installed for the granular pe_gemm_* calls of one test (pe_debug_set_ptr), removed afterwards"""
