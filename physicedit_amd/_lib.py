@@ -212,7 +212,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        # experiment knobs (see pe_debug_set in include/physicedit_amd.h), e.g. PE_DEBUG="attn_variant=0,gemm_variant=10"
+        # experiment knobs (see pe_debug_set in include/physicedit_amd.h), e.g. PE_DEBUG="attn_variant=0,gemm_variant=17"
         for item in filter(None, os.environ.get("PE_DEBUG", "").split(",")):
             key, _, val = item.partition("=")
             if handle.pe_debug_set(key.strip().encode(), int(val)) != 0:
