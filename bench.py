@@ -44,6 +44,19 @@ def flops_image(height, width, steps, T_pos, T_neg, cfg, layers=60, edit_hw=(102
     return f + vae
 
 
+def flops_trimmed_last_block(height, width, steps, T_pos, T_neg, cfg, edit_hw=(1024, 1024)):
+    """FLOPs per image that the library does NOT execute (dit.hip, round 6): of the last block only the S0 noise rows' post-attention
+    work survives the slice behind it (qwen_image_physical.py:1398-1402), so the other rows' out-projection + MLP (169,869,312 FLOPs per
+    row) and attention queries (12,288 S per row) are not launched.  The algorithmic count keeps them."""
+    S0 = (height // 16) * (width // 16)
+    Se = (edit_hw[0] // 16) * (edit_hw[1] // 16)
+    f = 0.0
+    for T in ((T_pos, T_neg) if cfg != 1.0 else (T_pos,)):
+        S = S0 + Se + T
+        f += (S - S0) * (169_869_312 + 12_288 * S)
+    return steps * f
+
+
 def host_threads_per_rank(world, cpus=None):
     """the ranks of one node share its host: the CPU-side parts of the model build (LoRA / adapter / VAE tensors are generated with torch
     CPU ops) must not oversubscribe it N-fold, and more than 32 threads do not help a generator-bound build"""
@@ -340,6 +353,8 @@ def main():
             "determinism": (determinism or {}).get("bit_identical"),
             "self_check": determinism,
             "whole_path": {"algorithmic_pflop_per_image": fl / 1e15,
+                           "executed_pflop_per_image": (fl - flops_trimmed_last_block(H, W, args.inference_steps, args.t_pos, args.t_neg, args.cfg)
+                                                        * (1 if args.layers > 0 else 0)) / 1e15,
                            "achieved_tflops_per_gpu": fl * value / world / 1e12,
                            "frac_of_bf16_mfma_peak": fl * value / world / 1e12 / PEAK_BF16_TFLOPS,
                            "frac_of_operand_dtype_mfma_peak": fl * value / world / 1e12 / peak,

@@ -359,7 +359,7 @@ class GraphDecoder:
         self.captures = 0           # graphs captured so far (tests: calls of one bucket share one)
 
     def _weights_fingerprint(self):
-        """Addresses (and versions) of every tensor the captured launches take by pointer.  A captured hipGraph bakes them in: after
+        """Address, dtype and shape of every tensor the captured launches take by pointer.  A captured hipGraph bakes them in: after
         .to() / offload + reload / a LoRA merge that re-allocates / a dtype change, a replay would read freed or stale memory without
         any error, so generate() compares this with the fingerprint taken at capture time and re-captures on a mismatch."""
         ts = [self.lm.embed_tokens.weight, self.lm.norm.weight, self.model.lm_head.weight, self.model.lm_head.bias]
@@ -370,7 +370,8 @@ class GraphDecoder:
         return tuple((t.data_ptr(), t.dtype, tuple(t.shape)) if t is not None else None for t in ts)
 
     def reset(self):
-        """Drop the captured graphs and their static planes (the pipeline calls this when it moves or reloads the text encoder)."""
+        """Drop the captured graph and its static planes (28 KiB per cache row) now instead of at the next call.  Nothing has to call this
+        for correctness: generate() notices moved / re-allocated weights by itself (_weights_fingerprint) and captures again."""
         self._static = {}
 
     def _step(self, st):

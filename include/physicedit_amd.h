@@ -37,7 +37,10 @@ extern "C" {
 
 /* Last error message of the calling thread ("" if none). */
 const char* pe_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature, struct or documented-semantics change.
+ * 8 (round 6): counts round 5's additions (pe_decode_attention_workspace_bytes, pe_decode_step_attention_split, pe_flash_attn_fp8
+ * ignoring what the planes' pad columns hold) and round 6's (pe_dit_forward runs the LAST block only on the rows that survive it:
+ * the text stream and the edit-image rows of the handle's residual buffer keep block L - 2's values -- knob "dit_trim_last_block"). */
 int pe_abi_version(void);
 /* Hash of the kernel sources this library was built from (physicedit_amd/build.py:source_hash). */
 const char* pe_build_id(void);
@@ -56,6 +59,9 @@ const char* pe_build_id(void);
  * "gemm_direct_epilogue" (bit mask, default 1): bit 0 = complete tiles of the GELU / gate + residual epilogues skip the LDS round trip; bit 1 = so do
  * the q / k sections of the QKV epilogue (bit-identical, 1.2 % slower: off).  "gemm_band": M tiles per band of
  * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of the persistent schedules' grid (0 = one per CU).
+ * "dit_trim_last_block" (default 1): pe_dit_forward launches of the last block only what reaches the output -- the S0 noise rows' attention
+ * queries, out-projection, norm2 and MLP (the reference slices image[:, :S0] behind it: qwen_image_physical.py:1398-1402); 0 = the whole block
+ * (tests that read the text stream behind it).
  * "attn_variant": 5 default (4 waves x 64 query rows, one wave per SIMD, lazy running max, the softmax scale folded into Q and the max
  * fed through the MFMA C operand: pe_attn_q_prescale / pe_flash_attn_prescaled; same distance to an fp32 result as the reference's own
  * bf16 SDPA, profiles/r04_attention_notes.md); 6 = 5 with the textbook max update; 4 / 3 = the same schedule with scale and max applied
@@ -390,7 +396,9 @@ int pe_dit_set_hot_lora(pe_dit_handle h, const pe_dit_block_lora* blocks, int r)
 int pe_dit_add_hot_lora(pe_dit_handle h, const pe_dit_block_lora* blocks, int r);
 
 /* Bytes of workspace needed for sequences up to (S_img_max image tokens, T_max text tokens) and
- * n_steps prepared timesteps. */
+ * n_steps prepared timesteps.  The stream-K scratch (64 MiB) is part of it only while the opt-in schedule is switched on
+ * ("gemm_sk" != 0 or "gemm_variant" 19): pe_dit_workspace_bytes and pe_dit_bind_workspace must see the SAME knob state, and
+ * a handle bound without it never takes schedule 19 whatever the knob says later. */
 size_t pe_dit_workspace_bytes(pe_dit_handle h, int S_img_max, int T_max, int n_steps);
 
 /* Bind a workspace (zero-fills the regions that must start finite).  Must precede prepare/forward. */

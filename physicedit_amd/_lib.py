@@ -97,7 +97,7 @@ class DitCall(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/physicedit_amd.h declares
-ABI_VERSION = 7   # include/physicedit_amd.h: bumped on any signature / struct change
+ABI_VERSION = 8   # include/physicedit_amd.h: bumped on any signature / struct change
 
 SIGNATURES = {
     "pe_last_error": (C.c_char_p, []),

@@ -32,7 +32,7 @@ using namespace pe;
 extern "C" {
 
 const char* pe_last_error(void) { return g_err; }
-int pe_abi_version(void) { return 7; }
+int pe_abi_version(void) { return 8; }
 #ifndef PE_SRC_HASH
 #define PE_SRC_HASH "unknown"
 #endif
@@ -40,7 +40,13 @@ const char* pe_build_id(void) { return PE_SRC_HASH; }
 
 int pe_debug_set(const char* key, int value) {
     PE_REQUIRE(key != nullptr, "pe_debug_set: null key");
-    if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value == 0 ? GEMM_DEFAULT_VARIANT : value; return PE_OK; }
+    if (!strcmp(key, "gemm_variant")) {
+        PE_REQUIRE(value == 0 || value == 15 || value == 17 || value == 19 || value == 21 || value == 22,
+                   "gemm_variant %d does not exist (0 = default, 15, 17, 19, 21, 22)", value);
+        g_gemm_variant = value == 0 ? GEMM_DEFAULT_VARIANT : value;
+        return PE_OK;
+    }
+    if (!strcmp(key, "dit_trim_last_block")) { g_dit_trim_last_block = value != 0; return PE_OK; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
     if (!strcmp(key, "attn_fp8_variant")) { PE_REQUIRE(value >= 0 && value <= 2, "attn_fp8_variant: 0, 1 or 2"); g_attn_fp8_variant = value; return PE_OK; }
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return PE_OK; }

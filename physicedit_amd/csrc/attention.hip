@@ -1038,9 +1038,10 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
 int g_attn_slots = 256;      // CUs: concurrently resident work-groups = slots x (8 / waves per work-group)
 int g_attn_force_split = 0;  // tests: force an R / split decomposition on small problems
 
-static AttnPlan make_plan(int H, int S, bool have_ws, int Q_BLOCK, int slots) {
+// S_q: the query rows [0, S_q) are wanted (whole q-blocks are computed: rows up to the block's end come for free); keys are always [0, S)
+static AttnPlan make_plan(int H, int S, bool have_ws, int Q_BLOCK, int slots, int S_q) {
     AttnPlan p;
-    p.nqb = (S + Q_BLOCK - 1) / Q_BLOCK;
+    p.nqb = (S_q + Q_BLOCK - 1) / Q_BLOCK;
     const int total = H * p.nqb;
     p.n_full = total;
     p.split = 1;
@@ -1084,8 +1085,10 @@ size_t flash_attn_workspace_bytes(int H, int S) {
 
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
                       int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream, const void* words,
-                      int n_img, bool q_prescaled) {
+                      int n_img, bool q_prescaled, int S_q) {
     PE_REQUIRE(q && k && vt && out, "flash_attn: null pointer");
+    PE_REQUIRE(S_q >= 0 && S_q <= S, "flash_attn: S_q=%d query rows of S=%d", S_q, S);
+    if (S_q == 0) S_q = S;
     PE_REQUIRE(words == nullptr || (n_img >= 0 && n_img <= S && ((uintptr_t)words & 15) == 0),
                "flash_attn: token words need 0 <= n_img <= S and a 16-byte aligned buffer");      // always the 8-wave masked kernel
     PE_REQUIRE(H > 0 && S > 0, "flash_attn: empty problem (H=%d S=%d)", H, S);
@@ -1116,14 +1119,14 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
                          ((uintptr_t)workspace & 15) == 0;
     constexpr int Q_BLOCK = 256;                 // every variant: one work-group = 256 query rows of one head
     const int slots = g_attn_slots;
-    const AttnPlan plan = make_plan(H, S, have_ws, Q_BLOCK, slots);
+    const AttnPlan plan = make_plan(H, S, have_ws, Q_BLOCK, slots, S_q);
     const int total = H * plan.nqb;
     const int n_short = (total - plan.n_full) * plan.split;
     PE_REQUIRE(plan.split == 1 || n_short <= slots, "flash_attn: internal plan error");
     float* part_o = (float*)workspace;
     float* part_ml = part_o ? part_o + (size_t)g_attn_slots * 256 * 128 : nullptr;
     const float scale_log2 = q_prescaled ? 1.0f : scale * 1.44269504088896340736f;     // s . 1 - m is exact: Q carries the factor
-    const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);  // QK^T + PV
+    const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S_q * S * 128.0 * H, stream);  // QK^T + PV of the wanted query rows
     const dim3 grid(plan.n_full + (plan.split > 1 ? n_short : 0));
     if (words != nullptr)
         hipLaunchKernelGGL((flash_attn_kernel<8, true>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
@@ -1881,8 +1884,10 @@ size_t flash_attn_fp8_scratch_bytes(int H, int S_pad) {
 }
 
 int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
-                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream, int S_q) {
     PE_REQUIRE(q && k && vt && out && scratch, "flash_attn_fp8: null pointer");
+    PE_REQUIRE(S_q >= 0 && S_q <= S, "flash_attn_fp8: S_q=%d query rows of S=%d", S_q, S);
+    if (S_q == 0) S_q = S;       // (the three standard deviations are always those of the WHOLE tensors: torch.std over [1,H,S,128])
     PE_REQUIRE(H > 0 && S > 1 && S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn_fp8: bad shape (H=%d S=%d S_pad=%d)", H, S, S_pad);
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn_fp8: bad ldo=%d", ldo);
     PE_REQUIRE(scratch_bytes >= flash_attn_fp8_scratch_bytes(H, S_pad) && ((uintptr_t)scratch & 255) == 0,
@@ -1901,7 +1906,7 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
     uint8_t* vt8 = k8 + plane;
     float* stats = (float*)(vt8 + plane);
     double* part = (double*)((char*)stats + 256);
-    const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S * S * 128.0 * H, stream);
+    const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S_q * S * 128.0 * H, stream);
     hipLaunchKernelGGL(attn_fp8_stats_kernel, dim3(F8_STAT_WGS, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                        H, S, S_pad, part);
     hipLaunchKernelGGL(attn_fp8_stats_finish_kernel, dim3(1), dim3(192), 0, stream, (const double*)part, (double)H * S * 128.0, stats);
@@ -1911,7 +1916,7 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
     if (rc != PE_OK) { prof_end(slot, stream); return rc; }
     const bool have_ws = workspace != nullptr && workspace_bytes >= flash_attn_workspace_bytes(H, S) && ((uintptr_t)workspace & 15) == 0;
     constexpr int Q_BLOCK = 256;
-    const AttnPlan plan = make_plan(H, S, have_ws, Q_BLOCK, g_attn_slots);
+    const AttnPlan plan = make_plan(H, S, have_ws, Q_BLOCK, g_attn_slots, S_q);
     const int total = H * plan.nqb;
     const int n_short = (total - plan.n_full) * plan.split;
     float* part_o = (float*)workspace;

@@ -18,6 +18,8 @@
 
 using namespace pe;
 
+int pe::g_dit_trim_last_block = 1;
+
 namespace {
 constexpr int D = 3072, FF = 12288, HEADS = 24, TXT = 3584, PATCH = 64, AD_HID = 10752, MOD = 6 * D;
 constexpr int MAX_SPECIAL = 256;
@@ -138,7 +140,7 @@ static int dit_linear(pe_dit* h, int epi, GemmProblem* pp, int n, hipStream_t st
     const bool joint = n == 2 && pp[0].K == pp[1].K && pp[0].lda == pp[1].lda &&
                        (const char*)pp[1].A == (const char*)pp[0].A + (size_t)pp[0].M * pp[0].lda * 2;
     size_t off = 0, row = 0;
-    const bool prequantised = joint && h->pre_src != nullptr && h->pre_src == pp[0].A;   // a fused producer already wrote the rows
+    const bool prequantised = (joint || n == 1) && h->pre_src != nullptr && h->pre_src == pp[0].A;   // a fused producer already wrote the rows
     char* qbuf = prequantised ? h->pre_q : h->aq;
     float* qsc = prequantised ? h->pre_sc : h->asc;
     h->pre_src = nullptr;
@@ -174,7 +176,8 @@ static bool has_hot(const pe_dit* h, int l, int g) {
 //     y = Linear(x);  for every (A, B) in the module's lists:  y = y + (x @ A.T) @ B.T      (every op rounds)
 // The base Linear runs without epilogue into ybuf (row stride ldy); each set is two GEMMs, t = x @ A.T and
 // y = pre(y) + t @ B.T -- in place for all but the last set, which carries the real epilogue.
-static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], char* ybuf, int ldy, hipStream_t stream) {
+// n = 2: image + text stream; n = 1: the image stream's problem alone (the trimmed last block)
+static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], int n, char* ybuf, int ldy, hipStream_t stream) {
     int sets[pe_dit::MAX_LORA_SETS], ns = 0;
     for (int ls = 0; ls < h->n_lora; ++ls) {
         const void *a0, *b0, *a1, *b1;
@@ -182,7 +185,7 @@ static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], ch
         lora_ops(h, ls, l, g, 1, &a1, &b1);
         if (a0 && b0 && a1 && b1) sets[ns++] = ls;
     }
-    if (ns == 0) return dit_linear(h, epi, pp, 2, stream);
+    if (ns == 0) return dit_linear(h, epi, pp, n, stream);
     int rc;
     const void* xA[2] = {pp[0].A, pp[1].A};
     const int xlda[2] = {pp[0].lda, pp[1].lda};
@@ -190,11 +193,11 @@ static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], ch
     const size_t row0[2] = {0, (size_t)pp[0].M};
     GemmProblem y1[2];
     memset(y1, 0, sizeof(y1));
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < n; ++s) {
         y1[s].A = pp[s].A; y1[s].lda = pp[s].lda; y1[s].W = pp[s].W; y1[s].bias = pp[s].bias;
         y1[s].out = ybuf + row0[s] * ldy * 2; y1[s].ldo = ldy; y1[s].M = pp[s].M; y1[s].N = pp[s].N; y1[s].K = pp[s].K;
     }
-    if ((rc = dit_linear(h, EPI_BIAS, y1, 2, stream))) return rc;
+    if ((rc = dit_linear(h, EPI_BIAS, y1, n, stream))) return rc;
     for (int i = 0; i < ns; ++i) {
         const int r = h->lora_r[sets[i]];
         const int nl = (g == 0 ? 3 : 1) * r;
@@ -202,7 +205,7 @@ static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], ch
         GemmProblem ta[2], tb[2];
         memset(ta, 0, sizeof(ta));
         memset(tb, 0, sizeof(tb));
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < n; ++s) {
             const void *la, *lb;
             lora_ops(h, sets[i], l, g, s, &la, &lb);
             ta[s].A = xA[s]; ta[s].lda = xlda[s]; ta[s].W = la;
@@ -213,8 +216,8 @@ static int hot_linear(pe_dit* h, int l, int g, int epi, GemmProblem (&pp)[2], ch
             tb[s].pre = ybuf + row0[s] * ldy * 2; tb[s].ldp = ldy;
             if (!last) { tb[s].out = ybuf + row0[s] * ldy * 2; tb[s].ldo = ldy; }   // in place: a lane reads pre before the tile is stored
         }
-        if ((rc = launch_gemm(EPI_BIAS, ta, 2, stream, &h->gws))) return rc;
-        if ((rc = launch_gemm(last ? epi : EPI_BIAS, tb, 2, stream, &h->gws))) return rc;
+        if ((rc = launch_gemm(EPI_BIAS, ta, n, stream, &h->gws))) return rc;
+        if ((rc = launch_gemm(last ? epi : EPI_BIAS, tb, n, stream, &h->gws))) return rc;
     }
     return PE_OK;
 }
@@ -466,6 +469,16 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
         // copy is only needed by hot LoRA (x @ A.T runs in bf16)
         const bool fuse_q = h->w.weights_e4m3 != 0;
         const bool need_bf16_qkv = !fuse_q || has_hot(h, l, 0);
+        // The LAST block: the reference keeps image[:, :S0] behind it and never reads the text stream again (qwen_image_physical.py:1398-1402),
+        // so of this block only the S0 noise rows' post-attention work reaches the output: their attention queries (against ALL keys and
+        // values), out-projection, norm2, MLP and the two gated residuals.  Everything else of the block -- 4096 + T rows of out-proj / MLP,
+        // their query blocks -- is dead work (0.7 % of an image at the headline geometry) and is not launched.  K and V need every row's
+        // norm1 / projection, and so does the e4m3 attention's global q std: the QKV launch stays whole.  The rows of x beyond S0 keep
+        // their values from block L - 2.  Knob "dit_trim_last_block" = 0 runs the whole block (tests that read the text stream).
+        const bool trim = g_dit_trim_last_block != 0 && l == L - 1;
+        const int np = trim ? 1 : 2;                  // problems per launch behind the attention
+        const int M_img = trim ? S0 : S_img;          // image-stream rows behind the attention
+        const int rows_post = trim ? S0 : S;
         if ((rc = launch_ln_modulate_quant(h->x, need_bf16_qkv ? h->xmod : nullptr, S, D, S_img, sh(mod_img, 0), sc(mod_img, 0),
                                            sh(mod_txt, 0), sc(mod_txt, 0), 1e-6f, fuse_q ? h->aq : nullptr,
                                            fuse_q ? h->asc : nullptr, stream)))
@@ -486,14 +499,14 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].seq_off = s == 0 ? 0 : S_img; pp[s].S_pad = S_pad;
             pp[s].q_scale = q_scale;
         }
-        if ((rc = hot_linear(h, l, 0, EPI_QKV, pp, h->hbuf, 3 * D, stream))) return rc;
+        if ((rc = hot_linear(h, l, 0, EPI_QKV, pp, 2, h->hbuf, 3 * D, stream))) return rc;
         // joint attention
         if (fp8_attn)
             rc = launch_flash_attn_fp8(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, h->attn_f8, h->attn_f8_bytes, h->attn_ws,
-                                       h->attn_ws_bytes, stream);
+                                       h->attn_ws_bytes, stream, trim ? S0 : 0);
         else
             rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream,
-                                   c->attn_words, S_img, q_scale != 1.0f);
+                                   c->attn_words, S_img, q_scale != 1.0f, trim ? S0 : 0);
         if (rc) return rc;
         // output projections + gated residual (in place on x)
         memset(pp, 0, sizeof(pp));
@@ -504,11 +517,11 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].out = s == 0 ? x_img : x_txt; pp[s].ldo = D;
             pp[s].res = pp[s].out; pp[s].ldr = D;
             pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 0);
-            pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = D;
+            pp[s].M = s == 0 ? M_img : T; pp[s].N = D; pp[s].K = D;
         }
-        if ((rc = hot_linear(h, l, 1, EPI_GATE_RES, pp, h->xmod, D, stream))) return rc;
+        if ((rc = hot_linear(h, l, 1, EPI_GATE_RES, pp, np, h->xmod, D, stream))) return rc;
         // norm2 + modulate
-        if ((rc = launch_ln_modulate_quant(h->x, fuse_q ? nullptr : h->xmod, S, D, S_img, sh(mod_img, 1), sc(mod_img, 1),
+        if ((rc = launch_ln_modulate_quant(h->x, fuse_q ? nullptr : h->xmod, rows_post, D, M_img, sh(mod_img, 1), sc(mod_img, 1),
                                            sh(mod_txt, 1), sc(mod_txt, 1), 1e-6f, fuse_q ? h->aq : nullptr,
                                            fuse_q ? h->asc : nullptr, stream)))   // MLP-up is no LoRA target: no bf16 copy
             return rc;
@@ -520,7 +533,7 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].W = s == 0 ? B.img_mlp_up_w : B.txt_mlp_up_w;
             pp[s].bias = s == 0 ? B.img_mlp_up_b : B.txt_mlp_up_b;
             pp[s].out = h->hbuf + (s == 0 ? 0 : (size_t)S_img * FF * 2); pp[s].ldo = FF;
-            pp[s].M = s == 0 ? S_img : T; pp[s].N = FF; pp[s].K = D;
+            pp[s].M = s == 0 ? M_img : T; pp[s].N = FF; pp[s].K = D;
         }
         if (fuse_q) {
             // the GELU output is the MLP-down Linear's operand: the epilogue also writes it as e4m3 (aq2) and flags the rows whose
@@ -530,9 +543,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
                 pp[s].q8_out = h->aq2 + r0 * FF; pp[s].ldq8 = FF; pp[s].q8_flags = h->qflags + r0;
             }
         }
-        if ((rc = dit_linear(h, EPI_GELU_SIG, pp, 2, stream))) return rc;
+        if ((rc = dit_linear(h, EPI_GELU_SIG, pp, np, stream))) return rc;
         if (fuse_q) {
-            if ((rc = launch_requant_flagged_rows(h->hbuf, FF, S, FF, h->aq2, FF, h->asc2, h->qflags, stream))) return rc;
+            if ((rc = launch_requant_flagged_rows(h->hbuf, FF, rows_post, FF, h->aq2, FF, h->asc2, h->qflags, stream))) return rc;
             h->pre_src = h->hbuf; h->pre_q = h->aq2; h->pre_sc = h->asc2;
         }
         // MLP down + gated residual
@@ -544,9 +557,9 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].out = s == 0 ? x_img : x_txt; pp[s].ldo = D;
             pp[s].res = pp[s].out; pp[s].ldr = D;
             pp[s].gate = gt(s == 0 ? mod_img : mod_txt, 1);
-            pp[s].M = s == 0 ? S_img : T; pp[s].N = D; pp[s].K = FF;
+            pp[s].M = s == 0 ? M_img : T; pp[s].N = D; pp[s].K = FF;
         }
-        if ((rc = hot_linear(h, l, 2, EPI_GATE_RES, pp, h->attn, D, stream))) return rc;
+        if ((rc = hot_linear(h, l, 2, EPI_GATE_RES, pp, np, h->attn, D, stream))) return rc;
 
         // block-wise ControlNet on the noise rows (:1389-1396): image[:S0] += sum_i bf16(block_i(image[:S0], cond_i) * scale_i).
         // One input: folded into the second Linear's epilogue (0 + v is exact).  Several: the sum is formed first, as the

@@ -649,7 +649,11 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-int g_gemm_variant = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
+static int env_variant() {
+    const int v = env_int("PE_GEMM_VARIANT", GEMM_DEFAULT_VARIANT);
+    return v == 0 ? GEMM_DEFAULT_VARIANT : v;      // 0 = "the compiled default", as in pe_debug_set("gemm_variant", 0)
+}
+int g_gemm_variant = env_variant();
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_skip_ragged = env_int("PE_GEMM_SKIP_RAGGED", 1);
 int g_gemm_direct_epi = env_int("PE_GEMM_DIRECT_EPILOGUE", 1);

@@ -48,13 +48,14 @@ PE_DEV int perm16(int j) { return (j & 3) | ((j & 4) << 1) | ((j & 8) >> 1); }
 
 // VAR selects the main-loop schedule (A/B-tested in one process through pe_debug_set("gemm_variant"); the studies,
 // incl. the variants that no longer live here, are profiles/r01_gemm_ablation.md, r02_gemm_notes.md, r03_gemm_notes.md):
-//   10  (round-1 default, kept as the A/B reference) pipelined clusters: fragments double buffered in registers, tile barrier
-//       before the LAST cluster, staging spread over the clusters, MFMA / ds_read / LDS-DMA interleave pinned with
-//       sched_group_barrier, three-deep W ring and counted vmcnt
-//   15  (round-2 default) "ping-pong": the two wave groups run the same stream one barrier apart, 2 phases x 16 MFMAs per
-//       K tile, A half tiles staged by the group that reads them; one tile per work-group
-//   17  (default) 15's main loop in persistent work-groups with cross-tile prefetch (gemm_persistent below); launches of
-//       fewer than three rounds of tiles run 15
+//   15  (round-2 default) "ping-pong": the two wave groups run the same stream one barrier apart, 2 phases per K tile, A half
+//       tiles staged by the group that reads them; one tile per work-group (what the persistent schedules fall back to for
+//       launches of at most one round of tiles)
+//   17  (round 3 / 4 default) 15's main loop in persistent work-groups with cross-tile prefetch (gemm_persistent in gemm.hip)
+//   19  17 as stream-K (opt-in, measured slower)
+//   21  (DEFAULT since round 5, GEMM_DEFAULT_VARIANT) 17 with ONE matrix-pipe hand-off per K tile: a LOAD slot and a 64-MFMA slot
+//   22  four waves x 128 x 128, one per SIMD (gemm4.hip; opt-in)
+//   (10, the round-1 schedule, left the library in round 5)
 //
 // FP8 = true: operands are OCP e4m3 bytes (activation rows quantised by quantize_rows_e4m3, weights stored in e4m3),
 // the K tile is 128 elements (the SAME 128-B LDS rows, staging and swizzle), the MFMA is the CDNA4 block-scaled

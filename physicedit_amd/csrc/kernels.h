@@ -86,7 +86,9 @@ extern long long* g_gemm_dbg;   // device buffer for the time stamps of the prof
 int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad,
                       int ldo, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream,
                       const void* words = nullptr, int n_img = 0,    // words: EliGen token words (attention.hip), or null
-                      bool q_prescaled = false);                      // Q was written with GemmProblem.q_scale = attn_q_prescale(scale)
+                      bool q_prescaled = false,                       // Q was written with GemmProblem.q_scale = attn_q_prescale(scale)
+                      int S_q = 0);                                   // > 0: only the query rows [0, S_q) are wanted (keys stay [0, S)); rows of `out` beyond
+                                                                      // the last 256-row block that holds a wanted row are left untouched
 float attn_q_prescale(float scale);   // scale * log2(e) when the current attention variant wants it folded into Q, else 1
 size_t flash_attn_workspace_bytes(int H, int S);
 // the default attention kernel's schedule without its softmax (attainable-ceiling probe; the output is meaningless)
@@ -95,7 +97,8 @@ int launch_attn_mix_probe(const void* q, const void* k, const void* vt, void* ou
 // Q); scratch: flash_attn_fp8_scratch_bytes(H, S_pad), 256-byte aligned (e4m3 copies, the three std and their partial sums)
 size_t flash_attn_fp8_scratch_bytes(int H, int S_pad);
 int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
-                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream, int S_q = 0);
+extern int g_dit_trim_last_block;     // dit.hip: 1 (default) = the last block computes only what survives it (knob "dit_trim_last_block")
 extern int g_attn_slots, g_attn_force_split, g_attn_fp8_variant;
 
 // ---------------------------------------------------------------------------------------------

@@ -129,22 +129,23 @@ class CfgPairExchange:
 
     def agree_on_seed(self, seed):
         """The two ranks of a pair must draw the SAME noise (and the same RandomCrop in training mode): a job without a seed would
-        take it from each process's own global RNG.  The pair's even rank decides: its seed (a fresh random one when the job has
-        none) is broadcast inside the pair."""
-        if seed is not None:
-            return seed         # both ranks of the pair hold the same jobs list: nothing to agree on, no collective
-        if self.group is None:
-            # the default group is a pair only in a 2-rank world: anywhere else `src = 0` would take rank 0's seed for every pair
-            if dist.get_world_size() != 2:
-                raise ValueError("CfgPairExchange without a pair group is only valid in a 2-rank world (use make_pairs)")
-            src = 0
-        else:
-            src = dist.get_global_rank(self.group, 0)
-        if self.role == 0:
-            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        box = [seed]
-        dist.broadcast_object_list(box, src=src, group=self.group)
-        return box[0]
+        take it from each process's own global RNG, and two ranks that were handed different job lists would silently denoise
+        different latents and combine mismatched predictions.  One small object all-gather inside the pair per image (beside 40
+        per-step all-gathers of `noise_pred`) settles both: the even rank's seed decides (a fresh random one when it has none), and
+        two DIFFERENT explicit seeds are an error on both ranks instead of a wrong image."""
+        if self.group is None and dist.get_world_size() != 2:
+            # the default group is a pair only in a 2-rank world: anywhere else the gather would span every rank of the job
+            raise ValueError("CfgPairExchange without a pair group is only valid in a 2-rank world (use make_pairs)")
+        mine = seed
+        if mine is None and self.role == 0:
+            mine = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        both = [None, None]
+        dist.all_gather_object(both, (seed is not None, mine), group=self.group)
+        (even_explicit, even_seed), (odd_explicit, odd_seed) = both
+        if even_explicit and odd_explicit and even_seed != odd_seed:
+            raise ValueError(f"the two ranks of a CFG pair hold different seeds for the same job ({even_seed} vs {odd_seed}): "
+                             "every rank must pass the same jobs list")
+        return even_seed
 
     def exchange(self, pred: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         both = [torch.empty_like(pred), torch.empty_like(pred)]

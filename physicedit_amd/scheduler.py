@@ -1,9 +1,11 @@
 """Host-side flow-matching scheduler (scalar math on CPU fp32 tensors, like the reference's).
 
 API mirror of DiffSynth-Studio/diffsynth/schedulers/flow_match.py (FlowMatchScheduler:5-125): same
-constructor keywords, `set_timesteps`, `step`, `add_noise`, `training_target`, `sigmas`,
+constructor keywords, `set_timesteps`, `step`, `add_noise`, `return_to_timestep`, `sigmas`,
 `timesteps`.  The sampler's tensor work (CFG combine + Euler update) is done on the GPU by
-`pe_cfg_euler_step`; `step()` here is kept for API parity and for CPU tensors.
+`pe_cfg_euler_step`; `step()` here is kept for API parity and for CPU tensors.  The reference's
+training-only members (per-timestep loss weights, `training_target`) belong to its trainer, which is
+outside this path: they are not mirrored, and `set_timesteps(training=True)` says so.
 """
 from __future__ import annotations
 
@@ -27,12 +29,14 @@ class FlowMatchScheduler:
         self.exponential_shift = exponential_shift
         self.exponential_shift_mu = exponential_shift_mu
         self.shift_terminal = shift_terminal
-        self.training = False
         self.set_timesteps(num_inference_steps)
 
     # -- table construction (flow_match.py:34-69) ------------------------------------------------
     def set_timesteps(self, num_inference_steps=100, denoising_strength=1.0, training=False, shift=None,
                       dynamic_shift_len=None, exponential_shift_mu=None):
+        if training:
+            raise ValueError("FlowMatchScheduler.set_timesteps(training=True): the trainer's timestep weights are not part of the "
+                             "inference path this package replaces")
         if shift is not None:
             self.shift = shift
         start = self.sigma_min + (self.sigma_max - self.sigma_min) * denoising_strength
@@ -60,12 +64,6 @@ class FlowMatchScheduler:
             s = 1 - s
         self.sigmas = s
         self.timesteps = s * self.num_train_timesteps
-        if training:
-            x = self.timesteps
-            y = torch.exp(-2 * ((x - num_inference_steps / 2) / num_inference_steps) ** 2)
-            y = y - y.min()
-            self.linear_timesteps_weights = y * (num_inference_steps / y.sum())
-        self.training = bool(training)
 
     # -- lookups -----------------------------------------------------------------------------------
     def _index_of(self, timestep) -> int:
@@ -98,13 +96,6 @@ class FlowMatchScheduler:
     def add_noise(self, original_samples, noise, timestep):
         sigma = self.sigmas[self._index_of(timestep)]
         return (1 - sigma) * original_samples + sigma * noise
-
-    def training_target(self, sample, noise, timestep):
-        return noise - sample
-
-    def training_weight(self, timestep):
-        idx = torch.argmin((self.timesteps - timestep.to(self.timesteps.device)).abs())
-        return self.linear_timesteps_weights[idx]
 
     @staticmethod
     def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 8192, base_shift: float = 0.5,

@@ -340,8 +340,10 @@ def make_state_dict_device(layout: Iterable[Tuple[str, Shape]], seed: int, devic
 # --------------------------------------------------------------------------------------
 def hash_uniform(key32: int, numel: int, device, chunk: int = 1 << 20) -> torch.Tensor:
     """fp32 U[-1, 1) on a 2^-23 grid: element i = murmur3's 32-bit finaliser of (i * 0x9E3779B1 + key32) mod 2^32, top 24 bits.
-    Integer arithmetic in int64 with explicit masks (no signed overflow is relied on, no device RNG): torch CPU and torch on the GPU
-    compute the same function bit for bit.  Chunks keep the temporaries cache-resident on the host (65 s for the 60-layer DiT on 8 cores)."""
+    Integer arithmetic in int64 with explicit masks, no device RNG.  The products (a value below 2^32 times a 32-bit constant) can exceed
+    2^63: they WRAP modulo 2^64, which torch's int64 multiply does on the host and on the GPU alike (two's complement, no trap), and the
+    mask that follows keeps the low 32 bits -- the same function bit for bit on both; tests/test_gpu_parity_configs.py compares the
+    device-generated weights' checksums with the host's, and G21-G24 depend on it.  Chunks keep the temporaries cache-resident on the host (65 s for the 60-layer DiT on 8 cores)."""
     out = torch.empty(numel, dtype=torch.float32, device=device)
     n0 = min(numel, chunk)
     h = torch.empty(n0, dtype=torch.int64, device=device)

@@ -876,11 +876,107 @@ def _g21(O, sd, ad32, one_call, t_min, t_max):
     save("G21_60_layers_headline", tensors, meta=meta)
 
 
+def G25_40_steps_60_layers():
+    """The reference's own 40-step CFG-4 loop (qwen_image_physical.py:644-661) on the FULL 60-layer DiT + adapter, 256x256 + a 256x256 edit
+    image, T_pos 160 / T_neg 80 with 16 special tokens each (S = 672 / 592; G23's geometry and inputs, 40 steps instead of 2): 80
+    model_fn_qwen_image calls with forty in-place applications of the adapter to each branch's special rows (:1333-1336), the dynamic-shift
+    schedule and its terminal step (flow_match.py:72-82).  Stored: the latents after EVERY step, both branches' special rows after steps
+    1-4 and after step 40, and an fp32 evaluation of the same 40-step graph by the oracle (fp32 weights widened per access, the timesteps
+    rounded to bf16 as the reference rounds them): the fp32-distance criterion is the only form of "outputs match" that means anything
+    after 80 bf16 forwards.  Also adds the fp32 companion of G23's two steps to that file.  ~4 h on 8 cores: only when named.
+    PE_G25_PARTS=ref,g23,fp32 selects the stages (the file is re-written after each; 'fp32' needs the 'ref' stage's file)."""
+    import time
+    from safetensors import safe_open
+    import oracle.physicedit_oracle as O
+    parts = set(os.environ.get("PE_G25_PARTS", "g23,ref,fp32").split(","))
+    t0 = time.time()
+    sd = synth.make_state_dict_hashed(synth.dit_layout(60), 1234)
+    ad, adsd, (t_min, t_max) = build_adapter(4321)
+    ad32 = {k: v.float() for k, v in adsd.items()}
+    print(f"  60-layer weights ready in {time.time() - t0:.0f} s", flush=True)
+    h = w = 256
+    steps, cfg = 40, 4.0
+    noise = synth.make_noise(3, h, w)
+    g = torch.Generator().manual_seed(3 + 100)
+    edit = torch.randn((1, 16, h // 8, w // 8), generator=g).to(BF)
+    pe_p, mask_p = synth.make_prompt_emb(3 + 7, 160), synth.make_special_token_mask(160, 16)
+    pe_n, mask_n = synth.make_prompt_emb(11, 80), synth.make_special_token_mask(80, 16)
+
+    def load(name):
+        out = {}
+        with safe_open(os.path.join(HERE, name + ".safetensors"), "pt") as f:
+            meta = dict(f.metadata() or {})
+            for k in f.keys():
+                out[k] = f.get_tensor(k)
+        return out, {k: json.loads(v) for k, v in meta.items()} if meta else {}
+
+    def fp32_loop(n_steps, tag):
+        """the same graph in fp32: oracle model_fn on fp32 tensors, weights widened per access, bf16-rounded timesteps"""
+        tab = O.FlowMatchTables(n_steps, dynamic_shift_len=(h // 16) * (w // 16))
+        lat = noise.float()
+        pp, pn = pe_p.float().clone(), pe_n.float().clone()
+        sd32 = _F32View(sd)
+        outs = {}
+        for i, ts in enumerate(tab.timesteps):
+            t1 = time.time()
+            t = ts.unsqueeze(0).to(BF).float()
+            posi = O.model_fn(sd32, ad32, lat, t, pp, mask_p, h, w, edit.float(), t_min, t_max)
+            nega = O.model_fn(sd32, ad32, lat, t, pn, mask_n, h, w, edit.float(), t_min, t_max)
+            lat = tab.step(nega + cfg * (posi - nega), i, lat)
+            outs[f"latents_step{i}_fp32"] = lat.clone()
+            print(f"  {tag} fp32 step {i}: {time.time() - t1:.0f} s", flush=True)
+        outs["special_posi_after_fp32"], outs["special_nega_after_fp32"] = pp[mask_p].clone(), pn[mask_n].clone()
+        return outs
+
+    if "g23" in parts:
+        tensors, meta = load("G23_60_layers_two_cfg_steps")
+        tensors.update(fp32_loop(2, "G23"))
+        meta["fp32"] = "oracle, fp32 weights widened per access, bf16-rounded timesteps"
+        save("G23_60_layers_two_cfg_steps", tensors, meta=meta)
+
+    meta = {"hw": h, "T_pos": 160, "T_neg": 80, "n_special": 16, "seed": 3, "seed_nega": 11, "steps": steps, "cfg_scale": cfg, "layers": 60,
+            "weights": "synth.make_state_dict_hashed", "seed_weights": 1234, "seed_adapter": 4321}
+    if "ref" in parts:
+        with torch.device("meta"):
+            dit = QwenImageDiT(num_layers=60)
+        dit.load_state_dict(sd, assign=True, strict=True)
+        dit.pos_embed = QwenEmbedRope(theta=10000, axes_dim=[16, 56, 56], scale_rope=True)
+        dit.eval()
+        sch = ref_scheduler()
+        sch.set_timesteps(steps, denoising_strength=1.0, dynamic_shift_len=(h // 16) * (w // 16))
+        latents = noise.clone()
+        pp, pn = pe_p.clone(), pe_n.clone()
+        outs = {}
+        for progress_id, timestep in enumerate(sch.timesteps):  # :648-661
+            t1 = time.time()
+            timestep = timestep.unsqueeze(0).to(dtype=BF)
+            kw = dict(dit=dit, blockwise_controlnet=None, visual_thinking_adapter=ad, latents=latents, height=h, width=w, edit_latents=edit,
+                      is_train=False, timestep=timestep, progress_id=progress_id)
+            posi, _ = model_fn_qwen_image(prompt_emb=pp, prompt_emb_mask=torch.ones((1, 160), dtype=torch.long), special_token_mask=mask_p, **kw)
+            nega, _ = model_fn_qwen_image(prompt_emb=pn, prompt_emb_mask=torch.ones((1, 80), dtype=torch.long), special_token_mask=mask_n, **kw)
+            pred = nega + cfg * (posi - nega)
+            latents = sch.step(pred, sch.timesteps[progress_id], latents)
+            outs[f"latents_step{progress_id}"] = latents.clone()
+            if progress_id < 4:
+                outs[f"special_posi_step{progress_id}"], outs[f"special_nega_step{progress_id}"] = pp[mask_p].clone(), pn[mask_n].clone()
+            print(f"  reference loop step {progress_id}: {time.time() - t1:.0f} s", flush=True)
+            if progress_id % 8 == 7:
+                save("G25_40_steps_60_layers.partial", outs, meta=dict(meta, steps_done=progress_id + 1))
+        outs["special_posi_after"], outs["special_nega_after"] = pp[mask_p].clone(), pn[mask_n].clone()
+        save("G25_40_steps_60_layers", outs, meta=meta)
+        del dit
+    if "fp32" in parts:
+        tensors, meta2 = load("G25_40_steps_60_layers")
+        tensors.update(fp32_loop(steps, "G25"))
+        meta2["fp32"] = "oracle, fp32 weights widened per access, bf16-rounded timesteps"
+        save("G25_40_steps_60_layers", tensors, meta=meta2)
+
+
 GROUPS = {k: v for k, v in list(globals().items()) if k[0] == "G" and k[1].isdigit()}
 
 if __name__ == "__main__":
-    # G21 (the 60-layer model: 41 GB, tens of minutes) only when named
-    want = sys.argv[1:] or [g for g in sorted(GROUPS, key=lambda s: int(s[1:].split("_")[0])) if not g.startswith("G21")]
+    # G21 / G25 (the 60-layer model: 41 GB, tens of minutes / hours) only when named
+    want = sys.argv[1:] or [g for g in sorted(GROUPS, key=lambda s: int(s[1:].split("_")[0])) if not g.startswith(("G21", "G25"))]
     for name in want:
         fn = [v for k, v in GROUPS.items() if k.split("_")[0] == name.split("_")[0]][0]
         print("==", fn.__name__)

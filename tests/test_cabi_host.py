@@ -35,7 +35,7 @@ def test_header_symbols_exported(built_lib):
     for name in declared:
         assert hasattr(built_lib, name), name
     from physicedit_amd import _lib as _l
-    assert built_lib.pe_abi_version() == _l.ABI_VERSION == 7
+    assert built_lib.pe_abi_version() == _l.ABI_VERSION == 8
     from physicedit_amd import build as _b
     assert built_lib.pe_build_id().decode() == _b.source_hash()
     assert built_lib.pe_last_error() == b""

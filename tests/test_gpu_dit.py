@@ -154,6 +154,45 @@ def test_model_fn_fp8_attention(eng2):
     assert rms(got8, got) >= 0.5 * e_branch                 # and the branch was really taken
 
 
+@pytest.mark.parametrize("fp8_attention", [False, True])
+def test_last_block_trim(eng2, fp8_attention):
+    """The last block launches only what survives it (dit.hip: the S0 noise rows' attention queries, out-projection, norm2, MLP; the
+    reference slices image[:, :S0] behind block L - 1 and drops the text stream, qwen_image_physical.py:1398-1402).  Against the same
+    forward with the whole block (knob dit_trim_last_block = 0): the noise prediction is the same -- bit for bit with 24 attention
+    slots, where neither launch has split-KV items (which (head, q-block) items are split along the keys depends on the item count, and
+    a split item's fp32 merge rounds differently from a whole one's) -- the special rows of prompt_emb too, and the rows of x beyond S0
+    keep block L - 2's values."""
+    from physicedit_amd.dit import model_fn_qwen_image
+    from physicedit_amd._lib import lib
+    noise, edit, pe, mask = _model_fn_inputs(256, 256, 48, 16, 3)
+    kw = dict(dit=eng2, visual_thinking_adapter=True, latents=noise.cuda(), timestep=torch.tensor([700.0]).to(BF),
+              prompt_emb_mask=torch.ones((1, 48)), special_token_mask=mask, height=256, width=256, edit_latents=edit.cuda(),
+              is_train=False, enable_fp8_attention=fp8_attention)
+    S0, S = 256, 256 + 256 + 48
+    outs = {}
+    for slots in (24, 256):
+        for trim in (1, 0):
+            assert lib().pe_debug_set(b"dit_trim_last_block", trim) == 0 and lib().pe_debug_set(b"attn_slots", slots) == 0
+            try:
+                pe_run = pe.cuda().clone()
+                lat, _ = model_fn_qwen_image(prompt_emb=pe_run, **kw)
+                outs[trim] = (lat.cpu(), pe_run.cpu(), eng2.debug_tensor("x", (S, 3072)).cpu())
+            finally:
+                lib().pe_debug_set(b"dit_trim_last_block", 1)
+                lib().pe_debug_set(b"attn_slots", 256)
+        if slots == 24:
+            assert torch.equal(outs[1][0], outs[0][0])
+            assert torch.equal(outs[1][2][:S0], outs[0][2][:S0])
+        else:
+            # the default plan: 72 items split 3 ways against 24 items split 8 ways -- the same numbers up to the merge's rounding
+            u = ulps(outs[1][0], outs[0][0])
+            print(f"[parity] last-block trim, default attention plan: {(u == 0).float().mean().item() * 100:.2f} % of the latents identical, "
+                  f"max {u.max().item():.1f} ulp")
+            assert u.max().item() <= 2.0 and (u == 0).float().mean().item() > 0.9
+        assert torch.equal(outs[1][1], outs[0][1])
+        assert not torch.equal(outs[1][2][S0:], outs[0][2][S0:])      # the whole block moved the rows the trimmed one never touched
+
+
 def test_loop_dual_stream_is_bit_identical(eng2):
     """posi / nega forwards on two streams + two workspaces == the single-stream loop, bit for bit."""
     from physicedit_amd.pipeline import DenoiseLoop
@@ -598,8 +637,22 @@ def test_model_fn_eligen_G14(golden, eng2):
     # The latents are a weak witness of the mask (image rows see every image row either way); the TEXT stream is a strong one:
     # an entity prompt only sees its region.  Compare the residual streams after the last block with the oracle's, and show that
     # the same forward WITHOUT the mask is far from it.
+    # (the trimmed last block leaves the text stream where block L - 2 put it: run the whole block for this witness)
     S_img, T_all = 64, 12 + 20 + 40
-    x_masked = eng2.debug_tensor("x", (S_img + T_all, 3072))[S_img:]
+    from physicedit_amd._lib import lib
+    assert lib().pe_debug_set(b"dit_trim_last_block", 0) == 0
+    try:
+        model_fn_qwen_image(dit=eng2, latents=noise.cuda(), timestep=torch.tensor([500.0]).to(BF), prompt_emb=pe.cuda().clone(),
+                            special_token_mask=None, height=128, width=128, edit_latents=None,
+                            entity_prompt_emb=[e.cuda() for e in ents[:2]], entity_masks=emask[:, :2], is_train=False)
+        x_masked = eng2.debug_tensor("x", (S_img + T_all, 3072))[S_img:]
+        _eligen_text_witness(eng2, x_masked, noise, pe, ents, emask, S_img, T_all)
+    finally:
+        lib().pe_debug_set(b"dit_trim_last_block", 1)
+
+
+def _eligen_text_witness(eng2, x_masked, noise, pe, ents, emask, S_img, T_all):
+    from physicedit_amd.dit import model_fn_qwen_image
     cap = {}
     sd = synth.make_state_dict(synth.dit_layout(2), 1234)
     O.model_fn(sd, None, noise, torch.tensor([500.0]).to(BF), pe.clone(), None, 128, 128, None, entity_prompt_emb=ents[:2],

@@ -465,6 +465,21 @@ def test_graph_decoder_matches_generate():
     assert torch.equal(ref4, got4) and dec.captures == 2
     got5 = dec.generate(max_new_tokens=40, **inputs)               # back to a short prompt: its bucket was dropped, captured again
     assert torch.equal(ref, got5)
+    # a weight that MOVES between two calls (offload + reload, .to(), a LoRA merge that re-allocates).  The captured launches
+    # hold the old address: the decoder must notice (fingerprint of the addresses), capture again and still produce generate()'s tokens --
+    # here the old storage is overwritten with garbage first, so a stale replay could not pass by luck.
+    n_cap = dec.captures
+    lyr = m.model.language_model.layers[1]
+    old_w = lyr.mlp.down_proj.weight.data
+    lyr.mlp.down_proj.weight.data = old_w.clone()
+    old_w.normal_(0.0, 5.0)
+    got6 = dec.generate(max_new_tokens=40, **inputs)
+    assert dec.captures == n_cap + 1 and torch.equal(ref, got6)
+    got7 = dec.generate(max_new_tokens=40, **inputs)               # nothing moved: no further capture
+    assert dec.captures == n_cap + 1 and torch.equal(ref, got7)
+    dec.reset()                                                    # manual release: the next call builds planes and graph anew
+    assert dec._static == {}
+    assert torch.equal(ref, dec.generate(max_new_tokens=40, **inputs)) and dec.captures == n_cap + 2
 
 
 def test_is_train_runs_the_visual_prior_through_the_facade(tmp_path):

@@ -266,6 +266,41 @@ def test_split_cfg_unseeded_job_gets_one_seed_per_pair():
     assert np.array_equal(got[0][1], got[1][1])
 
 
+def _worker_mismatched_pair(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = parallel.CfgPairExchange.make_pairs()
+    out = []
+    # (what each rank holds for the same job, what the pair must settle on)
+    for mine in ((7, 7), (None, 5), (9, None), (3, 4)):
+        try:
+            out.append(cfg.agree_on_seed(mine[rank]))
+        except ValueError as e:
+            out.append("error: " + str(e)[:40])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg_pair_seed_agreement_is_verified():
+    """with an explicit seed agree_on_seed returned early and trusted both ranks to hold the same jobs list; two ranks with
+    different seeds denoised different latents and combined mismatched predictions, and a (None, seed) pair dead-locked.  Now one
+    object all-gather inside the pair per image: equal seeds pass, a missing one takes the even rank's, different ones raise on BOTH."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mismatched_pair, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1]
+    assert got[0][0] == 7 and got[0][2] == 9 and isinstance(got[0][1], int) and got[0][3].startswith("error")
+
+
 def _worker_loop_pair(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
