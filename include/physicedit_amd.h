@@ -98,6 +98,11 @@ enum {
  * pe_dit_workspace_bytes() includes one per handle.  The granular pe_gemm_* calls run the unsplit schedules unless a test installs
  * a zeroed buffer with pe_debug_set_ptr("gemm_workspace", p). */
 size_t pe_gemm_workspace_bytes(void);
+/* Bytes of the deferred-epilogue stash of the persistent GEMM schedule (round 6: a tile parks y = bf16(acc + bias) there and its GELU /
+ * gate + residual epilogue runs inside the next tile's main loop; 128 KiB per CU; any contents; outputs bit-identical).
+ * pe_dit_workspace_bytes() includes one per handle.  The granular pe_gemm_* calls run every epilogue at its tile's end unless a test
+ * installs a stash with pe_debug_set_ptr("gemm_stash", p). */
+size_t pe_gemm_stash_bytes(void);
 /* out[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias[N]); bf16, fp32 accumulate.
  * gate[N] (nullable => 1) and res[M,N] (row stride ldr, may alias out) only for PE_EPI_GATE_RES.
  * Requires K % 64 == 0, N % 8 == 0, lda/ldo/ldr % 8 == 0. */
@@ -448,8 +453,10 @@ int pe_nchw_to_nhwc(const void* in, void* out, int C, int HW, int Cp, int mode, 
 int pe_nhwc_to_nchw(const void* in, void* out, int C, int HW, int Cp, int mode, const void* ta, const void* tb,
                     void* stream);
 
-/* single-head attention, D = 384 (QwenImageAttentionBlock, :173-198): qkv [N][1152] (q|k|v),
- * vt_scratch >= 384*round_up(N,32) bf16, out [N][384]. */
+/* single-head attention, D = 384 (QwenImageAttentionBlock, :173-198): qkv [N][1152] (q|k|v), out [N][384];
+ * vt_scratch: pe_vae_attention_scratch_bytes(N) bytes, 256-byte aligned (the transposed V, and -- round 6, ABI 8 -- the fp32 partials
+ * of the key split that fills the CUs when there are fewer than 256 query blocks). */
+size_t pe_vae_attention_scratch_bytes(int N);
 int pe_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

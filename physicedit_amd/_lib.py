@@ -120,6 +120,7 @@ SIGNATURES = {
     "pe_flash_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                               c_size_t, c_void_p]),
     "pe_gemm_workspace_bytes": (c_size_t, []),
+    "pe_gemm_stash_bytes": (c_size_t, []),
     "pe_attn_q_prescale": (c_float, [c_float]),
     "pe_qkv_rmsnorm_rope_scaled": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
@@ -177,6 +178,7 @@ SIGNATURES = {
     "pe_vae_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pe_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pe_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pe_vae_attention_scratch_bytes": (c_size_t, [c_int]),
     "pe_vae_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pe_vae_create": (c_int, [C.POINTER(VaeWeights), C.POINTER(c_void_p)]),
     "pe_vae_destroy": (None, [c_void_p]),

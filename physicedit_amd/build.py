@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libphysicedit_amd.so")
 SOURCES = ["api.hip", "gemm.hip", "gemm4.hip", "attention.hip", "elementwise.hip", "dit.hip", "vae.hip", "vae_graph.hip", "profile.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_tile.h", "attention_w4_body.inc", "attention_w5_body.inc", "attention_w5_probe_body.inc", "attention_w7_body.inc", os.path.join("..", "..", "include", "physicedit_amd.h")]
+HEADERS = ["common.h", "kernels.h", "gemm_tile.h", "attention_w4_body.inc", "attention_w5_body.inc", "attention_w5_probe_body.inc", "attention_w7_body.inc", "attention_w9_body.inc", os.path.join("..", "..", "include", "physicedit_amd.h")]
 # -ffp-contract=off is LOAD-BEARING for parity: with bf16-typed operands LLVM narrows
 # float(bf16(a*b)) + float(c) to bf16 fmul/fadd and the default -ffp-contract=fast then fuses them
 # into one fma, silently deleting a bf16 rounding the reference performs (measured: 29 % of
@@ -24,7 +24,9 @@ HEADERS = ["common.h", "kernels.h", "gemm_tile.h", "attention_w4_body.inc", "att
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # per-source extras.  attention.hip: no SLP vectorisation -- it turns adjacent fp32 adds / muls / fmas of the softmax into v_pk_*_f32, which
 # on gfx950 costs more than the two plain VALU it replaces when issued beside MFMAs
-EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+# gemm.hip (round 6): the deferred epilogue's slices run beside the other wave group's MFMAs and are written in scalar fp32 for the same reason
+# (v_pk_*_f32 does not overlap with an MFMA at all); the tile-end epilogues use explicit two-element vectors and keep their packed operations
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "gemm.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

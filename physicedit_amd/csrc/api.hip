@@ -52,6 +52,9 @@ int pe_debug_set(const char* key, int value) {
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return PE_OK; }
     if (!strcmp(key, "gemm4_x")) { g_gemm4_x = value; return PE_OK; }
     if (!strcmp(key, "gemm_skip_ragged")) { g_gemm_skip_ragged = value; return PE_OK; }
+    if (!strcmp(key, "gemm_defer_epilogue")) { g_gemm_defer = value != 0; return PE_OK; }
+    if (!strcmp(key, "gemm_continuous")) { g_gemm_cont = value != 0; return PE_OK; }
+    if (!strcmp(key, "gemm_no_epilogue")) { g_gemm_no_epi = value != 0; return PE_OK; }
     if (!strcmp(key, "gemm_direct_epilogue")) { g_gemm_direct_epi = value; return PE_OK; }
     if (!strcmp(key, "gemm_mfma16")) { g_gemm_mfma16 = value; return PE_OK; }
     if (!strcmp(key, "gemm_persist_min_rounds")) { PE_REQUIRE(value >= 1 && value <= 64, "gemm_persist_min_rounds out of range"); g_gemm_persist_min_rounds = value; return PE_OK; }
@@ -67,11 +70,13 @@ int pe_debug_set_ptr(const char* key, void* p) {
     if (!strcmp(key, "gemm_stamps")) { g_gemm_dbg = (long long*)p; return PE_OK; }
     if (!strcmp(key, "attn_stamps")) { g_attn_dbg = (long long*)p; return PE_OK; }
     // tests: a zeroed device buffer of pe_gemm_workspace_bytes() bytes (256-byte aligned) for the granular pe_gemm_* calls, or null
+    if (!strcmp(key, "gemm_stash")) { g_gemm_ws.stash = p; g_gemm_ws.stash_bytes = p ? gemm_stash_bytes() : 0; return PE_OK; }
     if (!strcmp(key, "gemm_workspace")) { g_gemm_ws.sync = p; g_gemm_ws.bytes = p ? gemm_workspace_bytes() : 0; return PE_OK; }
     return set_error(PE_ERR_INVALID_ARG, "pe_debug_set_ptr: unknown key %s", key);
 }
 
 size_t pe_gemm_workspace_bytes(void) { return gemm_workspace_bytes(); }
+size_t pe_gemm_stash_bytes(void) { return gemm_stash_bytes(); }
 
 int pe_gemm_bf16(int epilogue, const void* A, int lda, const void* W, const void* bias, void* out, int ldo,
                  int M, int N, int K, const void* gate, const void* res, int ldr, void* stream) {
@@ -340,6 +345,7 @@ int pe_nhwc_to_nchw(const void* in, void* out, int C, int HW, int Cp, int mode, 
     return launch_nhwc_to_nchw(in, out, C, HW, Cp, mode, ta, tb, (hipStream_t)stream);
 }
 
+size_t pe_vae_attention_scratch_bytes(int N) { return vae_attention_scratch_bytes(N); }
 int pe_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, void* stream) {
     return launch_vae_attention(qkv, vt_scratch, out, N, (hipStream_t)stream);
 }

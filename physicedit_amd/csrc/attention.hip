@@ -454,12 +454,14 @@ constexpr int v_wait2(int f) { return f <= 12 ? 2 : 0; }       // before MFMA 2f
 // PROBE (pe_attn_mix_probe): the folded schedule without its softmax -- the MFMAs, their LDS fragment reads, the LDS-DMA stream and the
 // barrier of every iteration; P is whatever bf16 data K's first rows hold.  What it sustains on N(0,1) operands is the ceiling of this
 // tiling and staging, as pe_gemm_mix_probe's is for the GEMM.  Its output is meaningless.
-template <bool FOLD, bool PROBE = false>
+// MODE (FOLD only): 0 = the kernel, 1 = the mix probe, 2 = the kernel with the row sums taken from the packed bf16 pairs (variants 9 / 10)
+template <bool FOLD, int MODE = 0>
 __global__ void __launch_bounds__(256, 1)
 flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
                      bf16* __restrict__ out, int S, int S_pad, int ldo, float scale_log2, AttnPlan plan,
                      float* __restrict__ part_o, float* __restrict__ part_ml, float tau, long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool PROBE = MODE == 1;
     constexpr int Q_BLOCK = 256;
     constexpr int KT_BYTES = KV_TILE * 256;        // 16 KiB
     constexpr int V_BASE = PP_STAGES * KT_BYTES;   // K ring [0, 64 KiB), Vt ring [64 KiB, 128 KiB); tile t sits in slot t & 3
@@ -656,6 +658,16 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
             l_run[b] = 1.0f;
         }
 #include "attention_w5_probe_body.inc"
+        stamp_loop = (long long)__builtin_readcyclecounter();
+        for (int i = 0; i < n; i += 4) {
+            iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
+        }
+    } else if constexpr (FOLD && MODE == 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[b][r] = 0.f;
+#include "attention_w9_body.inc"
         stamp_loop = (long long)__builtin_readcyclecounter();
         for (int i = 0; i < n; i += 4) {
             iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
@@ -1064,7 +1076,7 @@ int launch_attn_mix_probe(const void* q, const void* k, const void* vt, void* ou
                    ((uintptr_t)out & 15) == 0, "attn_mix_probe: bad arguments");
     static std::atomic<bool> configured{false};
     if (!configured.load(std::memory_order_acquire)) {
-        const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "attn_mix_probe: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
@@ -1072,7 +1084,7 @@ int launch_attn_mix_probe(const void* q, const void* k, const void* vt, void* ou
     plan.nqb = (S + 255) / 256;
     plan.n_full = H * plan.nqb;
     plan.split = 1;
-    hipLaunchKernelGGL((flash_attn_w4_kernel<true, true>), dim3(plan.n_full), dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k,
+    hipLaunchKernelGGL((flash_attn_w4_kernel<true, 1>), dim3(plan.n_full), dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k,
                        (const bf16*)vt, (bf16*)out, S, S_pad, ldo, 1.0f, plan, (float*)nullptr, (float*)nullptr, 8.0f, (long long*)nullptr);
     return check_launch("flash_attn_w4_kernel<probe>");
 }
@@ -1095,10 +1107,10 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
                S_pad, KV_TILE, S);
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
-    PE_REQUIRE(g_attn_variant == 0 || (g_attn_variant >= 3 && g_attn_variant <= 8), "flash_attn: attn_variant %d does not exist", g_attn_variant);
+    PE_REQUIRE(g_attn_variant == 0 || (g_attn_variant >= 3 && g_attn_variant <= 10), "flash_attn: attn_variant %d does not exist", g_attn_variant);
     // variants 5 / 6 need Q = q . scale . log2(e) (attn_q_prescale()); a caller with a plain Q gets the same schedule's exact form
     int variant = g_attn_variant;
-    if (variant >= 5 && !q_prescaled) variant = (variant == 6 || variant == 8) ? 3 : 4;      // (7 -> 4, 8 -> 3: the 32 x 32 schedule's exact forms)
+    if (variant >= 5 && !q_prescaled) variant = (variant == 6 || variant == 8 || variant == 10) ? 3 : 4;      // (7, 9 -> 4; 8, 10 -> 3: the 32 x 32 schedule's exact forms)
     // the one-wave-per-SIMD kernels store 16-byte vectors: rows must be 16-byte aligned (the 8-wave kernel needs 8)
     if (variant >= 3 && (ldo % 8 != 0 || ((uintptr_t)out & 15) != 0)) variant = 0;
     static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
@@ -1110,6 +1122,8 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
             e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_w7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1131,6 +1145,9 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     if (words != nullptr)
         hipLaunchKernelGGL((flash_attn_kernel<8, true>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
                            (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)words, n_img);
+    else if (variant >= 9)      // 9 / 10 = 5 / 6 with the row sums taken from the packed bf16 pairs (v_dot2c_f32_bf16)
+        hipLaunchKernelGGL((flash_attn_w4_kernel<true, 2>), grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                           (bf16*)out, S, S_pad, ldo, 1.0f, plan, part_o, part_ml, variant == 9 ? 8.0f : 0.0f, g_attn_dbg);
     else if (variant >= 7)      // 8 = 7 with the textbook max update (tests: the raise path on nearly every tile)
         hipLaunchKernelGGL(flash_attn_w7_kernel, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                            (bf16*)out, S, S_pad, ldo, plan, part_o, part_ml, variant == 7 ? 8.0f : 0.0f);

@@ -46,7 +46,8 @@ struct pe_dit {
     char* attn_f8;                      // e4m3 attention (pe_dit_call.fp8_attention): e4m3 copies of Q / K / Vt, the three std, partial sums
     size_t attn_f8_bytes = 0;
     char* gemm_ws;                      // stream-K scratch of the block Linears (gemm.hip schedule 19): zeroed once, private to this handle
-    GemmWorkspace gws = {nullptr, 0};
+    char* gemm_stash;                   // deferred-epilogue stash of the block Linears (gemm_tile.h): 128 KiB per CU, any contents, private to this handle
+    GemmWorkspace gws = {nullptr, 0, nullptr, 0};
     char* lora_t;                       // [S, 3*128] bf16 scratch for x @ A.T
     char* aq;                           // e4m3 mode: quantised activation rows of the Linear being run [S, FF] bytes
     float* asc;                         // e4m3 mode: their per-row scales
@@ -114,6 +115,9 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->gemm_ws, sk_bytes);
     h->gws.sync = sk_bytes ? h->gemm_ws : nullptr;
     h->gws.bytes = sk_bytes;
+    h->gws.stash_bytes = gemm_stash_bytes();
+    take(&h->gemm_stash, h->gws.stash_bytes);
+    h->gws.stash = h->gemm_stash;
     const size_t rows = S > (size_t)n_steps ? S : (size_t)n_steps;
     take(&h->lora_t, rows * 3 * 128 * 2);
     if (h->w.weights_e4m3) {

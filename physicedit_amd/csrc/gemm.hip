@@ -246,7 +246,12 @@ __device__ __forceinline__ void gemm_tile(const KARG GemmArgs& args, char* smem,
     char* E = smem + w * 16384;
     long long* stamp4 = nullptr;
     if constexpr (VAR == 15) stamp4 = args.dbg != nullptr ? args.dbg + (size_t)blockIdx.x * 8 + 4 : nullptr;
-    gemm_epilogue<EPI, FP8, false, 2, 0, S16 ? 1 : 0>(P, M, N, acc, m0, n0, E, E + 8192, lane, w, stamp4, args.direct_epi);
+    if (args.no_epi) {      // timing build: keep the accumulators alive, store nothing
+#pragma unroll
+        for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(accT.quad(j)));
+    } else {
+        gemm_epilogue<EPI, FP8, false, 2, 0, S16 ? 1 : 0>(P, M, N, acc, m0, n0, E, E + 8192, lane, w, stamp4, args.direct_epi);
+    }
     PE_STAMP(5);
 }
 
@@ -365,6 +370,26 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
 
     int ab = 0, ws = 0;     // A buffer / W ring slot of K tile 0 of the current segment
     bool have = false;      // K tiles 0 (A, W) and 1 (W) of the current segment were requested by the previous one
+    // Round 6 ("gemm_continuous", schedule 21 only): the previous tile left the two wave groups ONE SLOT APART -- it skipped the re-align
+    // barrier in front of its epilogue, so this tile skips its opening barrier and the stagger.  The operand stream is already one stream
+    // over the work-group's tiles (stream index nk = K tile 0 of the next tile: same buffers, same waits, same barriers between a request,
+    // its retirement and its first read as inside a tile), so the slot sequence simply runs on: group 0's {epilogue, L(0) of the next tile}
+    // is concurrent with group 1's M(nk - 1), group 0's M(0) with group 1's {epilogue, L(0)}.  Only for tiles whose epilogue touches no
+    // LDS (the direct forms: with the groups a slot apart, the regions an LDS epilogue stages in are still being read / already being
+    // re-filled by the other group) and whose successor is prefetched.  What it removes per tile: the slot group 0 idles in front of the
+    // re-align barrier, the slot group 1 idles behind the stagger, and each group's epilogue VALU / store issue runs beside the other
+    // group's MFMAs instead of beside the other group's epilogue.
+    bool skewed = false;
+    // Round 6 ("gemm_defer_epilogue"): the previous tile parked y = bf16(acc + bias) in the stash; its epilogue proper runs as DEFER_SLICES
+    // slices inside this tile's main loop (gemm_tile.h, "Deferred epilogue").  pm0 / pn0: that tile's origin (same problem as this one).
+    // Only the gated-residual form: its slice is 2 loads, 20 VALU operations and a store.  The GELU form (110 VALU per slice, 16 of them
+    // transcendental) was built the same way and measured +2.7 ... +4.5 % per Linear: an L slot has no slack against the other group's
+    // 1024-cycle M slot, and spreading the stream through the shadows of the wave's own MFMAs is beyond hipcc's allocator (186 spilled
+    // registers in the K loop) -- profiles/r06_gemm_notes.md.
+    constexpr bool DEFER = PH == 1 && !SK && S16 && EPI == EPI_GATE_RES;
+    constexpr int NL = 2;      // loads a slice requests: stash chunk + residual chunk
+    bool pend = false;
+    int pm0 = 0, pn0 = 0;
     for (int sidx = 0;; ++sidx) {
         const Seg cur = seg_at(sidx);
         if (!cur.valid) break;
@@ -536,8 +561,10 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(0), W(0) landed; W(1) may still fly
         }
         // (have: this wave's pieces of A(0), W(0) were retired by the vmcnt(4) of the previous tile's last iteration)
-        PE_BAR();
-        if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger
+        if (!skewed) {
+            PE_BAR();
+            if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger
+        }
         int abk = ab, wsk = ws;
         if constexpr (PH == 1) {
             // Schedule 21 (round 5): ONE hand-off per K tile and wave group instead of two.  A group alternates a LOAD slot (20 fragment
@@ -552,6 +579,11 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
             // with vmcnt(4) at the end of M(kt), a barrier before L(kt+1).  WAR: W(kt+2) overwrites W(kt-1), last read by group 1 in
             // L(kt-1) = slot 2kt-1 (reads drained before its closing barrier), requested from slot 2kt on; A(kt+1) overwrites A(kt-1),
             // whose last reads were consumed by the group's own MFMAs in M(kt-1).  Same K order per output: bit-identical to 15 / 17.
+            // deferred slices of the PREVIOUS tile (DEFER): stash chunk / residual chunk / gate chunk of slice kt, requested at the start of
+            // M(kt), consumed behind the operand wait of L(kt + 1).  vmcnt retires in order: those loads are older than L(kt + 1)'s eight
+            // LDS-DMA requests, so its vmcnt(8) covers them; the slice's store (issued behind that wait) and the next slice's loads are
+            // NEWER than the A(kt + 1) pieces M(kt)'s closing wait is for, so that wait allows for them.
+            u32x4 sl_v = {0, 0, 0, 0}, sl_r = {0, 0, 0, 0};
             for (int kt = 0; kt < nk; ++kt) {
                 const char* Sa = a_base + abk * A_BYTES;
                 const int ws_n1 = wsk == 2 ? 0 : wsk + 1;
@@ -560,9 +592,35 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
                 rd_a1(Sa, 0); rd_w4(w_base + wsk * W_BYTES);
                 st_a4(kt + 1, abk ^ 1);
                 st_w4(kt + 2, ws_n2);
-                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // this wave's pieces of W(kt+1) landed; its fragment reads done
+                // this wave's pieces of W(kt+1) landed; its fragment reads done.  (DEFER: so has the slice the previous M slot requested with asm
+                // loads -- the registers are tied to this wait, which is where the compiler may first touch them)
+                if constexpr (DEFER) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : "+v"(sl_v), "+v"(sl_r) : : "memory");
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                int newer = 0;                 // VMEM operations of this K tile that are newer than its A(kt+1) requests, beyond the 4 of W(kt+2)
+                if constexpr (DEFER) {
+                    if (pend && kt >= 1 && kt <= DEFER_SLICES) {      // wave-uniform: slice kt - 1, beside the other wave group's MFMAs
+                        __builtin_amdgcn_sched_barrier(0);
+                        defer_slice_emit<EPI, FP8>(P, defer_pos(kt - 1, pm0, pn0, lane, w), sl_v, sl_r);
+                        __builtin_amdgcn_sched_barrier(0);
+                        newer = 1;
+                    }
+                }
                 PE_BAR();
                 // M slot
+                if constexpr (DEFER) {
+                    if (pend && kt < DEFER_SLICES) {
+                        // asm loads (wave-uniform base + 32-bit lane offset): invisible to the compiler's own wait insertion, which would
+                        // otherwise put an s_waitcnt vmcnt(0) in front of the consumer and drain the operand stream once per K tile
+                        const char* sb = args.stash + (size_t)blockIdx.x * DEFER_STASH_BYTES + (size_t)kt * (GEMM_THREADS * 16) + (size_t)w * 1024;
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sl_v) : "v"(lane * 16), "s"(sb) : "memory");
+                        const int l15 = lane & 15, g4 = lane >> 4, ncol = (g4 & 1) * 16 + 8 * (g4 >> 1);
+                        const int mu = pm0 + wm * 64 + (kt >> 2) * 16, nu = pn0 + wn * 128 + (kt & 3) * 32;      // wave-uniform part of the chunk's position
+                        const char* rb = (const char*)P.res + ((size_t)mu * P.ldr + nu) * 2;
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sl_r) : "v"((l15 * P.ldr + ncol) * 2), "s"(rb) : "memory");
+                        newer += NL;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -579,7 +637,17 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
                 }
                 mma16(1);
                 __builtin_amdgcn_s_setprio(0);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's pieces of A(kt+1) landed
+                // this wave's pieces of A(kt+1) landed: everything but the 4 requests of W(kt+2) and the slice traffic behind them
+                if constexpr (DEFER) {
+                    switch (newer) {
+                        case 0: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                        case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;      // the last slice's store
+                        case 2: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;      // the first slice's two loads
+                        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;     // a store and two loads
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                }
                 PE_BAR();
                 abk ^= 1;
                 wsk = ws_n1;
@@ -605,14 +673,32 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
                 wsk = ws_n1;
             }
         }
-        if (grp == 0) __builtin_amdgcn_s_barrier();        // re-align the two groups: every fragment read of the tile is done
+        // stay a slot apart across the tile boundary?  (wave-uniform; have_next implies both tiles complete and one problem)
+        bool keep_skew = false;
+        if constexpr (PH == 1 && !SK && kDirectEpi<EPI>) keep_skew = args.cont != 0 && have_next && (args.direct_epi & 1) != 0 && P.pre == nullptr && !args.no_epi;
+        if (!keep_skew) {
+            if (grp == 0) __builtin_amdgcn_s_barrier();    // re-align the two groups: every fragment read of the tile is done
+        }
+        skewed = keep_skew;
         __builtin_amdgcn_sched_barrier(0);
 #undef PE_MMA16
         // abk / wsk = where stream index nk lives (next tile's K tile 0); the regions of K tile nk - 1 are free
         const int a_free = abk ^ 1;
         const int w_free = wsk == 0 ? 2 : wsk - 1;
         char* E = w < 4 ? a_base + a_free * A_BYTES + w * 8192 : w_base + w_free * W_BYTES + (w - 4) * 8192;
-        if (sk_publish) {
+        bool defer_this = false;
+        if constexpr (DEFER) {
+            // park this tile's y and run its epilogue inside the next tile's loop?  The next tile must be this work-group's prefetched successor
+            // (same problem, both complete: have_next) with room for the slices; a gated form needs its gate vector
+            defer_this = args.defer != 0 && args.stash != nullptr && have_next && (args.direct_epi & 1) != 0 && P.pre == nullptr && !args.no_epi &&
+                         nk >= DEFER_SLICES + 2 && P.gate != nullptr;
+            if (defer_this) gemm_epilogue_dump16<EPI, FP8>(P, acc, m0, n0, lane, w, args.stash + (size_t)blockIdx.x * DEFER_STASH_BYTES + (size_t)(w * 64 + lane) * 16);
+            pend = defer_this;
+            pm0 = m0;
+            pn0 = n0;
+        }
+        if (defer_this) {
+        } else if (sk_publish) {
             // a head: write-through (sc1) 16-byte stores of the accumulators, every wave's drained, then the flag (guide: publish-large /
             // handoff-flag); the tail's holder acquires and reads them with plain loads
             char* img = sk_image(sk_pos);
@@ -624,6 +710,9 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(args.sk_sync + SK_FLAG0 + sk_pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (args.no_epi) {      // timing build: keep the accumulators alive, store nothing
+#pragma unroll
+            for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(accT.quad(j)));
         } else {
             gemm_epilogue<EPI, FP8, true, 2, 0, S16 ? 1 : 0>(P, M, N, acc, m0, n0, E, E, lane, w, nullptr, args.direct_epi);
         }
@@ -657,6 +746,9 @@ int g_gemm_variant = env_variant();
 int g_gemm_band = env_int("PE_GEMM_BAND", GEMM_DEFAULT_BAND);
 int g_gemm_skip_ragged = env_int("PE_GEMM_SKIP_RAGGED", 1);
 int g_gemm_direct_epi = env_int("PE_GEMM_DIRECT_EPILOGUE", 1);
+int g_gemm_no_epi = 0;      // timing only: knob "gemm_no_epilogue"
+int g_gemm_defer = env_int("PE_GEMM_DEFER_EPILOGUE", 1);      // schedule 21: a tile's epilogue proper runs inside the next tile's main loop (knob "gemm_defer_epilogue"; needs a stash)
+int g_gemm_cont = env_int("PE_GEMM_CONTINUOUS", 0);      // schedule 21: the wave groups stay a slot apart across tile boundaries (knob "gemm_continuous"; bit-identical, measured +0.2 ... +2.6 % per Linear: off)
 // MFMA shape of the 8-wave schedules, a bit mask: bit 0 = bf16 on v_mfma_f32_16x16x32_bf16, bit 1 = e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (both
 // default since round 5); a clear bit = that dtype on the 32 x 32 blocks of rounds 1 - 4 (schedules 15 / 17 only: the A/B reference).  e4m3: the
 // 16 x 16 x 128 form is 2 - 10 % slower per Linear in isolation and 1 % FASTER per image in the two-stream pipeline (less energy per FLOP: the
@@ -668,7 +760,7 @@ int g_gemm_sk = env_int("PE_GEMM_SK", 0);     // schedule 19 where it applies (A
 // the 1.6-round Linears tie between 15 and 17.  In the two-stream pipeline 1 is 0.9 % faster per image (three interleaved A/B pairs on
 // one box: 11.59 / 11.61 / 11.61 s with 3, 11.50 / 11.49 / 11.50 s with 1; profiles/r04_gemm_notes.md section 5): the default since round 4.
 int g_gemm_persist_min_rounds = 1;
-GemmWorkspace g_gemm_ws = {nullptr, 0};
+GemmWorkspace g_gemm_ws = {nullptr, 0, nullptr, 0};
 constexpr size_t SK_SYNC_BYTES = 4096;        // ticket + flags (<= 992 work-groups), then the accumulator images
 
 static int persistent_grid() {
@@ -687,6 +779,7 @@ static int persistent_grid() {
     return n;
 }
 
+size_t gemm_stash_bytes() { return (size_t)persistent_grid() * DEFER_STASH_BYTES; }
 size_t gemm_workspace_bytes() { return SK_SYNC_BYTES + (size_t)persistent_grid() * SK_PART_BYTES; }
 
 template <int EPI, int VAR, bool FP8, bool S16>
@@ -710,6 +803,10 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     const int ntiles = args.ntiles;
     int var = g_gemm_variant;
     const int G = persistent_grid();
+#ifdef PE_GEMM_DEV_EPI      // development only (register / ISA checks of one instantiation: hipcc -DPE_GEMM_DEV_EPI=1 -S): never set by build.py
+    (void)ntiles; (void)var;
+    return fp8 ? launch_v<EPI, 21, true, true>(args, G, stream) : launch_v<EPI, 21, false, true>(args, G, stream);
+#else
     // 19 (stream-K) wherever it applies -- a workspace was given, more than one round of tiles that do not fill whole rounds, one K --
     // because it is the only schedule whose time does not round T / G up; it only exists for the epilogues of the DiT block's Linears.
     // "gemm_variant" 19 forces it on every launch it can run (tests), 17 / 15 / 10 never take it.
@@ -735,6 +832,7 @@ static int launch_t(const GemmArgs& args, bool fp8, hipStream_t stream) {
     if (var == 17) return fp8 ? launch_v<EPI, 17, true, true>(args, G, stream) : launch_v<EPI, 17, false, true>(args, G, stream);
     if (var == 21) return fp8 ? launch_v<EPI, 21, true, true>(args, G, stream) : launch_v<EPI, 21, false, true>(args, G, stream);
     return fp8 ? launch_v<EPI, 15, true, true>(args, ntiles, stream) : launch_v<EPI, 15, false, true>(args, ntiles, stream);
+#endif
 }
 
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace) {
@@ -783,10 +881,16 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     args.band = g_gemm_band;
     args.skip_ragged = g_gemm_skip_ragged;
     args.direct_epi = g_gemm_direct_epi;
+    args.no_epi = g_gemm_no_epi;
+    args.cont = g_gemm_cont;
+    args.defer = g_gemm_defer;
+    args.stash = nullptr;
     args.dbg = g_gemm_dbg;
     args.sk_sync = nullptr;
     args.sk_part = nullptr;
-    if (workspace == nullptr && g_gemm_ws.sync != nullptr) workspace = &g_gemm_ws;      // tests: pe_debug_set_ptr("gemm_workspace", p)
+    if (workspace == nullptr && (g_gemm_ws.sync != nullptr || g_gemm_ws.stash != nullptr)) workspace = &g_gemm_ws;      // tests: pe_debug_set_ptr("gemm_workspace", p)
+    if (workspace != nullptr && workspace->stash != nullptr && workspace->stash_bytes >= gemm_stash_bytes() && ((uintptr_t)workspace->stash & 255) == 0)
+        args.stash = (char*)workspace->stash;
     if (workspace != nullptr && workspace->sync != nullptr && workspace->bytes >= gemm_workspace_bytes() && ((uintptr_t)workspace->sync & 255) == 0) {
         args.sk_sync = (unsigned*)workspace->sync;
         args.sk_part = (char*)workspace->sync + SK_SYNC_BYTES;
@@ -796,12 +900,16 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     const int slot = prof_begin(PROF_GEMM, flops, stream);
     int rc;
     switch (epilogue) {
+#ifdef PE_GEMM_DEV_EPI
+        case PE_GEMM_DEV_EPI: rc = launch_t<PE_GEMM_DEV_EPI>(args, fp8, stream); break;
+#else
         case EPI_BIAS: rc = launch_t<EPI_BIAS>(args, fp8, stream); break;
         case EPI_GELU_SIG: rc = launch_t<EPI_GELU_SIG>(args, fp8, stream); break;
         case EPI_GELU_ERF: rc = launch_t<EPI_GELU_ERF>(args, fp8, stream); break;
         case EPI_GATE_RES: rc = launch_t<EPI_GATE_RES>(args, fp8, stream); break;
         case EPI_QKV: rc = launch_t<EPI_QKV>(args, fp8, stream); break;
         case EPI_SILU: rc = launch_t<EPI_SILU>(args, fp8, stream); break;
+#endif
         default: rc = set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
     }
     prof_end(slot, stream);

@@ -23,6 +23,10 @@ struct GemmArgs {
     int band;         // M tiles per band of the tile order
     int direct_epi;   // 1: complete tiles of the element-wise epilogues skip the LDS round trip (A/B knob "gemm_direct_epilogue", default 1)
     int skip_ragged;  // 1: row blocks beyond M skip their MFMAs (A/B knob "gemm_skip_ragged", default 1)
+    int defer;        // 1: schedule 21 parks y in `stash` at a tile's end and runs the epilogue proper inside the next tile's main loop (knob "gemm_defer_epilogue")
+    char* stash;      // DEFER_STASH_BYTES per work-group of the persistent grid, or null (no deferral)
+    int cont;         // 1: schedule 21 keeps the two wave groups one slot apart across tile boundaries (A/B knob "gemm_continuous"; gemm.hip)
+    int no_epi;       // TIMING ONLY (knob "gemm_no_epilogue"): the 8-wave schedules stop a tile behind its main loop, nothing is stored -- prices the epilogue
     long long* dbg;   // per work-group s_memtime stamps [grid][8] of schedule 15 (pe_debug_set_ptr("gemm_stamps", p)), or null
     unsigned* sk_sync;   // schedule 19: [0] arrivals, [1 + c] position counter of chunk c, [SK_FLAG0 + pos] flag of the seam behind position pos; zero at rest
     char* sk_part;       // schedule 19: fp32 accumulator images, SK_PART_BYTES per seam
@@ -746,6 +750,100 @@ __device__ __forceinline__ void gemm_epilogue_direct16_qk(const KARG GemmProblem
             *(u32x4*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Deferred epilogue (round 6, schedule 21, 16 x 16 accumulator layout, the direct epilogues' tiles).  At the end of a tile a wave only
+// rounds y = bf16(acc + bias) and parks it in the work-group's STASH (device memory, written and read back by the same lane: it lives in
+// the L2 / Infinity Cache) -- a quarter of the direct epilogue's instructions and nothing that waits on a load.  The epilogue proper (GELU;
+// gate x y + residual) runs in DEFER_SLICES slices inside the NEXT tile's main loop: slice s = the lane's 16-byte chunk of (row block s >> 2,
+// column-block pair s & 3) is requested at the start of M slot s (stash chunk; residual chunk and gate chunk for the gated form) and
+// computed + stored behind the operand wait of L slot s + 1, i.e. beside the other wave group's MFMAs.  Same operations and roundings per
+// element as gemm_epilogue_direct16: bit-identical.  Stash layout: slice-major, then wave, then lane: every store / load instruction of a
+// wave covers 1 KiB contiguous.
+// ------------------------------------------------------------------------------------------
+constexpr int DEFER_SLICES = 16;
+constexpr size_t DEFER_STASH_BYTES = (size_t)BM * BN * 2;      // per work-group of the persistent grid
+
+// EPI_GATE_RES parks z = bf16(gate * y) -- the gated form's next rounding, taken here where the fragment registers are free for the gate
+// vector -- so that its slices need the stash chunk and the residual chunk only (out = bf16(res + z)).
+template <int EPI, bool FP8>
+__device__ __forceinline__ void gemm_epilogue_dump16(const KARG GemmProblem& P, const f32x4 (&acc)[4][8], int m0, int n0, int lane, int w, char* stash_lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int nw0 = n0 + wn * 128, mw0 = m0 + wm * 64;
+    const bf16* bias = (const bf16*)P.bias;
+    float sa[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (FP8) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) sa[mb] = P.scale_a[mw0 + mb * 16 + l15];
+    }
+    bf16x4 bvs[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) bvs[nb] = bf16x4{0, 0, 0, 0};
+    if (bias != nullptr) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) bvs[nb] = *(const bf16x4*)(bias + nw0 + nb * 16 + 4 * g4);
+    }
+    u32x4 gv[EPI == EPI_GATE_RES ? 4 : 1];
+    if constexpr (EPI == EPI_GATE_RES) {
+        const int ncol = (g4 & 1) * 16 + 8 * (g4 >> 1);
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) gv[p_] = *(const u32x4*)((const bf16*)P.gate + nw0 + p_ * 32 + ncol);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            uint32_t yp[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int nb = 2 * p_ + e;
+                const bf16x4 b4 = bvs[nb];
+                if constexpr (FP8) {
+                    yp[e][0] = pk2(f32x2{acc[mb][nb][0] * sa[mb] + (float)b4[0], acc[mb][nb][1] * sa[mb] + (float)b4[1]});
+                    yp[e][1] = pk2(f32x2{acc[mb][nb][2] * sa[mb] + (float)b4[2], acc[mb][nb][3] * sa[mb] + (float)b4[3]});
+                } else {
+                    yp[e][0] = pk2(f32x2{acc[mb][nb][0] + (float)b4[0], acc[mb][nb][1] + (float)b4[1]});
+                    yp[e][1] = pk2(f32x2{acc[mb][nb][2] + (float)b4[2], acc[mb][nb][3] + (float)b4[3]});
+                }
+            }
+            const auto s0 = __builtin_amdgcn_permlane16_swap(yp[0][0], yp[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(yp[0][1], yp[1][1], false, false);
+            u32x4 vp = {s0[0], s1[0], s0[1], s1[1]};
+            if constexpr (EPI == EPI_GATE_RES) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) vp[jj] = pk2(up2(gv[p_][jj]) * up2(vp[jj]));
+            }
+            *(u32x4*)(stash_lane + (size_t)(mb * 4 + p_) * (GEMM_THREADS * 16)) = vp;
+        }
+}
+
+// the chunk a lane holds in slice s: row m0 + wm * 64 + (s >> 2) * 16 + (lane & 15), columns n0 + wn * 128 + (s & 3) * 32 + ncol .. + 7
+struct DeferPos { int m, n; };
+PE_DEV DeferPos defer_pos(int s, int pm0, int pn0, int lane, int w) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    DeferPos d;
+    d.m = pm0 + (w >> 1) * 64 + (s >> 2) * 16 + l15;
+    d.n = pn0 + (w & 1) * 128 + (s & 3) * 32 + (g4 & 1) * 16 + 8 * (g4 >> 1);
+    return d;
+}
+template <int EPI, bool FP8>
+__device__ __forceinline__ void defer_slice_emit(const KARG GemmProblem& P, DeferPos d, u32x4 vp, u32x4 rp) {
+    u32x4 op;
+    if constexpr (EPI == EPI_GATE_RES) {
+#pragma unroll
+        // vp = bf16(gate * y): rounded when it was parked.  SCALAR adds (build.py compiles gemm.hip without SLP vectorisation): a slice runs beside
+        // the other wave group's MFMAs, and v_pk_*_f32 does not overlap with an MFMA at all on gfx950 (profiles/r03_valu_rate.log: 8 packed
+        // operations + 1 MFMA take the SUM of their times, 8 plain ones + 1 MFMA little more than the longer of the two)
+        for (int jj = 0; jj < 4; ++jj)
+            op[jj] = pk2(f32x2{__uint_as_float(rp[jj] << 16) + __uint_as_float(vp[jj] << 16),
+                               __uint_as_float(rp[jj] & 0xffff0000u) + __uint_as_float(vp[jj] & 0xffff0000u)});
+    } else {
+        const f32x2 g2[4] = {f32x2{1.f, 1.f}, f32x2{1.f, 1.f}, f32x2{1.f, 1.f}, f32x2{1.f, 1.f}};
+        op = direct_epi_math<EPI, FP8>(P, vp, rp, g2, d.m, d.n);
+    }
+    *(u32x4*)((bf16*)P.out + (size_t)d.m * P.ldo + d.n) = op;
 }
 
 template <int EPI, bool FP8, int NMI = 2, int MI0 = 0, int LAY = 0, typename ACC>

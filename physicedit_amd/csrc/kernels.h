@@ -65,13 +65,18 @@ struct GemmProblem {
 struct GemmWorkspace {
     void* sync;
     size_t bytes;
+    // round 6: the deferred epilogue's stash (gemm_tile.h): `stash_bytes` >= gemm_stash_bytes(), 256-byte aligned, any contents, private to one
+    // stream at a time.  Without it the persistent schedule runs every epilogue at its tile's end.
+    void* stash;
+    size_t stash_bytes;
 };
 size_t gemm_workspace_bytes();
+size_t gemm_stash_bytes();
 extern GemmWorkspace g_gemm_ws;
 // the GEMM schedule production runs (pe_debug_set("gemm_variant", 0) returns to it): 21 since round 5 (17 with one hand-off per K tile; with the
 // 16 x 16 MFMA shapes it is 2 - 4 % faster per block Linear and 0.7 - 1.2 % per image than 17: profiles/r05_gemm_notes.md section 7)
 constexpr int GEMM_DEFAULT_VARIANT = 21;
-extern int g_gemm_sk, g_gemm_persist_min_rounds, g_gemm4_x, g_gemm_skip_ragged, g_gemm_direct_epi, g_gemm_mfma16;
+extern int g_gemm_sk, g_gemm_persist_min_rounds, g_gemm4_x, g_gemm_skip_ragged, g_gemm_direct_epi, g_gemm_mfma16, g_gemm_no_epi, g_gemm_cont, g_gemm_defer;
 int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t stream, const GemmWorkspace* workspace = nullptr);
 extern int g_gemm_band;          // M tiles per band of the tile order (default 4)
 extern int g_gemm_persist_wgs;   // schedule 17: work-groups of the persistent grid (0 = one per CU)
@@ -164,6 +169,7 @@ int launch_nchw_to_nhwc(const void* in, void* out, int C, int HW, int Cp, int mo
                         hipStream_t stream);
 int launch_nhwc_to_nchw(const void* in, void* out, int C, int HW, int Cp, int mode, const void* ta, const void* tb,
                         hipStream_t stream);
+size_t vae_attention_scratch_bytes(int N);      // Vt + (when the keys are split over several work-groups per query block) the fp32 partials
 int launch_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

@@ -355,9 +355,13 @@ __global__ void __launch_bounds__(256) vae_vt_kernel(const bf16* __restrict__ qk
     }
 }
 
+// Round 6: (a) the keys are SPLIT over gridDim.y work-groups per query block (flash-decoding style: 128 query blocks at 1024 x 1024 filled
+// half of the 256 CUs) -- a part writes its un-normalised (O, m, l) in fp32 and vae_attn_combine_kernel merges them; (b) the 192 O
+// accumulators are rescaled only in tiles where some row of the wave raised its maximum (alpha = 1 for every row otherwise: the
+// multiply it skips is exact), which after the first tiles is almost never.
 __global__ void __launch_bounds__(VA_THREADS, 1)
 vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16* __restrict__ out, int N, int Np,
-                float scale_log2) {
+                float scale_log2, float* __restrict__ part_o, float* __restrict__ part_ml) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
     const int w = wave_id();
@@ -385,7 +389,9 @@ vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16*
         const int vchunk = (lane & 3) ^ ((vrow >> 2) & 3);
         v_src[i] = Vt + (size_t)vrow * Np + vchunk * 8;
     }
-    const int nt = (N + VA_KV - 1) / VA_KV;
+    const int nt_all = (N + VA_KV - 1) / VA_KV;
+    const int nsplit = (int)gridDim.y, part = (int)blockIdx.y;
+    const int t_begin = (int)((long long)nt_all * part / nsplit), t_end = (int)((long long)nt_all * (part + 1) / nsplit);
     auto stage = [&](int buf, int t) {
         char* base = smem + buf * VA_STAGE + w * 6144;
 #pragma unroll
@@ -410,12 +416,12 @@ vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16*
     const int v_off = VA_KV * VA_D * 2 + l31 * 64;
     const int vsw = (l31 >> 2) & 3;
 
-    stage(0, 0);
-    for (int t = 0; t < nt; ++t) {
+    stage(0, t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-        const char* Sb = smem + (t & 1) * VA_STAGE;
+        if (t + 1 < t_end) stage((t - t_begin + 1) & 1, t + 1);
+        const char* Sb = smem + ((t - t_begin) & 1) * VA_STAGE;
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -424,9 +430,9 @@ vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16*
             const int c = kk * 2 + h;
             const bf16x8 kf = *(const bf16x8*)(Sb + k_off + (((c & ~15) | ((c ^ ksw) & 15)) << 4));
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
-            if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep <= 4 K fragments in flight (register budget)
+            if ((kk & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // keep <= 8 K fragments in flight (register budget)
         }
-        if (t == nt - 1 && (N & (VA_KV - 1)) != 0) {
+        if (t == nt_all - 1 && (N & (VA_KV - 1)) != 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = t * VA_KV + 8 * (r >> 2) + 4 * h + (r & 3);
@@ -448,10 +454,12 @@ vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16*
             psum += p;
         }
         l_run = __builtin_fmaf(l_run, alpha, psum);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {      // wave-uniform: some row's maximum moved (x 1.0f elsewhere: exact)
 #pragma unroll
-        for (int dt = 0; dt < 12; ++dt)
+            for (int dt = 0; dt < 12; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             bf16x8 pf;
@@ -469,8 +477,25 @@ vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16*
             }
         }
     }
-    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int q = q0 + l31;
+    if (nsplit > 1) {
+        // un-normalised partial: O [part][q][384] fp32 in the output's column order, (m, l) [part][q][2]
+        if (q < N) {
+            float* po = part_o + ((size_t)part * N + q) * VA_D + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 12; ++dt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    *(f32x4*)(po + dt * 32 + 8 * a) = f32x4{o[dt][4 * a], o[dt][4 * a + 1], o[dt][4 * a + 2], o[dt][4 * a + 3]};
+            if (h == 0) {
+                part_ml[((size_t)part * N + q) * 2] = m_run;
+                part_ml[((size_t)part * N + q) * 2 + 1] = l_tot;
+            }
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
     if (q < N) {
         bf16* op = out + (size_t)q * VA_D + 4 * h;
 #pragma unroll
@@ -485,9 +510,55 @@ vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16*
     }
 }
 
+// O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M): one thread = four columns of one query row
+__global__ void __launch_bounds__(256) vae_attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                               bf16* __restrict__ out, int N, int nsplit) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t q = e / (VA_D / 4);
+    const int c = (int)(e - q * (VA_D / 4));
+    if (q >= (size_t)N) return;
+    float M = -INFINITY;
+    for (int i = 0; i < nsplit; ++i) M = fmaxf(M, part_ml[((size_t)i * N + q) * 2]);
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < nsplit; ++i) {
+        const float wgt = __builtin_amdgcn_exp2f(part_ml[((size_t)i * N + q) * 2] - M);
+        L = __builtin_fmaf(part_ml[((size_t)i * N + q) * 2 + 1], wgt, L);
+        const f32x4 v = *(const f32x4*)(part_o + ((size_t)i * N + q) * VA_D + c * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v[j], wgt, acc[j]);
+    }
+    const float inv = 1.0f / L;
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[j] * inv);
+    *(bf16x4*)(out + q * VA_D + c * 4) = o;
+}
+
+// how many ways the keys are split: as many as fill the CUs once (the combine's traffic grows with every part)
+static int vae_attention_split(int N) {
+    const int nqb = (N + 127) / 128, nt = (N + VA_KV - 1) / VA_KV;
+    int s = 256 / nqb;
+    if (s > 4) s = 4;
+    if (s > nt) s = nt;
+    return s < 1 ? 1 : s;
+}
+
+size_t vae_attention_scratch_bytes(int N) {
+    if (N <= 0) return 0;
+    const size_t Np = (size_t)(N + 31) / 32 * 32;
+    const size_t vt = ((size_t)VA_D * Np * 2 + 255) / 256 * 256;
+    const int s = vae_attention_split(N);
+    return vt + (s > 1 ? (size_t)s * N * (VA_D + 2) * sizeof(float) : 0);
+}
+
 int launch_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, hipStream_t stream) {
     PE_REQUIRE(qkv && vt_scratch && out && N > 0, "vae_attention: bad arguments");
+    PE_REQUIRE(((uintptr_t)vt_scratch & 255) == 0, "vae_attention: the scratch must be 256-byte aligned");
     const int Np = (N + 31) / 32 * 32;
+    const int nsplit = vae_attention_split(N);
+    float* part_o = (float*)((char*)vt_scratch + ((size_t)VA_D * Np * 2 + 255) / 256 * 256);
+    float* part_ml = part_o + (size_t)nsplit * N * VA_D;
     {
         const size_t total = (size_t)VA_D * Np;
         const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -503,10 +574,16 @@ int launch_vae_attention(const void* qkv, void* vt_scratch, void* out, int N, hi
     }
     const float scale_log2 = (float)(1.0 / sqrt((double)VA_D)) * 1.44269504088896340736f;
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)N * N * VA_D, stream);
-    hipLaunchKernelGGL(vae_attn_kernel, dim3((N + 127) / 128), dim3(VA_THREADS), VA_LDS, stream, (const bf16*)qkv,
-                       (const bf16*)vt_scratch, (bf16*)out, N, Np, scale_log2);
+    hipLaunchKernelGGL(vae_attn_kernel, dim3((N + 127) / 128, nsplit), dim3(VA_THREADS), VA_LDS, stream, (const bf16*)qkv,
+                       (const bf16*)vt_scratch, (bf16*)out, N, Np, scale_log2, part_o, part_ml);
+    int rc = check_launch("vae_attn_kernel");
+    if (rc == PE_OK && nsplit > 1) {
+        hipLaunchKernelGGL(vae_attn_combine_kernel, dim3((unsigned)(((size_t)N * (VA_D / 4) + 255) / 256)), dim3(256), 0, stream, (const float*)part_o,
+                           (const float*)part_ml, (bf16*)out, N, nsplit);
+        rc = check_launch("vae_attn_combine_kernel");
+    }
     prof_end(slot, stream);
-    return check_launch("vae_attn_kernel");
+    return rc;
 }
 
 }  // namespace pe

@@ -192,7 +192,7 @@ void pe_vae_destroy(pe_vae_handle h) { delete h; }
 size_t pe_vae_workspace_bytes(int H, int W) {
     if (H <= 0 || W <= 0) return 0;
     const size_t N = (size_t)(H / 8) * (W / 8);
-    return 4 * slot_bytes(H, W) + align_up(384 * align_up(N, 32) * 2, 256);      // + Vt scratch of the mid-block attention
+    return 4 * slot_bytes(H, W) + align_up(vae_attention_scratch_bytes((int)N), 256);      // + the mid-block attention's scratch (Vt, key-split partials)
 }
 
 int pe_vae_encode(pe_vae_handle h, const void* image, int input_format, int H, int W, void* latents, void* ws, size_t ws_bytes,

@@ -47,11 +47,13 @@ class DenoiseLoop:
                  denoising_strength: float = 1.0, blockwise_controlnet=None, blockwise_controlnet_inputs=None,
                  blockwise_controlnet_conditioning=None, eligen_posi=None, eligen_nega=None,
                  input_latents: Optional[torch.Tensor] = None, inpaint_mask: Optional[torch.Tensor] = None,
-                 edit_rope_interpolation: bool = False, enable_fp8_attention: bool = False) -> torch.Tensor:
+                 edit_rope_interpolation: bool = False, enable_fp8_attention: bool = False, on_step=None) -> torch.Tensor:
         """noise [1,16,H/8,W/8] (for an image-to-image run: already `scheduler.add_noise(input_latents, noise, timesteps[0])`);
         prompt_emb_* [1,T,3584] DEVICE tensors, mutated in place on their special rows across the steps exactly like
         `inputs_posi["prompt_emb"]` in the reference.  `inpaint_mask` [1,1,H/8,W/8] + `input_latents`: the blend of
-        BasePipeline.step (utils/__init__.py:150-156) rides in the CFG / Euler kernel."""
+        BasePipeline.step (utils/__init__.py:150-156) rides in the CFG / Euler kernel.
+        `on_step(i, latents)`: called on the loop's stream behind step i's update (the reference's progress hook, :648; the latents
+        tensor is re-used two steps later: clone what is kept)."""
         dev = self.device
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps, denoising_strength=denoising_strength,
@@ -138,4 +140,6 @@ class DenoiseLoop:
             else:
                 ops.cfg_euler_step(pred_p, pred_n, latents, cfg_scale, sch.dsigma(i), out=nxt)
             latents, nxt = nxt, latents
+            if on_step is not None:
+                on_step(i, latents)
         return latents

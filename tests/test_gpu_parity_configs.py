@@ -241,9 +241,13 @@ def test_60_layers_two_cfg_steps(golden):
     torch.cuda.synchronize()
     ref = fx["latents_step1"]
     st = record("configs[1]", "60 layers, 256x256 + 256x256 edit, TWO CFG-4 steps of the loop (two streams) vs the REFERENCE's loop (G23)",
-                got, ref)
+                got, ref, fx["latents_step1_fp32"])
     assert torch.isfinite(got.float()).all()
-    assert st["mean_abs_diff"] <= 2e-2 and st["max_abs_diff"] <= 0.25, st
+    # round 6: the fixture carries an fp32 evaluation of the same two steps, so "as good as the reference's own bf16 run" is shown for the
+    # loop too (rms distance to fp32 within 1.25 x the reference's), and the element-wise bound is 1.5 x / 1.7 x what was measured
+    # (mean 9.3e-3, max 0.070) instead of 2 x / 3.5 x
+    assert st["fp32_distance_ratio"] <= 1.25, st
+    assert st["mean_abs_diff"] <= 1.4e-2 and st["max_abs_diff"] <= 0.12, st
     # the loop owns its prompt embeddings like the reference's `inputs_posi` / `inputs_nega` entries: the adapter rewrote the special
     # rows (twice), nothing else -- and to the reference's values
     mp, mn = mask_p[0].bool(), mask_n[0].bool()
@@ -252,6 +256,58 @@ def test_60_layers_two_cfg_steps(golden):
     for name, rows, want in (("posi", pp[0].cpu()[mp], fx["special_posi_after"]), ("nega", pn[0].cpu()[mn], fx["special_nega_after"])):
         sp = parity_stats(rows, want)
         assert sp["max_ulp"] <= 6.0 and sp["frac_bit_identical"] >= 0.7, (name, sp)
+
+
+def test_60_layers_40_step_loop(golden):
+    """The FULL loop at depth: 40 CFG-4 steps x 60 layers through DenoiseLoop's default form (two streams) at 256x256 + a 256x256 edit
+    image (S = 672 / 592; G23's inputs), against fixture G25: the REFERENCE's own loop (`qwen_image_physical.py:644-661`, 80
+    `model_fn_qwen_image` forwards) -- forty in-place applications of the adapter to each branch's special rows (`:1333-1336`), the
+    dynamic-shift schedule with its terminal step (`flow_match.py:72-82`), 80 forwards of error accumulation -- and an fp32 evaluation
+    of the same 40-step graph.  After 80 bf16 forwards two correct bf16 runs differ element-wise by far more than 1e-3 (the
+    reference's own bf16 run is that far from fp32), so the criterion is the distance to fp32: rms(hip - fp32) <= 1.25 x
+    rms(reference_bf16 - fp32) at the end AND along the trajectory.  The first steps, where the runs have not drifted yet, are also
+    held element-wise: latents within 16 ulp, both branches' special rows within 4 ulp of the reference's."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from physicedit_amd.pipeline import DenoiseLoop
+    fx = golden("G25_40_steps_60_layers")
+    sd_dev, ad, eng, host = model60()
+    noise, edit, pe_p, mask_p = _inputs(256, 256, 256, 256, 160, 16, 3)
+    pe_n = synth.make_prompt_emb(11, 80)
+    mask_n = synth.make_special_token_mask(80, 16)
+    mp, mn = mask_p[0].bool().cuda(), mask_n[0].bool().cuda()
+    loop = DenoiseLoop(eng, dual_stream=True)
+    pp, pn = pe_p.cuda().clone(), pe_n.cuda().clone()
+    traj, specials = {}, {}
+
+    def keep(i, lat):
+        traj[i] = lat.clone()
+        if i < 4:
+            specials[i] = (pp[0][mp].clone(), pn[0][mn].clone())
+    got = loop(noise.cuda(), pp, pn, mask_p, mask_n, 256, 256, num_inference_steps=40, cfg_scale=4.0, edit_latents=edit.cuda(), on_step=keep)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all() and torch.equal(got, traj[39])
+    ratios = {}
+    for i in (0, 1, 3, 9, 19, 29, 39):
+        st = parity_stats(traj[i], fx[f"latents_step{i}"], fx[f"latents_step{i}_fp32"])
+        ratios[i] = st["fp32_distance_ratio"]
+        print(f"[parity] 40-step loop, after step {i + 1}: rms to fp32 hip {st['rms_to_fp32_hip']:.4e} reference-bf16 "
+              f"{st['rms_to_fp32_reference_bf16']:.4e} (ratio {ratios[i]:.3f}); vs reference mean|d| {st['mean_abs_diff']:.3e} max {st['max_ulp']:.1f} ulp")
+        if i < 4:
+            assert st["max_ulp"] <= 16.0, (i, st)
+    st = record("configs[1]", "60 layers, 256x256 + 256x256 edit, the FULL 40-step CFG-4 loop (two streams) vs the REFERENCE's loop (G25)",
+                got, fx["latents_step39"], fx["latents_step39_fp32"], trajectory_fp32_distance_ratio={str(k): v for k, v in ratios.items()})
+    assert max(ratios.values()) <= 1.25, ratios
+    for i in range(4):
+        for name, rows, want in (("posi", specials[i][0], fx[f"special_posi_step{i}"]), ("nega", specials[i][1], fx[f"special_nega_step{i}"])):
+            sp = parity_stats(rows, want)
+            assert sp["max_ulp"] <= 4.0, (i, name, sp)
+    # after step 40: every special row has been through the adapter forty times on both sides
+    for name, rows, want, want32 in (("posi", pp[0][mp], fx["special_posi_after"], fx["special_posi_after_fp32"]),
+                                     ("nega", pn[0][mn], fx["special_nega_after"], fx["special_nega_after_fp32"])):
+        sp = parity_stats(rows, want, want32)
+        print(f"[parity] 40-step loop, {name} special rows after step 40: max {sp['max_ulp']:.1f} ulp, fp32-distance ratio {sp['fp32_distance_ratio']:.3f}")
+        assert sp["fp32_distance_ratio"] <= 1.25, (name, sp)
 
 
 def test_60_layers_configs4_geometry(golden):

@@ -102,9 +102,9 @@ def test_vae_attention(vae_mod, N):
     q, k, v = qkv[None, None].chunk(3, dim=-1)
     ref = F.scaled_dot_product_attention(q, k, v)[0, 0]
     ref32 = F.scaled_dot_product_attention(q.float(), k.float(), v.float())[0, 0]
-    vt = torch.empty((384 * ((N + 31) // 32 * 32),), dtype=BF, device="cuda")
+    vt = torch.empty((int(lib().pe_vae_attention_scratch_bytes(N)) + 256,), dtype=torch.uint8, device="cuda")
     out = torch.empty((N, 384), dtype=BF, device="cuda")
-    check(lib().pe_vae_attention(qkv.cuda().data_ptr(), vt.data_ptr(), out.data_ptr(), N, stream_ptr()))
+    check(lib().pe_vae_attention(qkv.cuda().data_ptr(), (vt.data_ptr() + 255) // 256 * 256, out.data_ptr(), N, stream_ptr()))
     report(f"vae_attention N={N}", out, ref, 3.01, 0.45)   # P is bf16 in both; summation order differs
     e_gpu = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
     e_cpu = (ref.float() - ref32).pow(2).mean().sqrt().item()

@@ -26,6 +26,9 @@ import os
 
 PROBE = False     # set by main(): the folded body WITHOUT its softmax (no pairs, max, state, mask, rescale): attention_w5_probe_body.inc
 FOLD = False      # set by main(): False -> attention_w4_body.inc (variants 3 / 4), True -> attention_w5_body.inc (variants 5 / 6)
+DOT2 = False      # set by main() (round 6, FOLD only): attention_w9_body.inc (variants 9 / 10) -- the row sums are taken from the PACKED bf16 pair with one
+                  # v_dot2c_f32_bf16 (ps += p0 * 1 + p1 * 1) instead of two v_add_f32 on the fp32 exponentials: 32 issue slots of ~600 per tile less,
+                  # and l sums exactly the P the numerator multiplies (as variant 7's ones . P does)
 DMA_SLOTS = int(os.environ.get("W4_DMA_SLOTS", "3"))      # issue slots an LDS-DMA piece (address + m0 + buffer_load ... lds) is booked with
 EARLY_PAIRS = int(os.environ.get("W4_EARLY_PAIRS", "5"))   # per block: pairs 0..4 of softmax(i+1) run in phase 2 of iteration i, pairs 5..15 in phase 1 of i+1
 # FOLD: where in phase 1 the O rescale branches sit (a knob: any gap of phase 1 is legal -- after P.V(i), before P.V(i+1))
@@ -112,6 +115,8 @@ def pair_stream(pairs, P, tagp):
                      uses={f"sc{j}_{T}": score(P, b, 2 * q + j), "sl": "scale_log2", f"sub{b}": f"sm_sub[{b}]"}, sreg=("sl",)) for j in (0, 1)]
             E = [Ins(f"v_exp_f32 %[e{j}_{T}], %[e{j}_{T}]", rmw={f"e{j}_{T}": f"e{j}_{T}"}, slots=2) for j in (0, 1)]
         S = [Ins(f"v_add_f32 %[ps{b}], %[ps{b}], %[e{j}_{T}]", rmw={f"ps{b}": f"sm_psum[{b}]"}, uses={f"e{j}_{T}": f"e{j}_{T}"}) for j in (0, 1)]
+        if DOT2:        # one instruction on the packed pair (0x3f803f80 = bf16 1.0, 1.0)
+            S = [Ins(f"v_dot2c_f32_bf16 %[ps{b}], 0x3f803f80, %[pw_{T}]", rmw={f"ps{b}": f"sm_psum[{b}]"}, uses={f"pw_{T}": f"pw_{T}"})]
         C = Ins(f"v_cvt_pk_bf16_f32 %[pw_{T}], %[e0_{T}], %[e1_{T}]", defs={f"pw_{T}": f"pw_{T}"},
                 uses={f"e0_{T}": f"e0_{T}", f"e1_{T}": f"e1_{T}"}, after=f"{pk_slot(P, b, q)} = pw_{T};")
         return F, E, S, C
@@ -121,12 +126,16 @@ def pair_stream(pairs, P, tagp):
         F, E, S, C = parts(k)
         if prev is None:
             out += F + [E[0], E[1]]
+        elif DOT2:      # exp cvt' exp dot2' : the convert reads exponentials three instructions old, the dot product a word two instructions old
+            pS, pC = prev
+            out += [E[0], pC, E[1], pS[0]]
         else:
             pS, pC = prev
             out += [E[0], pS[0], E[1], pS[1], pC] if FOLD else F + [pS[0], E[0], pS[1], E[1], pC]
         prev = (S, C)
     if prev is not None:
-        out += [prev[0][0], prev[0][1], prev[1]]
+        # (DOT2: the stream's last convert would read an exponential only two instructions old: it waits, as variant 7's does)
+        out += [Ins("s_nop 1"), prev[1], prev[0][0]] if DOT2 else [prev[0][0], prev[0][1], prev[1]]
     return out
 
 
@@ -422,16 +431,18 @@ def gen_prologue(out):
 
 
 def main():
-    global FOLD, PROBE
+    global FOLD, PROBE, DOT2
     here = os.path.dirname(os.path.abspath(__file__))
     only = os.environ.get("W4_ONLY")        # "w4" / "w5": regenerate one of the bodies (knob sweeps)
-    for fold, probe, name, kern in ((False, False, "attention_w4_body.inc", "flash_attn_w4_kernel<false> (variants 3 / 4)"),
-                                    (True, False, "attention_w5_body.inc", "flash_attn_w4_kernel<true> (variants 5 / 6: folded scale and max)"),
-                                    (True, True, "attention_w5_probe_body.inc", "flash_attn_w4_kernel<true, true>: the folded schedule without "
-                                     "its softmax (pe_attn_mix_probe: MFMAs, LDS fragment reads, LDS-DMA stream, barrier)")):
+    for fold, probe, dot2, name, kern in ((False, False, False, "attention_w4_body.inc", "flash_attn_w4_kernel<false> (variants 3 / 4)"),
+                                          (True, False, False, "attention_w5_body.inc", "flash_attn_w4_kernel<true> (variants 5 / 6: folded scale and max)"),
+                                          (True, False, True, "attention_w9_body.inc", "flash_attn_w4_kernel<true, 2> (variants 9 / 10: 5 / 6 with the row sums "
+                                           "taken from the packed bf16 pairs by v_dot2c_f32_bf16)"),
+                                          (True, True, False, "attention_w5_probe_body.inc", "flash_attn_w4_kernel<true, 1>: the folded schedule without "
+                                           "its softmax (pe_attn_mix_probe: MFMAs, LDS fragment reads, LDS-DMA stream, barrier)")):
         if only and (only != name[10:12] or probe):
             continue
-        FOLD, PROBE = fold, probe
+        FOLD, PROBE, DOT2 = fold, probe, dot2
         out = ["// GENERATED by tools/gen_attn_w4.py -- do not edit; the schedule tables and their rationale are in that script.",
                f"// Included inside {kern} (attention.hip), which declares every name used here.", ""]
         for st in range(4):

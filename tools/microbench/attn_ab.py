@@ -53,6 +53,9 @@ for S in (8704, 8464, 11497):
     if 5 in outs and 7 in outs:
         d = (outs[5].float() - outs[7].float()).abs()
         print(f"   v7 vs v5: identical {(d == 0).float().mean().item()*100:.1f} %, max |d| {d.max().item():.3e}", flush=True)
+    if 5 in outs and 9 in outs:
+        d = (outs[5].float() - outs[9].float()).abs()
+        print(f"   v9 vs v5: identical {(d == 0).float().mean().item()*100:.1f} %, max |d| {d.max().item():.3e}", flush=True)
     if 5 in outs and 4 in outs:
         d = (outs[5].float() - outs[4].float()).abs()
         print(f"   v5 vs v4: identical {(d == 0).float().mean().item()*100:.1f} %, max |d| {d.max().item():.3e}", flush=True)

@@ -1,5 +1,5 @@
 """Attention variants 5 / 7 timed per launch (HIP events) alone and with two block-sized GEMM launches in front of every attention launch, as in
-the pipeline (run on the GPU box from the repo root):  python tools/microbench/attn_after_gemm.py"""
+the pipeline (run on the GPU box from the repo root):  python tools/microbench/attn_after_gemm.py [variants, default 5,7]"""
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -20,7 +20,7 @@ w2 = (torch.randn((3072, 12288), generator=g, device='cuda') * 12288 ** -0.5).to
 hbuf = torch.empty((8704, 12288), dtype=BF, device='cuda'); ybuf = torch.empty((8704, 3072), dtype=BF, device='cuda')
 for mode in ("alone", "after 2 GEMMs"):
     for rnd in range(2):
-        for v in (5, 7):
+        for v in ([int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else (5, 7)):
             assert lib().pe_debug_set(b"attn_variant", v) == 0
             evs = []
             for i in range(60):

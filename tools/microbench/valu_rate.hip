@@ -78,6 +78,34 @@ __global__ void __launch_bounds__(256, 1) k(long long* out, float seed) {
                              "v_rcp_f32 %4, %4\n\tv_rcp_f32 %5, %5\n\tv_rcp_f32 %6, %6\n\tv_rcp_f32 %7, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
             }
+        } else if constexpr (MODE == 10) {  // v_dot2c_f32_bf16 (VOP2: d += a.lo * b.lo + a.hi * b.hi; round 6: one of these on the packed P replaces two row-sum adds)
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (MFMA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(fa), "v"(fb));
+                asm volatile("v_dot2c_f32_bf16 %0, 0x3f803f80, %8\n\tv_dot2c_f32_bf16 %1, 0x3f803f80, %8\n\tv_dot2c_f32_bf16 %2, 0x3f803f80, %8\n\tv_dot2c_f32_bf16 %3, 0x3f803f80, %8\n\t"
+                             "v_dot2c_f32_bf16 %4, 0x3f803f80, %8\n\tv_dot2c_f32_bf16 %5, 0x3f803f80, %8\n\tv_dot2c_f32_bf16 %6, 0x3f803f80, %8\n\tv_dot2c_f32_bf16 %7, 0x3f803f80, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(cs));
+            }
+        } else if constexpr (MODE == 11) {  // v_dot2_f32_bf16 (VOP3P)
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (MFMA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(fa), "v"(fb));
+                asm volatile("v_dot2_f32_bf16 %0, %8, %8, %0\n\tv_dot2_f32_bf16 %1, %8, %8, %1\n\tv_dot2_f32_bf16 %2, %8, %8, %2\n\tv_dot2_f32_bf16 %3, %8, %8, %3\n\t"
+                             "v_dot2_f32_bf16 %4, %8, %8, %4\n\tv_dot2_f32_bf16 %5, %8, %8, %5\n\tv_dot2_f32_bf16 %6, %8, %8, %6\n\tv_dot2_f32_bf16 %7, %8, %8, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(cs));
+            }
+        } else if constexpr (MODE == 12) {  // ONE dependent chain of v_dot2c_f32_bf16 (the row sum is one accumulator per block)
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (MFMA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(fa), "v"(fb));
+                asm volatile("v_dot2c_f32_bf16 %0, 0x3f803f80, %1\n\tv_dot2c_f32_bf16 %0, 0x3f803f80, %1\n\tv_dot2c_f32_bf16 %0, 0x3f803f80, %1\n\tv_dot2c_f32_bf16 %0, 0x3f803f80, %1\n\t"
+                             "v_dot2c_f32_bf16 %0, 0x3f803f80, %1\n\tv_dot2c_f32_bf16 %0, 0x3f803f80, %1\n\tv_dot2c_f32_bf16 %0, 0x3f803f80, %1\n\tv_dot2c_f32_bf16 %0, 0x3f803f80, %1"
+                             : "+v"(a0) : "v"(cs));
+            }
+        } else if constexpr (MODE == 13) {  // ONE dependent chain of v_add_f32 (what the row sum is today)
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (MFMA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(fa), "v"(fb));
+                asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\t"
+                             "v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1"
+                             : "+v"(a0) : "v"(cs));
+            }
         } else if constexpr (MODE == 8) {   // nothing but the MFMAs
             for (int g = 0; g < 4; ++g) {
                 if constexpr (MFMA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(fa), "v"(fb));
@@ -121,5 +149,9 @@ int main() {
     run<7, false>("v_rcp_f32", d);       run<7, true>("v_rcp_f32", d);
     run<5, false>("v_cvt_pk_bf16_f32", d); run<5, true>("v_cvt_pk_bf16_f32", d);
     run<9, false>("v_lshlrev_b32", d);   run<9, true>("v_lshlrev_b32", d);
+    run<10, false>("v_dot2c_f32_bf16", d); run<10, true>("v_dot2c_f32_bf16", d);
+    run<11, false>("v_dot2_f32_bf16", d);  run<11, true>("v_dot2_f32_bf16", d);
+    run<12, false>("v_dot2c chain", d);    run<12, true>("v_dot2c chain", d);
+    run<13, false>("v_add_f32 chain", d);  run<13, true>("v_add_f32 chain", d);
     return 0;
 }
