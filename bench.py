@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--fp8-attention", action="store_true",
                     help="with --fp8: also enable_fp8_attention=True (e4m3 attention, pe_flash_attn_fp8) in the timed loop -- the third "
                          "`secondary` line of the default run as the primary workload (profiling); reported in config.workload")
-    ap.add_argument("--attn-variant", type=int, default=5, choices=[0, 3, 4, 5, 6, 7, 9],
+    ap.add_argument("--attn-variant", type=int, default=5, choices=[0, 3, 4, 5, 6, 7],
                     help="flash-attention kernel: 5 = library default since round 4 (4 waves x 64 rows, one wave per SIMD, lazy running max; "
                          "the softmax scale is folded into Q by the QKV epilogue and the max enters through the MFMA C operand: "
                          "profiles/r04_attention_notes.md); 4 = round 3's default (same schedule, scale and max applied per score); 6 / 3 = "

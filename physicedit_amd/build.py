@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libphysicedit_amd.so")
 SOURCES = ["api.hip", "gemm.hip", "gemm4.hip", "attention.hip", "elementwise.hip", "dit.hip", "vae.hip", "vae_graph.hip", "profile.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_tile.h", "attention_w4_body.inc", "attention_w5_body.inc", "attention_w5_probe_body.inc", "attention_w7_body.inc", "attention_w9_body.inc", os.path.join("..", "..", "include", "physicedit_amd.h")]
+HEADERS = ["common.h", "kernels.h", "gemm_tile.h", "attention_w4_body.inc", "attention_w5_body.inc", "attention_w5_probe_body.inc", "attention_w7_body.inc", os.path.join("..", "..", "include", "physicedit_amd.h")]
 # -ffp-contract=off is LOAD-BEARING for parity: with bf16-typed operands LLVM narrows
 # float(bf16(a*b)) + float(c) to bf16 fmul/fadd and the default -ffp-contract=fast then fuses them
 # into one fma, silently deleting a bf16 rounding the reference performs (measured: 29 % of

@@ -454,7 +454,9 @@ constexpr int v_wait2(int f) { return f <= 12 ? 2 : 0; }       // before MFMA 2f
 // PROBE (pe_attn_mix_probe): the folded schedule without its softmax -- the MFMAs, their LDS fragment reads, the LDS-DMA stream and the
 // barrier of every iteration; P is whatever bf16 data K's first rows hold.  What it sustains on N(0,1) operands is the ceiling of this
 // tiling and staging, as pe_gemm_mix_probe's is for the GEMM.  Its output is meaningless.
-// MODE (FOLD only): 0 = the kernel, 1 = the mix probe, 2 = the kernel with the row sums taken from the packed bf16 pairs (variants 9 / 10)
+// MODE (FOLD only): 0 = the kernel, 1 = the mix probe.  (2 was round 6's experiment -- the row sums taken from the packed bf16 pairs with
+// v_dot2c_f32_bf16, generated by tools/gen_attn_w4.py with W4_DOT2=1: correct, 32 issue slots per tile fewer, and 7 % SLOWER alone / 5.6 % per
+// image, because dot instructions, like v_pk_*_f32, do not overlap with an MFMA on gfx950: profiles/r06_attention_notes.md.  Not in the library.)
 template <bool FOLD, int MODE = 0>
 __global__ void __launch_bounds__(256, 1)
 flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
@@ -658,16 +660,6 @@ flash_attn_w4_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, con
             l_run[b] = 1.0f;
         }
 #include "attention_w5_probe_body.inc"
-        stamp_loop = (long long)__builtin_readcyclecounter();
-        for (int i = 0; i < n; i += 4) {
-            iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
-        }
-    } else if constexpr (FOLD && MODE == 2) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negm[b][r] = 0.f;
-#include "attention_w9_body.inc"
         stamp_loop = (long long)__builtin_readcyclecounter();
         for (int i = 0; i < n; i += 4) {
             iter0(i); iter1(i + 1); iter2(i + 2); iter3(i + 3);
@@ -1107,10 +1099,10 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     PE_REQUIRE(S_pad % KV_TILE == 0 && S_pad >= S, "flash_attn: S_pad=%d must be a multiple of %d and >= S=%d",
                S_pad, KV_TILE, S);
     PE_REQUIRE(ldo % 4 == 0 && ldo >= H * 128, "flash_attn: bad ldo=%d", ldo);
-    PE_REQUIRE(g_attn_variant == 0 || (g_attn_variant >= 3 && g_attn_variant <= 10), "flash_attn: attn_variant %d does not exist", g_attn_variant);
+    PE_REQUIRE(g_attn_variant == 0 || (g_attn_variant >= 3 && g_attn_variant <= 8), "flash_attn: attn_variant %d does not exist", g_attn_variant);
     // variants 5 / 6 need Q = q . scale . log2(e) (attn_q_prescale()); a caller with a plain Q gets the same schedule's exact form
     int variant = g_attn_variant;
-    if (variant >= 5 && !q_prescaled) variant = (variant == 6 || variant == 8 || variant == 10) ? 3 : 4;      // (7, 9 -> 4; 8, 10 -> 3: the 32 x 32 schedule's exact forms)
+    if (variant >= 5 && !q_prescaled) variant = (variant == 6 || variant == 8) ? 3 : 4;      // (7 -> 4, 8 -> 3: the 32 x 32 schedule's exact forms)
     // the one-wave-per-SIMD kernels store 16-byte vectors: rows must be 16-byte aligned (the 8-wave kernel needs 8)
     if (variant >= 3 && (ldo % 8 != 0 || ((uintptr_t)out & 15) != 0)) variant = 0;
     static std::atomic<bool> configured{false};   // racing first calls both configure: idempotent
@@ -1122,8 +1114,6 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
             e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)flash_attn_w4_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)flash_attn_w7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1145,9 +1135,6 @@ int launch_flash_attn(const void* q, const void* k, const void* vt, void* out, i
     if (words != nullptr)
         hipLaunchKernelGGL((flash_attn_kernel<8, true>), grid, dim3(512), ATT_LDS, stream, (const bf16*)q, (const bf16*)k,
                            (const bf16*)vt, (bf16*)out, S, S_pad, ldo, scale_log2, plan, part_o, part_ml, (const uint32_t*)words, n_img);
-    else if (variant >= 9)      // 9 / 10 = 5 / 6 with the row sums taken from the packed bf16 pairs (v_dot2c_f32_bf16)
-        hipLaunchKernelGGL((flash_attn_w4_kernel<true, 2>), grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                           (bf16*)out, S, S_pad, ldo, 1.0f, plan, part_o, part_ml, variant == 9 ? 8.0f : 0.0f, g_attn_dbg);
     else if (variant >= 7)      // 8 = 7 with the textbook max update (tests: the raise path on nearly every tile)
         hipLaunchKernelGGL(flash_attn_w7_kernel, grid, dim3(256), PP_LDS, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
                            (bf16*)out, S, S_pad, ldo, plan, part_o, part_ml, variant == 7 ? 8.0f : 0.0f);

@@ -12,7 +12,7 @@ CSRC = os.path.join(ROOT, "physicedit_amd", "csrc")
 
 
 @pytest.mark.parametrize("gen,bodies", [("gen_attn_w7.py", ["attention_w7_body.inc"]),
-                                        ("gen_attn_w4.py", ["attention_w4_body.inc", "attention_w5_body.inc", "attention_w9_body.inc", "attention_w5_probe_body.inc"])])
+                                        ("gen_attn_w4.py", ["attention_w4_body.inc", "attention_w5_body.inc", "attention_w5_probe_body.inc"])])
 def test_generated_body_matches_generator(tmp_path, monkeypatch, gen, bodies):
     for k in list(os.environ):
         if k.startswith("W4_") or k.startswith("W7_"):

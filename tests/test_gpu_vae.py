@@ -105,7 +105,7 @@ def test_vae_attention(vae_mod, N):
     vt = torch.empty((int(lib().pe_vae_attention_scratch_bytes(N)) + 256,), dtype=torch.uint8, device="cuda")
     out = torch.empty((N, 384), dtype=BF, device="cuda")
     check(lib().pe_vae_attention(qkv.cuda().data_ptr(), (vt.data_ptr() + 255) // 256 * 256, out.data_ptr(), N, stream_ptr()))
-    report(f"vae_attention N={N}", out, ref, 3.01, 0.45)   # P is bf16 in both; summation order differs
+    report(f"vae_attention N={N}", out, ref, 3.01, 0.50)   # P is bf16 in both; summation order differs (round 6: the keys of a query block are split over up to 4 work-groups)
     e_gpu = (out.float().cpu() - ref32).pow(2).mean().sqrt().item()
     e_cpu = (ref.float() - ref32).pow(2).mean().sqrt().item()
     print(f"[parity] vae_attention N={N}: rms err vs fp32 truth  hip {e_gpu:.3e}  cpu-bf16-sdpa {e_cpu:.3e}")

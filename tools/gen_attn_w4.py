@@ -26,9 +26,10 @@ import os
 
 PROBE = False     # set by main(): the folded body WITHOUT its softmax (no pairs, max, state, mask, rescale): attention_w5_probe_body.inc
 FOLD = False      # set by main(): False -> attention_w4_body.inc (variants 3 / 4), True -> attention_w5_body.inc (variants 5 / 6)
-DOT2 = False      # set by main() (round 6, FOLD only): attention_w9_body.inc (variants 9 / 10) -- the row sums are taken from the PACKED bf16 pair with one
-                  # v_dot2c_f32_bf16 (ps += p0 * 1 + p1 * 1) instead of two v_add_f32 on the fp32 exponentials: 32 issue slots of ~600 per tile less,
-                  # and l sums exactly the P the numerator multiplies (as variant 7's ones . P does)
+DOT2 = False      # set by main() when W4_DOT2=1 (round 6's experiment, FOLD only): also writes attention_w9_body.inc -- the row sums taken from the PACKED
+                  # bf16 pair with one v_dot2c_f32_bf16 (ps += p0 * 1 + p1 * 1) instead of two v_add_f32 on the fp32 exponentials: 32 issue slots of
+                  # ~600 per tile less, l sums exactly the P the numerator multiplies (as variant 7's ones . P does) -- and 7 % slower, because a dot
+                  # instruction does not overlap with an MFMA (profiles/r06_attention_notes.md, r06_valu_rate.log).  The library does not include it.
 DMA_SLOTS = int(os.environ.get("W4_DMA_SLOTS", "3"))      # issue slots an LDS-DMA piece (address + m0 + buffer_load ... lds) is booked with
 EARLY_PAIRS = int(os.environ.get("W4_EARLY_PAIRS", "5"))   # per block: pairs 0..4 of softmax(i+1) run in phase 2 of iteration i, pairs 5..15 in phase 1 of i+1
 # FOLD: where in phase 1 the O rescale branches sit (a knob: any gap of phase 1 is legal -- after P.V(i), before P.V(i+1))
@@ -441,6 +442,8 @@ def main():
                                           (True, True, False, "attention_w5_probe_body.inc", "flash_attn_w4_kernel<true, 1>: the folded schedule without "
                                            "its softmax (pe_attn_mix_probe: MFMAs, LDS fragment reads, LDS-DMA stream, barrier)")):
         if only and (only != name[10:12] or probe):
+            continue
+        if dot2 and not os.environ.get("W4_DOT2"):
             continue
         FOLD, PROBE, DOT2 = fold, probe, dot2
         out = ["// GENERATED by tools/gen_attn_w4.py -- do not edit; the schedule tables and their rationale are in that script.",
