@@ -430,7 +430,7 @@ vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16*
             const int c = kk * 2 + h;
             const bf16x8 kf = *(const bf16x8*)(Sb + k_off + (((c & ~15) | ((c ^ ksw) & 15)) << 4));
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
-            if ((kk & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // keep <= 8 K fragments in flight (register budget)
+            if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep <= 4 K fragments in flight (register budget)
         }
         if (t == nt_all - 1 && (N & (VA_KV - 1)) != 0) {
 #pragma unroll
@@ -455,28 +455,50 @@ vae_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ Vt, bf16*
         }
         l_run = __builtin_fmaf(l_run, alpha, psum);
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {      // wave-uniform: some row's maximum moved (x 1.0f elsewhere: exact)
+            // O lives in the accumulator half (the P.V MFMAs below are asm with "+a" operands: with builtins hipcc moved the 192 values through
+            // the arch half every tile -- 480 v_accvgpr moves and 22 spill reloads per 48 MFMAs, each reload behind an s_waitcnt vmcnt(0) that
+            // also waits for the NEXT tile's LDS-DMA: 4.7 us per tile).  Here, rarely, they are read out, scaled and written back; the empty
+            // statement re-defines every tuple at this point, so no copy can be hoisted to right behind an MFMA the compiler does not know
+            // about (the last P.V MFMA is 24 QK^T MFMAs old by now).
 #pragma unroll
-            for (int dt = 0; dt < 12; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            for (int dt = 0; dt < 12; ++dt) {
+                asm volatile("" : "+a"(o[dt]));
+                o[dt] *= alpha;
+                asm volatile("" : "+a"(o[dt]));
+            }
         }
+        // P of both 16-key chunks is packed BEFORE the first P.V MFMA.  The MFMAs are asm statements ("+a": O stays in the accumulator half),
+        // so three things are nobody's job but this code's (profiles/r04_attention_notes.md section 5): a VALU result needs wait states
+        // before an MFMA reads it as an operand (s_nop in front of the first one); an MFMA reads its A / B registers while it RUNS, so they
+        // must not be handed to another instruction before the next MFMA of the wave has issued (the empty "keep" statements); and nothing
+        // may read O before the last MFMA has drained (the s_nop pair + tuple re-definitions behind the loop).
+        bf16x8 pf2[2];
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            bf16x8 pf;
+        for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pf[e] = (bf16)st[(2 * k2) * 4 + e];
-                pf[4 + e] = (bf16)st[(2 * k2 + 1) * 4 + e];
+                pf2[k2][e] = (bf16)st[(2 * k2) * 4 + e];
+                pf2[k2][4 + e] = (bf16)st[(2 * k2 + 1) * 4 + e];
             }
+        asm volatile("s_nop 4" : "+v"(pf2[0]), "+v"(pf2[1]));
+        bf16x8 vprev = pf2[0];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
             const int vchunk = k2 * 2 + h;
 #pragma unroll
             for (int dt = 0; dt < 12; ++dt) {
                 const bf16x8 vf = *(const bf16x8*)(Sb + v_off + dt * 32 * 64 + ((vchunk ^ vsw) << 4));
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[dt]) : "v"(vf), "v"(pf2[k2]));
+                asm volatile("" : : "v"(vprev));      // keep: the fragment of the MFMA before this one
+                vprev = vf;
                 if ((dt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        asm volatile("s_nop 7" : : "v"(vprev), "v"(pf2[0]), "v"(pf2[1]));      // keep the last operands until the last MFMA has read them
     }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the last P.V MFMAs (asm: invisible to the hazard recognizer) -> reads of O
+#pragma unroll
+    for (int dt = 0; dt < 12; ++dt) asm volatile("" : "+a"(o[dt]));      // (volatile statements keep their order: every read of O is behind the drain)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int q = q0 + l31;
     if (nsplit > 1) {
