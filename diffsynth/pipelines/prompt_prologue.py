@@ -354,6 +354,12 @@ class GraphDecoder:
         for ly in self.layers:
             if ly.self_attn.o_proj.bias is not None or ly.mlp.down_proj.bias is not None or ly.mlp.gate_proj.bias is not None:
                 raise ValueError("GraphDecoder: unexpected biases in o_proj / the MLP")
+        # round 6, OPT-IN (PE_DECODE_LAYER_KERNEL=1): one launch per decoder layer (pe_decode_layer: a persistent grid walks the eight launches'
+        # work items with grid-wide barriers in between; same bits, so the same tokens -- and 71 - 109 tok/s against 298: a software grid
+        # barrier costs 40 - 67 us on the 8-XCD chip (agent-scope atomics serialise at the memory side), ten times the launch boundary it
+        # replaces.  Without its barriers (wrong results) the same kernel runs at 362 tok/s: profiles/r06_prologue_notes.md.)
+        self.layer_kernel = os.environ.get("PE_DECODE_LAYER_KERNEL", "0") == "1"
+        self._layer_w = None        # per layer: the C struct of its operands (addresses: rebuilt when the weights' fingerprint changes)
         self.split_attention = os.environ.get("PE_DECODE_SPLIT_ATTENTION", "1") != "0"  # pe_decode_step_attention_split (448 work-groups per launch) instead of the 28-work-group launch; same bits
         self._static = {}           # capacity bucket -> static planes, tables, counters and the captured decode step
         self.captures = 0           # graphs captured so far (tests: calls of one bucket share one)
@@ -378,7 +384,11 @@ class GraphDecoder:
         """one decode step on the current stream (captured); st: dict of static device tensors"""
         ops = self.ops
         x = ops.decode_embed(self.lm.embed_tokens.weight, st["token"])
-        for l, ly in enumerate(self.layers):
+        if self.layer_kernel:
+            for l, ly in enumerate(self.layers):
+                x = ops.decode_layer(st["layer_w"][l], x, st["xbuf"][l & 1], st["cos"], st["sin"], st["kc"][l], st["vc"][l], st["step"], st["base"],
+                                     float(ly.self_attn.scaling), st["layer_scratch"])
+        for l, ly in enumerate(() if self.layer_kernel else self.layers):
             at, mlp = ly.self_attn, ly.mlp
             # the two RMSNorms ride in the staging of the launches they feed (bit-identical to pe_rmsnorm): 6 launches per layer
             q = ops.decode_step_qkv(x, at.q_proj.weight, at.q_proj.bias, at.k_proj.weight, at.k_proj.bias, at.v_proj.weight,
@@ -434,6 +444,15 @@ class GraphDecoder:
             if self.split_attention:     # scratch of the three-launch single-query attention (layers run one after the other: one buffer)
                 st["attn_ws"] = self.ops.decode_attention_workspace(len(self.layers[0].self_attn.q_proj.weight) // 128, bucket, dev)
             st["sin"] = torch.zeros_like(st["cos"])
+            if self.layer_kernel:
+                at0, mlp0 = self.layers[0].self_attn, self.layers[0].mlp
+                st["layer_scratch"] = self.ops.decode_layer_scratch(at0.q_proj.out_features // 128, bucket, mlp0.gate_proj.out_features, dev)
+                st["xbuf"] = torch.zeros((2, self.lm.embed_tokens.weight.shape[1]), dtype=torch.bfloat16, device=dev)
+                st["layer_w"] = [self.ops.decode_layer_weights(
+                    ly.self_attn.q_proj.weight, ly.self_attn.q_proj.bias, ly.self_attn.k_proj.weight, ly.self_attn.k_proj.bias,
+                    ly.self_attn.v_proj.weight, ly.self_attn.v_proj.bias, ly.self_attn.o_proj.weight, ly.mlp.gate_proj.weight, ly.mlp.up_proj.weight,
+                    ly.mlp.down_proj.weight, ly.input_layernorm.weight, ly.input_layernorm.variance_epsilon, ly.post_attention_layernorm.weight,
+                    ly.post_attention_layernorm.variance_epsilon) for ly in self.layers]
             self._static = {bucket: st}                    # one bucket alive at a time (28 KiB per row of capacity and plane pair)
         kc, vc = st["kc"], st["vc"]
         for l in range(L):
@@ -479,6 +498,9 @@ class GraphDecoder:
                     for _ in range(n):
                         graph.replay()
                     new = st["out_ids"][Lp + done:Lp + done + n].tolist()            # synchronises
+                    if self.layer_kernel and self.ops.decode_layer_error(st["layer_scratch"]):
+                        raise RuntimeError("pe_decode_layer: a grid barrier timed out (the decode grid was not fully resident); "
+                                           "set PE_DECODE_LAYER_KERNEL=0")
                     done += n
                     stop = next((i for i, t in enumerate(new) if t in eos and len(tokens) + i + 1 >= max(min_new, 1)), None)
                     if stop is not None:

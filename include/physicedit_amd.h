@@ -267,6 +267,22 @@ size_t pe_decode_attention_workspace_bytes(int n_q_heads, int cache_len);
 int pe_decode_step_attention_split(const void* q, const void* k_cache, const void* v_cache, void* out, int n_q_heads, int n_kv_heads,
                                    const int* step, int base_len, int cache_len, float scale, void* workspace, size_t workspace_bytes,
                                    void* stream);
+/* ONE decoder layer of the decode step in one launch (round 6; transformers Qwen2_5_VLDecoderLayer.forward at q_len = 1): input norm +
+ * q / k / v + rotary + cache append, the single-query attention, o_proj + residual, post-attention norm + gate / up + SiLU, down_proj +
+ * residual -- the work items and summation orders of pe_decode_step_qkv, pe_decode_step_attention_split, pe_gemv_res_bf16 and
+ * pe_gemv_swiglu_norm_bf16, run by a persistent grid with grid-wide barriers between them: the same bits per output element, one launch
+ * instead of eight.  Text width 3584 (28 heads of 128), n_q_heads a multiple of n_kv_heads, ff <= 32768.
+ *   scratch: pe_decode_layer_scratch_bytes(n_q_heads, cache_len, ff) bytes, 256-byte aligned, ZERO when first used (the barrier counters
+ *   at its start are reset by the launches themselves), private to one stream.  Word 0 of the scratch is an error flag: non-zero after a
+ *   launch whose grid barrier timed out (the outputs are then meaningless); the caller reads it with the tokens. */
+typedef struct pe_decode_layer_weights {
+    const void *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *gate_w, *up_w, *down_w, *input_norm_w, *post_norm_w;
+    float input_norm_eps, post_norm_eps;
+    int n_q_heads, n_kv_heads, ff;
+} pe_decode_layer_weights;
+size_t pe_decode_layer_scratch_bytes(int n_q_heads, int cache_len, int ff);
+int pe_decode_layer(const pe_decode_layer_weights* w, const void* x, void* x_out, const void* cos_table, const void* sin_table, void* k_cache,
+                    void* v_cache, const int* step, int base_len, int cache_len, float scale, void* scratch, size_t scratch_bytes, void* stream);
 int pe_decode_embed(const void* table, const int* token, void* x, int dim, int vocab, void* stream);
 int pe_decode_argmax(const void* logits, int vocab, int* token, int* out_ids, int* step, int max_steps, void* stream);
 /* BlockWiseControlBlock input (models/qwen_image_controlnet.py:16-18): out = bf16(RMSNorm(x; wx) + RMSNorm(y; wy)), rows of

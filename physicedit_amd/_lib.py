@@ -45,6 +45,13 @@ class AdapterWeights(C.Structure):
         "dino_w0", "dino_b0", "dino_w2", "dino_b2", "vae_w0", "vae_b0", "vae_w2", "vae_b2")]
 
 
+class DecodeLayerWeights(C.Structure):
+    """pe_decode_layer_weights (include/physicedit_amd.h)"""
+    _fields_ = [(n, c_void_p) for n in ("q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "gate_w", "up_w", "down_w", "input_norm_w",
+                                        "post_norm_w")] + [("input_norm_eps", C.c_float), ("post_norm_eps", C.c_float),
+                                                           ("n_q_heads", c_int), ("n_kv_heads", c_int), ("ff", c_int)]
+
+
 class VaeConv(C.Structure):
     _fields_ = [("w", c_void_p), ("b", c_void_p), ("cin_p", c_int), ("cout_p", c_int), ("ksize", c_int)]
 
@@ -145,6 +152,9 @@ SIGNATURES = {
     "pe_decode_attention_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pe_decode_step_attention_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p,
                                                c_size_t, c_void_p]),
+    "pe_decode_layer_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pe_decode_layer": (c_int, [C.POINTER(DecodeLayerWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                c_int, C.c_float, c_void_p, c_size_t, c_void_p]),
     "pe_decode_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pe_decode_argmax": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pe_gemv_res_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

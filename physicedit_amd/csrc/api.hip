@@ -52,6 +52,8 @@ int pe_debug_set(const char* key, int value) {
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return PE_OK; }
     if (!strcmp(key, "gemm4_x")) { g_gemm4_x = value; return PE_OK; }
     if (!strcmp(key, "gemm_skip_ragged")) { g_gemm_skip_ragged = value; return PE_OK; }
+    if (!strcmp(key, "decode_layer_wgs_per_cu")) { PE_REQUIRE(value >= 1 && value <= 8, "decode_layer_wgs_per_cu: 1 .. 8"); g_decode_layer_wgs_per_cu = value; return PE_OK; }
+    if (!strcmp(key, "decode_layer_no_barrier")) { g_decode_layer_no_barrier = value != 0; return PE_OK; }
     if (!strcmp(key, "gemm_defer_epilogue")) { g_gemm_defer = value != 0; return PE_OK; }
     if (!strcmp(key, "gemm_continuous")) { g_gemm_cont = value != 0; return PE_OK; }
     if (!strcmp(key, "gemm_no_epilogue")) { g_gemm_no_epi = value != 0; return PE_OK; }
@@ -294,6 +296,41 @@ int pe_decode_step_attention_split(const void* q, const void* k_cache, const voi
                                    void* stream) {
     return launch_attn_decode_split(q, k_cache, v_cache, out, n_q_heads, n_kv_heads, cache_len, scale, (hipStream_t)stream, step, base_len,
                                     workspace, workspace_bytes);
+}
+
+static size_t dl_align(size_t x) { return (x + 255) / 256 * 256; }
+size_t pe_decode_layer_scratch_bytes(int n_q_heads, int cache_len, int ff) {
+    if (n_q_heads <= 0 || cache_len <= 0 || ff <= 0) return 0;
+    const size_t K = (size_t)n_q_heads * 128;
+    return 8192 + dl_align(K * 2) * 3 + dl_align((size_t)ff * 2) + dl_align(attn_decode_workspace_bytes(n_q_heads, cache_len));
+}
+int pe_decode_layer(const pe_decode_layer_weights* w, const void* x, void* x_out, const void* cos_table, const void* sin_table, void* k_cache,
+                    void* v_cache, const int* step, int base_len, int cache_len, float scale, void* scratch, size_t scratch_bytes, void* stream) {
+    PE_REQUIRE(w && x && x_out && scratch, "pe_decode_layer: null argument");
+    PE_REQUIRE(((uintptr_t)scratch & 255) == 0 && scratch_bytes >= pe_decode_layer_scratch_bytes(w->n_q_heads, cache_len, w->ff),
+               "pe_decode_layer: scratch of %zu bytes, 256-byte aligned, needed", pe_decode_layer_scratch_bytes(w->n_q_heads, cache_len, w->ff));
+    DecodeLayerArgs a;
+    memset(&a, 0, sizeof(a));
+    const size_t K = (size_t)w->n_q_heads * 128;
+    char* p = (char*)scratch;
+    a.err = (unsigned*)p; a.bar = (unsigned*)(p + 256); p += 8192;      // [0] error flag; 6 barriers x 9 lines of counters behind it
+    a.q = (bf16*)p; p += dl_align(K * 2);
+    a.a = (bf16*)p; p += dl_align(K * 2);
+    a.h1 = (bf16*)p; p += dl_align(K * 2);
+    a.hid = (bf16*)p; p += dl_align((size_t)w->ff * 2);
+    a.sc_g = (float*)p;
+    a.mx_g = a.sc_g + (size_t)w->n_q_heads * cache_len;
+    a.red_g = a.mx_g + (size_t)w->n_q_heads * 16;
+    a.part_g = a.red_g + (size_t)w->n_q_heads * 16;
+    a.x = (const bf16*)x; a.x_out = (bf16*)x_out;
+    a.Wq = (const bf16*)w->q_w; a.bq = (const bf16*)w->q_b; a.Wk = (const bf16*)w->k_w; a.bk = (const bf16*)w->k_b;
+    a.Wv = (const bf16*)w->v_w; a.bv = (const bf16*)w->v_b; a.Wo = (const bf16*)w->o_w; a.Wg = (const bf16*)w->gate_w;
+    a.Wu = (const bf16*)w->up_w; a.Wd = (const bf16*)w->down_w; a.ln1 = (const bf16*)w->input_norm_w; a.ln2 = (const bf16*)w->post_norm_w;
+    a.eps1 = w->input_norm_eps; a.eps2 = w->post_norm_eps;
+    a.cs = (const bf16*)cos_table; a.sn = (const bf16*)sin_table; a.Kc = (bf16*)k_cache; a.Vc = (bf16*)v_cache;
+    a.step = step; a.base = base_len; a.ld = cache_len; a.n_q = w->n_q_heads; a.n_kv = w->n_kv_heads; a.scale = scale;
+    a.K = (int)K; a.FF = w->ff;
+    return launch_decode_layer(a, (hipStream_t)stream);
 }
 
 int pe_decode_embed(const void* table, const int* token, void* x, int dim, int vocab, void* stream) {

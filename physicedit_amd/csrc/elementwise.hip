@@ -823,6 +823,278 @@ int launch_attn_decode_split(const void* q, const void* Kc, const void* Vc, void
     return check_launch("attn_decode_split");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 6: ONE launch per decoder layer of the captured decode step (instead of eight: q/k/v, three attention launches, o_proj, gate/up,
+// down_proj).  A persistent grid (two work-groups per CU, all resident) walks the SAME work items the separate kernels' blocks are --
+// every output element is computed by the same instructions in the same order (gemv_dot2 / wave_sum / the attention split's groupings), so
+// the greedy tokens are identical -- with a grid-wide barrier between the phases.  What it saves: per launch the ramp (first loads with an
+// empty memory pipeline), the tail and the launch gap, ~4 us each for kernels that stream 3 - 270 MB (profiles/r04_prologue.md: 466 MB per
+// layer in 105 us against 74 us at the achievable HBM rate).  A work-group stages its input row ONCE per phase, not once per 8 rows.
+//   barrier j: arrive on counter bar[j] (release: every wave has drained its own stores), wait until all G have arrived, one lane acquires
+//   (invalidates this CU's L1).  The last arriver of barrier j zeroes the counter of the barrier BEFORE it (everybody has left that one), the
+//   last arriver of barrier 0 the previous launch's last counter (stream order: that launch is over): no host reset, hipGraph-safe.
+//   Placement-independent (cdna guide): nothing assumes which work-group runs where; it assumes that all G are RESIDENT, which the launcher
+//   guarantees by grid size (2 per CU at 256 threads, 38 KiB LDS, <= 128 registers).  A wait that exceeds ~1 s gives up and raises
+//   *err (the host checks it): a wrong token beats a hung GPU.
+// ------------------------------------------------------------------------------------------------
+constexpr int DL_BARRIERS = 6;
+
+// Two-level arrival: work-group b adds to the counter of group b & 7 (its own 128-byte line; with the default dispatch order those are the
+// work-groups of one XCD, but nothing depends on that), the last arriver of a group adds to the barrier's global counter, everybody polls
+// that one word.  (One flat counter for 512 work-groups measured ~60 us per barrier: 512 agent-scope atomics on one line, serialised at the
+// memory side, under 512 pollers.)  Layout: barrier j owns 9 lines of 32 words at bar + j * 288: [0] global, [32 (1 + g)] group g.
+constexpr int DL_BAR_WORDS = 9 * 32;
+int g_decode_layer_wgs_per_cu = 4;      // knob "decode_layer_wgs_per_cu" (1 .. 8; capped by what is resident)
+int g_decode_layer_no_barrier = 0;      // TIMING ONLY (knob "decode_layer_no_barrier"): the phases run without grid barriers -- wrong results
+PE_DEV void dl_barrier(unsigned* bar, int j, int G, unsigned* err) {
+    if (bar == nullptr) { __syncthreads(); return; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // every wave: its own stores have left for the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* mine = bar + j * DL_BAR_WORDS;
+        unsigned* prev = bar + (j == 0 ? DL_BARRIERS - 1 : j - 1) * DL_BAR_WORDS;
+        const int g = (int)blockIdx.x & 7;
+        const unsigned in_group = (unsigned)((G - g + 7) >> 3);      // work-groups b < G with b & 7 == g
+        const unsigned old = __hip_atomic_fetch_add(mine + 32 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == in_group - 1) {
+            __hip_atomic_store(prev + 32 * (1 + g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // everybody has left the barrier before
+            const unsigned og = __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (og == 7u) __hip_atomic_store(prev, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int spins = 0;
+        while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 24)) { *err = 1u + (unsigned)j; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 (one lane + barrier)
+    }
+    __syncthreads();
+}
+
+// one wave's pair of rows of a Linear on the staged row: gemv_bf16_kernel's body
+PE_DEV void dl_gemv_rows(const bf16* xs, const bf16* W, const bf16* res, bf16* y, int N, int K, int ra, int lane) {
+    if (ra >= N) return;
+    const int rb = ra + 1;
+    float sa, sb;
+    gemv_dot2(xs, W + (size_t)ra * K, W + (size_t)min(rb, N - 1) * K, K, lane, sa, sb);
+    sa = wave_sum(sa);
+    sb = wave_sum(sb);
+    if (lane == 0) {
+        const float ya = bf16r(sa);
+        y[ra] = res ? (bf16)((float)res[ra] + ya) : (bf16)ya;
+        if (rb < N) {
+            const float yb = bf16r(sb);
+            y[rb] = res ? (bf16)((float)res[rb] + yb) : (bf16)yb;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 4) decode_layer_kernel(const DecodeLayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
+    __shared__ float red[4];
+    bf16* xs = (bf16*)gemv_smem;
+    const int G = (int)gridDim.x, b0 = (int)blockIdx.x;
+    const int t = (int)threadIdx.x, lane = lane_id(), w = t >> 6;
+    const int K = a.K, FF = a.FF;
+    const int st = *a.step;
+    const int pos = a.base + st;
+    if (pos >= a.ld) return;                       // cache full (every work-group alike): the host never replays that far
+    const int L = min(pos + 1, a.ld);
+    const int N0 = a.n_q * 128, N1 = a.n_kv * 128;
+
+    // ---- phase 1: q / k / v + rotary + cache append (gemv3_kernel: work item p = a pair of rows, one per wave)
+    {
+        const bf16* cs = a.cs + (size_t)st * 128;
+        const bf16* sn = a.sn + (size_t)st * 128;
+        const int npairs = (N0 + 2 * N1) / 2;
+        if (b0 * 4 < npairs) stage_row(xs, a.x, K, a.ln1, a.eps1);
+        for (int vb = b0; vb * 4 < npairs; vb += G) {
+            const int p = vb * 4 + w;
+            if (p >= npairs) continue;
+            const bf16* wr;
+            const bf16* br;
+            bf16* yr;
+            int ra, rb, q2 = p;
+            bool rope = true, cached = false;
+            if (q2 < N0 / 2) { wr = a.Wq; br = a.bq; yr = a.q; }
+            else if ((q2 -= N0 / 2) < N1 / 2) { wr = a.Wk; br = a.bk; yr = a.Kc; cached = true; }
+            else { q2 -= N1 / 2; wr = a.Wv; br = a.bv; yr = a.Vc; rope = false; cached = true; }
+            if (rope) { ra = (q2 >> 6) * 128 + (q2 & 63); rb = ra + 64; }
+            else { ra = q2 * 2; rb = ra + 1; }
+            float sa, sb;
+            gemv_dot2(xs, wr + (size_t)ra * K, wr + (size_t)rb * K, K, lane, sa, sb);
+            sa = wave_sum(sa);
+            sb = wave_sum(sb);
+            if (lane == 0) {
+                const float va = bf16r(sa + (br ? (float)br[ra] : 0.f));
+                const float vb2 = bf16r(sb + (br ? (float)br[rb] : 0.f));
+                const size_t oa = cached ? ((size_t)(ra >> 7) * a.ld + pos) * 128 + (ra & 127) : (size_t)ra;
+                const size_t ob = cached ? ((size_t)(rb >> 7) * a.ld + pos) * 128 + (rb & 127) : (size_t)rb;
+                if (rope) {
+                    const int i = ra & 127;
+                    yr[oa] = (bf16)(bf16r(va * (float)cs[i]) + bf16r(-vb2 * (float)sn[i]));
+                    yr[ob] = (bf16)(bf16r(vb2 * (float)cs[i + 64]) + bf16r(va * (float)sn[i + 64]));
+                } else {
+                    yr[oa] = (bf16)va;
+                    yr[ob] = (bf16)vb2;
+                }
+            }
+        }
+    }
+    dl_barrier(a.bar, 0, G, a.err);
+
+    // ---- phase 2: scores (attn_decode_scores_kernel: item = (head, block of 16))
+    for (int vb = b0; vb < a.n_q * DEC_SB; vb += G) {
+        const int h = vb / DEC_SB, b = vb - h * DEC_SB;
+        const int kvh = h / (a.n_q / a.n_kv);
+        const bf16* kb = a.Kc + (size_t)kvh * a.ld * 128;
+        float* sc = a.sc_g + (size_t)h * a.ld;
+        const int s4 = t & 3, g4 = t >> 2;
+        float qf[32];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bf16x8 t8 = *(const bf16x8*)(a.q + (size_t)h * 128 + s4 * 32 + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[c * 8 + j] = (float)t8[j];
+        }
+        float mx = -INFINITY;
+#pragma unroll 2
+        for (int j = b * 64 + g4; j < L; j += 64 * DEC_SB) {
+            const bf16* kr = kb + (size_t)j * 128 + s4 * 32;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bf16x8 k8 = *(const bf16x8*)(kr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qf[c * 8 + e], (float)k8[e], acc);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc *= a.scale;
+            if (s4 == 0) sc[j] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        __syncthreads();                               // (red is free again: the previous item's reader is done)
+        if ((t & 63) == 0) red[t >> 6] = mx;
+        __syncthreads();
+        if (t == 0) a.mx_g[h * DEC_SB + b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    dl_barrier(a.bar, 1, G, a.err);
+
+    // ---- phase 3: softmax sums + P.V (attn_decode_pv_kernel: item = (head, wave of 16) = ONE wave)
+    for (int it = b0 * 4 + w; it < a.n_q * DEC_SB; it += G * 4) {
+        const int h = it / DEC_SB, ww = it - h * DEC_SB;
+        const int kvh = h / (a.n_q / a.n_kv);
+        const bf16* vbp = a.Vc + (size_t)kvh * a.ld * 128;
+        const float* sc = a.sc_g + (size_t)h * a.ld;
+        float mx = a.mx_g[h * DEC_SB];
+#pragma unroll
+        for (int b = 1; b < DEC_SB; ++b) mx = fmaxf(mx, a.mx_g[h * DEC_SB + b]);
+        float sum = 0.f;
+        for (int j = ww * 64 + lane; j < L; j += 64 * DEC_SB) sum += __expf(sc[j] - mx);
+        sum = wave_sum(sum);
+        if (lane == 0) a.red_g[h * DEC_SB + ww] = sum;
+        const int sub = lane & 15, grp = 4 * ww + (lane >> 4);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int j = grp; j < L; j += 64) {
+            const bf16x8 v8 = *(const bf16x8*)(vbp + (size_t)j * 128 + sub * 8);
+            const float p = bf16r(__expf(sc[j] - mx));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)v8[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] += __shfl_xor(acc[e], 16, 64);
+            acc[e] += __shfl_xor(acc[e], 32, 64);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a.part_g[((size_t)h * DEC_SB + ww) * 128 + sub * 8 + e] = acc[e];
+        }
+    }
+    dl_barrier(a.bar, 2, G, a.err);
+
+    // ---- phase 4: combine (attn_decode_combine_kernel: 128 threads per head, two heads per work-group)
+    for (int h = b0 * 2 + (t >> 7); h < a.n_q; h += G * 2) {
+        const int c = t & 127;
+        float sum = 0.f, o = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < DEC_SB; ++ww) sum += a.red_g[h * DEC_SB + ww];
+#pragma unroll
+        for (int ww = 0; ww < DEC_SB; ++ww) o += a.part_g[((size_t)h * DEC_SB + ww) * 128 + c];
+        a.a[(size_t)h * 128 + c] = (bf16)(o / sum);
+    }
+    dl_barrier(a.bar, 3, G, a.err);
+
+    // ---- phase 5: h1 = x + o_proj(a)   (gemv_bf16_kernel<1>: 8 rows per item, 2 per wave)
+    {
+        if (b0 * 8 < K) stage_row(xs, a.a, N0, nullptr, 0.f);
+        for (int vb = b0; vb * 8 < K; vb += G) dl_gemv_rows(xs, a.Wo, a.x, a.h1, K, N0, vb * 8 + w * 2, lane);
+    }
+    dl_barrier(a.bar, 4, G, a.err);
+
+    // ---- phase 6: hid = silu(gate(n)) * up(n), n = RMSNorm(h1) * ln2   (gemv_swiglu_kernel: 8 rows per item, two rounds of one per wave)
+    {
+        if (b0 * 8 < FF) stage_row(xs, a.h1, K, a.ln2, a.eps2);
+        for (int vb = b0; vb * 8 < FF; vb += G) {
+#pragma unroll
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                const int n = vb * 8 + rnd * 4 + w;
+                if (n >= FF) break;
+                float sa, sb;
+                gemv_dot2(xs, a.Wg + (size_t)n * K, a.Wu + (size_t)n * K, K, lane, sa, sb);
+                sa = wave_sum(sa);
+                sb = wave_sum(sb);
+                if (lane == 0) {
+                    const float g = bf16r(sa), u = bf16r(sb);
+                    a.hid[n] = (bf16)(bf16r(g / (1.0f + __expf(-g))) * u);
+                }
+            }
+        }
+    }
+    dl_barrier(a.bar, 5, G, a.err);
+
+    // ---- phase 7: x_out = h1 + down_proj(hid)
+    {
+        if (b0 * 8 < K) stage_row(xs, a.hid, FF, nullptr, 0.f);
+        for (int vb = b0; vb * 8 < K; vb += G) dl_gemv_rows(xs, a.Wd, a.h1, a.x_out, K, FF, vb * 8 + w * 2, lane);
+    }
+}
+
+int launch_decode_layer(const DecodeLayerArgs& a, hipStream_t stream) {
+    PE_REQUIRE(a.x && a.x_out && a.Wq && a.Wk && a.Wv && a.Wo && a.Wg && a.Wu && a.Wd && a.ln1 && a.ln2 && a.cs && a.sn && a.Kc && a.Vc && a.step,
+               "decode_layer: null pointer");
+    PE_REQUIRE(a.q && a.a && a.h1 && a.hid && a.sc_g && a.bar && a.err, "decode_layer: null scratch");
+    PE_REQUIRE(a.FF <= 32768 && a.K <= 32768, "decode_layer: rows of at most 32768 elements");
+    PE_REQUIRE(a.K == 3584 && a.n_q * 128 == a.K && a.n_q % a.n_kv == 0 && a.FF > 0 && a.FF % 8 == 0 && a.FF <= 32768,
+               "decode_layer: shape (K=%d n_q=%d n_kv=%d FF=%d): the fused norms are for the text width 3584", a.K, a.n_q, a.n_kv, a.FF);
+    PE_REQUIRE(a.base >= 0 && a.ld > a.base && a.ld <= 15360, "decode_layer: cache of %d rows, base %d", a.ld, a.base);
+    static std::atomic<int> grid{0};
+    static std::atomic<int> grid_for{0};
+    int G = grid.load(std::memory_order_acquire);
+    const size_t lds = (size_t)(a.FF > a.K ? a.FF : a.K) * 2;      // the staged row of the widest phase
+    if (G == 0 || grid_for.load(std::memory_order_acquire) != g_decode_layer_wgs_per_cu) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        hipError_t e = hipFuncSetAttribute((const void*)decode_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_layer_kernel, 256, lds);
+        if (e != hipSuccess) return set_error(PE_ERR_HIP, "decode_layer: %s", hipGetErrorString(e));
+        PE_REQUIRE(per_cu >= 1, "decode_layer: the kernel does not fit a CU");
+        const int want = g_decode_layer_wgs_per_cu < 1 ? 1 : g_decode_layer_wgs_per_cu;
+        G = prop.multiProcessorCount * (per_cu < want ? per_cu : want);      // every work-group resident: the grid barrier's one assumption
+        grid.store(G, std::memory_order_release);
+        grid_for.store(g_decode_layer_wgs_per_cu, std::memory_order_release);
+    }
+    DecodeLayerArgs b = a;
+    if (g_decode_layer_no_barrier) b.bar = nullptr;
+    hipLaunchKernelGGL(decode_layer_kernel, dim3(G), dim3(256), lds, stream, b);
+    return check_launch("decode_layer_kernel");
+}
+
 // Training-loss head of the visual-thinking adapter (VisualThinkingDualAdapter.get_loss, pipelines/helpers.py:166-183), the part that
 // touches tensors: F.mse_loss(pred, gt, reduction='none').mean(dim=[1, 2]) for the two heads -- (pred - gt) rounded to bf16, its
 // square rounded to bf16, fp32 mean.  One work-group per head; out[head] = fp32 mean (the caller rounds it to bf16 as .mean() does).

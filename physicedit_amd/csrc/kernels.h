@@ -138,6 +138,25 @@ int launch_decode_qkv(const void* x, const void* Wq, const void* bq, const void*
                       int n_kv_heads, int K, hipStream_t stream, const int* step = nullptr, int base = 0, int ld = 0,
                       const void* norm_w = nullptr, float eps = 0.f);
 size_t attn_decode_workspace_bytes(int n_q_heads, int cache_len);
+// elementwise.hip: one decoder layer of the decode step in one launch (round 6)
+struct DecodeLayerArgs {
+    const bf16* x;          // layer input [K]
+    bf16* x_out;            // layer output [K]
+    const bf16 *Wq, *bq, *Wk, *bk, *Wv, *bv, *Wo, *Wg, *Wu, *Wd, *ln1, *ln2;
+    float eps1, eps2;
+    const bf16 *cs, *sn;    // rotary tables [steps][128]
+    bf16 *Kc, *Vc;          // caches [n_kv][ld][128]
+    const int* step;
+    int base, ld, n_q, n_kv;
+    float scale;
+    bf16 *q, *a, *h1, *hid; // scratch rows: [n_q*128], [n_q*128], [K], [FF]
+    float *sc_g, *mx_g, *red_g, *part_g;      // the split attention's workspace (attn_decode_workspace_bytes)
+    unsigned* bar;          // 8 counters, zero at rest
+    unsigned* err;
+    int K, FF;
+};
+int launch_decode_layer(const DecodeLayerArgs& a, hipStream_t stream);
+extern int g_decode_layer_wgs_per_cu, g_decode_layer_no_barrier;
 int launch_attn_decode_split(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int cache_len,
                              float scale, hipStream_t stream, const int* step, int base, void* workspace, size_t workspace_bytes);
 int launch_attn_decode(const void* q, const void* Kc, const void* Vc, void* out, int n_q_heads, int n_kv_heads, int L, float scale,

@@ -5,6 +5,7 @@ host.  These are what the `-m gpu` parity tests call, and what `physicedit_amd.d
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Optional, Tuple
 
@@ -382,6 +383,45 @@ def decode_step_attention(q, k_cache, v_cache, step, base_len: int, scale: float
                                          step.data_ptr(), int(base_len), cache_len, float(scale), stream_ptr()),
           "pe_decode_step_attention")
     return out
+
+
+def decode_layer_scratch(hq: int, cache_len: int, ff: int, device) -> torch.Tensor:
+    """zeroed scratch of pe_decode_layer (barrier counters + error flag, q / attention / hidden rows, the split attention's workspace);
+    one per decode stream, shared by all layers (they run one after the other)"""
+    n = int(lib().pe_decode_layer_scratch_bytes(hq, cache_len, ff))
+    buf = torch.zeros((n + 256,), dtype=torch.uint8, device=device)
+    off = (-buf.data_ptr()) % 256
+    return buf[off:off + n]
+
+
+def decode_layer_weights(q_w, q_b, k_w, k_b, v_w, v_b, o_w, gate_w, up_w, down_w, input_norm_w, input_norm_eps, post_norm_w, post_norm_eps):
+    """-> the C struct of one decoder layer's operands (borrowed device pointers: keep the tensors alive)"""
+    for t, n in ((q_w, "q_w"), (k_w, "k_w"), (v_w, "v_w"), (o_w, "o_w"), (gate_w, "gate_w"), (up_w, "up_w"), (down_w, "down_w"),
+                 (input_norm_w, "input_norm_w"), (post_norm_w, "post_norm_w")):
+        _chk(t, n)
+    w = _lib.DecodeLayerWeights()
+    w.q_w, w.q_b, w.k_w, w.k_b, w.v_w, w.v_b = q_w.data_ptr(), _ptr(q_b), k_w.data_ptr(), _ptr(k_b), v_w.data_ptr(), _ptr(v_b)
+    w.o_w, w.gate_w, w.up_w, w.down_w = o_w.data_ptr(), gate_w.data_ptr(), up_w.data_ptr(), down_w.data_ptr()
+    w.input_norm_w, w.post_norm_w = input_norm_w.data_ptr(), post_norm_w.data_ptr()
+    w.input_norm_eps, w.post_norm_eps = float(input_norm_eps), float(post_norm_eps)
+    w.n_q_heads, w.n_kv_heads, w.ff = q_w.shape[0] // 128, k_w.shape[0] // 128, gate_w.shape[0]
+    return w
+
+
+def decode_layer(w, x, x_out, cos_table, sin_table, k_cache, v_cache, step, base_len: int, scale: float, scratch) -> torch.Tensor:
+    """one decoder layer of the decode step in ONE launch (pe_decode_layer): x [3584] -> x_out [3584]; k_cache / v_cache
+    [n_kv, cache_len, 128] get row base_len + *step.  Same bits as decode_step_qkv + decode_step_attention + gemv(res) +
+    gemv_swiglu_norm + gemv(res)."""
+    _chk(x, "x"), _chk(x_out, "x_out"), _chk(k_cache, "k_cache"), _chk(v_cache, "v_cache"), _chk_i32(step, "step")
+    check(lib().pe_decode_layer(C.byref(w), x.data_ptr(), x_out.data_ptr(), cos_table.data_ptr(), sin_table.data_ptr(), k_cache.data_ptr(),
+                                v_cache.data_ptr(), step.data_ptr(), int(base_len), k_cache.shape[1], float(scale), scratch.data_ptr(),
+                                scratch.numel(), stream_ptr()), "pe_decode_layer")
+    return x_out
+
+
+def decode_layer_error(scratch) -> int:
+    """0, or 1 + the index of the grid barrier that timed out in some pe_decode_layer launch on this scratch (synchronises)"""
+    return int(scratch[0:4].view(torch.int32).item())
 
 
 def decode_embed(table, token) -> torch.Tensor:

@@ -1110,6 +1110,55 @@ def test_fused_rmsnorm_single_row_forms(ops):
     assert torch.equal(q1, q2) and torch.equal(kc1, kc2) and torch.equal(vc1, vc2) and kc1[:, 5].abs().sum() > 0
 
 
+@pytest.mark.parametrize("cap,base,stepv,ff", [(1024, 37, 0, 18944), (2048, 1390, 9, 18944), (96, 40, 5, 2048)])
+def test_decode_layer_bit_identical(ops, cap, base, stepv, ff):
+    """pe_decode_layer (round 6: ONE launch per decoder layer of the decode step -- a persistent grid walks the work items of q / k / v,
+    the split attention, o_proj, gate / up and down_proj with grid-wide barriers in between) against the eight launches it replaces: the
+    layer output, the appended cache rows and nothing else in the caches, bit for bit; three layers chained on one scratch and a
+    second token on the same scratch (the barrier counters must be back at zero; stale values in the scratch must not matter)."""
+    K, hq, hkv = 3584, 28, 4
+    gen = lambda shape, seed, sc=1.0: rnd(shape, seed, sc).cuda()
+    layers = []
+    for l in range(3):
+        s0 = 300 + 20 * l
+        layers.append(dict(wq=gen((hq * 128, K), s0, K ** -0.5), bq=gen((hq * 128,), s0 + 1, 0.1), wk=gen((hkv * 128, K), s0 + 2, K ** -0.5),
+                           bk=gen((hkv * 128,), s0 + 3, 0.1), wv=gen((hkv * 128, K), s0 + 4, K ** -0.5), bv=gen((hkv * 128,), s0 + 5, 0.1),
+                           wo=gen((K, K), s0 + 6, K ** -0.5), wg=gen((ff, K), s0 + 7, K ** -0.5), wu=gen((ff, K), s0 + 8, K ** -0.5),
+                           wd=gen((K, ff), s0 + 9, ff ** -0.5), n1=(1.0 + 0.1 * rnd((K,), s0 + 10).float()).to(BF).cuda(),
+                           n2=(1.0 + 0.1 * rnd((K,), s0 + 11).float()).to(BF).cuda()))
+    ang = torch.rand((cap, 128), generator=torch.Generator().manual_seed(77)) * 6.28
+    cs, sn = ang.cos().to(BF).cuda(), ang.sin().to(BF).cuda()
+    kc0 = [gen((hkv, cap, 128), 400 + l) for l in range(3)]
+    vc0 = [gen((hkv, cap, 128), 410 + l, 2.0) for l in range(3)]
+    x0 = gen((K,), 420)
+    scale = 128 ** -0.5
+    scratch = ops.decode_layer_scratch(hq, cap, ff, "cuda")
+    scratch[8192:].fill_(0x7f)      # stale garbage everywhere but the error flag / barrier counters
+    ws = ops.decode_attention_workspace(hq, cap, "cuda")
+    for token in range(2):
+        step = torch.tensor([stepv + token], dtype=torch.int32, device="cuda")
+        kr, vr = [t.clone() for t in kc0], [t.clone() for t in vc0]
+        kl, vl = [t.clone() for t in kc0], [t.clone() for t in vc0]
+        x_ref, x_new = x0, x0
+        bufs = torch.zeros((2, K), dtype=BF, device="cuda")
+        for l, w in enumerate(layers):
+            q = ops.decode_step_qkv(x_ref, w["wq"], w["bq"], w["wk"], w["bk"], w["wv"], w["bv"], cs, sn, kr[l], vr[l], step, base, norm_w=w["n1"], eps=1e-6)
+            a = ops.decode_step_attention(q, kr[l], vr[l], step, base, scale, workspace=ws)
+            h1 = ops.gemv(a, w["wo"], None, res=x_ref)
+            hid = ops.gemv_swiglu_norm(h1, w["n2"], 1e-6, w["wg"], w["wu"])
+            x_ref = ops.gemv(hid, w["wd"], None, res=h1)
+            cw = ops.decode_layer_weights(w["wq"], w["bq"], w["wk"], w["bk"], w["wv"], w["bv"], w["wo"], w["wg"], w["wu"], w["wd"], w["n1"], 1e-6,
+                                          w["n2"], 1e-6)
+            x_new = ops.decode_layer(cw, x_new, bufs[l & 1], cs, sn, kl[l], vl[l], step, base, scale, scratch)
+            torch.cuda.synchronize()
+            assert ops.decode_layer_error(scratch) == 0
+            assert torch.equal(x_new, x_ref), (token, l)
+            assert torch.equal(kl[l], kr[l]) and torch.equal(vl[l], vr[l]), (token, l)
+            assert not torch.equal(kl[l], kc0[l])          # the row was appended
+        assert torch.isfinite(x_new.float()).all()
+        assert int(scratch[256:256 + 5 * 9 * 128].view(torch.int32).abs().sum()) == 0      # barriers 0 .. 4: counters back at zero (the last one's are zeroed by the next launch)
+
+
 @pytest.mark.parametrize("rows,dim", [(64, 768), (832, 768), (304, 64), (7, 3072)])
 def test_layernorm_affine(ops, rows, dim):
     """pe_layernorm_affine vs torch.nn.functional.layer_norm on bf16 tensors (fp32 statistics, one rounding)."""
