@@ -622,12 +622,13 @@ def attention_ceiling(dev, S):
 def pmc_traffic(args):
     """HBM-side (L2-miss) bytes per launch and matrix-pipe utilisation of the block GEMMs, launch-weighted over QKV / out-proj /
     MLP-up / MLP-down.  PMC counters cannot be collected from inside this process: they come from the committed rocprofv3 --pmc
-    passes of tools/pmc_collect.sh (profiles/r05_pmc.json, which records its own command line).  They are per-launch properties
+    passes of tools/pmc_collect.sh (profiles/r06_pmc.json, which records its own command line).  They are per-launch properties
     of (kernel, shape), so they are reported ONLY when this run launches the same kernels on the same shapes -- same layer count,
     geometry, prompt lengths, operand dtype and stream count as the recorded command -- and are null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r05_pmc.json")
-    if not os.path.exists(path) and not args.fp8:
-        path = os.path.join(ROOT, "profiles", "r04_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_fp8.json" if args.fp8 else "r06_pmc.json")
+    for older in ("r05_pmc.json", "r04_pmc.json"):
+        if not os.path.exists(path) and not args.fp8:
+            path = os.path.join(ROOT, "profiles", older)
     if not os.path.exists(path):
         return None, None, None
     rec = json.load(open(path))

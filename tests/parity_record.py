@@ -1,14 +1,14 @@
 """Parity bookkeeping shared by the `-m gpu` end-to-end tests: every comparison of the HIP path with the oracle is
 reduced to the numbers the north-star sentence asks for (fraction of elements within 1e-3, max |d|, distance to an fp32
-evaluation of the same graph next to the reference-bf16's own distance) and appended to gpurun_out/parity_r05.json
-(scratch, never a tracked file), keyed by BASELINE.json config.  A copy is committed by hand as profiles/r04_parity.json."""
+evaluation of the same graph next to the reference-bf16's own distance) and appended to gpurun_out/parity_r06.json
+(scratch, never a tracked file), keyed by BASELINE.json config.  A copy is committed by hand as profiles/r06_parity.json."""
 import json
 import os
 
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out", "parity_r05.json")
+OUT = os.path.join(ROOT, "gpurun_out", "parity_r06.json")
 
 
 def parity_stats(got: torch.Tensor, ref: torch.Tensor, ref32: torch.Tensor = None) -> dict:
