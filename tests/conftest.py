@@ -1,6 +1,15 @@
 import os
 import sys
 
+# The oracle is torch CPU code and the fixtures under tests/golden/ are bf16 outputs of the reference run on a host: both are only
+# reproducible bit for bit on ONE matmul code path.  oneDNN picks its bf16 kernels by the host's ISA (AMX tiles, avx512_bf16 dot products
+# or the avx512 jit GEMM sum a K dimension in different orders: 1-ulp differences that 60 layers amplify), and splits work by thread
+# count.  Round 6 found the fixtures of rounds 1 - 5 (written on an AMX host) unreproducible on the build container's new host (AVX-512
+# with DL Boost only): 16 of 21 oracle tests off by an ulp here and there.  They were regenerated with the code path PINNED to what every
+# AVX-512 host has, and the pins below hold for every test process (set before torch / oneDNN initialise); make_golden.py sets the same.
+os.environ.setdefault("ONEDNN_MAX_CPU_ISA", "AVX512_CORE_VNNI")
+CPU_THREADS = 8      # the thread count the fixtures were written with (oneDNN partitions by it, whatever the core count)
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +19,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(CPU_THREADS)
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -17,6 +17,8 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
+# one matmul code path on every AVX-512 host, one thread count (tests/conftest.py explains; the same pins)
+os.environ.setdefault("ONEDNN_MAX_CPU_ISA", "AVX512_CORE_VNNI")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
@@ -55,12 +57,15 @@ from physicedit_amd import synth  # noqa: E402
 
 BF = torch.bfloat16
 torch.set_grad_enabled(False)
+torch.set_num_threads(8)
 
 
 def save(name, tensors, meta=None):
     tensors = {k: v.contiguous() for k, v in tensors.items()}
+    meta = dict(meta or {})
+    meta.setdefault("host_math", {"onednn_max_cpu_isa": os.environ.get("ONEDNN_MAX_CPU_ISA"), "threads": torch.get_num_threads(), "torch": torch.__version__})
     save_file(tensors, os.path.join(HERE, name + ".safetensors"),
-              metadata={k: json.dumps(v) for k, v in (meta or {}).items()})
+              metadata={k: json.dumps(v) for k, v in meta.items()})
     sz = os.path.getsize(os.path.join(HERE, name + ".safetensors"))
     print(f"wrote {name}.safetensors ({sz/1e6:.2f} MB)")
 
