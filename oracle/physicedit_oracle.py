@@ -18,7 +18,11 @@ at the same place, in bf16.  Each function cites the reference file:line it foll
 Pinning: the reference ships no tests and no golden vectors.  This oracle is
 pinned against outputs of the reference itself, imported in the build container by
 `tests/golden/make_golden.py`, which wrote the fixtures `tests/golden/*.safetensors`;
-`tests/test_oracle_golden.py` replays them (CPU, `-m "not gpu"`).
+`tests/test_oracle_golden.py` replays them (CPU, `-m "not gpu"`).  "Bit-exact" is a statement about ONE host code path: torch's CPU
+bf16 matmul is oneDNN's, which picks its kernel by the host's ISA (AMX, avx512_bf16 or the AVX-512 jit GEMM sum a K dimension in
+different orders) and partitions by thread count, so the reference run on another host differs from itself by an ulp here and there.
+The fixtures (round 6) were written, and the tests run, with that path pinned: ONEDNN_MAX_CPU_ISA=AVX512_CORE_VNNI, 8 threads
+(`tests/conftest.py`; each fixture records it under `host_math`).
 
 One optional branch cannot be pinned by CPU fixtures: the e4m3 "FP8 computation" Linear (`fp8_linear`, `fp8_quantize_rows`,
 `to_fp8_state_dict` below; BASELINE.json configs[2]).  The reference's implementation ends in torch._scaled_mm, which does
