@@ -98,8 +98,9 @@ enum {
  * pe_dit_workspace_bytes() includes one per handle.  The granular pe_gemm_* calls run the unsplit schedules unless a test installs
  * a zeroed buffer with pe_debug_set_ptr("gemm_workspace", p). */
 size_t pe_gemm_workspace_bytes(void);
-/* Bytes of the deferred-epilogue stash of the persistent GEMM schedule (round 6: a tile parks y = bf16(acc + bias) there and its GELU /
- * gate + residual epilogue runs inside the next tile's main loop; 128 KiB per CU; any contents; outputs bit-identical).
+/* Bytes of the deferred-epilogue stash of the persistent GEMM schedule (round 6 experiment: a tile parks bf16(gate * y) there and its
+ * gate + residual epilogue runs inside the next tile's main loop; outputs bit-identical).  0 unless the library was built with
+ * -DPE_GEMM_DEFER (measured slower per image: profiles/r06_gemm_notes.md); then 128 KiB per CU, any contents, and
  * pe_dit_workspace_bytes() includes one per handle.  The granular pe_gemm_* calls run every epilogue at its tile's end unless a test
  * installs a stash with pe_debug_set_ptr("gemm_stash", p). */
 size_t pe_gemm_stash_bytes(void);

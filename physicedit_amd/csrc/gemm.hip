@@ -386,7 +386,16 @@ __device__ __forceinline__ void gemm_persistent(const KARG GemmArgs& args, char*
     // transcendental) was built the same way and measured +2.7 ... +4.5 % per Linear: an L slot has no slack against the other group's
     // 1024-cycle M slot, and spreading the stream through the shadows of the wave's own MFMAs is beyond hipcc's allocator (186 spilled
     // registers in the K loop) -- profiles/r06_gemm_notes.md.
+    // COMPILED OUT by default (-DPE_GEMM_DEFER builds it in: tools/r06_build_ab.sh).  Against its own switched-off arm the deferred form is
+    // 3 % faster on out-proj (6 % e4m3) -- but a kernel that merely CONTAINS this code is 8 - 9 % slower on both gated-residual Linears
+    // than one that does not (out-proj 145.3 vs 132.8 us, MLP-down 541 vs 502 us, 10.58 vs 10.39 s per image on one box, three interleaved
+    // rounds: profiles/r06_gemm_lib_ab.log): two more live tuples and the wave-uniform slice branches cost the K loop of a kernel that
+    // sits at 256 registers more than the slices hide.  A/B between knobs of ONE binary cannot see that; A/B between binaries did.
+#ifdef PE_GEMM_DEFER
     constexpr bool DEFER = PH == 1 && !SK && S16 && EPI == EPI_GATE_RES;
+#else
+    constexpr bool DEFER = false;
+#endif
     constexpr int NL = 2;      // loads a slice requests: stash chunk + residual chunk
     bool pend = false;
     int pm0 = 0, pn0 = 0;
@@ -779,7 +788,11 @@ static int persistent_grid() {
     return n;
 }
 
+#ifdef PE_GEMM_DEFER
 size_t gemm_stash_bytes() { return (size_t)persistent_grid() * DEFER_STASH_BYTES; }
+#else
+size_t gemm_stash_bytes() { return 0; }      // the deferred epilogue is not compiled in: nobody needs a stash
+#endif
 size_t gemm_workspace_bytes() { return SK_SYNC_BYTES + (size_t)persistent_grid() * SK_PART_BYTES; }
 
 template <int EPI, int VAR, bool FP8, bool S16>
@@ -889,7 +902,8 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
     args.sk_sync = nullptr;
     args.sk_part = nullptr;
     if (workspace == nullptr && (g_gemm_ws.sync != nullptr || g_gemm_ws.stash != nullptr)) workspace = &g_gemm_ws;      // tests: pe_debug_set_ptr("gemm_workspace", p)
-    if (workspace != nullptr && workspace->stash != nullptr && workspace->stash_bytes >= gemm_stash_bytes() && ((uintptr_t)workspace->stash & 255) == 0)
+    if (gemm_stash_bytes() != 0 && workspace != nullptr && workspace->stash != nullptr && workspace->stash_bytes >= gemm_stash_bytes() &&
+        ((uintptr_t)workspace->stash & 255) == 0)
         args.stash = (char*)workspace->stash;
     if (workspace != nullptr && workspace->sync != nullptr && workspace->bytes >= gemm_workspace_bytes() && ((uintptr_t)workspace->sync & 255) == 0) {
         args.sk_sync = (unsigned*)workspace->sync;
