@@ -44,3 +44,19 @@ def test_gpus_8_launcher_command_and_thread_cap():
     r = _run(["--gpus", "8", "--no-cpu-baseline"])
     out = r.stderr + r.stdout
     assert "[bench] spawning 8 ranks" in out and "--nproc-per-node=8" in out
+
+
+def test_executed_flops_of_the_trimmed_last_block():
+    """`whole_path.executed_pflop_per_image` (round 6): the last block launches only the S0 noise rows' post-attention work, so per forward
+    (S - S0) rows skip out-proj + MLP (169,869,312 FLOPs per row) and their attention queries (12,288 S per row).  At the headline geometry
+    that is 0.72 % of the algorithmic count, and it must equal what the FLOP model says those launches were worth."""
+    import bench
+    alg = bench.flops_image(1024, 1024, 40, 512, 272, 4.0)
+    trim = bench.flops_trimmed_last_block(1024, 1024, 40, 512, 272, 4.0)
+    assert 0.0070 < trim / alg < 0.0075
+    # per-row terms against flops_forward's own coefficients: 226,492,416 per row = QKV 56,623,104 + the rest; 12,288 S^2 = 4 S^2 * 3072
+    assert 226_492_416 - 2 * 3072 * 9216 == 169_869_312
+    S0, S = 4096, 8192 + 512
+    one = bench.flops_trimmed_last_block(1024, 1024, 1, 512, 272, 1.0)
+    assert one == (S - S0) * (169_869_312 + 12_288 * S)
+    assert bench.flops_trimmed_last_block(1024, 1024, 40, 512, 272, 1.0) == 40 * one      # CFG off: one forward per step
