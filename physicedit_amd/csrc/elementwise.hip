@@ -844,7 +844,7 @@ constexpr int DL_BARRIERS = 6;
 // that one word.  (One flat counter for 512 work-groups measured ~60 us per barrier: 512 agent-scope atomics on one line, serialised at the
 // memory side, under 512 pollers.)  Layout: barrier j owns 9 lines of 32 words at bar + j * 288: [0] global, [32 (1 + g)] group g.
 constexpr int DL_BAR_WORDS = 9 * 32;
-int g_decode_layer_wgs_per_cu = 4;      // knob "decode_layer_wgs_per_cu" (1 .. 8; capped by what is resident)
+int g_decode_layer_wgs_per_cu = 2;      // knob "decode_layer_wgs_per_cu" (1 .. 8; capped by what is resident; 2 measured best: a barrier costs its fan-in)
 int g_decode_layer_no_barrier = 0;      // TIMING ONLY (knob "decode_layer_no_barrier"): the phases run without grid barriers -- wrong results
 PE_DEV void dl_barrier(unsigned* bar, int j, int G, unsigned* err) {
     if (bar == nullptr) { __syncthreads(); return; }
