@@ -1260,6 +1260,33 @@ __global__ void __launch_bounds__(192) attn_fp8_stats_finish_kernel(const double
     }
 }
 
+// The same three standard deviations from the QKV epilogue's partial sums (EPI_QKV_STATS, gemm_tile.h): wave z adds the n_part entries of
+// section z in index order (lane l: entries l, l + 64, ...), then the lanes meet in a fixed butterfly -- no pass over q / k / vt.
+__global__ void __launch_bounds__(192) attn_fp8_stats_finish_parts_kernel(const double* __restrict__ part, int n_part, double n, float* __restrict__ stats) {
+    __shared__ float sd[3];
+    const int z = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    double a = 0.0, b = 0.0;
+    for (int i = lane; i < n_part; i += 64) {
+        a += part[((size_t)z * n_part + i) * 2];
+        b += part[((size_t)z * n_part + i) * 2 + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if (lane == 0) {
+        const double mean = a / n;
+        const double var = (b - n * mean * mean) / (n - 1.0);           // torch.std: unbiased
+        sd[z] = bf16r((float)sqrt(var > 0.0 ? var : 0.0));
+        stats[z] = sd[z];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float qk = bf16r(sd[0] * sd[1]);
+        stats[3] = bf16r(qk / 11.3137084989847603904f) * 1.44269504088896340736f;
+    }
+}
+
 // Q8 / K8: thread = 16 consecutive elements of a row; Vt8: thread = 16 consecutive BYTE positions of a row's tile (two 8-element groups of
 // the perm16 source order: see the layout note above)
 __global__ void __launch_bounds__(256) attn_fp8_quant_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
@@ -1888,7 +1915,7 @@ size_t flash_attn_fp8_scratch_bytes(int H, int S_pad) {
 }
 
 int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
-                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream, int S_q) {
+                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream, int S_q, const double* qkv_stats) {
     PE_REQUIRE(q && k && vt && out && scratch, "flash_attn_fp8: null pointer");
     PE_REQUIRE(S_q >= 0 && S_q <= S, "flash_attn_fp8: S_q=%d query rows of S=%d", S_q, S);
     if (S_q == 0) S_q = S;       // (the three standard deviations are always those of the WHOLE tensors: torch.std over [1,H,S,128])
@@ -1911,9 +1938,14 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
     float* stats = (float*)(vt8 + plane);
     double* part = (double*)((char*)stats + 256);
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S_q * S * 128.0 * H, stream);
-    hipLaunchKernelGGL(attn_fp8_stats_kernel, dim3(F8_STAT_WGS, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                       H, S, S_pad, part);
-    hipLaunchKernelGGL(attn_fp8_stats_finish_kernel, dim3(1), dim3(192), 0, stream, (const double*)part, (double)H * S * 128.0, stats);
+    if (qkv_stats != nullptr) {      // the QKV epilogue left the sums (EPI_QKV_STATS): 2 slots x row blocks x heads entries per section
+        hipLaunchKernelGGL(attn_fp8_stats_finish_parts_kernel, dim3(1), dim3(192), 0, stream, qkv_stats, 2 * qkv_stats_row_blocks(S_pad) * H,
+                           (double)H * S * 128.0, stats);
+    } else {
+        hipLaunchKernelGGL(attn_fp8_stats_kernel, dim3(F8_STAT_WGS, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                           H, S, S_pad, part);
+        hipLaunchKernelGGL(attn_fp8_stats_finish_kernel, dim3(1), dim3(192), 0, stream, (const double*)part, (double)H * S * 128.0, stats);
+    }
     hipLaunchKernelGGL(attn_fp8_quant_kernel, dim3(1024, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt, q8, k8,
                        vt8, H, S_pad, (const float*)stats);
     int rc = check_launch("attn_fp8_quant_kernel");

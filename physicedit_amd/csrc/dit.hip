@@ -19,6 +19,7 @@
 using namespace pe;
 
 int pe::g_dit_trim_last_block = 1;
+int pe::g_dit_qkv_stats = 1;
 
 namespace {
 constexpr int D = 3072, FF = 12288, HEADS = 24, TXT = 3584, PATCH = 64, AD_HID = 10752, MOD = 6 * D;
@@ -43,6 +44,7 @@ struct pe_dit {
     char *sp_in, *sp_hid, *sp_dino, *sp_vae;
     char* attn_ws;
     size_t attn_ws_bytes = 0;
+    char* qkv_stats;                    // e4m3 attention: the QKV epilogue's partial sums (EPI_QKV_STATS), zeroed per launch
     char* attn_f8;                      // e4m3 attention (pe_dit_call.fp8_attention): e4m3 copies of Q / K / Vt, the three std, partial sums
     size_t attn_f8_bytes = 0;
     char* gemm_ws;                      // stream-K scratch of the block Linears (gemm.hip schedule 19): zeroed once, private to this handle
@@ -109,6 +111,7 @@ static size_t carve(pe_dit* h, int S_img, int T, int n_steps, char* base) {
     take(&h->attn_ws, h->attn_ws_bytes);
     h->attn_f8_bytes = flash_attn_fp8_scratch_bytes(HEADS, (int)S_pad);
     take(&h->attn_f8, h->attn_f8_bytes);
+    take(&h->qkv_stats, qkv_stats_bytes(HEADS, (int)S_pad));
     // stream-K scratch (4 KiB + 256 KiB per CU = 64 MiB) only where the opt-in schedule is switched on when the workspace is sized AND
     // bound (pe_debug_set "gemm_sk" / "gemm_variant" 19 before pe_dit_workspace_bytes); without it launch_gemm never takes schedule 19
     const size_t sk_bytes = (g_gemm_sk != 0 || g_gemm_variant == 19) ? gemm_workspace_bytes() : 0;
@@ -503,11 +506,19 @@ int pe_dit_forward(pe_dit_handle h, const pe_dit_call* c, void* stream_) {
             pp[s].seq_off = s == 0 ? 0 : S_img; pp[s].S_pad = S_pad;
             pp[s].q_scale = q_scale;
         }
-        if ((rc = hot_linear(h, l, 0, EPI_QKV, pp, 2, h->hbuf, 3 * D, stream))) return rc;
+        // e4m3 attention: the QKV epilogue also leaves the sums its global statistics need (round 6; knob "dit_qkv_stats" = 0: the separate
+        // pass over q / k / vt of round 4)
+        const bool qkv_stats = fp8_attn && g_dit_qkv_stats != 0;
+        if (qkv_stats) {
+            const hipError_t e = hipMemsetAsync(h->qkv_stats, 0, qkv_stats_bytes(HEADS, S_pad), stream);
+            if (e != hipSuccess) return set_error(PE_ERR_HIP, "pe_dit_forward: hipMemsetAsync: %s", hipGetErrorString(e));
+            for (int s = 0; s < 2; ++s) { pp[s].qkv_stats = (double*)h->qkv_stats; pp[s].stat_rb = qkv_stats_row_blocks(S_pad); pp[s].stat_slot = s; }
+        }
+        if ((rc = hot_linear(h, l, 0, qkv_stats ? EPI_QKV_STATS : EPI_QKV, pp, 2, h->hbuf, 3 * D, stream))) return rc;
         // joint attention
         if (fp8_attn)
             rc = launch_flash_attn_fp8(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, h->attn_f8, h->attn_f8_bytes, h->attn_ws,
-                                       h->attn_ws_bytes, stream, trim ? S0 : 0);
+                                       h->attn_ws_bytes, stream, trim ? S0 : 0, qkv_stats ? (const double*)h->qkv_stats : nullptr);
         else
             rc = launch_flash_attn(h->q, h->k, h->vt, h->attn, HEADS, S, S_pad, D, scale, h->attn_ws, h->attn_ws_bytes, stream,
                                    c->attn_words, S_img, q_scale != 1.0f, trim ? S0 : 0);

@@ -871,7 +871,9 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
         }
         PE_REQUIRE(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);
         PE_REQUIRE(p.A && p.W, "gemm: null operand");
-        if (epilogue == EPI_QKV) {
+        if (epilogue == EPI_QKV || epilogue == EPI_QKV_STATS) {
+            PE_REQUIRE(epilogue == EPI_QKV || (p.qkv_stats != nullptr && p.stat_rb >= (p.M + 63) / 64 && (p.stat_slot == 0 || p.stat_slot == 1)),
+                       "gemm(qkv + statistics): missing partial-sum table");
             PE_REQUIRE(p.N % 384 == 0, "gemm(qkv): N=%d must be 3*H*128", p.N);
             PE_REQUIRE(p.q_out && p.k_out && p.vt_out && p.norm_q_w && p.norm_k_w && p.rope_cos && p.rope_sin,
                        "gemm(qkv): missing qkv epilogue pointers");
@@ -922,6 +924,7 @@ int launch_gemm(int epilogue, GemmProblem* problems, int nproblems, hipStream_t 
         case EPI_GELU_ERF: rc = launch_t<EPI_GELU_ERF>(args, fp8, stream); break;
         case EPI_GATE_RES: rc = launch_t<EPI_GATE_RES>(args, fp8, stream); break;
         case EPI_QKV: rc = launch_t<EPI_QKV>(args, fp8, stream); break;
+        case EPI_QKV_STATS: rc = launch_t<EPI_QKV_STATS>(args, fp8, stream); break;
         case EPI_SILU: rc = launch_t<EPI_SILU>(args, fp8, stream); break;
 #endif
         default: rc = set_error(PE_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);

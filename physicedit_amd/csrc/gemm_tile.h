@@ -131,6 +131,14 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
     // NMI / MI0: the accumulator array holds NMI 32-row blocks, this call emits blocks MI0, MI0 + 1 as the 64 x 128 block of (virtual)
     // wave `w` (the 4-wave kernel's 128 x 128 wave tile is two such calls)
     static_assert(LAY == 0 || (NMI == 2 && MI0 == 0), "layout 1 is the 8-wave kernels'");
+    constexpr bool QKV = EPI == EPI_QKV || EPI == EPI_QKV_STATS;
+    constexpr bool STATS = EPI == EPI_QKV_STATS;      // also: sum and sum of squares of the bf16 values this wave stores (one head of one section)
+    float st1 = 0.f, st2 = 0.f;
+    auto stat2 = [&](uint32_t pk) __attribute__((always_inline)) {      // two packed bf16 outputs
+        const float a = __uint_as_float(pk << 16), b = __uint_as_float(pk & 0xffff0000u);
+        st1 += a; st1 += b;
+        st2 = __builtin_fmaf(a, a, st2); st2 = __builtin_fmaf(b, b, st2);
+    };
     const int l31 = lane & 31, h = lane >> 5;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
@@ -286,7 +294,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
     auto emit_rows = [&](int mi, auto held_tag, const bf16x8 (&held)[8]) __attribute__((always_inline)) {
         constexpr bool HELD = decltype(held_tag)::value;
         const char* Eb = mi == 0 ? E0 : E1;
-        if constexpr (EPI == EPI_QKV) {
+        if constexpr (QKV) {
             const int HD = N / 3;
             const int section = nw0 / HD;  // wave-uniform: the wave's 128 columns are exactly one head
             const int head = (nw0 - section * HD) >> 7;
@@ -346,6 +354,10 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
                             o[jj] = pk2(f32x2{a.x - b.x, a.y + b.y} * qs);
                         }
                         *(u32x4*)(dst + ((size_t)head * S_pad + P.seq_off + m) * 128 + c * 8) = o;
+                        if constexpr (STATS) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) stat2(o[jj]);
+                        }
                     }
                 }
             } else {
@@ -374,11 +386,18 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
 #pragma unroll
                             for (int j = 0; j < 4; ++j) pk[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
                             *(u32x4*)dstp = pk;
+                            if constexpr (STATS) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) stat2(pk[j]);
+                            }
                         } else {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const int tok = gi * 16 + (j < 4 ? 4 * hh + j : 8 + 4 * hh + (j - 4));
-                                if (tok < valid) ((unsigned short*)dstp)[j] = e[j];
+                                if (tok < valid) {
+                                    ((unsigned short*)dstp)[j] = e[j];
+                                    if constexpr (STATS) stat2((uint32_t)e[j] << 16);      // (the low half is +0: adds nothing)
+                                }
                             }
                         }
                     }
@@ -392,6 +411,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
                             const unsigned short e =
                                 *(const unsigned short*)(Eb + lrow * 256 + (((d >> 3) ^ (lrow & 15)) << 4) + (((d & 7) * 2) ^ (lrow & 8)));
                             ((unsigned short*)vt)[(size_t)d * S_pad + pos] = e;
+                            if constexpr (STATS) stat2((uint32_t)e << 16);
                         }
                     }
                 }
@@ -486,7 +506,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
         // behind them.
         // Not for the gated-residual and QKV epilogues: with their 16 prefetched residual rows / RoPE operands the held rows
         // push the kernel over the 256-register budget (19-31 spilled registers measured).
-        constexpr bool EARLY_STAGE = EPI != EPI_GATE_RES && EPI != EPI_QKV;
+        constexpr bool EARLY_STAGE = EPI != EPI_GATE_RES && !QKV;
         if constexpr (EARLY_STAGE) {
             stage_rows(0, 1);
             load_rows(0, rows);
@@ -505,6 +525,22 @@ __device__ __forceinline__ void gemm_epilogue_body(const KARG GemmProblem& P, co
         if (stamp4 != nullptr && threadIdx.x == 0) *stamp4 = (long long)__builtin_readcyclecounter();
         emit_rows(0, std::false_type{}, rows);
         emit_rows(1, std::false_type{}, rows);
+    }
+    if constexpr (STATS) {
+        // the wave's 64 rows x 128 columns are one 64-row block of one head of one section: one entry of the partial-sum table, whoever
+        // computes the tile (fixed summation order per entry, fixed order of the entries in the finish kernel: deterministic)
+        double d1 = (double)st1, d2 = (double)st2;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            d1 += __shfl_xor(d1, o, 64);
+            d2 += __shfl_xor(d2, o, 64);
+        }
+        if (lane == 0 && P.qkv_stats != nullptr) {
+            const int HD = N / 3, section = nw0 / HD, head = (nw0 - section * HD) >> 7, rb = (m0 >> 6) + wm;
+            double* dst = P.qkv_stats + ((((size_t)section * 2 + P.stat_slot) * P.stat_rb + rb) * (HD >> 7) + head) * 2;
+            dst[0] = d1;
+            dst[1] = d2;
+        }
     }
 }
 
@@ -975,7 +1011,7 @@ __device__ __forceinline__ void gemm_epilogue(const KARG GemmProblem& P, const i
             return;
         }
     }
-    if constexpr (EPI == EPI_QKV && LAY == 1) {
+    if constexpr (EPI == EPI_QKV && LAY == 1) {      // (not EPI_QKV_STATS: its sums are taken in the LDS form)
         // bit 1 of "gemm_direct_epilogue": the q / k sections of complete tiles (wave-uniform: a wave's 128 columns are one head of one section)
         if ((direct & 2) && m0 + BM <= M && n0 + BN <= N && P.pre == nullptr) {
             const int HD = N / 3;

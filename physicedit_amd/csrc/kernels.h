@@ -17,6 +17,8 @@ enum GemmEpilogue {
     EPI_GATE_RES = 3,  // out = res + gate[n] * y, each op rounded (qwen_image_dit.py:386-387,398-399)
     EPI_QKV = 4,       // per-head RMSNorm(q,k) + RoPE(q,k), head-major Q/K and transposed V
     EPI_SILU = 5,      // y -> silu(y) (time MLP linear_1 + SiLU; AdaLN's silu(temb) is a separate tensor)
+    EPI_QKV_STATS = 6, // EPI_QKV that also leaves the sum and the sum of squares of what it wrote (round 6: the e4m3 attention's global standard
+                       // deviations of q, k, v without a pass over the 160 MB it has just written; only pe_dit_forward with fp8_attention takes it)
 };
 
 struct GemmProblem {
@@ -46,6 +48,10 @@ struct GemmProblem {
     float q_scale;          // Q is stored as bf16(rope(q) * q_scale), the factor applied in fp32 before that one rounding; 0 = 1
     int seq_off;            // joint-sequence row of this problem's row 0
     int S_pad;
+    // EPI_QKV_STATS: partial sums [section 3][slot 2][stat_rb][H][2] doubles (sum, sum of squares of the bf16 outputs of one 64-row block and
+    // head, fp32 per lane over its <= 512 values, then double); the caller zeroes the buffer (blocks that do not exist stay zero)
+    double* qkv_stats;
+    int stat_rb, stat_slot;
     int tilesM, tilesN;     // filled by the launcher
     // e4m3 operands (fp8_linear, vram_management/layers.py:115-151): A [M,K] and W [N,K] are OCP e4m3 bytes
     // (lda in elements = bytes, K % 128 == 0); y = bf16(acc * scale_a[m] + bias[n]) before the epilogue proper
@@ -101,8 +107,13 @@ int launch_attn_mix_probe(const void* q, const void* k, const void* vt, void* ou
 // the reference's enable_fp8_attention branch (attention.hip, "e4m3 attention"): q, k, vt in the bf16 layouts of launch_flash_attn (plain
 // Q); scratch: flash_attn_fp8_scratch_bytes(H, S_pad), 256-byte aligned (e4m3 copies, the three std and their partial sums)
 size_t flash_attn_fp8_scratch_bytes(int H, int S_pad);
+// EPI_QKV_STATS' partial sums for a joint sequence of up to S_pad rows in two problems (image, text): row blocks per slot, bytes
+inline int qkv_stats_row_blocks(int S_pad) { return S_pad / 64 + 4; }
+inline size_t qkv_stats_bytes(int H, int S_pad) { return (size_t)3 * 2 * qkv_stats_row_blocks(S_pad) * H * 2 * sizeof(double); }
 int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* out, int H, int S, int S_pad, int ldo, void* scratch,
-                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream, int S_q = 0);
+                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream, int S_q = 0,
+                          const double* qkv_stats = nullptr);      // the QKV epilogue's partial sums (EPI_QKV_STATS): no statistics pass over q / k / vt
+extern int g_dit_qkv_stats;           // dit.hip: 1 (default) = the e4m3 attention's statistics come from the QKV epilogue (knob "dit_qkv_stats")
 extern int g_dit_trim_last_block;     // dit.hip: 1 (default) = the last block computes only what survives it (knob "dit_trim_last_block")
 extern int g_attn_slots, g_attn_force_split, g_attn_fp8_variant;
 

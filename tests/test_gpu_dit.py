@@ -193,6 +193,35 @@ def test_last_block_trim(eng2, fp8_attention):
         assert not torch.equal(outs[1][2][S0:], outs[0][2][S0:])      # the whole block moved the rows the trimmed one never touched
 
 
+@pytest.mark.parametrize("hw,ehw,T", [(256, 256, 48), (208, 256, 45), (128, None, 40)])
+def test_fp8_attention_statistics_from_the_qkv_epilogue(eng2, hw, ehw, T):
+    """enable_fp8_attention: q / k / v are divided by their GLOBAL standard deviations (torch.std over [1, H, S, 128], a bf16 scalar each;
+    qwen_image_dit.py:24-35).  Since round 6 the QKV epilogue leaves the sums (EPI_QKV_STATS: fp32 per lane over <= 512 stored values, double
+    per (64-row block, head), a fixed order in the finish kernel) instead of a pass over the 160 MB it has just written.  Against that pass
+    (knob dit_qkv_stats = 0): the three standard deviations round to the same bf16 values, so the forward is bit-identical -- aligned
+    geometry, a 169-token image stream with an unaligned text offset (the element-wise V path, ragged tiles), no edit image."""
+    from physicedit_amd.dit import model_fn_qwen_image
+    from physicedit_amd._lib import lib
+    noise, edit, pe, mask = _model_fn_inputs(hw, hw, T, 8, 5)
+    if ehw is None:
+        edit = None
+    elif ehw != hw:
+        edit = torch.randn((1, 16, ehw // 8, ehw // 8), generator=torch.Generator().manual_seed(9)).to(BF)
+    kw = dict(dit=eng2, visual_thinking_adapter=True, latents=noise.cuda(), timestep=torch.tensor([640.0]).to(BF), prompt_emb_mask=torch.ones((1, T)),
+              special_token_mask=mask, height=hw, width=hw, edit_latents=None if edit is None else edit.cuda(), is_train=False,
+              enable_fp8_attention=True)
+    outs = {}
+    for knob in (1, 0):
+        assert lib().pe_debug_set(b"dit_qkv_stats", knob) == 0
+        try:
+            outs[knob], _ = model_fn_qwen_image(prompt_emb=pe.cuda().clone(), **kw)
+            outs[knob] = outs[knob].cpu()
+        finally:
+            lib().pe_debug_set(b"dit_qkv_stats", 1)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[1], outs[0])
+
+
 def test_loop_dual_stream_is_bit_identical(eng2):
     """posi / nega forwards on two streams + two workspaces == the single-stream loop, bit for bit."""
     from physicedit_amd.pipeline import DenoiseLoop
