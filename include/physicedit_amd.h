@@ -59,6 +59,8 @@ const char* pe_build_id(void);
  * "gemm_direct_epilogue" (bit mask, default 1): bit 0 = complete tiles of the GELU / gate + residual epilogues skip the LDS round trip; bit 1 = so do
  * the q / k sections of the QKV epilogue (bit-identical, 1.2 % slower: off).  "gemm_band": M tiles per band of
  * the XCD-aware tile order (default 4).  "gemm_persist_wgs": work-groups of the persistent schedules' grid (0 = one per CU).
+ * "dit_qkv_stats" (default 1): with fp8_attention the QKV epilogue leaves the sums the e4m3 attention's global q / k / v standard deviations
+ * need (bit-identical to the separate pass, 0, which reads the three tensors again).
  * "dit_trim_last_block" (default 1): pe_dit_forward launches of the last block only what reaches the output -- the S0 noise rows' attention
  * queries, out-projection, norm2 and MLP (the reference slices image[:, :S0] behind it: qwen_image_physical.py:1398-1402); 0 = the whole block
  * (tests that read the text stream behind it).
