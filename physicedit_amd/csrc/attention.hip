@@ -1262,26 +1262,36 @@ __global__ void __launch_bounds__(192) attn_fp8_stats_finish_kernel(const double
 
 // The same three standard deviations from the QKV epilogue's partial sums (EPI_QKV_STATS, gemm_tile.h): wave z adds the n_part entries of
 // section z in index order (lane l: entries l, l + 64, ...), then the lanes meet in a fixed butterfly -- no pass over q / k / vt.
-__global__ void __launch_bounds__(192) attn_fp8_stats_finish_parts_kernel(const double* __restrict__ part, int n_part, double n, float* __restrict__ stats) {
+__global__ void __launch_bounds__(1024) attn_fp8_stats_finish_parts_kernel(const double* __restrict__ part, int n_part, double n, float* __restrict__ stats) {
+    // one work-group of 16 waves: per section, thread t adds entries t, t + 1024, ... in that order, the waves meet in a fixed butterfly and
+    // thread z adds the 16 wave sums in wave order (a single wave walking all ~6800 entries took 40 us: as long as the pass it replaces)
+    __shared__ double red[3][16][2];
     __shared__ float sd[3];
-    const int z = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    double a = 0.0, b = 0.0;
-    for (int i = lane; i < n_part; i += 64) {
-        a += part[((size_t)z * n_part + i) * 2];
-        b += part[((size_t)z * n_part + i) * 2 + 1];
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-    }
-    if (lane == 0) {
-        const double mean = a / n;
-        const double var = (b - n * mean * mean) / (n - 1.0);           // torch.std: unbiased
-        sd[z] = bf16r((float)sqrt(var > 0.0 ? var : 0.0));
-        stats[z] = sd[z];
+    const int t = (int)threadIdx.x, lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int z = 0; z < 3; ++z) {
+        double a = 0.0, b = 0.0;
+        for (int i = t; i < n_part; i += 1024) {
+            a += part[((size_t)z * n_part + i) * 2];
+            b += part[((size_t)z * n_part + i) * 2 + 1];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if (lane == 0) { red[z][w][0] = a; red[z][w][1] = b; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (t < 3) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < 16; ++i) { a += red[t][i][0]; b += red[t][i][1]; }
+        const double mean = a / n;
+        const double var = (b - n * mean * mean) / (n - 1.0);           // torch.std: unbiased
+        sd[t] = bf16r((float)sqrt(var > 0.0 ? var : 0.0));
+        stats[t] = sd[t];
+    }
+    __syncthreads();
+    if (t == 0) {
         const float qk = bf16r(sd[0] * sd[1]);
         stats[3] = bf16r(qk / 11.3137084989847603904f) * 1.44269504088896340736f;
     }
@@ -1939,7 +1949,7 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
     double* part = (double*)((char*)stats + 256);
     const int slot = prof_begin(PROF_ATTN, 4.0 * (double)S_q * S * 128.0 * H, stream);
     if (qkv_stats != nullptr) {      // the QKV epilogue left the sums (EPI_QKV_STATS): 2 slots x row blocks x heads entries per section
-        hipLaunchKernelGGL(attn_fp8_stats_finish_parts_kernel, dim3(1), dim3(192), 0, stream, qkv_stats, 2 * qkv_stats_row_blocks(S_pad) * H,
+        hipLaunchKernelGGL(attn_fp8_stats_finish_parts_kernel, dim3(1), dim3(1024), 0, stream, qkv_stats, 2 * qkv_stats_row_blocks(S_pad) * H,
                            (double)H * S * 128.0, stats);
     } else {
         hipLaunchKernelGGL(attn_fp8_stats_kernel, dim3(F8_STAT_WGS, 3), dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
