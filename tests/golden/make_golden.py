@@ -881,11 +881,14 @@ def _g21(O, sd, ad32, one_call, t_min, t_max):
     save("G21_60_layers_headline", tensors, meta=meta)
 
 
+G25_KEEP = {0, 1, 2, 3, 4, 9, 14, 19, 24, 29, 34, 39}      # the steps whose latents the fixture keeps (bf16 and fp32)
+
+
 def G25_40_steps_60_layers():
     """The reference's own 40-step CFG-4 loop (qwen_image_physical.py:644-661) on the FULL 60-layer DiT + adapter, 256x256 + a 256x256 edit
     image, T_pos 160 / T_neg 80 with 16 special tokens each (S = 672 / 592; G23's geometry and inputs, 40 steps instead of 2): 80
     model_fn_qwen_image calls with forty in-place applications of the adapter to each branch's special rows (:1333-1336), the dynamic-shift
-    schedule and its terminal step (flow_match.py:72-82).  Stored: the latents after EVERY step, both branches' special rows after steps
+    schedule and its terminal step (flow_match.py:72-82).  Stored: the latents after steps 1 - 5 and every fifth step (G25_KEEP), both branches' special rows after steps
     1-4 and after step 40, and an fp32 evaluation of the same 40-step graph by the oracle (fp32 weights widened per access, the timesteps
     rounded to bf16 as the reference rounds them): the fp32-distance criterion is the only form of "outputs match" that means anything
     after 80 bf16 forwards.  Also adds the fp32 companion of G23's two steps to that file.  ~4 h on 8 cores: only when named.
@@ -928,7 +931,8 @@ def G25_40_steps_60_layers():
             posi = O.model_fn(sd32, ad32, lat, t, pp, mask_p, h, w, edit.float(), t_min, t_max)
             nega = O.model_fn(sd32, ad32, lat, t, pn, mask_n, h, w, edit.float(), t_min, t_max)
             lat = tab.step(nega + cfg * (posi - nega), i, lat)
-            outs[f"latents_step{i}_fp32"] = lat.clone()
+            if n_steps <= 4 or i in G25_KEEP:
+                outs[f"latents_step{i}_fp32"] = lat.clone()
             print(f"  {tag} fp32 step {i}: {time.time() - t1:.0f} s", flush=True)
         outs["special_posi_after_fp32"], outs["special_nega_after_fp32"] = pp[mask_p].clone(), pn[mask_n].clone()
         return outs
@@ -961,7 +965,8 @@ def G25_40_steps_60_layers():
             nega, _ = model_fn_qwen_image(prompt_emb=pn, prompt_emb_mask=torch.ones((1, 80), dtype=torch.long), special_token_mask=mask_n, **kw)
             pred = nega + cfg * (posi - nega)
             latents = sch.step(pred, sch.timesteps[progress_id], latents)
-            outs[f"latents_step{progress_id}"] = latents.clone()
+            if progress_id in G25_KEEP:
+                outs[f"latents_step{progress_id}"] = latents.clone()
             if progress_id < 4:
                 outs[f"special_posi_step{progress_id}"], outs[f"special_nega_step{progress_id}"] = pp[mask_p].clone(), pn[mask_n].clone()
             print(f"  reference loop step {progress_id}: {time.time() - t1:.0f} s", flush=True)
