@@ -64,6 +64,15 @@ def test_invalid_args_fail_loudly_without_gpu(built_lib):
     assert rc == -1 and b"null e4m3 output" in built_lib.pe_last_error()
     with pytest.raises(_lib.PeError):
         _lib.check(rc, "x")
+    # knobs are validated where they are set: a schedule that does not exist fails at the call site, 0 = the compiled default
+    assert built_lib.pe_debug_set(b"gemm_variant", 10) == -1 and b"does not exist" in built_lib.pe_last_error()
+    assert built_lib.pe_debug_set(b"gemm_variant", 0) == 0 and built_lib.pe_debug_set(b"gemm_variant", 21) == 0
+    assert built_lib.pe_debug_set(b"decode_layer_wgs_per_cu", 0) == -1 and built_lib.pe_debug_set(b"no_such_knob", 1) == -1
+    # round 6 entry points refuse what they cannot run, before any launch
+    assert built_lib.pe_decode_layer_scratch_bytes(28, 1024, 18944) > 8192 and built_lib.pe_decode_layer_scratch_bytes(0, 1024, 18944) == 0
+    assert built_lib.pe_vae_attention_scratch_bytes(16384) > 384 * 16384 * 2 and built_lib.pe_vae_attention_scratch_bytes(0) == 0
+    rc = built_lib.pe_vae_attention(256, 257, 256, 64, None)
+    assert rc == -1 and b"256-byte aligned" in built_lib.pe_last_error()
 
 
 def test_no_cpu_fallback():
@@ -153,7 +162,8 @@ def test_struct_layouts_match_the_header(tmp_path):
               "pe_control_input": (L.ControlInput, ["blocks", "conditioning", "scale"]),
               "pe_controlnet_block": (L.ControlNetBlock, ["x_rms_w", "out_b"]),
               "pe_dit_weights": (L.DitWeights, ["num_layers", "blocks", "weights_e4m3"]),
-              "pe_adapter_weights": (L.AdapterWeights, ["dino_w0", "vae_b2"])}
+              "pe_adapter_weights": (L.AdapterWeights, ["dino_w0", "vae_b2"]),
+              "pe_decode_layer_weights": (L.DecodeLayerWeights, ["q_w", "post_norm_w", "input_norm_eps", "post_norm_eps", "n_q_heads", "ff"])}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "physicedit_amd.h"', "int main(void) {"]
     for cname, (_, names) in fields.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
