@@ -75,7 +75,11 @@ const char* pe_build_id(void);
  * slices of the softmax of S(t); the softmax reference is raised lazily, by tiles whose maximum exceeds it by 2^8 -- oracle:
  * flash_attention_fp8(kv_tile=64, lazy_tau_log2=8)); 2 = 1 with a maximum-free fast path (a row keeps its reference while its 64 P of
  * the tile sum to 448 at most, else the wave redoes the tile with the maximum; oracle: lazy_sum_limit=448; -5 % alone, -0.4 % per
- * configs[2] image); 0 = the plain kernel (running maximum; oracle: kv_tile=64). */
+ * configs[2] image); 3 = the arithmetic of 1, value for value, with one wave per SIMD (4 waves x 64 query rows, O and Q in fixed
+ * accumulator registers; round 6: bit-identical with 1, the same time alone, +0.5 % per image); 4 = 3 with the row sums taken by the
+ * matrix pipe from the e4m3 P (l += ones . P: 64 v_add_f32 per lane and tile fewer; oracle: row_sum_quantised=True; -10 % alone,
+ * -1.5 % per configs[2] image; not FlashAttention-3's published form, hence opt-in); 0 = the plain kernel (running maximum; oracle:
+ * kv_tile=64). */
 int pe_debug_set(const char* key, int value);
 /* Device buffer for a profiling variant's output ("gemm_stamps": long long [work-groups][8] s_memtime stamps of
  * gemm variant 15; "attn_stamps": long long [work-groups][10] of attention variants 3 - 6 built with -DPE_W4_STAMPS=1; "gemm_workspace": stream-K scratch for the granular pe_gemm_* calls);

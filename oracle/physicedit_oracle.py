@@ -234,7 +234,7 @@ def _heads(x: torch.Tensor, h: int = 24) -> torch.Tensor:
 
 
 def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dtype=torch.float8_e4m3fn, kv_tile: Optional[int] = None,
-                        lazy_tau_log2: float = 0.0, lazy_sum_limit: Optional[float] = None) -> torch.Tensor:
+                        lazy_tau_log2: float = 0.0, lazy_sum_limit: Optional[float] = None, row_sum_quantised: bool = False) -> torch.Tensor:
     """qwen_image_flash_attention(enable_fp8_attention=True), qwen_image_dit.py:24-35: q, k, v [B, H, S, D] bf16 are divided by their
     global standard deviations (torch.std: unbiased, over the whole tensor, a bf16 scalar), cast to float8_e4m3fn, handed to
     FlashAttention-3 with softmax_scale = q_std * k_std / sqrt(D), and the output (bf16) is multiplied by v_std.
@@ -251,6 +251,8 @@ def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dty
     lazy_sum_limit = L restates the library's max-free fast path (attn_fp8_variant 2): a row keeps its reference m as long as its P of
     the tile, exp(s - m), sum to L at most (L = 448, the largest e4m3: then no single P saturates); a row over the limit (always on
     the first tile: m = -inf) moves m to the tile's maximum and recomputes its P.
+    row_sum_quantised=True restates attn_fp8_variant 4: the row sum l adds up the e4m3 P the numerator multiplies (the library takes it
+    from the matrix pipe, ones . P) instead of the fp32 exp values -- not the published FlashAttention-3 form, the library's opt-in.
     All these forms differ by e4m3 rounding noise of P only (same size, different rounding points).  Everything outside the kernel
     (the three std, the two casts, the scale, the output product and its roundings) is the reference's own arithmetic.
     -> [B, H, S, D] bf16."""
@@ -277,7 +279,7 @@ def flash_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p_dty
                 m_new = torch.where(m_tile - m > lazy_tau_log2 * math.log(2.0), m_tile, m)
             alpha = torch.exp(m - m_new)
             e = torch.exp(st - m_new)
-            l = l * alpha + e.sum(dim=-1, keepdim=True)
+            l = l * alpha + (e.to(p_dtype).float() if row_sum_quantised else e).sum(dim=-1, keepdim=True)
             acc = acc * alpha + torch.matmul(e.to(p_dtype).float(), vf[..., t0:t0 + kv_tile, :])
             m = m_new
         x = acc / l

@@ -49,7 +49,7 @@ int pe_debug_set(const char* key, int value) {
     if (!strcmp(key, "dit_qkv_stats")) { g_dit_qkv_stats = value != 0; return PE_OK; }
     if (!strcmp(key, "dit_trim_last_block")) { g_dit_trim_last_block = value != 0; return PE_OK; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return PE_OK; }
-    if (!strcmp(key, "attn_fp8_variant")) { PE_REQUIRE(value >= 0 && value <= 2, "attn_fp8_variant: 0, 1 or 2"); g_attn_fp8_variant = value; return PE_OK; }
+    if (!strcmp(key, "attn_fp8_variant")) { PE_REQUIRE(value >= 0 && value <= 4, "attn_fp8_variant: 0 ... 4"); g_attn_fp8_variant = value; return PE_OK; }
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return PE_OK; }
     if (!strcmp(key, "gemm4_x")) { g_gemm4_x = value; return PE_OK; }
     if (!strcmp(key, "gemm_skip_ragged")) { g_gemm_skip_ragged = value; return PE_OK; }

@@ -1920,6 +1920,479 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
     }
 }
 
+#define F8W_CLOB "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+// registers of matrix slot m (the assembler evaluates the index expressions): Q of row block m & 1, k half m >> 2; O of row block m & 1, channels 32 ((m >> 1) - 4) ..
+#define F8W_QREG(m) "a[96+((" #m ")&1)*16+((" #m ")>>2)*8:96+((" #m ")&1)*16+((" #m ")>>2)*8+7]"
+#define F8W_OREG(m) "a[128+((" #m ")&1)*64+(((" #m ")>>1)-4)*16:128+((" #m ")&1)*64+(((" #m ")>>1)-4)*16+15]"
+#define F8W_OBASE(rb, dt) "128+" #rb "*64+" #dt "*16"
+#define F8W_MM_(m, sn, f, p, TAIL)                                                                                                         \
+    do {                                                                                                                                   \
+        if constexpr ((m) < 4)                                                                                                             \
+            asm volatile(F8_MFMA "%0, %1, " F8W_QREG((m) & 7) ", 0, %2, %2 op_sel_hi:[0,0,0]" TAIL : "=&v"(sn[(m) & 1][((m) >> 1) & 1]) : "v"(f), "v"(unit) : F8W_CLOB); \
+        else if constexpr ((m) < 8)                                                                                                        \
+            asm volatile(F8_MFMA "%0, %1, " F8W_QREG((m) & 7) ", %0, %2, %2 op_sel_hi:[0,0,0]" TAIL : "+v"(sn[(m) & 1][((m) >> 1) & 1]) : "v"(f), "v"(unit) : F8W_CLOB); \
+        else                                                                                                                               \
+            asm volatile(F8_MFMA F8W_OREG((m) | 8) ", %0, %1, " F8W_OREG((m) | 8) ", %2, %2 op_sel_hi:[0,0,0]" TAIL ::"v"(f), "v"(p[(m) & 1]), "v"(unit) : F8W_CLOB); \
+    } while (0)
+// row sums by the matrix pipe (variant 4): L of row block rb at a[64 + 16 rb ..] += ones . P
+#define F8W_LREG(rb) "a[64+" #rb "*16:64+" #rb "*16+15]"
+#define F8W_ML_(rb, p, TAIL) asm volatile(F8_MFMA F8W_LREG(rb) ", %0, %1, " F8W_LREG(rb) ", %2, %2 op_sel_hi:[0,0,0]" TAIL ::"v"(ones8), "v"(p[rb]), "v"(unit) : F8W_CLOB)
+#define F8W_RESCALE1(B, al)                                                                                                                \
+    do {                                                                                                                                   \
+        float t0_;                                                                                                                         \
+        asm volatile("v_accvgpr_read_b32 %0, a[" B "]\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a[" B "], %0" : "=&v"(t0_) : "v"(al) : F8W_CLOB); \
+    } while (0)
+#define F8W_MM(m, sn, f, p) F8W_MM_(m, sn, f, p, "")
+#define F8W_MM_DRAIN(m, sn, f, p) F8W_MM_(m, sn, f, p, F8_DRAIN)
+// O tuple -> 16 floats (after a drained MFMA)
+#define F8W_RD(B, i) "v_accvgpr_read_b32 %" #i ", a[" B "+" #i "]\n\t"
+#define F8W_READ16(B, d)                                                                                                                   \
+    asm volatile(F8W_RD(B, 0) F8W_RD(B, 1) F8W_RD(B, 2) F8W_RD(B, 3) F8W_RD(B, 4) F8W_RD(B, 5) F8W_RD(B, 6) F8W_RD(B, 7) F8W_RD(B, 8)       \
+                 F8W_RD(B, 9) F8W_RD(B, 10) F8W_RD(B, 11) F8W_RD(B, 12) F8W_RD(B, 13) F8W_RD(B, 14) F8W_RD(B, 15)                          \
+                 : "=v"(d[0]), "=v"(d[1]), "=v"(d[2]), "=v"(d[3]), "=v"(d[4]), "=v"(d[5]), "=v"(d[6]), "=v"(d[7]), "=v"(d[8]), "=v"(d[9]),  \
+                   "=v"(d[10]), "=v"(d[11]), "=v"(d[12]), "=v"(d[13]), "=v"(d[14]), "=v"(d[15])::F8W_CLOB)
+// O tuple *= alpha (the rare pass over O): read, multiply, write back, four temporaries in turn
+#define F8W_RS(B, i, t) "v_accvgpr_read_b32 %" #t ", a[" B "+" #i "]\n\tv_mul_f32 %" #t ", %" #t ", %4\n\tv_accvgpr_write_b32 a[" B "+" #i "], %" #t "\n\t"
+#define F8W_RESCALE16(B, al)                                                                                                               \
+    do {                                                                                                                                   \
+        float t0_, t1_, t2_, t3_;                                                                                                          \
+        asm volatile(F8W_RS(B, 0, 0) F8W_RS(B, 1, 1) F8W_RS(B, 2, 2) F8W_RS(B, 3, 3) F8W_RS(B, 4, 0) F8W_RS(B, 5, 1) F8W_RS(B, 6, 2)          \
+                     F8W_RS(B, 7, 3) F8W_RS(B, 8, 0) F8W_RS(B, 9, 1) F8W_RS(B, 10, 2) F8W_RS(B, 11, 3) F8W_RS(B, 12, 0) F8W_RS(B, 13, 1)      \
+                     F8W_RS(B, 14, 2) F8W_RS(B, 15, 3)                                                                                      \
+                     : "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_) : "v"(al) : F8W_CLOB);                                                 \
+    } while (0)
+#define F8W_ZR(i) "v_accvgpr_write_b32 a[128+" #i "], 0\n\t"
+#define F8W_ZR8(i) F8W_ZR(i) F8W_ZR(i + 1) F8W_ZR(i + 2) F8W_ZR(i + 3) F8W_ZR(i + 4) F8W_ZR(i + 5) F8W_ZR(i + 6) F8W_ZR(i + 7)
+#define F8W_ZR32(i) F8W_ZR8(i) F8W_ZR8(i + 8) F8W_ZR8(i + 16) F8W_ZR8(i + 24)
+#define F8W_QW(B, i) "v_accvgpr_write_b32 a[" B "+" #i "], %" #i "\n\t"
+#define F8W_QWRITE(B, q)                                                                                                                   \
+    asm volatile(F8W_QW(B, 0) F8W_QW(B, 1) F8W_QW(B, 2) F8W_QW(B, 3) F8W_QW(B, 4) F8W_QW(B, 5) F8W_QW(B, 6) F8W_QW(B, 7)                     \
+                 ::"v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]) : F8W_CLOB)
+
+// Variant 3: variant 1's arithmetic, value for value, with ONE wave per SIMD: 4 waves x 64 query rows (two 32-row blocks rb) instead of
+// 8 x 32.  In variant 1 the two waves of a SIMD share its VALU port by age (the older wave finishes its tile in ~1550 cycles and waits
+// ~1100 in the barrier, profiles/r04_attention_notes.md); one wave with twice the rows has the port to itself, every K8 / Vt8 fragment
+// it reads from LDS feeds two MFMAs (half the ds_read_b128 per score), and a tile's barrier is met by 4 waves.  The registers of two
+// waves in one: O (64 rows x 128: 128 registers) and Q (32) live in the accumulator half, in FIXED registers a[128:255] / a[96:127] that
+// only the asm statements below name (every one of them lists a96 ... a255 as clobbered, so the compiler keeps nothing of its own there;
+// a C++ value with an "a" constraint is copied to architectural registers at every basic-block boundary: 128 v_accvgpr_read per tile
+// in the ISA of the first build); S(t), S(t+1), P(t-1), P(t) and four fragments in the 256 architectural registers.
+// tools/mfma_asm_hazards.py checks that nothing outside the asm statements touches a[96:255].  16 matrix slots per iteration
+// (8 of S(t+1), 8 of P(t-1) V(t-1)), one softmax chunk of S(t) behind each.  Per row the operations and their order are variant 1's
+// (the two partial row sums per lane included): outputs are bit-identical with it.
+// LSUM (variant 4): the row sums come from the matrix pipe -- two more MFMAs per tile, L += ones . P on the e4m3 P the numerator multiplies,
+// in a third pair of accumulator tuples -- instead of 64 v_add_f32 per lane and tile: l is then the sum of the QUANTISED P (the oracle
+// restates it: row_sum_quantised=True).  Not the published FlashAttention-3 form (fp32 sums of the unquantised P): opt-in.
+template <bool LSUM>
+__global__ void __launch_bounds__(256, 1)
+flash_attn_fp8w_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict__ K8, const uint8_t* __restrict__ Vt8,
+                       bf16* __restrict__ out, int S, int S_pad, int ldo, const float* __restrict__ stats, AttnPlan plan,
+                       float* __restrict__ part_o, float* __restrict__ part_ml) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Q_BLOCK = 256;
+    constexpr int RING = KV_TILE * 128;           // one K8 or Vt8 tile: 8 KiB
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int l31 = lane & 31, h = lane >> 5;
+    const float scale_log2 = stats[3], v_std = stats[2];
+    const int nqb = plan.nqb;
+    const int nt_all = (S + KV_TILE - 1) / KV_TILE;
+    int item, t_begin = 0, t_end = nt_all, part_slot = -1;
+    if ((int)blockIdx.x < plan.n_full) {
+        item = xcd_remap((int)blockIdx.x, plan.n_full);
+    } else {
+        const int j = (int)blockIdx.x - plan.n_full;
+        item = plan.n_full + j / plan.split;
+        const int part = j - (j / plan.split) * plan.split;
+        if (plan.split > 1) {
+            t_begin = (int)((long long)nt_all * part / plan.split);
+            t_end = (int)((long long)nt_all * (part + 1) / plan.split);
+            part_slot = j;
+        }
+    }
+    const int head = item / nqb;
+    const int qb = item - head * nqb;
+    const int q0 = qb * Q_BLOCK + w * 64;
+    const uint8_t* Qh = Q8 + (size_t)head * S_pad * 128;
+    const uint8_t* Kh = K8 + (size_t)head * S_pad * 128;
+    const uint8_t* Vh = Vt8 + (size_t)head * 128 * S_pad;
+
+    // Q: [rb][kk] at a[96 + 16 rb + 8 kk ..]
+    {
+        i32x8f qv[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int qrow = min(q0 + rb * 32 + l31, S - 1);
+            const uint8_t* qp = Qh + (size_t)qrow * 128 + h * 32;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const i32x4f lo = *(const i32x4f*)(qp + kk * 64), hi = *(const i32x4f*)(qp + kk * 64 + 16);
+                qv[rb][kk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+        F8W_QWRITE("96", qv[0][0]);
+        F8W_QWRITE("96+8", qv[0][1]);
+        F8W_QWRITE("96+16", qv[1][0]);
+        F8W_QWRITE("96+24", qv[1][1]);
+    }
+    // a wave stages two 1 KiB pieces of K8 (8 keys each, 32 keys apart) and two of Vt8 (16 channels each, 64 apart): the swizzles only
+    // look at the low row bits, which the two pieces share
+    const uint8_t* k_src;
+    const uint8_t* v_src;
+    {
+        const int krow = w * 8 + (lane >> 3);
+        k_src = Kh + (size_t)krow * 128 + (((lane & 7) ^ (krow & 7)) << 4);
+        const int vrow = w * 16 + (lane >> 2);
+        v_src = Vh + (size_t)vrow * S_pad + (((lane & 3) ^ ((vrow >> 1) & 3)) << 4);
+    }
+    const size_t v_piece = (size_t)64 * S_pad;
+    auto stage_k = [&](int buf, int t) {
+        glds16(k_src + (size_t)t * KV_TILE * 128, smem + buf * RING + w * 1024);
+        glds16(k_src + (size_t)t * KV_TILE * 128 + 32 * 128, smem + buf * RING + (w + 4) * 1024);
+    };
+    auto stage_v = [&](int buf, int t) {
+        glds16(v_src + t * KV_TILE, smem + (2 + buf) * RING + w * 1024);
+        glds16(v_src + v_piece + t * KV_TILE, smem + (2 + buf) * RING + (w + 4) * 1024);
+    };
+    asm volatile(F8W_ZR32(0) F8W_ZR32(32) F8W_ZR32(64) F8W_ZR32(96)::: F8W_CLOB);      // O = 0
+    i32x8f ones8;
+    if constexpr (LSUM) {
+        asm volatile(F8W_ZR32(0 - 64)::: F8W_CLOB);                                    // L = 0 (a[64:95])
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones8[j] = 0x38383838;                             // 1.0 as e4m3, 32 k-slots per lane
+        asm volatile("" : "+v"(ones8));
+    }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const int ksw = l31 & 7, vsw = (l31 >> 1) & 3;
+    const int krow_off = l31 * 128, vrow_off = l31 * 64;
+
+    auto rd32 = [&](const char* rowp, int c0, int sw) -> i32x8f {
+        const i32x4f lo = *(const i32x4f*)(rowp + ((c0 ^ sw) << 4)), hi = *(const i32x4f*)(rowp + (((c0 + 1) ^ sw) << 4));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // fragment fr of an iteration: 0..3 = K8 (s2 = fr & 1, kk = fr >> 1), 4..7 = Vt8 (dt = fr - 4); matrix slot m uses fragment m >> 1 for row block m & 1
+    auto frag = [&](const char* Kb, const char* Vb, int fr) -> i32x8f {
+        return fr < 4 ? rd32(Kb + (fr & 1) * 32 * 128 + krow_off, (fr >> 1) * 4 + 2 * h, ksw) : rd32(Vb + (fr - 4) * 32 * 64 + vrow_off, 2 * h, vsw);
+    };
+    int unit = 0x7f7f7f7f;
+    asm volatile("" : "+v"(unit));
+    // the asm-MFMA rules of variant 1 (above): volatile statements, operands kept live until the next MFMA has issued, the wait states of
+    // a result that is read right away inside the statement (F8W_MM / F8W_MM_DRAIN)
+    auto sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    const int n = t_end - t_begin;
+    const bool tail = (S & (KV_TILE - 1)) != 0 && t_end == nt_all;
+    // iteration i (tile t = t_begin + i), parity P = i & 1: K(t+1) sits in K ring 1 - P, V(t-1) in V ring 1 - P; K(t+2) -> K ring P, V(t) -> V ring P.
+    // sc: S(t) (in), sn: S(t+1) (out); pq: P(t-1) (in), pc: P(t) (out)
+    auto iter = [&](int t, auto par_tag, auto prev_tag, auto last_tag, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], const i32x8f (&pq)[2],
+                    i32x8f (&pc)[2]) {
+        constexpr int P = decltype(par_tag)::value;
+        constexpr bool PREV = decltype(prev_tag)::value, LAST = decltype(last_tag)::value;
+        const char* Kb = smem + (1 - P) * RING;
+        const char* Vb = smem + (2 + 1 - P) * RING;
+        auto on = [](int m) { return m < 8 ? !LAST : PREV; };
+        sync();
+        if constexpr (!LAST) {
+            if (t + 2 < t_end) stage_k(P, t + 2);
+        }
+        stage_v(P, t);
+        i32x8f f[4];
+        if (on(0)) {
+            f[0] = frag(Kb, Vb, 0);
+            f[1] = frag(Kb, Vb, 1);
+        } else if (on(8)) {                          // the last iteration has no S MFMAs: its first fragments are Vt8's
+            f[0] = frag(Kb, Vb, 4);
+            f[1] = frag(Kb, Vb, 5);
+        }
+        F8_FENCE();
+#define F8_KEEP(x) asm volatile("" ::"v"(x))
+        // slot m: MFMA m (fragment m >> 1, row block m & 1); behind the second MFMA of a fragment the LDS reads of the fragment two ahead
+        // (the first two of an iteration are read in front of slot 0)
+#define F8W_SLOT(m)                                                                   \
+        F8_FENCE();                                                                   \
+        if (on(m)) F8W_MM(m, sn, f[((m) >> 1) & 3], pq);                              \
+        if ((m) >= 1 && on((m) - 1)) F8_KEEP(f[(((m) - 1) >> 1) & 3]);                \
+        if (((m) & 1) && (m) + 3 < 16 && on(m) && on((m) + 3)) f[(((m) + 3) >> 1) & 3] = frag(Kb, Vb, ((m) + 3) >> 1); \
+        F8_FENCE();
+        if constexpr (LAST) {
+            if (tail) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = t * KV_TILE + s2 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                            if (key >= S) sc[rb][s2][r] = -INFINITY;
+                        }
+            }
+            F8_FENCE();
+        }
+        float alpha[2], nm[2], ps0[2] = {0.f, 0.f}, ps1[2] = {0.f, 0.f};
+        bool moved[2];
+        auto max_a = [&](int rb) -> float {
+            float mx0 = sc[rb][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx0 = fmaxf(mx0, sc[rb][0][r]);
+            asm volatile("" : "+v"(mx0));            // pins: pure arithmetic is otherwise placed wherever instruction selection likes
+            return mx0;
+        };
+        auto max_b = [&](int rb, float mx0) -> float {
+            float mx = sc[rb][1][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[rb][1][r]);
+            mx = fmaxf(mx, mx0);
+            asm volatile("" : "+v"(mx));
+            return mx;
+        };
+        auto reference = [&](int rb, float mx) {     // lazily raised reference (variant 1): m moves only when the tile's maximum is 2^F8_TAU above it
+            mx = max_with_lane_xor32(mx);
+            const float m_tile = mx * scale_log2;
+            moved[rb] = m_tile - m_run[rb] > F8_TAU;
+            const float m_new = moved[rb] ? m_tile : m_run[rb];
+            alpha[rb] = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+            m_run[rb] = m_new;
+            nm[rb] = -m_new;
+        };
+        auto group = [&](int rb, int g) {            // scores 4 a .. 4 a + 3 of accumulator s2 -> dword g = 4 s2 + a of this lane's k-slots
+            const int s2 = g >> 2, a = g & 3;
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[rb][s2][4 * a], scale_log2, nm[rb]));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[rb][s2][4 * a + 1], scale_log2, nm[rb]));
+            const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[rb][s2][4 * a + 2], scale_log2, nm[rb]));
+            const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[rb][s2][4 * a + 3], scale_log2, nm[rb]));
+            if constexpr (!LSUM) {
+                ps0[rb] += p0;
+                ps1[rb] += p1;
+                ps0[rb] += p2;
+                ps1[rb] += p3;
+            }
+            int v = pc[rb][g];                       // both halves are overwritten: no zero fill
+            v = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, v, false);
+            v = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, v, true);
+            pc[rb][g] = v;
+            asm volatile("" : "+v"(pc[rb][g]));      // computed HERE (not sunk to its reader in the next iteration)
+        };
+        auto row_sum = [&](int rb) {
+            if constexpr (!LSUM) {
+                l_run[rb] = __builtin_fmaf(l_run[rb], alpha[rb], ps0[rb] + ps1[rb]);
+                asm volatile("" : "+v"(l_run[rb]));
+            }
+        };
+        // the softmax of S(t) needs nothing of this iteration's MFMAs: its first chunks run while the first fragment reads are in flight
+        float mx = max_a(0);
+        mx = max_b(0, mx);
+        F8W_SLOT(0)
+        reference(0, mx);
+        group(0, 0);
+        F8W_SLOT(1)
+        mx = max_a(1);
+        F8W_SLOT(2)
+        mx = max_b(1, mx);
+        F8W_SLOT(3)
+        reference(1, mx);
+        group(0, 1);
+        F8W_SLOT(4)
+        group(0, 2);
+        F8W_SLOT(5)
+        group(0, 3);
+        F8W_SLOT(6)
+        group(0, 4);
+        F8W_SLOT(7)
+        group(0, 5);
+        F8W_SLOT(8)
+        group(0, 6);
+        F8W_SLOT(9)
+        group(0, 7);
+        row_sum(0);
+        F8W_SLOT(10)
+        group(1, 0);
+        F8W_SLOT(11)
+        group(1, 1);
+        F8W_SLOT(12)
+        group(1, 2);
+        F8W_SLOT(13)
+        group(1, 3);
+        F8W_SLOT(14)
+        group(1, 4);
+        F8W_SLOT(15)
+        group(1, 5);
+        if constexpr (LSUM) {
+            F8_FENCE();
+            if (on(15)) {
+                F8W_ML_(0, pq, "");
+                F8_KEEP(f[3]);
+            }
+            F8_FENCE();
+        }
+        group(1, 6);
+        if constexpr (LSUM) {
+            F8_FENCE();
+            if (on(15)) F8W_ML_(1, pq, "");
+            F8_FENCE();
+        }
+        group(1, 7);
+        row_sum(1);
+        if (on(15)) {
+            F8_KEEP(f[3]);
+            F8_KEEP(pq[0]);
+            F8_KEEP(pq[1]);
+            if constexpr (LSUM) F8_KEEP(ones8);
+        } else if (on(7)) {
+            F8_KEEP(f[3]);                           // no MFMA behind slot 7 in the first iteration: fragment 3 lives to the tail
+        }
+        F8_FENCE();
+        // the pass over O (rare: the reference moved).  The last P.V MFMA is four softmax groups (> 300 cycles) upstream
+        if (__any(moved[0])) {
+            F8W_RESCALE16(F8W_OBASE(0, 0), alpha[0]);
+            F8W_RESCALE16(F8W_OBASE(0, 1), alpha[0]);
+            F8W_RESCALE16(F8W_OBASE(0, 2), alpha[0]);
+            F8W_RESCALE16(F8W_OBASE(0, 3), alpha[0]);
+            if constexpr (LSUM) F8W_RESCALE1("64", alpha[0]);
+        }
+        if (__any(moved[1])) {
+            F8W_RESCALE16(F8W_OBASE(1, 0), alpha[1]);
+            F8W_RESCALE16(F8W_OBASE(1, 1), alpha[1]);
+            F8W_RESCALE16(F8W_OBASE(1, 2), alpha[1]);
+            F8W_RESCALE16(F8W_OBASE(1, 3), alpha[1]);
+            if constexpr (LSUM) F8W_RESCALE1("64+16", alpha[1]);
+        }
+#undef F8W_SLOT
+#undef F8_KEEP
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using No = std::false_type;
+    using Yes = std::true_type;
+    f32x16 sa[2][2], sb[2][2];
+    i32x8f pa[2], pb[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pa[rb][j] = pb[rb][j] = 0;
+    if (n > 0) {                                     // a part of a split item may own no tile at all (more parts than tiles)
+        stage_k(0, t_begin);
+        sync();
+        if (n > 1) stage_k(1, t_begin + 1);
+        {                                                                         // S(t_begin)
+            i32x8f f4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f4[j] = frag(smem, smem, j);
+            F8W_MM(0, sa, f4[0], pa);
+            F8W_MM(1, sa, f4[0], pa);
+            F8W_MM(2, sa, f4[1], pa);
+            F8W_MM(3, sa, f4[1], pa);
+            F8W_MM_DRAIN(4, sa, f4[2], pa);                                       // drained: the first iteration reads S
+            F8W_MM_DRAIN(5, sa, f4[2], pa);
+            F8W_MM_DRAIN(6, sa, f4[3], pa);
+            F8W_MM_DRAIN(7, sa, f4[3], pa);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(f4[j]));            // live while the matrix pipe reads them
+        }
+        // even iterations: S in sa -> sb, P(t) -> pa (P(t-1) in pb); odd iterations the other way round
+        if (n == 1) {
+            iter(t_begin, P0{}, No{}, Yes{}, sa, sb, pb, pa);
+        } else {
+            iter(t_begin, P0{}, No{}, No{}, sa, sb, pb, pa);
+            int i = 1;
+            for (; i + 2 <= n - 1; i += 2) {
+                iter(t_begin + i, P1{}, Yes{}, No{}, sb, sa, pa, pb);
+                iter(t_begin + i + 1, P0{}, Yes{}, No{}, sa, sb, pb, pa);
+            }
+            if (i < n - 1) {
+                iter(t_begin + i, P1{}, Yes{}, No{}, sb, sa, pa, pb);
+                ++i;
+            }
+            if (i & 1) iter(t_begin + i, P1{}, Yes{}, Yes{}, sb, sa, pa, pb);
+            else iter(t_begin + i, P0{}, Yes{}, Yes{}, sa, sb, pb, pa);
+        }
+        i32x8f pl[2];                                    // P(t_end - 1), selected before the barrier (a VALU write needs distance to the MFMA)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pl[rb][j] = ((n - 1) & 1) ? pb[rb][j] : pa[rb][j];
+            asm volatile("" : "+v"(pl[rb]));
+        }
+        sync();                                          // V(t_end - 1) landed
+        {
+            const char* Vb = smem + (2 + ((n - 1) & 1)) * RING;
+            i32x8f f4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f4[j] = frag(Vb, Vb, 4 + j);
+            if constexpr (LSUM) {
+                F8W_ML_(0, pl, "");
+                F8W_ML_(1, pl, "");
+            }
+            F8W_MM(8, sa, f4[0], pl);
+            F8W_MM(9, sa, f4[0], pl);
+            F8W_MM(10, sa, f4[1], pl);
+            F8W_MM(11, sa, f4[1], pl);
+            F8W_MM(12, sa, f4[2], pl);
+            F8W_MM(13, sa, f4[2], pl);
+            F8W_MM(14, sa, f4[3], pl);
+            F8W_MM_DRAIN(15, sa, f4[3], pl);                                      // drained (the pipe is in order): the epilogue reads O
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(f4[j]));
+            asm volatile("" ::"v"(pl[0]), "v"(pl[1]));
+            if constexpr (LSUM) asm volatile("" ::"v"(ones8));
+            asm volatile("" ::"v"(pa[0]), "v"(pa[1]), "v"(pb[0]), "v"(pb[1]), "v"(unit));      // nothing an MFMA reads is ever "dead" before the end
+        }
+    }
+    float ov[2][4][16];
+    F8W_READ16(F8W_OBASE(0, 0), ov[0][0]);
+    F8W_READ16(F8W_OBASE(0, 1), ov[0][1]);
+    F8W_READ16(F8W_OBASE(0, 2), ov[0][2]);
+    F8W_READ16(F8W_OBASE(0, 3), ov[0][3]);
+    F8W_READ16(F8W_OBASE(1, 0), ov[1][0]);
+    F8W_READ16(F8W_OBASE(1, 1), ov[1][1]);
+    F8W_READ16(F8W_OBASE(1, 2), ov[1][2]);
+    F8W_READ16(F8W_OBASE(1, 3), ov[1][3]);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        float l_tot;
+        if constexpr (LSUM) {            // every register of L's tuple holds the whole row's sum (all 64 k-slots): the first one
+            if (rb == 0) asm volatile("v_accvgpr_read_b32 %0, a[64]" : "=v"(l_tot)::F8W_CLOB);
+            else asm volatile("v_accvgpr_read_b32 %0, a[64+16]" : "=v"(l_tot)::F8W_CLOB);
+        } else {
+            l_tot = sum_with_lane_xor32(l_run[rb]);
+        }
+        const int row = w * 64 + rb * 32 + l31;
+        if (part_slot >= 0) {
+            float* po = part_o + ((size_t)part_slot * Q_BLOCK + row) * 128 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = ov[rb][dt][4 * a + r];
+                    *(f32x4*)(po + dt * 32 + 8 * a) = v;
+                }
+            if (h == 0) {
+                float* pm = part_ml + ((size_t)part_slot * Q_BLOCK + row) * 2;
+                pm[0] = m_run[rb];
+                pm[1] = l_tot;
+            }
+            continue;
+        }
+        const float inv = 1.0f / l_tot;
+        const int q = qb * Q_BLOCK + row;
+        if (q < S) {
+            bf16* op = out + (size_t)q * ldo + head * 128 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (bf16)((float)(bf16)(ov[rb][dt][4 * a + r] * inv) * v_std);     // x.to(bf16) * v_std
+                    *(bf16x4*)(op + dt * 32 + 8 * a) = v;
+                }
+        }
+    }
+}
+
 size_t flash_attn_fp8_scratch_bytes(int H, int S_pad) {
     return 3 * (size_t)H * S_pad * 128 + 256 + (size_t)3 * F8_STAT_WGS * 2 * sizeof(double) + 256;
 }
@@ -1938,6 +2411,8 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
         hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fp8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_fp8p_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_fp8p_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_fp8w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_fp8w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);
         if (e != hipSuccess) return set_error(PE_ERR_HIP, "flash_attn_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.store(true, std::memory_order_release);
     }
@@ -1975,8 +2450,16 @@ int launch_flash_attn_fp8(const void* q, const void* k, const void* vt, void* ou
         hipLaunchKernelGGL((flash_attn_fp8p_kernel<8, false>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
                            (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
                            part_o, part_ml);
-    else
+    else if (g_attn_fp8_variant == 2)
         hipLaunchKernelGGL((flash_attn_fp8p_kernel<8, true>), dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(512), F8_LDS, stream,
+                           (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
+                           part_o, part_ml);
+    else if (g_attn_fp8_variant == 3)
+        hipLaunchKernelGGL(flash_attn_fp8w_kernel<false>, dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(256), F8_LDS, stream,
+                           (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
+                           part_o, part_ml);
+    else
+        hipLaunchKernelGGL(flash_attn_fp8w_kernel<true>, dim3(plan.n_full + (plan.split > 1 ? n_short : 0)), dim3(256), F8_LDS, stream,
                            (const uint8_t*)q8, (const uint8_t*)k8, (const uint8_t*)vt8, (bf16*)out, S, S_pad, ldo, (const float*)stats, plan,
                            part_o, part_ml);
     rc = check_launch("flash_attn_fp8_kernel");

@@ -184,10 +184,11 @@ def test_struct_layouts_match_the_header(tmp_path):
 
 
 def test_asm_mfma_hazards_of_the_e4m3_attention_kernel():
-    """flash_attn_fp8p_kernel places its MFMAs as asm statements, so the compiler neither keeps their source registers alive while the
-    matrix pipe reads them nor waits before it touches their results (both happened: profiles/r04_attention_notes.md section 5.2).
-    tools/mfma_asm_hazards.py compiles the file to gfx950 assembly and checks the two rules statically: a compiler upgrade or an edit
-    that re-opens one of them fails here, without a GPU."""
+    """flash_attn_fp8p_kernel and flash_attn_fp8w_kernel place their MFMAs as asm statements, so the compiler neither keeps their source
+    registers alive while the matrix pipe reads them nor waits before it touches their results (both happened:
+    profiles/r04_attention_notes.md section 5.2); the one-wave kernel also keeps O, Q and L in fixed accumulator registers that only its
+    asm statements may name.  tools/mfma_asm_hazards.py compiles the file to gfx950 assembly and checks the rules statically on all four
+    instantiations: a compiler upgrade or an edit that re-opens one of them fails here, without a GPU."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("mfma_asm_hazards", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "mfma_asm_hazards.py"))

@@ -713,8 +713,10 @@ def _fp8_attn(ops, q, k, v, S, workspace=True, want_stats=False, stale_pad=None)
 
 @pytest.fixture
 def fp8_variant(request):
-    """attn_fp8_variant knob for one test: 2 = software-pipelined with the max-free fast path (reference kept while a row's tile sum <= 448),
-    1 = software-pipelined, reference raised by tiles 2^8 above it, 0 = the plain kernel (running max)"""
+    """attn_fp8_variant knob for one test: 4 = variant 3 with the row sums taken by the matrix pipe from the e4m3 P (ones . P),
+    3 = variant 1's arithmetic with one wave per SIMD (4 waves x 64 query rows), 2 = software-pipelined
+    with the max-free fast path (reference kept while a row's tile sum <= 448), 1 = software-pipelined, reference raised by tiles 2^8 above
+    it, 0 = the plain kernel (running max)"""
     from physicedit_amd._lib import lib, check
     check(lib().pe_debug_set(b"attn_fp8_variant", request.param), "attn_fp8_variant")
     yield request.param
@@ -728,7 +730,11 @@ FP8_ATTN_DEFAULT = 1
 @pytest.mark.parametrize("S,scales,fp8_variant", [(64, (1.0, 1.0, 1.0), 1), (100, (1.0, 1.0, 1.0), 1), (700, (0.7, 1.9, 3.1), 1),
                                                   (1093, (2.5, 0.4, 0.05), 1), (2208, (1.0, 1.3, 0.8), 1),
                                                   (100, (1.0, 1.0, 1.0), 0), (1093, (2.5, 0.4, 0.05), 0), (2208, (1.0, 1.3, 0.8), 0),
-                                                  (100, (1.0, 1.0, 1.0), 2), (700, (0.7, 1.9, 3.1), 2), (1093, (2.5, 0.4, 0.05), 2)],
+                                                  (100, (1.0, 1.0, 1.0), 2), (700, (0.7, 1.9, 3.1), 2), (1093, (2.5, 0.4, 0.05), 2),
+                                                  (64, (1.0, 1.0, 1.0), 3), (100, (1.0, 1.0, 1.0), 3), (700, (0.7, 1.9, 3.1), 3),
+                                                  (1093, (2.5, 0.4, 0.05), 3), (2208, (1.0, 1.3, 0.8), 3),
+                                                  (64, (1.0, 1.0, 1.0), 4), (100, (1.0, 1.0, 1.0), 4), (700, (0.7, 1.9, 3.1), 4),
+                                                  (1093, (2.5, 0.4, 0.05), 4), (2208, (1.0, 1.3, 0.8), 4)],
                          indirect=["fp8_variant"])
 def test_flash_attn_fp8(ops, S, scales, fp8_variant):
     """The e4m3 attention operator against the oracle's restatement of the reference branch (global std of q, k, v in bf16, e4m3 casts,
@@ -741,9 +747,10 @@ def test_flash_attn_fp8(ops, S, scales, fp8_variant):
     q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in scales)
     torch.set_num_threads(max(torch.get_num_threads(), 16))
     ref = O.flash_attention_fp8(q[None], k[None], v[None])[0].permute(1, 0, 2).reshape(S, H * 128)
-    tau = 8.0 if fp8_variant == 1 else 0.0      # the pipelined kernels raise their reference lazily (oracle: lazy_tau_log2 / lazy_sum_limit)
+    tau = 8.0 if fp8_variant in (1, 3, 4) else 0.0      # the pipelined kernels raise their reference lazily (oracle: lazy_tau_log2 / lazy_sum_limit)
     ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64, lazy_tau_log2=tau,
-                                  lazy_sum_limit=448.0 if fp8_variant == 2 else None)[0].permute(1, 0, 2).reshape(S, H * 128)
+                                  lazy_sum_limit=448.0 if fp8_variant == 2 else None,
+                                  row_sum_quantised=fp8_variant == 4)[0].permute(1, 0, 2).reshape(S, H * 128)
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
     out, stats = _fp8_attn(ops, q, k, v, S, workspace=False, want_stats=True)
     assert torch.isfinite(out.float()).all()
@@ -800,22 +807,47 @@ def test_flash_attn_fp8_every_peeled_path(ops, H, S):
     q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in (1.0, 1.2, 0.9))
     outs = []
     try:
-        for variant in (0, 1, 2):
+        for variant in (0, 1, 2, 3, 4):
             check(lib().pe_debug_set(b"attn_fp8_variant", variant), "attn_fp8_variant")
             outs.append(_fp8_attn(ops, q, k, v, S))
     finally:
         check(lib().pe_debug_set(b"attn_fp8_variant", FP8_ATTN_DEFAULT), "attn_fp8_variant")
     ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
     e0 = _rms(outs[0], ref32)
-    for variant in (1, 2):
+    for variant in (1, 2, 4):
         e1, d = _rms(outs[variant], ref32), _rms(outs[variant], outs[0])
         print(f"[parity] flash_attn_fp8 peeled paths H={H} S={S} variant {variant}: vs fp32 truth plain {e0:.3e} pipelined {e1:.3e}; pipelined vs plain {d:.3e}")
         assert torch.isfinite(outs[variant].float()).all()
         assert e1 <= 1.1 * e0 + 1e-6 and d <= 0.9 * e0 + 1e-6
+    # variant 3 is variant 1 with one wave per SIMD: per row the same operations in the same order
+    assert torch.equal(outs[3], outs[1]), f"one-wave layout differs from variant 1: max |d| {(outs[3].float() - outs[1].float()).abs().max().item():.3e}"
     if H == 256 and S <= 192:       # no KV split (every part of a split item starts its own reference sequence), and seconds of CPU
-        for variant, kw in ((1, dict(lazy_tau_log2=8.0)), (2, dict(lazy_sum_limit=448.0))):
+        for variant, kw in ((1, dict(lazy_tau_log2=8.0)), (2, dict(lazy_sum_limit=448.0)), (4, dict(lazy_tau_log2=8.0, row_sum_quantised=True))):
             ref_t = O.flash_attention_fp8(q[None], k[None], v[None], kv_tile=64, **kw)[0].permute(1, 0, 2).reshape(S, H * 128)
             assert _rms(outs[variant], ref_t) <= 0.05 * e0 + 1e-6
+
+
+@pytest.mark.parametrize("S,scales", [(300, (3.0, 3.0, 1.0)), (1093, (3.0, 3.0, 1.0)), (2208, (2.0, 4.0, 0.5)), (2208, (1.0, 1.0, 1.0))])
+def test_flash_attn_fp8_one_wave_layout_is_variant_1(ops, S, scales):
+    """attn_fp8_variant 3 (4 waves x 64 query rows, O and Q in fixed accumulator registers) performs variant 1's operations per row in
+    variant 1's order: bit-identical outputs, with and without the KV-split plan, also on logits whose tile maxima keep moving (q_std k_std
+    = 8 ... 9: the pass over O, which this kernel does in asm on the accumulator registers, runs on most tiles)."""
+    from physicedit_amd._lib import lib, check
+    H = 24
+    g = torch.Generator().manual_seed(5100 + S)
+    q, k, v = ((torch.randn((H, S, 128), generator=g) * sc).to(BF) for sc in scales)
+    outs = {}
+    try:
+        for variant in (1, 3):
+            check(lib().pe_debug_set(b"attn_fp8_variant", variant), "attn_fp8_variant")
+            outs[variant] = (_fp8_attn(ops, q, k, v, S, workspace=False), _fp8_attn(ops, q, k, v, S))
+    finally:
+        check(lib().pe_debug_set(b"attn_fp8_variant", FP8_ATTN_DEFAULT), "attn_fp8_variant")
+    ref32 = F.scaled_dot_product_attention(q[None].float(), k[None].float(), v[None].float())[0].permute(1, 0, 2).reshape(S, H * 128)
+    print(f"[parity] flash_attn_fp8 one-wave layout S={S} scales {scales}: rms vs fp32 truth {_rms(outs[3][0], ref32):.3e} (variant 1: {_rms(outs[1][0], ref32):.3e})")
+    for a, b in zip(outs[1], outs[3]):
+        assert torch.isfinite(b.float()).all()
+        assert torch.equal(a, b), f"max |d| {(a.float() - b.float()).abs().max().item():.3e}"
 
 
 # ------------------------------------------------------------------------------------------------

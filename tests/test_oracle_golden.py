@@ -433,3 +433,27 @@ def test_G11_hot_lora(golden):
     O.lora_merge(merged, synth.make_lora(4321, 1, meta["rank"]))
     _, image_m = O.block_forward(merged, 0, image, text, temb, rope)
     assert not torch.equal(image_m, image_o)
+
+
+def test_fp8_attention_restatements_agree():
+    """`flash_attention_fp8` restates what the e4m3 attention kernels do inside (FlashAttention-3 cannot run here: parity of P's quantisation is
+    unpinned, see the oracle's header): the online forms the kernels are pinned to -- running maximum, the lazily raised reference, the
+    sum-limited fast path, and the row sums of the quantised P (attn_fp8_variant 0 / 1 + 3 / 2 / 4) -- must all sit at the same distance from
+    the fp32 attention as the form that knows the final maximum, and differ from it by a fraction of that distance: they move the rounding
+    points of P, nothing else."""
+    g = torch.Generator().manual_seed(77)
+    q, k, v = ((torch.randn((1, 2, 333, 128), generator=g) * s).to(torch.bfloat16) for s in (1.3, 0.9, 2.0))
+    truth = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    base = O.flash_attention_fp8(q, k, v)
+    rms = lambda a, b: float((a.float() - b.float()).pow(2).mean().sqrt())
+    e0 = rms(base, truth)
+    assert 0 < e0 < 0.05
+    forms = {"running max": dict(kv_tile=64), "lazy 2^8": dict(kv_tile=64, lazy_tau_log2=8.0), "sum limit": dict(kv_tile=64, lazy_sum_limit=448.0),
+             "lazy 2^8, quantised row sums": dict(kv_tile=64, lazy_tau_log2=8.0, row_sum_quantised=True)}
+    for name, kw in forms.items():
+        out = O.flash_attention_fp8(q, k, v, **kw)
+        assert torch.isfinite(out.float()).all(), name
+        assert rms(out, truth) <= 1.1 * e0, (name, rms(out, truth), e0)
+        assert rms(out, base) <= 0.9 * e0, (name, rms(out, base), e0)
+    # without quantising P every online form is the plain softmax
+    assert rms(O.flash_attention_fp8(q, k, v, p_dtype=None), truth) <= e0

@@ -1,8 +1,10 @@
-"""Static check of the hand-placed (asm volatile) MFMAs of flash_attn_fp8p_kernel against the two things the compiler cannot know about
-them (profiles/r04_attention_notes.md section 5.2): an MFMA runs for 16 passes after its statement, so
+"""Static check of the hand-placed (asm volatile) MFMAs of flash_attn_fp8p_kernel and flash_attn_fp8w_kernel against the things the compiler
+cannot know about them (profiles/r04_attention_notes.md section 5.2): an MFMA runs for 16 passes after its statement, so
   * nothing may WRITE its A / B source registers (the allocator considers them dead) and
   * nothing may READ or WRITE its result
 before 18 wait states have passed, unless another MFMA of the wave was issued in between (in-order issue: that one waited for the pipe).
+flash_attn_fp8w_kernel also keeps O, Q and L in FIXED accumulator registers a[64:255] that only its asm statements name:
+  * no instruction outside an asm statement (;;#ASMSTART ... ;;#ASMEND in the listing) may touch a64 ... a255.
 Compiles physicedit_amd/csrc/attention.hip to gfx950 assembly (no GPU needed) and walks the kernel's instruction list in layout order.
 python tools/mfma_asm_hazards.py  ->  exit code 1 and a listing if a hazard is found."""
 import os
@@ -12,14 +14,32 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN2pe22flash_attn_fp8p_kernelILi8"
+KERNELS = ("_ZN2pe22flash_attn_fp8p_kernelILi8", "_ZN2pe22flash_attn_fp8w_kernelILb")
+FIXED_AGPR = 64      # flash_attn_fp8w_kernel: a[64:255] belong to the asm statements
+AGPR = 1000          # accumulator register n is register AGPR + n in the sets below
+
+
+def _index(expr: str) -> int:
+    """a register index as the assembler reads it: a number or an expression of numbers (the fp8w kernel writes 128+((13)&1)*64+...)"""
+    if not re.fullmatch(r"[0-9+\-*&|>< ()]+", expr):
+        raise ValueError(f"register index {expr!r}")
+    return int(eval(expr, {"__builtins__": {}}))
 
 
 def regs(tok: str):
-    tok = tok.strip().split()[0] if tok.strip() else ""
+    tok = tok.strip()
+    if tok.startswith("a["):                      # accumulator registers, indices may be expressions with blanks
+        inner = tok[2:tok.index("]")]
+        lo, _, hi = inner.partition(":")
+        lo = _index(lo)
+        return set(range(AGPR + lo, AGPR + (_index(hi) if hi else lo) + 1))
+    tok = tok.split()[0] if tok else ""
     m = re.match(r"v\[(\d+):(\d+)\]", tok)
     if m:
         return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"a(\d+)$", tok)
+    if m:
+        return {AGPR + int(m.group(1))}
     m = re.match(r"v(\d+)$", tok)
     return {int(m.group(1))} if m else set()
 
@@ -35,10 +55,35 @@ def kernel_bodies(asm: str):
     lines = asm.split("\n")
     out = {}
     for st, l in enumerate(lines):
-        if l.startswith(KERNEL) and ":" in l and not l.startswith("\t"):
+        if l.startswith(KERNELS) and ":" in l and not l.startswith("\t"):
             en = [i for i in range(st, len(lines)) if ".amdhsa_kernel" in lines[i] or lines[i].startswith(".Lfunc_end")][0]
             out[l.split(":")[0]] = [x.strip() for x in lines[st + 1:en] if x.strip() and not x.strip().startswith((";", ".", "_Z"))]
     return out
+
+
+def fixed_agprs_outside_asm(asm: str):
+    """-> [(symbol, line)] : instructions of flash_attn_fp8w_kernel outside its asm statements that name a register a[FIXED_AGPR:255]"""
+    found, sym, inside = [], None, False
+    for l in asm.split("\n"):
+        if l.startswith(KERNELS[1]) and ":" in l:
+            sym = l.split(":")[0]
+            continue
+        if sym is None:
+            continue
+        if ".amdhsa_kernel" in l or l.startswith(".Lfunc_end"):
+            sym = None
+            continue
+        s = l.strip()
+        if "#ASMSTART" in s:
+            inside = True
+        elif "#ASMEND" in s:
+            inside = False
+        elif not inside and s and not s.startswith((";", ".")):
+            named = [int(x) for x in re.findall(r"\ba(\d+)\b", s)] + [int(x) for x in re.findall(r"\ba\[(\d+)[:\]]", s)] + \
+                    [int(x) for x in re.findall(r"\ba\[\d+:(\d+)\]", s)]
+            if any(n >= FIXED_AGPR for n in named):
+                found.append((sym, s))
+    return found
 
 
 def scan(body):
@@ -79,8 +124,12 @@ def main() -> int:
         if r.returncode != 0:
             print(r.stderr)
             return 2
-        bodies = kernel_bodies(open(out).read())
-    bad = 0
+        asm = open(out).read()
+        bodies = kernel_bodies(asm)
+    outside = fixed_agprs_outside_asm(asm)
+    bad = len(outside)
+    for sym, line in outside:
+        print(f"{sym}: `{line[:100]}` names a fixed accumulator register outside an asm statement")
     for sym, body in bodies.items():
         n = sum(1 for l in body if l.startswith("v_mfma_scale"))
         found = scan(body)
@@ -88,8 +137,8 @@ def main() -> int:
         print(f"{sym}: {len(body)} instructions, {n} MFMAs, {len(found)} hazard(s)")
         for i, k, what, ins, nxt in found:
             print(f"  +{k}: `{nxt[:70]}` {what} `{ins[:90]}` (instruction {i})")
-    if not bodies:
-        print("kernel not found in the assembly")
+    if len(bodies) < 4:          # fp8p<8, false>, fp8p<8, true>, fp8w<false>, fp8w<true>
+        print("kernels not found in the assembly:", sorted(bodies))
         return 2
     return 1 if bad else 0
 
