@@ -1,5 +1,7 @@
 """pe_flash_attn_fp8 (statistics + quantisation + e4m3 flash kernel) at S = 8704 / 8464, H = 24: median of 5 x 10 launches.
+ATTN_FP8_ONLY=<variant>: that variant at S = 8704 only, 20 launches (the form the PMC passes of profiles/r06_attn_fp8_pmc.md were taken on).
 python tools/microbench/attn_fp8_time.py  (GPU box, from the repo root; under rocprofv3 --kernel-trace --stats for the per-kernel split)"""
+import os
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import torch
@@ -8,7 +10,8 @@ from physicedit_amd._lib import lib, check, stream_ptr
 BF = torch.bfloat16
 g = torch.Generator(device='cuda').manual_seed(0)
 H = 24
-for S in (8704, 8464):
+ONLY = os.environ.get("ATTN_FP8_ONLY")
+for S in ((8704,) if ONLY else (8704, 8464)):
     sp = ops.s_pad_of(S)
     q = torch.zeros((H, sp, 128), dtype=BF, device='cuda'); q[:, :S] = torch.randn((H, S, 128), generator=g, device='cuda').to(BF)
     k = torch.zeros((H, sp, 128), dtype=BF, device='cuda'); k[:, :S] = torch.randn((H, S, 128), generator=g, device='cuda').to(BF)
@@ -21,6 +24,11 @@ for S in (8704, 8464):
     nb = lib().pe_flash_attn_workspace_bytes(H, S); ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
     def run():
         check(lib().pe_flash_attn_fp8(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, S, sp, H * 128, base, n, ws.data_ptr(), nb, stream_ptr()), "fp8")
+    if ONLY:
+        check(lib().pe_debug_set(b"attn_fp8_variant", int(ONLY)), "knob")
+        for _ in range(20): run()
+        torch.cuda.synchronize()
+        continue
     ref = None
     for variant in (0, 1, 2, 3, 4):
         check(lib().pe_debug_set(b"attn_fp8_variant", variant), "knob")
