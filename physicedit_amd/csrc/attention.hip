@@ -1961,9 +1961,10 @@ flash_attn_fp8p_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
                      F8W_RS(B, 14, 2) F8W_RS(B, 15, 3)                                                                                      \
                      : "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_) : "v"(al) : F8W_CLOB);                                                 \
     } while (0)
-#define F8W_ZR(i) "v_accvgpr_write_b32 a[128+" #i "], 0\n\t"
-#define F8W_ZR8(i) F8W_ZR(i) F8W_ZR(i + 1) F8W_ZR(i + 2) F8W_ZR(i + 3) F8W_ZR(i + 4) F8W_ZR(i + 5) F8W_ZR(i + 6) F8W_ZR(i + 7)
-#define F8W_ZR32(i) F8W_ZR8(i) F8W_ZR8(i + 8) F8W_ZR8(i + 16) F8W_ZR8(i + 24)
+// 32 accumulator registers from a[B] on = 0
+#define F8W_ZR(B, i) "v_accvgpr_write_b32 a[" B "+" #i "], 0\n\t"
+#define F8W_ZR8(B, i) F8W_ZR(B, i) F8W_ZR(B, i + 1) F8W_ZR(B, i + 2) F8W_ZR(B, i + 3) F8W_ZR(B, i + 4) F8W_ZR(B, i + 5) F8W_ZR(B, i + 6) F8W_ZR(B, i + 7)
+#define F8W_ZR32(B) F8W_ZR8(B, 0) F8W_ZR8(B, 8) F8W_ZR8(B, 16) F8W_ZR8(B, 24)
 #define F8W_QW(B, i) "v_accvgpr_write_b32 a[" B "+" #i "], %" #i "\n\t"
 #define F8W_QWRITE(B, q)                                                                                                                   \
     asm volatile(F8W_QW(B, 0) F8W_QW(B, 1) F8W_QW(B, 2) F8W_QW(B, 3) F8W_QW(B, 4) F8W_QW(B, 5) F8W_QW(B, 6) F8W_QW(B, 7)                     \
@@ -2054,10 +2055,10 @@ flash_attn_fp8w_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict
         glds16(v_src + t * KV_TILE, smem + (2 + buf) * RING + w * 1024);
         glds16(v_src + v_piece + t * KV_TILE, smem + (2 + buf) * RING + (w + 4) * 1024);
     };
-    asm volatile(F8W_ZR32(0) F8W_ZR32(32) F8W_ZR32(64) F8W_ZR32(96)::: F8W_CLOB);      // O = 0
+    asm volatile(F8W_ZR32("128") F8W_ZR32("160") F8W_ZR32("192") F8W_ZR32("224")::: F8W_CLOB);      // O = 0
     i32x8f ones8;
     if constexpr (LSUM) {
-        asm volatile(F8W_ZR32(0 - 64)::: F8W_CLOB);                                    // L = 0 (a[64:95])
+        asm volatile(F8W_ZR32("64")::: F8W_CLOB);                                      // L = 0 (a[64:95])
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones8[j] = 0x38383838;                             // 1.0 as e4m3, 32 k-slots per lane
         asm volatile("" : "+v"(ones8));
